@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Golden-vector generator — ORACLE / TEST INFRASTRUCTURE, runs in the BUILD
+CONTAINER ONLY (it needs /root/reference, which does not exist on the GPU box).
+
+Imports the reference's own `model.py`, `data.py`, `training.py` *unchanged*
+from /root/reference over the pure-torch PyG stand-in in `oracle/pyg_shim/`
+(the real torch_geometric / torch_scatter / torch_sparse are not installed and
+not vendored; see oracle/pyg_shim/README.md) and writes the captured tensors to
+`tests/golden/*.npz`.  Only tensors are committed — no reference source travels.
+
+What is captured:
+  graphs.npz      reference `graph_from_tensor` (data.py:141-204) on structure.json
+                  and on seeded random / corner-case structures -> edges, types, distances
+  <case>.npz      a tiny VAE (reference `VAE(**cfg)` under torch.manual_seed(0)):
+                  on-disk samples, the reference-built batch, the reference-keyed
+                  state_dict, injected eps; eval-mode outputs; train-mode outputs
+                  with GCL message dropout forced to 0 (public attribute, model.py:48);
+                  the 7 loss values (training.py:298-347); gradients of every
+                  parameter; buffers + parameters after 1 and 2 Adam steps
+                  (train.py:181, training.py:152-172, lr from ExpDecayLRScheduler).
+
+Usage:  python oracle/make_golden.py      (from the repo root)
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, "oracle", "pyg_shim"))
+
+_cwd = os.getcwd()
+os.chdir(REF)            # generation_config.py:14 opens its yaml relative to cwd
+import data as ref_data          # noqa: E402
+import model as ref_model        # noqa: E402
+import training as ref_training  # noqa: E402
+from torch_geometric.data import Batch  # noqa: E402  (the shim)
+os.chdir(_cwd)
+
+from polyphemus_amd import constants as C          # noqa: E402
+from polyphemus_amd.synthetic import disk_sample   # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(1)
+
+
+def graph_record(s):
+    """reference graph_from_tensor on a [nb,4,32] bool tensor -> int arrays."""
+    g = ref_data.graph_from_tensor(s.clone())
+    return dict(
+        s=s.numpy().astype(np.uint8),
+        edge_index=g.edge_index.numpy().astype(np.int32),
+        etype=g.edge_attrs[:, 0].numpy().astype(np.int8),
+        edist=g.edge_attrs[:, 1:].argmax(1).numpy().astype(np.int8),
+        bars=g.bars.numpy().astype(np.int8),
+        is_drum=g.is_drum.numpy().astype(np.uint8),
+        num_nodes=np.int32(int(g.num_nodes)))
+
+
+def make_graphs():
+    out = {}
+    cases = {}
+    cases["structure_json"] = torch.tensor(json.load(open(os.path.join(REF, "structure.json")))).bool()
+    rng = np.random.default_rng(7)
+    for p in (0.05, 0.1, 0.25, 0.5, 1.0):
+        cases[f"bern_p{p}"] = torch.from_numpy(rng.random((2, 4, 32)) < p)
+    cases["bern3_p0.25"] = torch.from_numpy(rng.random((3, 4, 32)) < 0.25)
+    s = torch.zeros(2, 4, 32, dtype=torch.bool)          # bar 0 empty -> forced [0,0]; bar 1 single node track 2
+    s[1, 2, 17] = True
+    cases["empty_and_single"] = s
+    s = torch.zeros(1, 4, 32, dtype=torch.bool)          # one timestep only -> next-edges early exit (data.py:97-98)
+    s[0, :, 5] = True
+    cases["one_timestep"] = s
+    s = torch.zeros(1, 4, 32, dtype=torch.bool)          # one track only
+    s[0, 3, ::3] = True
+    cases["one_track"] = s
+    for name, s in cases.items():
+        for k, v in graph_record(s).items():
+            out[f"{name}/{k}"] = v
+    out["names"] = np.array(sorted(cases.keys()))
+    np.savez_compressed(os.path.join(OUT, "graphs.npz"), **out)
+    print("graphs.npz:", len(cases), "cases")
+
+
+def build_batch(tmpdir, disk, n_bars):
+    """Write samples in the reference's .npz layout, read them back through the
+    reference's own PolyphemusDataset (data.py:207-271) and collate them the way
+    the reference's DataLoader does."""
+    for i, (c, s) in enumerate(disk):
+        np.savez(os.path.join(tmpdir, f"{i:04d}.npz"), c_tensor=c, s_tensor=s)
+    ds = ref_data.PolyphemusDataset(tmpdir, n_bars=n_bars)
+    ds.files = sorted(ds.files, key=lambda e: e.name)
+    return Batch.from_data_list([ds[i] for i in range(len(ds))])
+
+
+def capture_case(name, cfg, batch_size, p, seed, corner=False):
+    rng = np.random.default_rng(seed)
+    nb = cfg["n_bars"]
+    disk = [disk_sample(rng, nb, p) for _ in range(batch_size)]
+    if corner:
+        c, s = disk[0]                                   # sample 0: bar 0 silent, bar 1 a single (non-drum) cell
+        s[:] = False
+        s[2, C.N_TIMESTEPS + 9] = True
+        # bar 0 stays empty here: data.py:152-153 switches cell [0,0] on at load time
+    out = {}
+    for i, (c, s) in enumerate(disk):
+        out[f"disk/{i}/c_tensor"] = c
+        out[f"disk/{i}/s_tensor"] = s
+    with tempfile.TemporaryDirectory() as td:
+        graph = build_batch(td, disk, nb)
+
+    out["in/edge_index"] = graph.edge_index.numpy().astype(np.int32)
+    out["in/etype"] = graph.edge_attrs[:, 0].numpy().astype(np.int8)
+    out["in/edist"] = graph.edge_attrs[:, 1:].argmax(1).numpy().astype(np.int8)
+    out["in/tokens"] = np.stack([graph.c_tensor[..., :C.N_PITCH_TOKENS].argmax(-1).numpy(),
+                                 graph.c_tensor[..., C.N_PITCH_TOKENS:].argmax(-1).numpy()], -1).astype(np.int16)
+    assert float(graph.c_tensor.sum()) == graph.c_tensor.shape[0] * 32      # strictly one-hot pairs
+    out["in/s_tensor"] = graph.s_tensor.numpy().astype(np.uint8)
+    out["in/is_drum"] = graph.is_drum.numpy().astype(np.uint8)
+    out["in/bars"] = graph.bars.numpy().astype(np.int16)
+    out["in/batch"] = graph.batch.numpy().astype(np.int16)
+    out["in/num_nodes"] = np.int32(int(graph.num_nodes))
+    out["cfg"] = np.array(json.dumps(cfg))
+
+    torch.manual_seed(0)
+    vae = ref_model.VAE(**cfg, device=torch.device("cpu"))
+    sd0 = {k: v.clone() for k, v in vae.state_dict().items()}
+    for k, v in sd0.items():
+        out[f"sd/{k}"] = v.numpy()
+    out["param_names"] = np.array([n for n, _ in vae.named_parameters()])
+    B = batch_size
+    eps = torch.from_numpy(np.random.default_rng(seed + 1).standard_normal((B, cfg["d"])).astype(np.float32))
+    out["in/eps"] = eps.numpy()
+
+    def fwd(model, g):
+        mu, lv = model.encoder(g)                        # == model.py:668-676 with eps injected
+        z = torch.exp(0.5 * lv) * eps + mu
+        s_logits, c_logits = model.decoder(z, g)
+        return s_logits, c_logits, mu, lv
+
+    # ---- eval mode -----------------------------------------------------------
+    vae.eval()
+    with torch.no_grad():
+        s_logits, c_logits, mu, lv = fwd(vae, graph)
+    out["eval/s_logits"], out["eval/c_logits"] = s_logits.numpy(), c_logits.numpy()
+    out["eval/mu"], out["eval/log_var"] = mu.numpy(), lv.numpy()
+
+    # ---- train mode, message dropout off, two optimizer steps ----------------
+    vae.train()
+    for m in vae.modules():
+        if isinstance(m, ref_model.GCL):
+            m.dropout = 0.0
+    tj = json.load(open(os.path.join(REF, "training.json")))
+    opt = torch.optim.Adam(vae.parameters(), **tj["optimizer"])          # train.py:181
+    sched = ref_training.ExpDecayLRScheduler(optimizer=opt, **tj["lr_scheduler"])
+    trainer = ref_training.PolyphemusTrainer("unused", vae, opt, lr_scheduler=sched)
+    trainer.beta = 0                                                     # training.py:116
+    out["opt"] = np.array(json.dumps(dict(optimizer=tj["optimizer"], lr_scheduler=tj["lr_scheduler"])))
+    opt.zero_grad()
+    for step in (1, 2):
+        s_logits, c_logits, mu, lv = fwd(vae, graph)
+        tot, losses = trainer._losses(graph.s_tensor, s_logits, graph.c_tensor, c_logits, mu, lv)
+        tot.backward()                                                   # training.py:155
+        pre = f"train{step}"
+        out[f"{pre}/lr"] = np.float64(opt.param_groups[0]["lr"])
+        if step == 1:
+            out[f"{pre}/s_logits"], out[f"{pre}/c_logits"] = s_logits.detach().numpy(), c_logits.detach().numpy()
+            out[f"{pre}/mu"], out[f"{pre}/log_var"] = mu.detach().numpy(), lv.detach().numpy()
+            none = []
+            for n, q in vae.named_parameters():
+                if q.grad is None:
+                    none.append(n)
+                else:
+                    out[f"{pre}/grad/{n}"] = q.grad.numpy().copy()
+            out[f"{pre}/grad_none"] = np.array(none)
+        out[f"{pre}/losses"] = np.array(json.dumps(losses))
+        opt.step()                                                       # training.py:164
+        opt.zero_grad()
+        sched.step()                                                     # training.py:170
+        for k, v in vae.state_dict().items():
+            out[f"{pre}/sd_after/{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz: N={int(graph.num_nodes)} E={graph.edge_index.shape[1]} "
+          f"params={sum(q.numel() for q in vae.parameters())} losses={losses}")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    make_graphs()
+    capture_case("lmd2_tiny", dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8),
+                 batch_size=8, p=0.06, seed=11, corner=True)
+    capture_case("nb3_tiny", dict(dropout=0, batch_norm=True, gnn_n_layers=1, d=16, n_bars=3, resolution=8),
+                 batch_size=6, p=0.05, seed=12)

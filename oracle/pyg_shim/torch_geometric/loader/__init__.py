@@ -1,0 +1,10 @@
+"""`torch_geometric.loader.DataLoader`."""
+import torch.utils.data
+from ..data import Batch
+
+
+class DataLoader(torch.utils.data.DataLoader):
+    def __init__(self, dataset, batch_size=1, shuffle=False, **kwargs):
+        kwargs.pop("collate_fn", None)
+        super().__init__(dataset, batch_size, shuffle,
+                         collate_fn=lambda lst: Batch.from_data_list(lst), **kwargs)

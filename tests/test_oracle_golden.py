@@ -1,0 +1,104 @@
+"""Pin the CPU restatement (oracle/vae_cpu.py) to the vectors captured from the
+reference's own model.py / training.py (oracle/make_golden.py): eval outputs, train
+outputs, the 7 losses, every gradient, BN running stats and Adam-updated parameters."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae_cpu
+from util import REL_TOL, batch_from_golden, load_case, rel_err, state_dict_from_golden
+
+CASES = ["lmd2_tiny", "nb3_tiny"]
+
+
+@pytest.fixture(autouse=True)
+def _single_thread():
+    """The goldens were captured with one CPU thread; reductions are then bit-reproducible
+    (multi-threaded sums differ in the last bits, which tiny-batch BatchNorm amplifies)."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_eval_forward(case):
+    z, cfg = load_case(case)
+    g = batch_from_golden(z, cfg)
+    P, _ = vae_cpu.split_state(state_dict_from_golden(z), [str(n) for n in z["param_names"]])
+    with torch.no_grad():
+        (s_logits, c_logits), mu, lv = vae_cpu.vae_forward(g, P, cfg, False, torch.from_numpy(z["in/eps"]))
+    for name, got in (("s_logits", s_logits), ("c_logits", c_logits), ("mu", mu), ("log_var", lv)):
+        assert rel_err(got, z[f"eval/{name}"]) < 1e-6, name
+    # eval mode leaves every buffer untouched
+    for k, v in state_dict_from_golden(z).items():
+        assert torch.equal(P[k].detach(), v), k
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_two_train_steps(case):
+    z, cfg = load_case(case)
+    g = batch_from_golden(z, cfg)
+    names = [str(n) for n in z["param_names"]]
+    P, names = vae_cpu.split_state(state_dict_from_golden(z), names)
+    optcfg = json.loads(str(z["opt"]))
+    opt = torch.optim.Adam([P[n] for n in names], **optcfg["optimizer"])
+    eps = torch.from_numpy(z["in/eps"])
+    none = set(str(n) for n in z["train1/grad_none"])
+    # SURVEY B-1: the structure decoder gets no gradient in the reference
+    assert none == {n for n in names if n.startswith("decoder.s_decoder.")}
+    for step in (1, 2):
+        assert abs(opt.param_groups[0]["lr"] - float(z[f"train{step}/lr"])) < 1e-15
+        outs, parts, grads = vae_cpu.train_step(g, P, names, cfg, opt, eps, msg_dropout=0.0)
+        want = json.loads(str(z[f"train{step}/losses"]))
+        for k, v in want.items():
+            assert abs(float(parts[k].detach()) - v) <= 1e-5 * max(1.0, abs(v)), (step, k)   # kld cancels: 1+lv-e^lv
+        if step == 1:
+            for name, got in zip(("s_logits", "c_logits", "mu", "log_var"), outs):
+                assert rel_err(got.detach(), z[f"train1/{name}"]) < 1e-6, name
+            for n in names:
+                if n in none:
+                    assert grads[n] is None, n
+                else:
+                    assert rel_err(grads[n], z[f"train1/grad/{n}"]) < 1e-5, n
+        lr = vae_cpu.exp_decay_lr(step, **optcfg["lr_scheduler"])          # training.py:169-170
+        for pg in opt.param_groups:
+            pg["lr"] = lr
+        after = state_dict_from_golden(z, f"train{step}/sd_after/")
+        for k, v in after.items():
+            got = P[k].detach()
+            if v.dtype.is_floating_point:
+                assert rel_err(got, v) < 2e-6, (step, k)
+            else:
+                assert torch.equal(got, v), (step, k)
+
+
+def test_losses_quirk_structure_on_target():
+    """training.py:307 replaces the logits by the target: the loss ignores s_logits."""
+    z, cfg = load_case("lmd2_tiny")
+    g = batch_from_golden(z, cfg)
+    s_logits = torch.randn(8, 2, 4, 32, requires_grad=True)
+    c_logits = torch.from_numpy(z["train1/c_logits"].copy())
+    mu = torch.from_numpy(z["train1/mu"].copy())
+    lv = torch.from_numpy(z["train1/log_var"].copy())
+    tot, parts = vae_cpu.losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, lv)
+    want = json.loads(str(z["train1/losses"]))
+    assert abs(float(parts["structure"]) - want["structure"]) < 1e-6
+    assert not tot.requires_grad
+
+
+def test_exp_decay_lr_schedule():
+    kw = dict(peak_lr=1e-4, warmup_steps=8000, final_lr_scale=0.01, decay_steps=800000)
+    assert vae_cpu.exp_decay_lr(1, **kw) == 1e-4 and vae_cpu.exp_decay_lr(8000, **kw) == 1e-4
+    assert abs(vae_cpu.exp_decay_lr(808000, **kw) - 1e-6) < 1e-12
+
+
+def test_binary_from_logits_forces_empty_bars():
+    s = torch.full((2, 2, 4, 32), -3.0)
+    s[0, 0, 1, 5] = 2.0
+    b = vae_cpu.binary_from_logits(s)
+    assert b[0, 0].sum() == 1 and b[0, 0, 1, 5]
+    for i, j in ((0, 1), (1, 0), (1, 1)):
+        assert b[i, j].sum() == 1 and b[i, j, 0, 0]

@@ -1,0 +1,222 @@
+/*
+ * polyphemus_hip.h — C ABI of libpolyphemus_hip.so: the MI355X (gfx950) kernels of
+ * the Polyphemus graph-VAE hot path.
+ *
+ * The reference has no FFI of its own (it is pure Python over torch /
+ * torch_geometric / torch_scatter); the drop-in boundary is the
+ * `nn.Module` surface of `model.VAE`.  Each entry point below replaces the
+ * chain of ATen / torch_scatter kernels that one stretch of the reference's
+ * Python launches today; the stretch is cited as `file:line` into the
+ * reference tree.  The Python mirror (`polyphemus_amd/model.py`) binds these
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by
+ *     the caller (PyTorch); the library never allocates, frees or synchronises;
+ *   - work is enqueued on the caller's `stream` (graph-capturable);
+ *   - floats are fp32, row-major, contiguous unless a leading dimension is given;
+ *     indices are int32 unless stated;
+ *   - return value: 0 = PM_OK, <0 = error (PM_E_*); no exceptions cross the ABI.
+ */
+#ifndef POLYPHEMUS_HIP_H
+#define POLYPHEMUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pm_stream_t; /* hipStream_t */
+
+enum {
+  PM_OK = 0,
+  PM_E_INVALID = -1, /* bad argument (shape, alignment, null pointer) */
+  PM_E_LAUNCH = -2,  /* hipGetLastError() != hipSuccess after a launch */
+  PM_E_UNSUPPORTED = -3
+};
+
+enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR = 99, PM_N_TOK = 230 };
+
+/* Library / device identification (host only, no GPU needed). */
+int pm_abi_version(void);
+const char* pm_build_info(void);
+
+/* ------------------------------------------------------------------ graph plan
+ * Replaces the per-layer boolean-mask edge selection `edge_index[:, edge_type == i]`
+ * (model.py:30-38,104-105, 96 times per forward) and the host syncs of
+ * `torch.unique(distinct_bars)` (model.py:543) and `batch[-1].item()` (PyG
+ * GlobalAttention, model.py:409) by ONE device-side pass per batch:
+ * CSR by (dst, relation), CSC by src, per-edge 1/in-degree, bar offsets,
+ * drum / non-drum node lists, token histograms.  All integer work, bit-exact.
+ *
+ * The plan lives in one caller-allocated int32 buffer; `pm_plan_layout` returns the
+ * field offsets (in int32 elements) so the host can slice views of it. */
+enum {
+  PM_PLAN_ROWPTR = 0,   /* [N*6+1] CSR offsets, key = dst*6 + relation            */
+  PM_PLAN_CSR_SRC,      /* [E] source node of the edge at this CSR slot           */
+  PM_PLAN_CSR_DIST,     /* [E] timestep distance 0..31                            */
+  PM_PLAN_CSR_EID,      /* [E] position of the edge in the input edge_index       */
+  PM_PLAN_COLPTR,       /* [N+1] CSC offsets, key = src                           */
+  PM_PLAN_CSC_DST,      /* [E]                                                    */
+  PM_PLAN_CSC_RELDIST,  /* [E] relation | distance << 8                           */
+  PM_PLAN_CSC_EID,      /* [E]                                                    */
+  PM_PLAN_CSC_INVCNT,   /* [E] float bits: 1 / max(#in-edges of (dst, relation),1) */
+  PM_PLAN_NODE_BAR,     /* [N] distinct bar id = bars + n_bars*batch (model.py:403) */
+  PM_PLAN_BAR_PTR,      /* [G+1] node offsets of each bar                         */
+  PM_PLAN_GROUP_LIST,   /* [N] drum nodes (ascending) then non-drum nodes         */
+  PM_PLAN_GROUP_CNT,    /* [4] {n_drum, n_non_drum, 0, 0}                         */
+  PM_PLAN_TOK_HIST,     /* [4][131] token counts over slots 1..15:
+                           0 drum pitch, 1 non-drum pitch, 2 drum dur, 3 non-drum dur */
+  PM_PLAN_SCRATCH,      /* cursors + scan partials                                */
+  PM_PLAN_NFIELDS
+};
+int pm_plan_layout(int32_t N, int32_t E, int32_t G, int64_t* offsets /* [PM_PLAN_NFIELDS+1] */);
+int pm_plan_build(const int64_t* edge_index /* [2,E] row0=src,row1=dst (data.py:173) */,
+                  const int32_t* edge_type /* [E] 0..5 */, const int32_t* edge_dist /* [E] 0..31 */,
+                  const int64_t* bars /* [N] */, const int64_t* batch /* [N] */,
+                  const uint8_t* is_drum /* [N] */, const int32_t* tokens /* [N,16,2] */,
+                  int32_t n_bars, int32_t N, int32_t E, int32_t G, int32_t* plan, pm_stream_t stream);
+/* Reference-format inputs -> compact ids (the reference feeds one-hots, data.py:179-182,235-268). */
+int pm_edge_attrs_to_ids(const float* edge_attrs /* [E,33] */, int32_t E, int32_t* edge_type,
+                         int32_t* edge_dist, pm_stream_t stream);
+int pm_tokens_from_onehot(const float* c_tensor /* [N,16,230] */, int32_t N, int32_t* tokens /* [N,16,2] */,
+                          pm_stream_t stream);
+
+/* ------------------------------------------------------------------ message aggregation
+ * `GCL.message` + PyG `propagate` + torch_scatter mean (model.py:110,123-135):
+ *   A[n, r*d:(r+1)*d] = mean_{e: dst=n, type=r} keep_e * relu(x[src_e] * T[dist_e]) / (1-p)
+ *   A[n, 6d:7d]       = x[n]                       (root operand of model.py:116)
+ * T[dist] = edge_nn.weight[:, dist] + edge_nn.bias  (Linear on a one-hot, model.py:127).
+ * keep_e is the counter-based dropout mask pm_dropout_keep(seed, layer, eid, channel). */
+int pm_edge_table(const float* nn_weight /* [d,32] */, const float* nn_bias /* [d] */, int32_t d,
+                  float* T /* [32,d] */, pm_stream_t stream);
+int pm_edge_table_bwd(const float* dT /* [32,d] */, int32_t d, float* d_nn_weight /* += */,
+                      float* d_nn_bias /* += */, pm_stream_t stream);
+int pm_segreduce_fwd(const float* x /* [N,d] */, const float* T /* [32,d] */, const int32_t* plan,
+                     int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
+                     uint32_t layer_uid, float* A /* [N,7d] */, pm_stream_t stream);
+int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] */,
+                     const float* dres /* [N,d] or NULL: added to dx (residual path, model.py:206) */,
+                     const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p,
+                     uint32_t seed, uint32_t layer_uid, float* dx /* [N,d] */, float* dT /* [32,d] += */,
+                     pm_stream_t stream);
+
+/* ------------------------------------------------------------------ dense contraction (fp32 MFMA)
+ * C[M,N] (=|+=) op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU), v_mfma_f32_32x32x2_f32.
+ * Replaces `addmm`/`mm` of every nn.Linear and of `h @ weight[i]`, `x_r @ root`
+ * (model.py:112,116) — with A = [h_0|..|h_5|x] the 7 GEMMs of a GCL are one call.
+ * transA: A is stored [K,M]; transB: B is stored [N,K] (nn.Linear weight).
+ * rowmap (optional): the gathered dimension (M when !transA, else K) is indirect:
+ *   physical row = rowmap[r / rows_per_entry] * rows_per_entry + r % rows_per_entry
+ *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
+ *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
+enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2 };
+int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
+                int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
+                pm_stream_t stream);
+
+/* ------------------------------------------------------------------ batch normalisation
+ * nn.BatchNorm1d / BatchNorm2d / PyG BatchNorm (model.py:203,222,228,282,359-375,338,475,638).
+ * Tensors are viewed as [O, C, I] (row-major [M,C]: O=M, I=1; NCHW: O=G, I=H*W). */
+int pm_bn_stats(const float* x, int32_t O, int32_t C, int32_t I, float* mean /* [C] */,
+                float* var /* [C] biased */, float* running_mean /* NULL or [C], updated */,
+                float* running_var, float momentum, double* scratch /* [64*2*C] */, pm_stream_t stream);
+int pm_bn_apply(const float* x, int32_t O, int32_t C, int32_t I, const float* mean, const float* var,
+                float eps, const float* gamma, const float* beta, const float* residual /* or NULL */,
+                int relu, float* y, pm_stream_t stream);
+/* dx = BN'(du), du = dy * [relu ? bn(x) > 0 : 1]; dgamma/dbeta accumulate. */
+int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
+              const float* var, float eps, const float* gamma, const float* beta, int relu,
+              float* dgamma /* += */, float* dbeta /* += */, float* dx, double* scratch /* [64*2*C+2*C] */,
+              pm_stream_t stream);
+
+/* ------------------------------------------------------------------ element-wise helpers */
+int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
+int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
+int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);
+int pm_reparam_fwd(const float* mu, const float* log_var, const float* eps, int64_t n, float* z, pm_stream_t stream);
+int pm_reparam_bwd(const float* dz, const float* log_var, const float* eps, int64_t n, float* dmu /* += */,
+                   float* dlog_var /* += */, pm_stream_t stream);
+
+/* ------------------------------------------------------------------ token embedding front
+ * ContentEncoder embeddings (model.py:355-377): Linear(131|99 -> d/2) on one-hot tokens is
+ * a row lookup, and BatchNorm1d over those rows is a count-weighted statistic of the
+ * table, so the stage is: normalise 4 small tables, then gather. */
+int pm_embed_tables(const float* w_pitch_drum /* [d/2,131] */, const float* b_pitch_drum,
+                    const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur /* [d/2,99] */,
+                    const float* b_dur, const float* bn_drum_g, const float* bn_drum_b,
+                    const float* bn_nd_g, const float* bn_nd_b, const float* bn_dur_g, const float* bn_dur_b,
+                    float* rm_drum, float* rv_drum, float* rm_nd, float* rv_nd, float* rm_dur, float* rv_dur,
+                    const int32_t* tok_hist /* [4][131] */, int32_t d, int training, float eps, float momentum,
+                    float* tables /* [4][131][d/2] normalised */, float* stats /* [4][2][d/2] mean,var */,
+                    pm_stream_t stream);
+int pm_embed_gather(const float* tables, const int32_t* tokens /* [N,16,2] */, const uint8_t* is_drum,
+                    int32_t N, int32_t d, float* X /* [N,15,d] */, pm_stream_t stream);
+int pm_embed_bwd_scatter(const float* dX /* [N,15,d] */, const int32_t* tokens, const int32_t* plan, int32_t N,
+                         int32_t E, int32_t G, int32_t d, float* S /* [4][131][d/2], zeroed by the call */,
+                         pm_stream_t stream);
+int pm_embed_tables_bwd(const float* S, const float* w_pitch_drum, const float* b_pitch_drum,
+                        const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur, const float* b_dur,
+                        const float* bn_drum_g, const float* bn_nd_g, const float* bn_dur_g, const float* stats,
+                        const int32_t* tok_hist, int32_t d, float eps, float* dw_pitch_drum, float* db_pitch_drum,
+                        float* dw_pitch_nd, float* db_pitch_nd, float* dw_dur, float* db_dur, float* dg_drum,
+                        float* dbeta_drum, float* dg_nd, float* dbeta_nd, float* dg_dur, float* dbeta_dur,
+                        pm_stream_t stream);
+
+/* ------------------------------------------------------------------ bar pooling / broadcast
+ * PyG GlobalAttention over the nodes of each bar (model.py:335-340,408-409) and the
+ * bar -> node broadcast `repeat_interleave(out, counts)` (model.py:543-545). */
+int pm_gate_fwd(const float* x /* [N,d] */, const float* w /* [d] */, const float* b /* [1] */, int32_t N,
+                int32_t d, float* g /* [N] */, pm_stream_t stream);
+int pm_attnpool_fwd(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                    const float* bn_g, const float* bn_b, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                    int32_t d, float* alpha /* [N] softmax weights */, float* out /* [G,d] */, pm_stream_t stream);
+int pm_attnpool_bwd(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                    const float* bn_g, const float* alpha, const float* dout /* [G,d] */, const float* gate_w,
+                    const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx /* [N,d] */,
+                    float* d_gate_w /* [d] += */, float* d_gate_b /* [1] += */, float* d_bn_g /* [1] += */,
+                    float* d_bn_b /* [1] += */, float* scratch /* [3*N + 8] */, pm_stream_t stream);
+int pm_bar_broadcast_fwd(const float* bars /* [G,d] */, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                         int32_t d, float* x /* [N,d] */, pm_stream_t stream);
+int pm_bar_broadcast_bwd(const float* dx /* [N,d] */, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                         int32_t d, float* dbars /* [G,d] */, pm_stream_t stream);
+
+/* ------------------------------------------------------------------ structure CNN (4x32 bar grids)
+ * CNNEncoder / CNNDecoder convolutions (model.py:219-230,279-285): 3x3, padding 1, NCHW;
+ * `up4` fuses nn.Upsample(scale_factor=(1,4)) in front of the convolution (model.py:280-281);
+ * pool4 = nn.MaxPool2d((1,4)) (model.py:225). */
+int pm_conv3x3_fwd(const float* x, const float* w, const float* b, int32_t G, int32_t Ci, int32_t Co, int32_t H,
+                   int32_t W, int up4, float* y, pm_stream_t stream);
+int pm_conv3x3_bwd_data(const float* dy, const float* w, int32_t G, int32_t Ci, int32_t Co, int32_t H, int32_t W,
+                        int up4, float* dx, pm_stream_t stream);
+int pm_conv3x3_bwd_weight(const float* x, const float* dy, int32_t G, int32_t Ci, int32_t Co, int32_t H, int32_t W,
+                          int up4, float* dw /* += */, float* db /* += */, pm_stream_t stream);
+int pm_maxpool4_fwd(const float* x, int64_t n_out, float* y, pm_stream_t stream);
+int pm_maxpool4_bwd(const float* x, const float* dy, int64_t n_out, float* dx, pm_stream_t stream);
+
+/* ------------------------------------------------------------------ loss (training.py:298-347)
+ * Fused softmax cross-entropy of the pitch (131, ignore 130) and duration (99, ignore 98)
+ * logits with their gradient, KL divergence, and the structure BCE.  `out` receives
+ * {pitch, dur, structure, kld} (float64[4], zeroed by the call). */
+int pm_content_ce(const float* c_logits /* [N,15,230] */, const int32_t* tokens /* [N,16,2] */,
+                  const int32_t* tok_hist, int32_t N, float grad_scale, float* d_logits /* or NULL */, double* out,
+                  pm_stream_t stream);
+int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
+           float* dlog_var, double* out, pm_stream_t stream);
+int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,
+                  double* out, pm_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser (train.py:181, training.py:160-166)
+ * torch.optim.Adam (no weight decay, no amsgrad) over one flat fp32 buffer. */
+int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t step, float grad_scale, pm_stream_t stream);
+
+/* Counter-based dropout mask shared by device code and the oracle (host-callable). */
+uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYPHEMUS_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libpolyphemus_hip.so (the C ABI in include/polyphemus_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, the
+product path raises.  torch is used only for device memory and the stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpolyphemus_hip.so")
+
+PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", "csc_reldist", "csc_eid",
+               "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "scratch"]
+
+# argument codes: p = device pointer, i = int32, l = int64, f = float, u = uint32, s = stream
+_SIGS = {
+    "pm_plan_layout": "iiip",
+    "pm_plan_build": "pppppppiiiips",
+    "pm_edge_attrs_to_ids": "pipps",
+    "pm_tokens_from_onehot": "pips",
+    "pm_edge_table": "ppips",
+    "pm_edge_table_bwd": "pipps",
+    "pm_segreduce_fwd": "pppiiiifuups",
+    "pm_segreduce_bwd": "pppppiiiifuupps",
+    "pm_gemm_f32": "iiiiipipipipiipips",
+    "pm_bn_stats": "piiippppfps",
+    "pm_bn_apply": "piiippfpppips",
+    "pm_bn_bwd": "ppiiippfppipppps",
+    "pm_relu_bwd": "pplps",
+    "pm_add": "pplps",
+    "pm_colsum_acc": "piiips",
+    "pm_reparam_fwd": "ppplps",
+    "pm_reparam_bwd": "ppplpps",
+    "pm_embed_tables": "pppppppppppppppppppiiffpps",
+    "pm_embed_gather": "pppiips",
+    "pm_embed_bwd_scatter": "pppiiiips",
+    "pm_embed_tables_bwd": "ppppppppppppifpppppppppppps",
+    "pm_gate_fwd": "pppiips",
+    "pm_attnpool_fwd": "ppppfpppiiiipps",
+    "pm_attnpool_bwd": "ppppfpppppiiiipppppps",
+    "pm_bar_broadcast_fwd": "ppiiiips",
+    "pm_bar_broadcast_bwd": "ppiiiips",
+    "pm_conv3x3_fwd": "pppiiiiiips",
+    "pm_conv3x3_bwd_data": "ppiiiiiips",
+    "pm_conv3x3_bwd_weight": "ppiiiiiipps",
+    "pm_maxpool4_fwd": "plps",
+    "pm_maxpool4_bwd": "pplps",
+    "pm_content_ce": "pppifpps",
+    "pm_kld": "ppiifppps",
+    "pm_bce_logits": "pplfpps",
+    "pm_adam_step": "pppplffffifs",
+}
+_CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p}
+EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash"])
+
+_lib: Optional[C.CDLL] = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the HIP extension (once).  Raises HipExtensionError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f"{LIB_PATH} is missing: build it with `python -m polyphemus_amd.build` "
+                "(__graft_entry__.build()).  There is no CPU fallback for the HIP path.")
+        L = C.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = [_CT[c] for c in sig]
+            fn.restype = C.c_int
+        L.pm_abi_version.restype = C.c_int
+        L.pm_build_info.restype = C.c_char_p
+        L.pm_dropout_hash.argtypes = [C.c_uint32] * 4
+        L.pm_dropout_hash.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ERR = {-1: "PM_E_INVALID (bad argument)", -2: "PM_E_LAUNCH (kernel launch failed)", -3: "PM_E_UNSUPPORTED"}
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise HipExtensionError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def plan_layout(N: int, E: int, G: int):
+    """Field offsets (int32 elements) of the plan buffer; host-only call."""
+    off = (C.c_int64 * (len(PLAN_FIELDS) + 1))()
+    rc = lib().pm_plan_layout(N, E, G, C.cast(off, C.c_void_p))
+    if rc != 0:
+        raise HipExtensionError(f"pm_plan_layout({N},{E},{G}) failed: {_ERR.get(rc, rc)}")
+    return list(off)

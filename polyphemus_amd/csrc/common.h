@@ -1,0 +1,73 @@
+// common.h — shared device/host helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/polyphemus_hip.h"
+
+#define PM_WAVE 64
+
+static inline int pm_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
+}
+
+static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t pm_align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+// Plan field accessor (offsets are a pure function of N, E, G — see plan.hip).
+struct PmPlanView {
+  const int32_t* rowptr; const int32_t* csr_src; const int32_t* csr_dist; const int32_t* csr_eid;
+  const int32_t* colptr; const int32_t* csc_dst; const int32_t* csc_reldist; const int32_t* csc_eid;
+  const float* csc_invcnt; const int32_t* node_bar; const int32_t* bar_ptr; const int32_t* group_list;
+  const int32_t* group_cnt; const int32_t* tok_hist;
+};
+void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off);
+static inline PmPlanView pm_plan_view(const int32_t* plan, int32_t N, int32_t E, int32_t G) {
+  int64_t o[PM_PLAN_NFIELDS + 1];
+  pm_plan_offsets(N, E, G, o);
+  PmPlanView v;
+  v.rowptr = plan + o[PM_PLAN_ROWPTR]; v.csr_src = plan + o[PM_PLAN_CSR_SRC];
+  v.csr_dist = plan + o[PM_PLAN_CSR_DIST]; v.csr_eid = plan + o[PM_PLAN_CSR_EID];
+  v.colptr = plan + o[PM_PLAN_COLPTR]; v.csc_dst = plan + o[PM_PLAN_CSC_DST];
+  v.csc_reldist = plan + o[PM_PLAN_CSC_RELDIST]; v.csc_eid = plan + o[PM_PLAN_CSC_EID];
+  v.csc_invcnt = reinterpret_cast<const float*>(plan + o[PM_PLAN_CSC_INVCNT]);
+  v.node_bar = plan + o[PM_PLAN_NODE_BAR]; v.bar_ptr = plan + o[PM_PLAN_BAR_PTR];
+  v.group_list = plan + o[PM_PLAN_GROUP_LIST]; v.group_cnt = plan + o[PM_PLAN_GROUP_CNT];
+  v.tok_hist = plan + o[PM_PLAN_TOK_HIST];
+  return v;
+}
+
+// lowbias32 integer mix; the dropout stream is a pure function of (seed, layer, edge id, channel)
+// so the backward pass and the CPU oracle regenerate the same mask.
+__host__ __device__ static inline uint32_t pm_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ static inline uint32_t pm_edge_key(uint32_t seed, uint32_t layer_uid, uint32_t eid) {
+  return pm_mix32(pm_mix32(seed ^ (layer_uid + 1u) * 0x9E3779B9U) ^ (eid * 0x85EBCA6BU + 0x27D4EB2FU));
+}
+__host__ __device__ static inline uint32_t pm_elem_hash(uint32_t edge_key, uint32_t channel) {
+  return pm_mix32(edge_key + channel * 0xC2B2AE35U);
+}
+// keep iff top 24 bits >= p * 2^24
+__host__ __device__ static inline uint32_t pm_keep_threshold(float p) {
+  return (uint32_t)(p * 16777216.0f);
+}
+
+#ifdef __HIPCC__
+__device__ static inline float pm_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline double pm_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline float pm_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif

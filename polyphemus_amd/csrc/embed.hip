@@ -1,0 +1,215 @@
+// embed.hip — token embedding front of the content encoder.
+//
+// Reference (model.py:352-377): split nodes into drums / non-drums (boolean masks), apply
+// Linear(131 -> d/2) / Linear(99 -> d/2) to one-hot tokens, BatchNorm1d over the (nodes*15) rows of
+// each group, concatenate.  A Linear on a one-hot is a row lookup T[v] = W[:, v] + b, and batch
+// statistics over looked-up rows are count-weighted statistics of the 131 (99) table rows, so:
+//   1. pm_embed_tables  : 4 tiny tables, normalised with weights = token histogram (from the plan)
+//   2. pm_embed_gather  : X[n, s, :] = [ Tp[group(n)][pitch(n,s)] | Td[group(n)][dur(n,s)] ]
+// The 14.7 KB/node one-hot tensor and the 3450*N*d flops on zeros are never touched.
+// Table ids: 0 = drum pitch (bn_drums), 1 = non-drum pitch (bn_non_drums),
+//            2 = drum duration, 3 = non-drum duration (both bn_dur: applied to the drum rows first,
+//            then to the non-drum rows, so its running stats are updated twice — model.py:362,375).
+#include "common.h"
+
+#define EMB_V PM_N_PITCH   /* rows allocated per table (duration tables use the first 99) */
+
+struct EmbParams {
+  const float* w[3]; const float* b[3];        // 0 drum pitch, 1 non-drum pitch, 2 duration
+  const float* g[3]; const float* be[3];       // bn_drums, bn_non_drums, bn_dur
+  float* rm[3]; float* rv[3];
+};
+
+__device__ static inline void table_src(int t, int& wsel, int& vocab) {
+  wsel = t < 2 ? t : 2; vocab = t < 2 ? PM_N_PITCH : PM_N_DUR;
+}
+
+// one thread per (kind, channel); kind 2 (duration) handles tables 2 and 3 in order.
+__global__ void k_embed_tables(EmbParams P, const int* __restrict__ hist, int dh, int training, float eps,
+                               float momentum, float* __restrict__ tables, float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * dh) return;
+  const int kind = i / dh, c = i % dh;
+  const int t0 = kind < 2 ? kind : 2, t1 = kind < 2 ? kind + 1 : 4;
+  for (int t = t0; t < t1; ++t) {
+    int wsel, V;
+    table_src(t, wsel, V);
+    const float* w = P.w[wsel] + (int64_t)c * V;
+    const float bias = P.b[wsel][c];
+    const int* h = hist + t * EMB_V;
+    double cnt = 0, s0 = 0, s1 = 0;
+    for (int v = 0; v < V; ++v) {
+      const double tv = (double)(w[v] + bias), hv = (double)h[v];
+      cnt += hv; s0 += hv * tv; s1 += hv * tv * tv;
+    }
+    float mean, var;
+    if (training) {
+      if (cnt < 1) { stats[(t * 2) * dh + c] = 0.f; stats[(t * 2 + 1) * dh + c] = 1.f; continue; }  // empty group
+      const double mu = s0 / cnt;
+      double vv = s1 / cnt - mu * mu;
+      if (vv < 0) vv = 0;
+      mean = (float)mu; var = (float)vv;
+      const double unb = cnt > 1 ? vv * cnt / (cnt - 1) : vv;
+      P.rm[wsel][c] = (float)((1.0 - momentum) * P.rm[wsel][c] + momentum * mu);
+      P.rv[wsel][c] = (float)((1.0 - momentum) * P.rv[wsel][c] + momentum * unb);
+    } else { mean = P.rm[wsel][c]; var = P.rv[wsel][c]; }
+    stats[(t * 2) * dh + c] = mean;
+    stats[(t * 2 + 1) * dh + c] = var;
+    const float rstd = rsqrtf(var + eps), ga = P.g[wsel][c], be = P.be[wsel][c];
+    for (int v = 0; v < V; ++v) tables[((int64_t)t * EMB_V + v) * dh + c] = ((w[v] + bias) - mean) * rstd * ga + be;
+  }
+}
+
+extern "C" int pm_embed_tables(const float* w_pd, const float* b_pd, const float* w_pn, const float* b_pn,
+                               const float* w_du, const float* b_du, const float* g_d, const float* be_d,
+                               const float* g_n, const float* be_n, const float* g_u, const float* be_u, float* rm_d,
+                               float* rv_d, float* rm_n, float* rv_n, float* rm_u, float* rv_u, const int32_t* tok_hist,
+                               int32_t d, int training, float eps, float momentum, float* tables, float* stats,
+                               pm_stream_t stream) {
+  if (!w_pd || !w_pn || !w_du || !tok_hist || !tables || !stats || d <= 0 || (d & 7)) return PM_E_INVALID;
+  EmbParams P;
+  P.w[0] = w_pd; P.w[1] = w_pn; P.w[2] = w_du; P.b[0] = b_pd; P.b[1] = b_pn; P.b[2] = b_du;
+  P.g[0] = g_d; P.g[1] = g_n; P.g[2] = g_u; P.be[0] = be_d; P.be[1] = be_n; P.be[2] = be_u;
+  P.rm[0] = rm_d; P.rm[1] = rm_n; P.rm[2] = rm_u; P.rv[0] = rv_d; P.rv[1] = rv_n; P.rv[2] = rv_u;
+  const int dh = d / 2;
+  hipLaunchKernelGGL(k_embed_tables, dim3(pm_cdiv(3 * dh, 64)), dim3(64), 0, (hipStream_t)stream, P, tok_hist, dh,
+                     training, eps, momentum, tables, stats);
+  return pm_check_launch();
+}
+
+// one wave per (node, slot): d floats = [pitch half | duration half], float4 per lane
+__global__ void __launch_bounds__(256) k_embed_gather(const float* __restrict__ tables, const int* __restrict__ tok,
+                                                      const uint8_t* __restrict__ is_drum, int64_t rows, int d,
+                                                      float* __restrict__ X) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, dh = d / 2;
+  const int n = (int)(row / PM_N_SLOTS), s = (int)(row % PM_N_SLOTS) + 1;     // SOS slot dropped (model.py:349)
+  const int grp = is_drum[n] ? 0 : 1;
+  const int p = tok[((int64_t)n * 16 + s) * 2], du = tok[((int64_t)n * 16 + s) * 2 + 1];
+  const float* tp = tables + ((int64_t)grp * EMB_V + p) * dh;
+  const float* td = tables + ((int64_t)(2 + grp) * EMB_V + du) * dh;
+  float* out = X + row * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = c < dh ? *reinterpret_cast<const float4*>(tp + c) : *reinterpret_cast<const float4*>(td + c - dh);
+    *reinterpret_cast<float4*>(out + c) = v;
+  }
+}
+extern "C" int pm_embed_gather(const float* tables, const int32_t* tokens, const uint8_t* is_drum, int32_t N, int32_t d,
+                               float* X, pm_stream_t stream) {
+  if (!tables || !tokens || !is_drum || !X || N <= 0 || d <= 0 || (d & 7)) return PM_E_INVALID;
+  const int64_t rows = (int64_t)N * PM_N_SLOTS;
+  hipLaunchKernelGGL(k_embed_gather, dim3(pm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, tables, tokens,
+                     is_drum, rows, d, X);
+  return pm_check_launch();
+}
+
+// Backward, step 1: S[t][v][:] = sum of dX half-rows whose token is v in table t.
+// grid = (blocks, 4 tables); the table of a block lives in LDS ([V][d/2] floats, ds_add_f32) and is
+// flushed once with global float atomics.  PAD rows dominate (>= 10 of 15 slots), so almost all
+// adds collide on one LDS row and never reach L2.
+__global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restrict__ dX, const int* __restrict__ tok,
+                                                           const int* __restrict__ group_list,
+                                                           const int* __restrict__ group_cnt, int d,
+                                                           float* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) float sS[];
+  const int t = blockIdx.y, grp = t & 1, kind = t >> 1, dh = d / 2;
+  const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
+  for (int i = threadIdx.x; i < V * dh; i += blockDim.x) sS[i] = 0.f;
+  __syncthreads();
+  const int nd = group_cnt[0];
+  const int cnt = grp == 0 ? nd : group_cnt[1];
+  const int* list = group_list + (grp == 0 ? 0 : nd);
+  const int64_t rows = (int64_t)cnt * PM_N_SLOTS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int n = list[row / PM_N_SLOTS], s = (int)(row % PM_N_SLOTS) + 1;
+    const int v = tok[((int64_t)n * 16 + s) * 2 + kind];
+    const float* src = dX + ((int64_t)n * PM_N_SLOTS + (s - 1)) * d + kind * dh;
+    for (int c = lane; c < dh; c += 64) {
+      const float g = src[c];
+      if (g != 0.f) atomicAdd(&sS[v * dh + c], g);
+    }
+  }
+  __syncthreads();
+  float* out = S + (int64_t)t * EMB_V * dh;
+  for (int i = threadIdx.x; i < V * dh; i += blockDim.x) {
+    const float v = sS[i];
+    if (v != 0.f) atomicAdd(&out[i], v);
+  }
+}
+extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E,
+                                    int32_t G, int32_t d, float* S, pm_stream_t stream) {
+  if (!dX || !tokens || !plan || !S || N <= 0 || d <= 0 || (d & 7)) return PM_E_INVALID;
+  const int dh = d / 2;
+  const size_t lds = sizeof(float) * EMB_V * dh;
+  if (lds > 160 * 1024) return PM_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  hipMemsetAsync(S, 0, sizeof(float) * 4 * EMB_V * dh, st);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+  int nb = (int)pm_cdiv((int64_t)N * PM_N_SLOTS, 4 * 64);
+  if (nb > 96) nb = 96;
+  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(256), lds, st, dX, tokens, pv.group_list, pv.group_cnt, d, S);
+  return pm_check_launch();
+}
+
+// Backward, step 2 (tiny): BatchNorm + lookup backward on the tables.
+//   dbeta = sum_v S[v];  dgamma = sum_v S[v]*xhat[v];
+//   dT[v] = gamma*rstd*(S[v] - h[v]*dbeta/M - h[v]*xhat[v]*dgamma/M);  dW[:, v] += dT[v];  db += sum_v dT[v]
+struct EmbGrads { float* dw[3]; float* db[3]; float* dg[3]; float* dbe[3]; };
+__global__ void k_embed_tables_bwd(const float* __restrict__ S, EmbParams P, EmbGrads Gd, const float* __restrict__ stats,
+                                   const int* __restrict__ hist, int dh, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * dh) return;
+  const int kind = i / dh, c = i % dh;
+  const int t0 = kind < 2 ? kind : 2, t1 = kind < 2 ? kind + 1 : 4;
+  for (int t = t0; t < t1; ++t) {
+    int wsel, V;
+    table_src(t, wsel, V);
+    const float* w = P.w[wsel] + (int64_t)c * V;
+    const float bias = P.b[wsel][c];
+    const int* h = hist + t * EMB_V;
+    const float* s = S + (int64_t)t * EMB_V * dh + c;
+    const float mean = stats[(t * 2) * dh + c], rstd = rsqrtf(stats[(t * 2 + 1) * dh + c] + eps);
+    const float ga = P.g[wsel][c];
+    double cnt = 0, db = 0, dg = 0;
+    for (int v = 0; v < V; ++v) {
+      const double sv = s[(int64_t)v * dh];
+      cnt += h[v]; db += sv; dg += sv * (double)(((w[v] + bias) - mean) * rstd);
+    }
+    if (cnt < 1) continue;
+    Gd.dbe[wsel][c] += (float)db;
+    Gd.dg[wsel][c] += (float)dg;
+    double dbias = 0;
+    float* dw = Gd.dw[wsel] + (int64_t)c * V;
+    for (int v = 0; v < V; ++v) {
+      const double xh = (double)(((w[v] + bias) - mean) * rstd);
+      const double dt = (double)ga * rstd * ((double)s[(int64_t)v * dh] - h[v] * db / cnt - h[v] * xh * dg / cnt);
+      dw[v] += (float)dt;
+      dbias += dt;
+    }
+    Gd.db[wsel][c] += (float)dbias;
+  }
+}
+extern "C" int pm_embed_tables_bwd(const float* S, const float* w_pd, const float* b_pd, const float* w_pn,
+                                   const float* b_pn, const float* w_du, const float* b_du, const float* g_d,
+                                   const float* g_n, const float* g_u, const float* stats, const int32_t* tok_hist,
+                                   int32_t d, float eps, float* dw_pd, float* db_pd, float* dw_pn, float* db_pn,
+                                   float* dw_du, float* db_du, float* dg_d, float* dbe_d, float* dg_n, float* dbe_n,
+                                   float* dg_u, float* dbe_u, pm_stream_t stream) {
+  if (!S || !stats || !tok_hist || d <= 0 || (d & 7)) return PM_E_INVALID;
+  EmbParams P;
+  P.w[0] = w_pd; P.w[1] = w_pn; P.w[2] = w_du; P.b[0] = b_pd; P.b[1] = b_pn; P.b[2] = b_du;
+  P.g[0] = g_d; P.g[1] = g_n; P.g[2] = g_u;
+  for (int i = 0; i < 3; ++i) { P.be[i] = nullptr; P.rm[i] = nullptr; P.rv[i] = nullptr; }
+  EmbGrads Gd;
+  Gd.dw[0] = dw_pd; Gd.dw[1] = dw_pn; Gd.dw[2] = dw_du; Gd.db[0] = db_pd; Gd.db[1] = db_pn; Gd.db[2] = db_du;
+  Gd.dg[0] = dg_d; Gd.dg[1] = dg_n; Gd.dg[2] = dg_u; Gd.dbe[0] = dbe_d; Gd.dbe[1] = dbe_n; Gd.dbe[2] = dbe_u;
+  const int dh = d / 2;
+  hipLaunchKernelGGL(k_embed_tables_bwd, dim3(pm_cdiv(3 * dh, 64)), dim3(64), 0, (hipStream_t)stream, S, P, Gd, stats,
+                     tok_hist, dh, eps);
+  return pm_check_launch();
+}

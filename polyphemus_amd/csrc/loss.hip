@@ -1,0 +1,127 @@
+// loss.hip — fused loss kernels of the training step.
+//
+// Reference: PolyphemusTrainer._losses (training.py:298-347): CrossEntropyLoss(ignore_index=PAD) on
+// the pitch (131) and duration (99) logits of every (node, slot) row — there as log_softmax + nll_loss
+// + argmax over the one-hot targets — BCEWithLogits on the structure grid and the KL divergence.
+// Memory-bound: one pass over the [N,15,230] logits produces the two losses AND d(loss)/d(logits).
+#include "common.h"
+
+// one wave per (node, slot) row.  out[0] += pitch CE / n_valid_pitch, out[1] += dur CE / n_valid_dur.
+__global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ logits, const int* __restrict__ tok,
+                                                    const int* __restrict__ hist, int64_t rows, float grad_scale,
+                                                    float* __restrict__ dlogits, double* __restrict__ out) {
+  __shared__ double sh[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // valid rows = all rows - PAD rows (token histogram of the plan: tables 0/1 pitch, 2/3 duration)
+  const double np = (double)rows - (double)(hist[0 * PM_N_PITCH + 130] + hist[1 * PM_N_PITCH + 130]);
+  const double nd = (double)rows - (double)(hist[2 * PM_N_PITCH + 98] + hist[3 * PM_N_PITCH + 98]);
+  const float inv_p = (float)(1.0 / np), inv_d = (float)(1.0 / nd);
+  double lp = 0, ld = 0;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int n = (int)(row / PM_N_SLOTS), s = (int)(row % PM_N_SLOTS) + 1;
+    const int tp = tok[((int64_t)n * 16 + s) * 2], td = tok[((int64_t)n * 16 + s) * 2 + 1];
+    const float* r = logits + row * PM_N_TOK;
+    float v[4];                                               // lanes cover 230 = 3 full passes + 38
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = lane + j * 64; v[j] = c < PM_N_TOK ? r[c] : -INFINITY; }
+    // column c belongs to the pitch block iff c < 131
+    float mp = -INFINITY, md = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = lane + j * 64; if (c < PM_N_PITCH) mp = fmaxf(mp, v[j]); else md = fmaxf(md, v[j]); }
+    mp = pm_wave_max(mp); md = pm_wave_max(md);
+    float sp = 0.f, sd = 0.f, e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + j * 64;
+      if (c < PM_N_PITCH) { e[j] = expf(v[j] - mp); sp += e[j]; }
+      else if (c < PM_N_TOK) { e[j] = expf(v[j] - md); sd += e[j]; }
+      else e[j] = 0.f;
+    }
+    sp = pm_wave_sum(sp); sd = pm_wave_sum(sd);
+    const bool vp = tp != 130, vd = td != 98;                 // ignore_index = PAD (training.py:101-102)
+    if (lane == 0) {
+      if (vp) lp += (double)(logf(sp) + mp - r[tp]);
+      if (vd) ld += (double)(logf(sd) + md - r[PM_N_PITCH + td]);
+    }
+    if (dlogits) {
+      float* g = dlogits + row * PM_N_TOK;
+      const float kp = vp ? grad_scale * inv_p : 0.f, kd = vd ? grad_scale * inv_d : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = lane + j * 64;
+        if (c < PM_N_PITCH) g[c] = kp * (e[j] / sp - (c == tp ? 1.f : 0.f));
+        else if (c < PM_N_TOK) g[c] = kd * (e[j] / sd - (c - PM_N_PITCH == td ? 1.f : 0.f));
+      }
+    }
+  }
+  if (lane == 0) { sh[0][wave] = lp; sh[1][wave] = ld; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / np);
+    atomicAdd(&out[1], (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / nd);
+  }
+}
+extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist, int32_t N,
+                             float grad_scale, float* d_logits, double* out, pm_stream_t stream) {
+  if (!c_logits || !tokens || !tok_hist || !out || N <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(out, 0, 2 * sizeof(double), st);
+  const int64_t rows = (int64_t)N * PM_N_SLOTS;
+  int nb = (int)pm_cdiv(rows, 4 * 8);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(256), 0, st, c_logits, tokens, tok_hist, rows, grad_scale, d_logits, out);
+  return pm_check_launch();
+}
+
+// kld = mean_b( -0.5 * sum_d (1 + lv - mu^2 - exp(lv)) )   (training.py:329-331)
+__global__ void __launch_bounds__(256) k_kld(const float* __restrict__ mu, const float* __restrict__ lv, int B, int d,
+                                             float beta, float* dmu, float* dlv, double* out) {
+  __shared__ double sh[4];
+  const int64_t n = (int64_t)B * d;
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float m = mu[i], l = lv[i], e = expf(l);
+    acc += (double)(1.f + l - m * m - e);
+    if (dmu && beta != 0.f) { dmu[i] += beta * m / (float)B; dlv[i] += beta * 0.5f * (e - 1.f) / (float)B; }
+  }
+  acc = pm_wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[3], -0.5 * (sh[0] + sh[1] + sh[2] + sh[3]) / B);
+}
+extern "C" int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu,
+                      float* dlog_var, double* out, pm_stream_t stream) {
+  if (!mu || !log_var || !out || B <= 0 || d <= 0 || (dmu && !dlog_var)) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(out + 3, 0, sizeof(double), st);
+  int nb = (int)pm_cdiv((int64_t)B * d, 256 * 4);
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(k_kld, dim3(nb), dim3(256), 0, st, mu, log_var, B, d, beta, dmu, dlog_var, out);
+  return pm_check_launch();
+}
+
+// BCEWithLogitsLoss(reduction='none').mean()  (training.py:310-312)
+__global__ void __launch_bounds__(256) k_bce(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                             float grad_scale, float* dx, double* out) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], tv = t[i];
+    acc += (double)(fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv))));
+    if (dx) dx[i] = grad_scale * (1.f / (1.f + expf(-xv)) - tv) / (float)n;
+  }
+  acc = pm_wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[2], (sh[0] + sh[1] + sh[2] + sh[3]) / (double)n);
+}
+extern "C" int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits,
+                             double* out, pm_stream_t stream) {
+  if (!logits || !target || !out || n <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(out + 2, 0, sizeof(double), st);
+  int nb = (int)pm_cdiv(n, 256 * 4);
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(k_bce, dim3(nb), dim3(256), 0, st, logits, target, n, grad_scale, dlogits, out);
+  return pm_check_launch();
+}

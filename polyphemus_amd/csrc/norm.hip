@@ -1,0 +1,304 @@
+// norm.hip — batch normalisation (training + eval) and small element-wise helpers.
+//
+// Reference: nn.BatchNorm1d over all N nodes between GCL layers (PyG BatchNorm wrapper,
+// model.py:180,186,203), BatchNorm1d on the heads (model.py:461,475,588,638), BatchNorm1d(1) of
+// the attention gate (model.py:338), BatchNorm2d of the structure CNN (model.py:222,228,282).
+// All are viewed as [O, C, I] (row-major [M,C]: I = 1; NCHW: I = H*W).  HBM-bound:
+// stats = one read of x; apply = read x (+ residual), write y.  Column sums are accumulated in
+// fp64 so that var = E[x^2] - E[x]^2 keeps fp32 parity.
+#include "common.h"
+
+#define BN_MAX_CHUNKS 64
+
+// MODE 0: (x, x*x)      MODE 1: (du, du*xhat) with du = dy * [relu ? bn(x) > 0 : 1]
+struct BnCtx {
+  const float* mean; const float* var; const float* gamma; const float* beta; float eps; int relu;
+};
+template <int MODE>
+__device__ static inline void bn_pair(float xv, float dyv, float m, float rstd, float ga, float be, int relu,
+                                      double& a, double& b) {
+  if (MODE == 0) { a += (double)xv; b += (double)xv * (double)xv; }
+  else {
+    const float xh = (xv - m) * rstd;
+    float du = dyv;
+    if (relu && !(xh * ga + be > 0.f)) du = 0.f;
+    a += (double)du; b += (double)du * (double)xh;
+  }
+}
+
+// fast path: I == 1, C % 4 == 0.  grid = (ceil(C/256), nchunk), 4 waves split the rows of a chunk.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_colreduce_rows(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        int O, int C, BnCtx ctx, int rows_per_chunk,
+                                                        double* __restrict__ partial) {
+  __shared__ double sh[4][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const bool ok = c < C;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float m[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+  if (MODE == 1 && ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = ctx.mean[c + j]; rs[j] = rsqrtf(ctx.var[c + j] + ctx.eps);
+      ga[j] = ctx.gamma[c + j]; be[j] = ctx.beta[c + j];
+    }
+  }
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > O) r1 = O;
+  if (ok) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * C + c);
+      float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1) dv = *reinterpret_cast<const float4*>(dy + (int64_t)r * C + c);
+      bn_pair<MODE>(xv.x, dv.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4]);
+      bn_pair<MODE>(xv.y, dv.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5]);
+      bn_pair<MODE>(xv.z, dv.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6]);
+      bn_pair<MODE>(xv.w, dv.w, m[3], rs[3], ga[3], be[3], ctx.relu, acc[3], acc[7]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sh[wave][lane][j] = acc[j];
+  __syncthreads();
+  if (wave == 0 && ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double s = sh[0][lane][j] + sh[1][lane][j] + sh[2][lane][j] + sh[3][lane][j];
+      partial[((int64_t)blockIdx.y * 2 + (j >> 2)) * C + c + (j & 3)] = s;
+    }
+  }
+}
+
+// generic path: one workgroup per channel, any I (NCHW) or C (e.g. the 1-channel gate).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_colreduce_chan(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        int O, int C, int I, BnCtx ctx, double* __restrict__ partial) {
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x;
+  float m = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
+  if (MODE == 1) { m = ctx.mean[c]; rs = rsqrtf(ctx.var[c] + ctx.eps); ga = ctx.gamma[c]; be = ctx.beta[c]; }
+  double a = 0, b = 0;
+  const int64_t total = (int64_t)O * I;
+  for (int64_t j = threadIdx.x; j < total; j += blockDim.x) {
+    const int64_t idx = ((j / I) * C + c) * I + (j % I);
+    bn_pair<MODE>(x[idx], MODE == 1 ? dy[idx] : 0.f, m, rs, ga, be, ctx.relu, a, b);
+  }
+  a = pm_wave_sum_d(a); b = pm_wave_sum_d(b);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[c] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    partial[C + c] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+__global__ void k_bn_finalize_stats(const double* __restrict__ partial, int nchunk, int C, double count, float* mean,
+                                    float* var, float* rmean, float* rvar, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int k = 0; k < nchunk; ++k) { s0 += partial[((int64_t)k * 2) * C + c]; s1 += partial[((int64_t)k * 2 + 1) * C + c]; }
+  const double mu = s0 / count;
+  double v = s1 / count - mu * mu;
+  if (v < 0) v = 0;
+  mean[c] = (float)mu;
+  var[c] = (float)v;
+  if (rmean) {                                  // running stats: unbiased variance, momentum 0.1 (torch default)
+    const double unb = count > 1 ? v * count / (count - 1) : v;
+    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+  }
+}
+__global__ void k_bn_finalize_bwd(const double* __restrict__ partial, int nchunk, int C, double count, float* dgamma,
+                                  float* dbeta, double* means) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int k = 0; k < nchunk; ++k) { s0 += partial[((int64_t)k * 2) * C + c]; s1 += partial[((int64_t)k * 2 + 1) * C + c]; }
+  if (dbeta) dbeta[c] += (float)s0;
+  if (dgamma) dgamma[c] += (float)s1;
+  means[c] = s0 / count;
+  means[C + c] = s1 / count;
+}
+
+template <int MODE>
+static int run_reduce(const float* x, const float* dy, int O, int C, int I, BnCtx ctx, double* partial, int* nchunk,
+                      hipStream_t st) {
+  if (I == 1 && (C % 4) == 0 && ((uintptr_t)x % 16) == 0 && (MODE == 0 || ((uintptr_t)dy % 16) == 0)) {
+    int nc = (int)pm_cdiv(O, 64);
+    if (nc > BN_MAX_CHUNKS) nc = BN_MAX_CHUNKS;
+    if (nc < 1) nc = 1;
+    const int rpc = (int)pm_cdiv(O, nc);
+    nc = (int)pm_cdiv(O, rpc);
+    hipLaunchKernelGGL((k_colreduce_rows<MODE>), dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc,
+                       partial);
+    *nchunk = nc;
+  } else {
+    hipLaunchKernelGGL((k_colreduce_chan<MODE>), dim3(C), dim3(256), 0, st, x, dy, O, C, I, ctx, partial);
+    *nchunk = 1;
+  }
+  return PM_OK;
+}
+
+extern "C" int pm_bn_stats(const float* x, int32_t O, int32_t C, int32_t I, float* mean, float* var,
+                           float* running_mean, float* running_var, float momentum, double* scratch,
+                           pm_stream_t stream) {
+  if (!x || !mean || !var || !scratch || O <= 0 || C <= 0 || I <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  int nchunk = 1;
+  run_reduce<0>(x, nullptr, O, C, I, ctx, scratch, &nchunk, st);
+  hipLaunchKernelGGL(k_bn_finalize_stats, dim3(pm_cdiv(C, 128)), dim3(128), 0, st, scratch, nchunk, C,
+                     (double)O * (double)I, mean, var, running_mean, running_var, momentum);
+  return pm_check_launch();
+}
+
+// y = [res +] relu?( (x - mean) * rsqrt(var + eps) * gamma + beta )
+__global__ void __launch_bounds__(256) k_bn_apply4(const float* __restrict__ x, int64_t n4, int C, BnCtx ctx,
+                                                   const float* __restrict__ res, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = (xs[j] - ctx.mean[c + j]) * rsqrtf(ctx.var[c + j] + ctx.eps) * ctx.gamma[c + j] + ctx.beta[c + j];
+      if (ctx.relu) v = fmaxf(v, 0.f);
+      o[j] = v;
+    }
+    if (res) {
+      const float4 rv = reinterpret_cast<const float4*>(res)[i];
+      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+__global__ void __launch_bounds__(256) k_bn_apply1(const float* __restrict__ x, int64_t n, int C, int I, BnCtx ctx,
+                                                   const float* __restrict__ res, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / I) % C);
+    float v = (x[i] - ctx.mean[c]) * rsqrtf(ctx.var[c] + ctx.eps) * ctx.gamma[c] + ctx.beta[c];
+    if (ctx.relu) v = fmaxf(v, 0.f);
+    if (res) v += res[i];
+    y[i] = v;
+  }
+}
+static inline int ew_grid(int64_t n) { int64_t g = pm_cdiv(n, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+extern "C" int pm_bn_apply(const float* x, int32_t O, int32_t C, int32_t I, const float* mean, const float* var,
+                           float eps, const float* gamma, const float* beta, const float* residual, int relu, float* y,
+                           pm_stream_t stream) {
+  if (!x || !mean || !var || !gamma || !beta || !y || O <= 0 || C <= 0 || I <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {mean, var, gamma, beta, eps, relu};
+  const int64_t n = (int64_t)O * C * I;
+  const bool al = ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0);
+  if (I == 1 && C % 4 == 0 && al)
+    hipLaunchKernelGGL(k_bn_apply4, dim3(ew_grid(n / 4)), dim3(256), 0, st, x, n / 4, C, ctx, residual, y);
+  else
+    hipLaunchKernelGGL(k_bn_apply1, dim3(ew_grid(n)), dim3(256), 0, st, x, n, C, I, ctx, residual, y);
+  return pm_check_launch();
+}
+
+// dx = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat))
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      int64_t n, int C, int I, BnCtx ctx,
+                                                      const double* __restrict__ means, float* __restrict__ dx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / I) % C);
+    const float rstd = rsqrtf(ctx.var[c] + ctx.eps), ga = ctx.gamma[c];
+    const float xh = (x[i] - ctx.mean[c]) * rstd;
+    float du = dy[i];
+    if (ctx.relu && !(xh * ga + ctx.beta[c] > 0.f)) du = 0.f;
+    dx[i] = ga * rstd * (du - (float)means[c] - xh * (float)means[C + c]);
+  }
+}
+extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
+                         const float* var, float eps, const float* gamma, const float* beta, int relu, float* dgamma,
+                         float* dbeta, float* dx, double* scratch, pm_stream_t stream) {
+  if (!x || !dy || !mean || !var || !gamma || !beta || !dx || !scratch || O <= 0 || C <= 0 || I <= 0)
+    return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {mean, var, gamma, beta, eps, relu};
+  int nchunk = 1;
+  run_reduce<1>(x, dy, O, C, I, ctx, scratch, &nchunk, st);
+  double* means = scratch + (int64_t)BN_MAX_CHUNKS * 2 * C;
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(pm_cdiv(C, 128)), dim3(128), 0, st, scratch, nchunk, C,
+                     (double)O * (double)I, dgamma, dbeta, means);
+  const int64_t n = (int64_t)O * C * I;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n)), dim3(256), 0, st, x, dy, n, C, I, ctx, means, dx);
+  return pm_check_launch();
+}
+
+// ---------------------------------------------------------------- element-wise helpers
+__global__ void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, int64_t n, float* dx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+extern "C" int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream) {
+  if (!dy || !y || !dx || n <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_relu_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);
+  return pm_check_launch();
+}
+extern "C" int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream) {
+  if (!a || !b || !out || n <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_add, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+  return pm_check_launch();
+}
+// out[c] += sum_m x[m, c]   (bias gradients): 64 columns x 4 row-waves per block, one atomic per column per block
+__global__ void __launch_bounds__(256) k_colsum_acc(const float* __restrict__ x, int M, int C, int ld,
+                                                    int rows_per_chunk, float* out) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (c < C) for (int r = r0 + wave; r < r1; r += 4) s += x[(int64_t)r * ld + c];
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) atomicAdd(&out[c], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+extern "C" int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out, pm_stream_t stream) {
+  if (!x || !out || M <= 0 || C <= 0 || ld < C) return PM_E_INVALID;
+  int nc = (int)pm_cdiv(M, 128);
+  if (nc > 128) nc = 128;
+  const int rpc = (int)pm_cdiv(M, nc);
+  nc = (int)pm_cdiv(M, rpc);
+  hipLaunchKernelGGL(k_colsum_acc, dim3(pm_cdiv(C, 64), nc), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, rpc, out);
+  return pm_check_launch();
+}
+
+// VAE reparametrisation (model.py:671-673): z = exp(0.5*log_var) * eps + mu
+__global__ void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                              int64_t n, float* z) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    z[i] = expf(0.5f * lv[i]) * eps[i] + mu[i];
+}
+__global__ void k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ lv, const float* __restrict__ eps,
+                              int64_t n, float* dmu, float* dlv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    dmu[i] += dz[i];
+    dlv[i] += dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]);
+  }
+}
+extern "C" int pm_reparam_fwd(const float* mu, const float* log_var, const float* eps, int64_t n, float* z,
+                              pm_stream_t stream) {
+  if (!mu || !log_var || !eps || !z || n <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_reparam_fwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, mu, log_var, eps, n, z);
+  return pm_check_launch();
+}
+extern "C" int pm_reparam_bwd(const float* dz, const float* log_var, const float* eps, int64_t n, float* dmu,
+                              float* dlog_var, pm_stream_t stream) {
+  if (!dz || !log_var || !eps || !dmu || !dlog_var || n <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_reparam_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dz, log_var, eps, n, dmu,
+                     dlog_var);
+  return pm_check_launch();
+}

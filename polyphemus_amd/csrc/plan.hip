@@ -1,0 +1,270 @@
+// plan.hip — per-batch graph plan: CSR by (dst, relation), CSC by src, bar offsets,
+// drum / non-drum node lists, token histograms.  Integer work only (bit-exact).
+//
+// Replaces (reference): masked_edge_index / masked_edge_attrs, model.py:30-38, called
+// 2 x 6 x 16 times per forward (model.py:104-105); torch.unique(return_counts)
+// (model.py:543); the boolean-mask drum / non-drum splits (model.py:352-353,552-553).
+#include "common.h"
+
+void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
+  int64_t sz[PM_PLAN_NFIELDS];
+  sz[PM_PLAN_ROWPTR] = (int64_t)N * PM_N_REL + 1;
+  sz[PM_PLAN_CSR_SRC] = E; sz[PM_PLAN_CSR_DIST] = E; sz[PM_PLAN_CSR_EID] = E;
+  sz[PM_PLAN_COLPTR] = (int64_t)N + 1;
+  sz[PM_PLAN_CSC_DST] = E; sz[PM_PLAN_CSC_RELDIST] = E; sz[PM_PLAN_CSC_EID] = E; sz[PM_PLAN_CSC_INVCNT] = E;
+  sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = N;
+  sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH;
+  // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums
+  sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;
+  int64_t o = 0;
+  for (int i = 0; i < PM_PLAN_NFIELDS; ++i) { off[i] = o; o += pm_align4(sz[i]); }
+  off[PM_PLAN_NFIELDS] = o;
+}
+
+extern "C" int pm_plan_layout(int32_t N, int32_t E, int32_t G, int64_t* offsets) {
+  if (N < 0 || E < 0 || G < 0 || !offsets) return PM_E_INVALID;
+  pm_plan_offsets(N, E, G, offsets);
+  return PM_OK;
+}
+
+// ---------------------------------------------------------------- exclusive scan (int32, in place)
+#define SCAN_ITEMS 8
+#define SCAN_THREADS 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_THREADS)
+
+__device__ static inline int block_exclusive_scan(int v, int* total) {
+  // 256 threads = 4 waves; wave scan by shuffles, then 4 wave totals through LDS.
+  __shared__ int wsum[SCAN_THREADS / PM_WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_THREADS / PM_WAVE; ++i) { if (i < w) base += wsum[i]; tot += wsum[i]; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(int* data, int64_t n, int* sums) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? data[base + i] : 0; s += v[i]; }
+  int tot;
+  int ex = block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) data[base + i] = ex; ex += v[i]; }
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(int* sums, int nb) {
+  int carry = 0;
+  for (int c0 = 0; c0 < nb; c0 += SCAN_THREADS) {      // sequential chunks, one block
+    int i = c0 + threadIdx.x;
+    int v = i < nb ? sums[i] : 0, tot;
+    int ex = block_exclusive_scan(v, &tot);
+    if (i < nb) sums[i] = ex + carry;
+    carry += tot;
+  }
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int* data, int64_t n, const int* sums) {
+  const int add = sums[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) data[base + i] += add;
+}
+static void exclusive_scan(int* data, int64_t n, int* sums, hipStream_t st) {
+  const int nb = (int)pm_cdiv(n, SCAN_TILE);
+  hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, st, data, n, sums);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, st, data, n, sums);
+  }
+}
+
+// ---------------------------------------------------------------- counting
+__global__ void k_count_edges(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E, int* rowcnt,
+                              int* colcnt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int s = (int)ei[e], d = (int)ei[(int64_t)E + e];
+  atomicAdd(&rowcnt[d * PM_N_REL + et[e]], 1);
+  atomicAdd(&colcnt[s], 1);
+}
+__global__ void k_count_nodes(const int64_t* __restrict__ bars, const int64_t* __restrict__ batch,
+                              const uint8_t* __restrict__ is_drum, int n_bars, int N, int* node_bar, int* barcnt,
+                              int* drumflag) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int b = (int)(bars[n] + (int64_t)n_bars * batch[n]);                  // model.py:403
+  node_bar[n] = b;
+  atomicAdd(&barcnt[b], 1);
+  drumflag[n] = is_drum[n] ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_tok_hist(const int32_t* __restrict__ tok, const uint8_t* __restrict__ is_drum,
+                                                  int N, int* hist) {
+  __shared__ int sh[4 * PM_N_PITCH];
+  for (int i = threadIdx.x; i < 4 * PM_N_PITCH; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const int64_t total = (int64_t)N * PM_N_SLOTS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / PM_N_SLOTS), s = (int)(i % PM_N_SLOTS) + 1;       // slot 0 = SOS is dropped (model.py:349)
+    const int g = is_drum[n] ? 0 : 1;
+    const int p = tok[((int64_t)n * 16 + s) * 2 + 0], du = tok[((int64_t)n * 16 + s) * 2 + 1];
+    atomicAdd(&sh[g * PM_N_PITCH + p], 1);
+    atomicAdd(&sh[(2 + g) * PM_N_PITCH + du], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * PM_N_PITCH; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// ---------------------------------------------------------------- fill + per-segment order
+__global__ void k_fill(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E,
+                       const int* __restrict__ rowptr, const int* __restrict__ colptr, int* cur_in, int* cur_out,
+                       int* csr_eid, int* csc_eid) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int s = (int)ei[e], d = (int)ei[(int64_t)E + e];
+  const int key = d * PM_N_REL + et[e];
+  csr_eid[rowptr[key] + atomicAdd(&cur_in[key], 1)] = e;
+  csc_eid[colptr[s] + atomicAdd(&cur_out[s], 1)] = e;
+}
+__device__ static inline void sort_segment(int* a, int beg, int end) {       // ascending edge id => deterministic sums
+  for (int i = beg + 1; i < end; ++i) {
+    const int v = a[i];
+    int j = i - 1;
+    while (j >= beg && a[j] > v) { a[j + 1] = a[j]; --j; }
+    a[j + 1] = v;
+  }
+}
+__global__ void k_finish_csr(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed, int E, int nseg,
+                             const int* __restrict__ rowptr, int* csr_eid, int* csr_src, int* csr_dist) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nseg) return;
+  const int beg = rowptr[k], end = rowptr[k + 1];
+  sort_segment(csr_eid, beg, end);
+  for (int p = beg; p < end; ++p) { const int e = csr_eid[p]; csr_src[p] = (int)ei[e]; csr_dist[p] = ed[e]; }
+}
+__global__ void k_finish_csc(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
+                             const int32_t* __restrict__ ed, int E, int N, const int* __restrict__ rowptr,
+                             const int* __restrict__ colptr, int* csc_eid, int* csc_dst, int* csc_reldist,
+                             float* csc_invcnt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int beg = colptr[n], end = colptr[n + 1];
+  sort_segment(csc_eid, beg, end);
+  for (int p = beg; p < end; ++p) {
+    const int e = csc_eid[p];
+    const int d = (int)ei[(int64_t)E + e], r = et[e];
+    const int cnt = rowptr[d * PM_N_REL + r + 1] - rowptr[d * PM_N_REL + r];
+    csc_dst[p] = d;
+    csc_reldist[p] = r | (ed[e] << 8);
+    csc_invcnt[p] = 1.0f / (float)(cnt > 1 ? cnt : 1);                      // scatter 'mean': sum / clamp(count, 1)
+  }
+}
+__global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int* list,
+                             int* cnt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) { cnt[0] = pos[N]; cnt[1] = N - pos[N]; cnt[2] = 0; cnt[3] = 0; }
+  if (n >= N) return;
+  const int nd = pos[N];
+  if (is_drum[n]) list[pos[n]] = n; else list[nd + (n - pos[n])] = n;
+}
+
+extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
+                             const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
+                             const int32_t* tokens, int32_t n_bars, int32_t N, int32_t E, int32_t G, int32_t* plan,
+                             pm_stream_t stream) {
+  if (!edge_index || !edge_type || !edge_dist || !bars || !batch || !is_drum || !plan || N <= 0 || E <= 0 || G <= 0)
+    return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t o[PM_PLAN_NFIELDS + 1];
+  pm_plan_offsets(N, E, G, o);
+  int* rowptr = plan + o[PM_PLAN_ROWPTR];
+  int* colptr = plan + o[PM_PLAN_COLPTR];
+  int* barptr = plan + o[PM_PLAN_BAR_PTR];
+  int* cur_in = plan + o[PM_PLAN_SCRATCH];
+  int* cur_out = cur_in + (int64_t)N * PM_N_REL;
+  int* drumpos = cur_out + N;
+  int* sums = drumpos + N + 1;
+  hipMemsetAsync(rowptr, 0, sizeof(int) * ((int64_t)N * PM_N_REL + 1), st);
+  hipMemsetAsync(colptr, 0, sizeof(int) * ((int64_t)N + 1), st);
+  hipMemsetAsync(barptr, 0, sizeof(int) * ((int64_t)G + 1), st);
+  hipMemsetAsync(plan + o[PM_PLAN_GROUP_CNT], 0, sizeof(int) * (o[PM_PLAN_SCRATCH] - o[PM_PLAN_GROUP_CNT]), st);
+  hipMemsetAsync(cur_in, 0, sizeof(int) * ((int64_t)N * PM_N_REL + N + N + 1), st);
+  const int T = 256;
+  hipLaunchKernelGGL(k_count_edges, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr);
+  hipLaunchKernelGGL(k_count_nodes, dim3(pm_cdiv(N, T)), dim3(T), 0, st, bars, batch, is_drum, n_bars, N,
+                     plan + o[PM_PLAN_NODE_BAR], barptr, drumpos);
+  if (tokens) {
+    int nb = (int)pm_cdiv((int64_t)N * PM_N_SLOTS, 4096);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_tok_hist, dim3(nb), dim3(256), 0, st, tokens, is_drum, N, plan + o[PM_PLAN_TOK_HIST]);
+  }
+  exclusive_scan(rowptr, (int64_t)N * PM_N_REL + 1, sums, st);
+  exclusive_scan(colptr, (int64_t)N + 1, sums, st);
+  exclusive_scan(barptr, (int64_t)G + 1, sums, st);
+  exclusive_scan(drumpos, (int64_t)N + 1, sums, st);
+  hipLaunchKernelGGL(k_fill, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr, cur_in,
+                     cur_out, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSC_EID]);
+  hipLaunchKernelGGL(k_finish_csr, dim3(pm_cdiv((int64_t)N * PM_N_REL, T)), dim3(T), 0, st, edge_index, edge_dist, E,
+                     N * PM_N_REL, rowptr, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSR_SRC],
+                     plan + o[PM_PLAN_CSR_DIST]);
+  hipLaunchKernelGGL(k_finish_csc, dim3(pm_cdiv(N, T)), dim3(T), 0, st, edge_index, edge_type, edge_dist, E, N, rowptr,
+                     colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
+                     reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
+  hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N,
+                     plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_GROUP_CNT]);
+  return pm_check_launch();
+}
+
+// ---------------------------------------------------------------- reference-format inputs -> ids
+__global__ void k_edge_attrs_to_ids(const float* __restrict__ ea, int E, int* et, int* ed) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float* row = ea + (int64_t)e * (PM_N_DIST + 1);
+  et[e] = (int)row[0];                                                       // column 0 = edge type as float (data.py:180)
+  int best = 0; float bv = row[1];
+  for (int j = 1; j < PM_N_DIST; ++j) if (row[1 + j] > bv) { bv = row[1 + j]; best = j; }
+  ed[e] = best;
+}
+extern "C" int pm_edge_attrs_to_ids(const float* edge_attrs, int32_t E, int32_t* edge_type, int32_t* edge_dist,
+                                    pm_stream_t stream) {
+  if (!edge_attrs || !edge_type || !edge_dist || E <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_edge_attrs_to_ids, dim3(pm_cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, edge_attrs, E,
+                     edge_type, edge_dist);
+  return pm_check_launch();
+}
+// one wave per (node, slot) row of 230 floats: first-index argmax of each one-hot half (training.py:317,322)
+__global__ void __launch_bounds__(256) k_tokens_from_onehot(const float* __restrict__ c, int64_t rows, int* tok) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* r = c + row * PM_N_TOK;
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int j = lane; j < PM_N_PITCH; j += 64) { float v = r[j]; if (v > bv) { bv = v; bi = j; } }
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  float dv = -INFINITY; int di = 0x7fffffff;
+  for (int j = lane; j < PM_N_DUR; j += 64) { float v = r[PM_N_PITCH + j]; if (v > dv) { dv = v; di = j; } }
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(dv, o, 64); int oi = __shfl_xor(di, o, 64);
+    if (ov > dv || (ov == dv && oi < di)) { dv = ov; di = oi; }
+  }
+  if (lane == 0) { tok[row * 2] = bi; tok[row * 2 + 1] = di; }
+}
+extern "C" int pm_tokens_from_onehot(const float* c_tensor, int32_t N, int32_t* tokens, pm_stream_t stream) {
+  if (!c_tensor || !tokens || N <= 0) return PM_E_INVALID;
+  const int64_t rows = (int64_t)N * 16;
+  hipLaunchKernelGGL(k_tokens_from_onehot, dim3(pm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, c_tensor, rows,
+                     tokens);
+  return pm_check_launch();
+}

@@ -1,0 +1,233 @@
+// segreduce.hip — relational message aggregation of one GCL layer (HBM-bound).
+//
+// Reference: GCL.message (model.py:123-135) + PyG propagate gather/scatter-mean
+// (model.py:110; torch_scatter reduce='mean' = sum / clamp(count,1)), executed there as
+// 6 x { index_select, addmm on one-hot, mul, relu, bernoulli_, scatter_add, div }.
+//
+// Here: one wave owns one destination node and walks its CSR row (sorted by relation, then
+// edge id).  Lanes own channels (float4 per lane), so every gather of x[src] and every
+// store of the aggregate is a 1 KiB coalesced row segment at d = 256.  x is <= 34 MB and is
+// served by L2 / Infinity Cache; the HBM stream is the [N, 7d] aggregate.
+//
+// Algorithmic HBM bytes: forward 4*d*N*(1+R) + 12*E (+4*d*N for the root copy
+// this kernel also writes), backward 4*d*N*(R+1) + 12*E + 4*32*d.
+#include "common.h"
+
+extern "C" uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel) {
+  return pm_elem_hash(pm_edge_key(seed, layer_uid, eid), channel) >> 8;
+}
+
+// ---------------------------------------------------------------- edge table  T[dist] = W[:, dist] + b
+__global__ void k_edge_table(const float* __restrict__ w, const float* __restrict__ b, int d, float* T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PM_N_DIST * d) return;
+  const int dist = i / d, c = i % d;
+  T[i] = w[c * PM_N_DIST + dist] + b[c];
+}
+__global__ void k_edge_table_bwd(const float* __restrict__ dT, int d, float* dw, float* db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float s = 0.f;
+  for (int dist = 0; dist < PM_N_DIST; ++dist) {
+    const float g = dT[dist * d + c];
+    dw[c * PM_N_DIST + dist] += g;
+    s += g;
+  }
+  db[c] += s;
+}
+extern "C" int pm_edge_table(const float* w, const float* b, int32_t d, float* T, pm_stream_t stream) {
+  if (!w || !b || !T || d <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_edge_table, dim3(pm_cdiv(PM_N_DIST * d, 256)), dim3(256), 0, (hipStream_t)stream, w, b, d, T);
+  return pm_check_launch();
+}
+extern "C" int pm_edge_table_bwd(const float* dT, int32_t d, float* dw, float* db, pm_stream_t stream) {
+  if (!dT || !dw || !db || d <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_edge_table_bwd, dim3(pm_cdiv(d, 64)), dim3(64), 0, (hipStream_t)stream, dT, d, dw, db);
+  return pm_check_launch();
+}
+
+// ---------------------------------------------------------------- forward
+// NV = float4 chunks per lane (d = 256 -> 1, d = 512 -> 2); general d handled by the guard c < d.
+template <int NV, bool DROP>
+__global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__ x, const float* __restrict__ T,
+                                                       const int* __restrict__ rowptr, const int* __restrict__ csr_src,
+                                                       const int* __restrict__ csr_dist, const int* __restrict__ csr_eid,
+                                                       int N, int d, uint32_t seed, uint32_t layer_uid,
+                                                       uint32_t thresh, float scale, float* __restrict__ A) {
+  const int lane = threadIdx.x & 63;
+  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (n >= N) return;
+  const int64_t arow = (int64_t)n * 7 * d;
+  int c[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { c[v] = (lane + v * 64) * 4; ok[v] = c[v] < d; }
+  int beg = rowptr[n * PM_N_REL];
+#pragma unroll 1
+  for (int r = 0; r < PM_N_REL; ++r) {
+    const int end = rowptr[n * PM_N_REL + r + 1];
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg; p < end; ++p) {
+      const int s = csr_src[p], dist = csr_dist[p];
+      uint32_t key = 0;
+      if (DROP) key = pm_edge_key(seed, layer_uid, (uint32_t)csr_eid[p]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if (!ok[v]) continue;
+        const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)s * d + c[v]);
+        const float4 tv = *reinterpret_cast<const float4*>(T + dist * d + c[v]);
+        float4 m = make_float4(fmaxf(xv.x * tv.x, 0.f), fmaxf(xv.y * tv.y, 0.f), fmaxf(xv.z * tv.z, 0.f),
+                               fmaxf(xv.w * tv.w, 0.f));
+        if (DROP) {
+          m.x = (pm_elem_hash(key, c[v] + 0) >> 8) >= thresh ? m.x * scale : 0.f;
+          m.y = (pm_elem_hash(key, c[v] + 1) >> 8) >= thresh ? m.y * scale : 0.f;
+          m.z = (pm_elem_hash(key, c[v] + 2) >> 8) >= thresh ? m.z * scale : 0.f;
+          m.w = (pm_elem_hash(key, c[v] + 3) >> 8) >= thresh ? m.w * scale : 0.f;
+        }
+        acc[v].x += m.x; acc[v].y += m.y; acc[v].z += m.z; acc[v].w += m.w;
+      }
+    }
+    const int cnt = end - beg;
+    const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (!ok[v]) continue;
+      float4 o = make_float4(acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv);
+      *reinterpret_cast<float4*>(A + arow + (int64_t)r * d + c[v]) = o;
+    }
+    beg = end;
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    if (!ok[v]) continue;
+    *reinterpret_cast<float4*>(A + arow + (int64_t)PM_N_REL * d + c[v]) =
+        *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
+  }
+}
+
+extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, float* A,
+                                pm_stream_t stream) {
+  if (!x || !T || !plan || !A || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f || dropout_p >= 1.f)
+    return PM_E_INVALID;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(pm_cdiv(N, 4)), block(256);
+  const bool drop = dropout_p > 0.f;
+  const uint32_t thresh = pm_keep_threshold(dropout_p);
+  const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
+#define LAUNCH(NV, DR)                                                                                              \
+  hipLaunchKernelGGL((k_segreduce_fwd<NV, DR>), grid, block, 0, st, x, T, pv.rowptr, pv.csr_src, pv.csr_dist,       \
+                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, A)
+  const int nv = (int)pm_cdiv(d, 256);
+  if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
+  else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
+  else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+  return pm_check_launch();
+}
+
+// ---------------------------------------------------------------- backward
+// One wave owns one SOURCE node and walks its CSC row:
+//   dx[n]     = dA[n, 6d:7d] (+ dres[n]) + sum_e  w_e * dA[dst_e, r_e*d:] * keep_e/(1-p) * T[dist_e] * [x[n]*T > 0]
+//   dT[dist] += sum_e  w_e * dA[dst_e, r_e*d:] * keep_e/(1-p) * x[n] * [x[n]*T > 0],   w_e = 1/clamp(count,1)
+// dT is reduced in LDS per workgroup (ds_add_f32) and flushed once with global float atomics.
+template <int NV, bool DROP>
+__global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__ x, const float* __restrict__ T,
+                                                       const float* __restrict__ dA, const float* __restrict__ dres,
+                                                       const int* __restrict__ colptr, const int* __restrict__ csc_dst,
+                                                       const int* __restrict__ csc_reldist,
+                                                       const int* __restrict__ csc_eid,
+                                                       const float* __restrict__ csc_invcnt, int N, int d,
+                                                       uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
+                                                       float* __restrict__ dx, float* __restrict__ dT) {
+  extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][d]
+  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) sT[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int c[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { c[v] = (lane + v * 64) * 4; ok[v] = c[v] < d; }
+  for (int n0 = blockIdx.x * 4; n0 < N; n0 += gridDim.x * 4) {
+    const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
+    if (n >= N) continue;
+    float4 xv[NV], acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (!ok[v]) continue;
+      xv[v] = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
+      acc[v] = *reinterpret_cast<const float4*>(dA + (int64_t)n * 7 * d + (int64_t)PM_N_REL * d + c[v]);
+      if (dres) {
+        const float4 rv = *reinterpret_cast<const float4*>(dres + (int64_t)n * d + c[v]);
+        acc[v].x += rv.x; acc[v].y += rv.y; acc[v].z += rv.z; acc[v].w += rv.w;
+      }
+    }
+    const int beg = colptr[n], end = colptr[n + 1];
+    for (int p = beg; p < end; ++p) {
+      const int dst = csc_dst[p], rd = csc_reldist[p];
+      const int r = rd & 0xff, dist = rd >> 8;
+      const float w = csc_invcnt[p] * scale;
+      uint32_t key = 0;
+      if (DROP) key = pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[p]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if (!ok[v]) continue;
+        const float4 g4 = *reinterpret_cast<const float4*>(dA + (int64_t)dst * 7 * d + (int64_t)r * d + c[v]);
+        const float4 tv = *reinterpret_cast<const float4*>(T + dist * d + c[v]);
+        float g[4] = {g4.x * w, g4.y * w, g4.z * w, g4.w * w};
+        const float xs[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w};
+        const float ts[4] = {tv.x, tv.y, tv.z, tv.w};
+        float* ap = reinterpret_cast<float*>(&acc[v]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bool on = xs[j] * ts[j] > 0.f;
+          if (DROP) on = on && ((pm_elem_hash(key, c[v] + j) >> 8) >= thresh);
+          const float gg = on ? g[j] : 0.f;
+          ap[j] += gg * ts[j];
+          const float gt = gg * xs[j];
+          if (gt != 0.f) atomicAdd(&sT[dist * d + c[v] + j], gt);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (!ok[v]) continue;
+      *reinterpret_cast<float4*>(dx + (int64_t)n * d + c[v]) = acc[v];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {
+    const float v = sT[i];
+    if (v != 0.f) atomicAdd(&dT[i], v);
+  }
+}
+
+extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
+                                int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
+                                uint32_t layer_uid, float* dx, float* dT, pm_stream_t stream) {
+  if (!x || !T || !dA || !plan || !dx || !dT || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f ||
+      dropout_p >= 1.f)
+    return PM_E_INVALID;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (int)pm_cdiv(N, 4);
+  if (nblk > 512) nblk = 512;
+  const dim3 grid(nblk), block(256);
+  const size_t lds = sizeof(float) * PM_N_DIST * d;
+  const bool drop = dropout_p > 0.f;
+  const uint32_t thresh = pm_keep_threshold(dropout_p);
+  const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
+#define LAUNCH(NV, DR)                                                                                               \
+  hipLaunchKernelGGL((k_segreduce_bwd<NV, DR>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,          \
+                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, dx, dT)
+  const int nv = (int)pm_cdiv(d, 256);
+  if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
+  else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
+  else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
+#undef LAUNCH
+  return pm_check_launch();
+}

@@ -1,0 +1,282 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point).
+
+Every wrapper checks device / dtype / contiguity, allocates outputs with torch (the
+library never allocates) and enqueues on torch's current stream.  No arithmetic
+happens here: if the HIP extension is missing these raise `HipExtensionError`.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import constants as C
+from ._lib import PLAN_FIELDS, HipExtensionError, call, plan_layout, ptr, stream
+
+F32, I32, I64, U8, F64 = torch.float32, torch.int32, torch.int64, torch.uint8, torch.float64
+
+
+def _chk(t: Optional[torch.Tensor], dtype, name: str, allow_none=False):
+    if t is None:
+        if allow_none:
+            return
+        raise ValueError(f"{name} is None")
+    if not t.is_cuda:
+        raise HipExtensionError(f"{name} lives on {t.device}: the HIP path needs device tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+class Plan:
+    """Device-side graph plan of one batch (see include/polyphemus_hip.h, pm_plan_build)."""
+
+    def __init__(self, buf: torch.Tensor, N: int, E: int, G: int, n_bars: int, tokens: torch.Tensor,
+                 is_drum: torch.Tensor):
+        self.buf, self.N, self.E, self.G, self.n_bars = buf, N, E, G, n_bars
+        self.B = G // n_bars
+        self.tokens, self.is_drum = tokens, is_drum
+        self._off = plan_layout(N, E, G)
+
+    def field(self, name: str) -> torch.Tensor:
+        i = PLAN_FIELDS.index(name)
+        v = self.buf[self._off[i]:self._off[i + 1]]
+        return v.view(torch.float32) if name == "csc_invcnt" else v
+
+    @property
+    def tok_hist(self) -> torch.Tensor:
+        return self.field("tok_hist")
+
+
+def edge_attrs_to_ids(edge_attrs: torch.Tensor):
+    _chk(edge_attrs, F32, "edge_attrs")
+    E = edge_attrs.shape[0]
+    et = torch.empty(E, dtype=I32, device=edge_attrs.device)
+    ed = torch.empty(E, dtype=I32, device=edge_attrs.device)
+    call("pm_edge_attrs_to_ids", ptr(edge_attrs), E, ptr(et), ptr(ed), stream())
+    return et, ed
+
+
+def tokens_from_onehot(c_tensor: torch.Tensor) -> torch.Tensor:
+    _chk(c_tensor, F32, "c_tensor")
+    N = c_tensor.shape[0]
+    tok = torch.empty(N, 16, 2, dtype=I32, device=c_tensor.device)
+    call("pm_tokens_from_onehot", ptr(c_tensor), N, ptr(tok), stream())
+    return tok
+
+
+def plan_build(edge_index, edge_type, edge_dist, bars, batch, is_drum, tokens, n_bars: int, G: int) -> Plan:
+    _chk(edge_index, I64, "edge_index"); _chk(edge_type, I32, "edge_type"); _chk(edge_dist, I32, "edge_dist")
+    _chk(bars, I64, "bars"); _chk(batch, I64, "batch"); _chk(tokens, I32, "tokens")
+    if is_drum.dtype == torch.bool:
+        is_drum = is_drum.view(U8)
+    _chk(is_drum, U8, "is_drum")
+    N, E = bars.shape[0], edge_index.shape[1]
+    off = plan_layout(N, E, G)
+    buf = torch.empty(off[-1], dtype=I32, device=bars.device)
+    call("pm_plan_build", ptr(edge_index), ptr(edge_type), ptr(edge_dist), ptr(bars), ptr(batch), ptr(is_drum),
+         ptr(tokens), n_bars, N, E, G, ptr(buf), stream())
+    return Plan(buf, N, E, G, n_bars, tokens, is_drum)
+
+
+def edge_table(nn_weight, nn_bias):
+    _chk(nn_weight, F32, "nn.weight"); _chk(nn_bias, F32, "nn.bias")
+    d = nn_weight.shape[0]
+    T = torch.empty(C.N_DISTS, d, dtype=F32, device=nn_weight.device)
+    call("pm_edge_table", ptr(nn_weight), ptr(nn_bias), d, ptr(T), stream())
+    return T
+
+
+def edge_table_bwd(dT, d_nn_weight, d_nn_bias):
+    call("pm_edge_table_bwd", ptr(dT), dT.shape[1], ptr(d_nn_weight), ptr(d_nn_bias), stream())
+
+
+def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int, out=None):
+    _chk(x, F32, "x"); _chk(T, F32, "T")
+    N, d = x.shape
+    A = out if out is not None else torch.empty(N, 7 * d, dtype=F32, device=x.device)
+    call("pm_segreduce_fwd", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, float(dropout_p),
+         seed & 0xFFFFFFFF, layer_uid, ptr(A), stream())
+    return A
+
+
+def segreduce_bwd(x, T, dA, dres, plan: Plan, dropout_p: float, seed: int, layer_uid: int, dT, out=None):
+    _chk(x, F32, "x"); _chk(dA, F32, "dA"); _chk(dres, F32, "dres", allow_none=True); _chk(dT, F32, "dT")
+    N, d = x.shape
+    dx = out if out is not None else torch.empty(N, d, dtype=F32, device=x.device)
+    call("pm_segreduce_bwd", ptr(x), ptr(T), ptr(dA), ptr(dres), ptr(plan.buf), N, plan.E, plan.G, d,
+         float(dropout_p), seed & 0xFFFFFFFF, layer_uid, ptr(dx), ptr(dT), stream())
+    return dx
+
+
+GEMM_RELU, GEMM_ACCUM = 1, 2
+
+
+def gemm(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
+         split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None):
+    """out[M,N] (=|+=) op(A) op(B) (+bias)(relu); A/B/out may be views with an element offset
+    (pass the sliced tensor: its data_ptr() carries the offset) and explicit leading dimensions."""
+    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0)
+    call("pm_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
+         flags, split_k, ptr(rowmap), rows_per_entry, ptr(dyn_entries), stream())
+    return out
+
+
+def linear(x, weight, bias=None, relu=False, out=None):
+    """y = x @ weight.T + bias for contiguous x [M,K], weight [N,K] (nn.Linear layout)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    y = out if out is not None else torch.empty(M, N, dtype=F32, device=x.device)
+    return gemm(x, weight, y, M, N, K, x.stride(0), weight.stride(0), y.stride(0), transB=True, bias=bias, relu=relu)
+
+
+def bn_scratch(C_: int, device) -> torch.Tensor:
+    return torch.empty(64 * 2 * C_ + 2 * C_, dtype=F64, device=device)
+
+
+def bn_stats(x, O, C_, I, running_mean=None, running_var=None, momentum=0.1, scratch=None):
+    mean = torch.empty(C_, dtype=F32, device=x.device)
+    var = torch.empty(C_, dtype=F32, device=x.device)
+    scratch = scratch if scratch is not None else bn_scratch(C_, x.device)
+    call("pm_bn_stats", ptr(x), O, C_, I, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var), momentum,
+         ptr(scratch), stream())
+    return mean, var
+
+
+def bn_apply(x, O, C_, I, mean, var, gamma, beta, eps=1e-5, residual=None, relu=False, out=None):
+    y = out if out is not None else torch.empty_like(x)
+    call("pm_bn_apply", ptr(x), O, C_, I, ptr(mean), ptr(var), eps, ptr(gamma), ptr(beta), ptr(residual), int(relu),
+         ptr(y), stream())
+    return y
+
+
+def bn_bwd(x, dy, O, C_, I, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, relu=False, out=None, scratch=None):
+    dx = out if out is not None else torch.empty_like(x)
+    scratch = scratch if scratch is not None else bn_scratch(C_, x.device)
+    call("pm_bn_bwd", ptr(x), ptr(dy), O, C_, I, ptr(mean), ptr(var), eps, ptr(gamma), ptr(beta), int(relu),
+         ptr(dgamma), ptr(dbeta), ptr(dx), ptr(scratch), stream())
+    return dx
+
+
+def relu_bwd(dy, y, out=None):
+    dx = out if out is not None else torch.empty_like(dy)
+    call("pm_relu_bwd", ptr(dy), ptr(y), dy.numel(), ptr(dx), stream())
+    return dx
+
+
+def add(a, b, out=None):
+    o = out if out is not None else torch.empty_like(a)
+    call("pm_add", ptr(a), ptr(b), a.numel(), ptr(o), stream())
+    return o
+
+
+def colsum_acc(x, M, C_, ld, out):
+    call("pm_colsum_acc", ptr(x), M, C_, ld, ptr(out), stream())
+
+
+def reparam_fwd(mu, log_var, eps):
+    z = torch.empty_like(mu)
+    call("pm_reparam_fwd", ptr(mu), ptr(log_var), ptr(eps), mu.numel(), ptr(z), stream())
+    return z
+
+
+def reparam_bwd(dz, log_var, eps, dmu, dlog_var):
+    call("pm_reparam_bwd", ptr(dz), ptr(log_var), ptr(eps), dz.numel(), ptr(dmu), ptr(dlog_var), stream())
+
+
+def gate_fwd(x, w, b):
+    N, d = x.shape
+    g = torch.empty(N, dtype=F32, device=x.device)
+    call("pm_gate_fwd", ptr(x), ptr(w), ptr(b), N, d, ptr(g), stream())
+    return g
+
+
+def attnpool_fwd(x, g, g_mean, g_var, bn_g, bn_b, plan: Plan, eps=1e-5):
+    N, d = x.shape
+    alpha = torch.empty(N, dtype=F32, device=x.device)
+    out = torch.empty(plan.G, d, dtype=F32, device=x.device)
+    call("pm_attnpool_fwd", ptr(x), ptr(g), ptr(g_mean), ptr(g_var), eps, ptr(bn_g), ptr(bn_b), ptr(plan.buf), N,
+         plan.E, plan.G, d, ptr(alpha), ptr(out), stream())
+    return alpha, out
+
+
+def attnpool_bwd(x, g, g_mean, g_var, bn_g, alpha, dout, gate_w, plan: Plan, d_gate_w, d_gate_b, d_bn_g, d_bn_b,
+                 eps=1e-5):
+    N, d = x.shape
+    dx = torch.empty_like(x)
+    scratch = torch.empty(3 * N + 8, dtype=F32, device=x.device)
+    call("pm_attnpool_bwd", ptr(x), ptr(g), ptr(g_mean), ptr(g_var), eps, ptr(bn_g), ptr(alpha), ptr(dout),
+         ptr(gate_w), ptr(plan.buf), N, plan.E, plan.G, d, ptr(dx), ptr(d_gate_w), ptr(d_gate_b), ptr(d_bn_g),
+         ptr(d_bn_b), ptr(scratch), stream())
+    return dx
+
+
+def bar_broadcast_fwd(bars, plan: Plan):
+    d = bars.shape[1]
+    x = torch.empty(plan.N, d, dtype=F32, device=bars.device)
+    call("pm_bar_broadcast_fwd", ptr(bars), ptr(plan.buf), plan.N, plan.E, plan.G, d, ptr(x), stream())
+    return x
+
+
+def bar_broadcast_bwd(dx, plan: Plan):
+    d = dx.shape[1]
+    db = torch.empty(plan.G, d, dtype=F32, device=dx.device)
+    call("pm_bar_broadcast_bwd", ptr(dx), ptr(plan.buf), plan.N, plan.E, plan.G, d, ptr(db), stream())
+    return db
+
+
+def conv3x3_fwd(x, w, b, G, Ci, Co, H, W, up4=False):
+    y = torch.empty(G, Co, H, W, dtype=F32, device=x.device)
+    call("pm_conv3x3_fwd", ptr(x), ptr(w), ptr(b), G, Ci, Co, H, W, int(up4), ptr(y), stream())
+    return y
+
+
+def conv3x3_bwd_data(dy, w, G, Ci, Co, H, W, up4=False):
+    dx = torch.empty(G, Ci, H, W // 4 if up4 else W, dtype=F32, device=dy.device)
+    call("pm_conv3x3_bwd_data", ptr(dy), ptr(w), G, Ci, Co, H, W, int(up4), ptr(dx), stream())
+    return dx
+
+
+def conv3x3_bwd_weight(x, dy, G, Ci, Co, H, W, dw, db, up4=False):
+    call("pm_conv3x3_bwd_weight", ptr(x), ptr(dy), G, Ci, Co, H, W, int(up4), ptr(dw), ptr(db), stream())
+
+
+def maxpool4_fwd(x):
+    y = torch.empty(*x.shape[:-1], x.shape[-1] // 4, dtype=F32, device=x.device)
+    call("pm_maxpool4_fwd", ptr(x), y.numel(), ptr(y), stream())
+    return y
+
+
+def maxpool4_bwd(x, dy):
+    dx = torch.empty_like(x)
+    call("pm_maxpool4_bwd", ptr(x), ptr(dy), dy.numel(), ptr(dx), stream())
+    return dx
+
+
+def content_ce(c_logits, plan: Plan, grad_scale=1.0, want_grad=True, out=None):
+    N = c_logits.shape[0]
+    out = out if out is not None else torch.empty(4, dtype=F64, device=c_logits.device)
+    dl = torch.empty_like(c_logits) if want_grad else None
+    call("pm_content_ce", ptr(c_logits), ptr(plan.tokens), ptr(plan.tok_hist), N, grad_scale, ptr(dl), ptr(out),
+         stream())
+    return out, dl
+
+
+def kld(mu, log_var, out, beta=0.0, dmu=None, dlog_var=None):
+    B, d = mu.shape
+    call("pm_kld", ptr(mu), ptr(log_var), B, d, beta, ptr(dmu), ptr(dlog_var), ptr(out), stream())
+    return out
+
+
+def bce_logits(logits, target, out, grad_scale=1.0, want_grad=False):
+    dl = torch.empty_like(logits) if want_grad else None
+    call("pm_bce_logits", ptr(logits), ptr(target), logits.numel(), grad_scale, ptr(dl), ptr(out), stream())
+    return out, dl
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for t, n in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, F32, n)
+    call("pm_adam_step", ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), lr, beta1, beta2,
+         eps, step, grad_scale, stream())

@@ -1,0 +1,74 @@
+"""C-ABI checks that need no GPU: the shared library loads, exports every symbol that
+include/polyphemus_hip.h declares, and the ctypes signature table matches the header."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from polyphemus_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "polyphemus_hip.h")
+
+
+def header_prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"\b(int|uint32_t|const char\*)\s+(pm_\w+)\s*\(([^;{]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        codes = ""
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                codes += "p"
+            elif a.startswith("pm_stream_t"):
+                codes += "s"
+            elif a.startswith("int64_t"):
+                codes += "l"
+            elif a.startswith("uint32_t"):
+                codes += "u"
+            elif a.startswith("float"):
+                codes += "f"
+            elif a.startswith("int32_t") or a.startswith("int "):
+                codes += "i"
+            else:
+                raise AssertionError(f"unparsed argument {a!r} of {name}")
+        protos[name] = codes
+    return protos
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    protos = header_prototypes()
+    assert len(protos) >= 35
+    for name in protos:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert L.pm_abi_version() == 1
+    assert b"gfx950" in L.pm_build_info()
+
+
+def test_ctypes_signatures_match_header():
+    protos = header_prototypes()
+    for name, sig in _lib._SIGS.items():
+        assert name in protos, name
+        assert protos[name] == sig, f"{name}: header {protos[name]} != binding {sig}"
+    for name in protos:
+        assert name in _lib.EXPORTED, f"{name} not bound"
+
+
+def test_plan_layout_host_only():
+    off = _lib.plan_layout(100, 400, 8)
+    assert len(off) == len(_lib.PLAN_FIELDS) + 1
+    assert off[0] == 0 and all(b > a for a, b in zip(off, off[1:])) and all(o % 4 == 0 for o in off)
+    assert off[1] - off[0] >= 100 * 6 + 1
+
+
+def test_dropout_hash_is_host_callable_and_stable():
+    L = _lib.lib()
+    a = L.pm_dropout_hash(1234, 3, 17, 5)
+    assert a == L.pm_dropout_hash(1234, 3, 17, 5) and 0 <= a < (1 << 24)
+    assert a != L.pm_dropout_hash(1234, 3, 17, 6)

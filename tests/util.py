@@ -43,3 +43,32 @@ def batch_from_golden(z, cfg) -> BarGraphBatch:
 
 def state_dict_from_golden(z, prefix="sd/"):
     return {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
+
+
+# ---- counter-based dropout stream of the HIP path, restated in numpy (csrc/common.h) ----
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x):
+    x = x.astype(np.uint64) & _M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def dropout_keep_np(seed, layer_uid, eids, d, p):
+    """keep[e, c] of pm_dropout_keep(seed, layer, eid, channel) for p in [0,1): float32 0/1."""
+    eids = np.asarray(eids, dtype=np.uint64)
+    k0 = _mix32(np.array([(seed & 0xFFFFFFFF) ^ (((layer_uid + 1) * 0x9E3779B9) & 0xFFFFFFFF)], np.uint64))[0]
+    ek = _mix32(k0 ^ ((eids * np.uint64(0x85EBCA6B) + np.uint64(0x27D4EB2F)) & _M32))
+    ch = (np.arange(d, dtype=np.uint64) * np.uint64(0xC2B2AE35)) & _M32
+    h = _mix32((ek[:, None] + ch[None, :]) & _M32)
+    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    return ((h >> np.uint64(8)) >= thresh).astype(np.float32)
+
+
+def layer_uid_of(key: str) -> int:
+    """GCL parameter prefix -> layer uid used by the HIP path (encoder GCN 0.., decoder GCN 1000..)."""
+    base = 0 if key.startswith("encoder.") else 1000
+    return base + int(key.rsplit(".", 1)[1])

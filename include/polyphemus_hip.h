@@ -64,7 +64,7 @@ enum {
   PM_PLAN_CSC_INVCNT,   /* [E] float bits: 1 / max(#in-edges of (dst, relation),1) */
   PM_PLAN_NODE_BAR,     /* [N] distinct bar id = bars + n_bars*batch (model.py:403) */
   PM_PLAN_BAR_PTR,      /* [G+1] node offsets of each bar                         */
-  PM_PLAN_GROUP_LIST,   /* [N] drum nodes (ascending) then non-drum nodes         */
+  PM_PLAN_GROUP_LIST,   /* [2N] drum nodes (ascending) in [0,n_drum); non-drum nodes in [N, N+n_non_drum) */
   PM_PLAN_GROUP_CNT,    /* [4] {n_drum, n_non_drum, 0, 0}                         */
   PM_PLAN_TOK_HIST,     /* [4][131] token counts over slots 1..15:
                            0 drum pitch, 1 non-drum pitch, 2 drum dur, 3 non-drum dur */
@@ -136,6 +136,9 @@ int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, 
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
 int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
 int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);
+/* same over an indirect row set (rows = rowmap[r / rpe] * rpe + r % rpe, entry count read on device) */
+int pm_colsum_rows_acc(const float* x, int32_t C, int32_t ld, const int32_t* rowmap, int32_t rows_per_entry,
+                       const int32_t* dyn_entries, int32_t max_entries, float* out /* [C] += */, pm_stream_t stream);
 int pm_reparam_fwd(const float* mu, const float* log_var, const float* eps, int64_t n, float* z, pm_stream_t stream);
 int pm_reparam_bwd(const float* dz, const float* log_var, const float* eps, int64_t n, float* dmu /* += */,
                    float* dlog_var /* += */, pm_stream_t stream);

@@ -34,6 +34,7 @@ _SIGS = {
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",
     "pm_colsum_acc": "piiips",
+    "pm_colsum_rows_acc": "piipipips",
     "pm_reparam_fwd": "ppplps",
     "pm_reparam_bwd": "ppplpps",
     "pm_embed_tables": "pppppppppppppppppppiiffpps",

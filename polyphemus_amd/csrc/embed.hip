@@ -110,7 +110,7 @@ extern "C" int pm_embed_gather(const float* tables, const int32_t* tokens, const
 // adds collide on one LDS row and never reach L2.
 __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restrict__ dX, const int* __restrict__ tok,
                                                            const int* __restrict__ group_list,
-                                                           const int* __restrict__ group_cnt, int d,
+                                                           const int* __restrict__ group_cnt, int N, int d,
                                                            float* __restrict__ S) {
   extern __shared__ __attribute__((aligned(16))) float sS[];
   const int t = blockIdx.y, grp = t & 1, kind = t >> 1, dh = d / 2;
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restri
   __syncthreads();
   const int nd = group_cnt[0];
   const int cnt = grp == 0 ? nd : group_cnt[1];
-  const int* list = group_list + (grp == 0 ? 0 : nd);
+  const int* list = group_list + (grp == 0 ? 0 : N);
   const int64_t rows = (int64_t)cnt * PM_N_SLOTS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -152,7 +152,7 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
                         (int)lds);
   int nb = (int)pm_cdiv((int64_t)N * PM_N_SLOTS, 4 * 64);
   if (nb > 96) nb = 96;
-  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(256), lds, st, dX, tokens, pv.group_list, pv.group_cnt, d, S);
+  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(256), lds, st, dX, tokens, pv.group_list, pv.group_cnt, N, d, S);
   return pm_check_launch();
 }
 

@@ -276,6 +276,38 @@ extern "C" int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, f
   return pm_check_launch();
 }
 
+__global__ void __launch_bounds__(256) k_colsum_rows_acc(const float* __restrict__ x, int C, int ld,
+                                                         const int* __restrict__ rowmap, int rpe,
+                                                         const int* __restrict__ dyn, int max_entries,
+                                                         int rows_per_chunk, float* out) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  int ne = dyn ? *dyn : max_entries;
+  if (ne > max_entries) ne = max_entries;
+  const int M = ne * rpe;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (c < C) for (int r = r0 + wave; r < r1; r += 4) s += x[((int64_t)rowmap[r / rpe] * rpe + r % rpe) * ld + c];
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C && r0 < M) atomicAdd(&out[c], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+extern "C" int pm_colsum_rows_acc(const float* x, int32_t C, int32_t ld, const int32_t* rowmap, int32_t rows_per_entry,
+                                  const int32_t* dyn_entries, int32_t max_entries, float* out, pm_stream_t stream) {
+  if (!x || !rowmap || !out || C <= 0 || ld < C || rows_per_entry <= 0 || max_entries <= 0) return PM_E_INVALID;
+  const int64_t M = (int64_t)max_entries * rows_per_entry;
+  int nc = (int)pm_cdiv(M, 128);
+  if (nc > 128) nc = 128;
+  const int rpc = (int)pm_cdiv(M, nc);
+  nc = (int)pm_cdiv(M, rpc);
+  hipLaunchKernelGGL(k_colsum_rows_acc, dim3(pm_cdiv(C, 64), nc), dim3(256), 0, (hipStream_t)stream, x, C, ld, rowmap,
+                     rows_per_entry, dyn_entries, max_entries, rpc, out);
+  return pm_check_launch();
+}
+
 // VAE reparametrisation (model.py:671-673): z = exp(0.5*log_var) * eps + mu
 __global__ void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
                               int64_t n, float* z) {

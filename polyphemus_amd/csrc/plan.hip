@@ -12,7 +12,7 @@ void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   sz[PM_PLAN_CSR_SRC] = E; sz[PM_PLAN_CSR_DIST] = E; sz[PM_PLAN_CSR_EID] = E;
   sz[PM_PLAN_COLPTR] = (int64_t)N + 1;
   sz[PM_PLAN_CSC_DST] = E; sz[PM_PLAN_CSC_RELDIST] = E; sz[PM_PLAN_CSC_EID] = E; sz[PM_PLAN_CSC_INVCNT] = E;
-  sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = N;
+  sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = 2 * (int64_t)N;
   sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH;
   // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums
   sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;
@@ -173,8 +173,7 @@ __global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restr
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n == 0) { cnt[0] = pos[N]; cnt[1] = N - pos[N]; cnt[2] = 0; cnt[3] = 0; }
   if (n >= N) return;
-  const int nd = pos[N];
-  if (is_drum[n]) list[pos[n]] = n; else list[nd + (n - pos[n])] = n;
+  if (is_drum[n]) list[pos[n]] = n; else list[N + (n - pos[n])] = n;   // non-drum list starts at N
 }
 
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,

@@ -48,6 +48,18 @@ class Plan:
     def tok_hist(self) -> torch.Tensor:
         return self.field("tok_hist")
 
+    @property
+    def drum_list(self) -> torch.Tensor:
+        return self.field("group_list")[:self.N]
+
+    @property
+    def nondrum_list(self) -> torch.Tensor:
+        return self.field("group_list")[self.N:2 * self.N]
+
+    @property
+    def group_cnt(self) -> torch.Tensor:
+        return self.field("group_cnt")
+
 
 def edge_attrs_to_ids(edge_attrs: torch.Tensor):
     _chk(edge_attrs, F32, "edge_attrs")
@@ -173,6 +185,11 @@ def add(a, b, out=None):
 
 def colsum_acc(x, M, C_, ld, out):
     call("pm_colsum_acc", ptr(x), M, C_, ld, ptr(out), stream())
+
+
+def colsum_rows_acc(x, C_, ld, rowmap, rows_per_entry, dyn_entries, max_entries, out):
+    call("pm_colsum_rows_acc", ptr(x), C_, ld, ptr(rowmap), rows_per_entry, ptr(dyn_entries), max_entries, ptr(out),
+         stream())
 
 
 def reparam_fwd(mu, log_var, eps):

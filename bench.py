@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — bar-graphs/sec of the graph-VAE training step on MI355X.
+
+One "step" = plan build + VAE forward + loss + backward + (DP: gradient all-reduce) + fused Adam
+on one synthetic LMD2 batch (BASELINE.json configs[1]: 2 bars, 4 tracks x 32 timesteps,
+batch 256 per GPU, d_hidden 256, 8 GNN layers; weak scaling: every rank gets its own 256 samples,
+configs[3] at 8 GPUs).  Inputs are resident in HBM before the timed region; host-side graph
+construction stays outside it, as in the reference (data.py runs in DataLoader workers).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel, timed live
+with HIP events on the launch stream), `roofline_segreduce` (the HBM-bound aggregation kernel) and
+`cpu_baseline` (the CPU oracle — a port of the reference op sequence — timed on the host cores,
+rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+PEAK_HBM_GBS = 8000.0              # HBM3E spec; ~6.3 TB/s achievable
+
+
+def flops_per_bar(n_nodes, n_bars_total, d, L):
+    """Algorithmic flops per bar-graph, forward+backward:
+    3 * mean_nodes_per_bar * [(60 + 28 L) d^2 + 6900 d]."""
+    return 3.0 * (n_nodes / n_bars_total) * ((60 + 28 * L) * d * d + 6900 * d)
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  os.cpu_count() reports
+    every core of the host even inside a CPU-limited container, and oversubscribing OpenMP threads
+    (256 threads on a 16-CPU quota) slows the oracle by orders of magnitude."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_subprocess(cfg, timeout_s=240):
+    """Run the CPU leg in a child process (never touches the GPU) under a hard timeout."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--d", str(cfg["d"]), "--n-bars",
+           str(cfg["n_bars"]), "--layers", str(cfg["gnn_n_layers"])]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(host_cores()))
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"cpu baseline exceeded {timeout_s}s"}
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """The CPU oracle (oracle/vae_cpu.py: reference op sequence, fp32, stock torch Adam) on a bounded
+    sample of the same workload: B=16 samples of the same synthetic distribution, all host cores."""
+    from oracle import vae_cpu
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.synthetic import synthetic_batch
+    torch.set_num_threads(host_cores())
+    B = 16
+    batch = synthetic_batch(B, cfg["n_bars"], p=0.25, seed=1234)
+    torch.manual_seed(0)
+    ref = VAE(**cfg, device=torch.device("cpu"))
+    names = [n for n, _ in ref.named_parameters()]
+    P, names = vae_cpu.split_state({k: v.detach().clone() for k, v in ref.state_dict().items()}, names)
+    opt = torch.optim.Adam([P[n] for n in names], lr=5e-6, betas=(0.9, 0.98), eps=1e-9)
+    _ = batch.c_tensor, batch.edge_attrs                      # reference-format inputs, built outside the timing
+    vae_cpu.train_step(batch, P, names, cfg, opt)             # warm-up
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 5 and (time.time() < t_end or len(times) < 2):
+        t0 = time.time()
+        vae_cpu.train_step(batch, P, names, cfg, opt)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B * cfg["n_bars"] / med, "unit": "bar-graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/vae_cpu.py train step (fwd+loss+bwd+Adam, message dropout on), B={B} 2-bar samples "
+                      f"({batch.num_nodes} nodes), d={cfg['d']}, L={cfg['gnn_n_layers']}, median of {len(times)} steps "
+                      f"= {med * 1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--n-bars", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--dense", action="store_true", help="BASELINE configs[4] dense-graph stress")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=args.layers, d=args.d, n_bars=args.n_bars, resolution=8)
+        print(json.dumps(cpu_baseline(cfg)))
+        return
+
+    from polyphemus_amd import ops, parallel
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.synthetic import synthetic_batch
+    from polyphemus_amd.trainer import HipTrainer
+
+    rank, local, world = parallel.init_from_env("nccl")
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=args.layers, d=args.d, n_bars=args.n_bars, resolution=8)
+
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=dev).to(dev)
+    vae.train()
+    tj = dict(peak_lr=1e-4, final_lr_scale=0.01, warmup_steps=8000, decay_steps=800000)      # training.json:19-24
+    trainer = HipTrainer(vae, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler=tj)        # training.json:11-18
+    batch = synthetic_batch(args.batch, args.n_bars, p=0.25, seed=1234 + rank, dense=args.dense).to(dev)
+    n_nodes, n_edges, G = batch.num_nodes, batch.edge_index.shape[1], batch.s_tensor.shape[0]
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    ops.PROF = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.train_step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROF = ops.PROF, None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot_nodes = torch.tensor([float(n_nodes), float(G)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tot_nodes)
+    elapsed = float(t.item())
+    losses = trainer.losses_dict(out)
+
+    def kernel_stats(name):
+        recs = prof[name]
+        if not recs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        work = sum(w for _, _, w in recs)
+        return dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), work=work)
+
+    if rank == 0:
+        gst = {k: kernel_stats(k) for k in prof}
+        gemm_keys = [k for k in gst if k.startswith("gemm") and gst[k]]
+        dom = max(gemm_keys, key=lambda k: gst[k]["total_ms"])
+        ds = gst[dom]
+        tf = ds["work"] / (ds["total_ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[-3:]},{dom[-3:]},{dom[5:7]}> (v_mfma_f32_32x32x2_f32)",
+                "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": ds["launches"] / args.steps, "avg_launch_us": round(ds["avg_us"], 2),
+                "other_gemm_classes": {k: {"TFLOP/s": round(gst[k]["work"] / (gst[k]["total_ms"] * 1e-3) / 1e12, 2),
+                                           "avg_us": round(gst[k]["avg_us"], 2),
+                                           "launches_per_step": gst[k]["launches"] / args.steps}
+                                       for k in gemm_keys if k != dom}}
+        ss = gst["segreduce_fwd"]
+        gbs = ss["work"] / (ss["total_ms"] * 1e-3) / 1e9
+        roof_seg = {"bound": "hbm", "kernel": "k_segreduce_fwd", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                    "launches_per_step": ss["launches"] / args.steps, "avg_launch_us": round(ss["avg_us"], 2),
+                    "algorithmic_bytes_per_launch": ss["work"] / ss["launches"]}
+        bars_total = float(tot_nodes[1].item())
+        value = bars_total * args.steps / elapsed
+        fpb = flops_per_bar(float(tot_nodes[0].item()), bars_total, args.d, args.layers)
+        line = {
+            "metric": "bar-graphs/sec VAE fwd+bwd (+loss +Adam), LMD2 4-track x 32-ts synthetic",
+            "value": round(value, 1), "unit": "bar-graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("dense-graph stress (BASELINE configs[4])" if args.dense else
+                                    "LMD2 2-bar, 4 tracks, 32 ts, batch=256 per GPU, d_hidden=256 (BASELINE configs[1]; "
+                                    "configs[3] when n_gpus=8)"),
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "n_bars": args.n_bars,
+                       "d": args.d, "gnn_n_layers": args.layers, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
+                       "message_dropout": 0.1, "parallelism": f"dp{world}", "weights": "default init, manual_seed(0)",
+                       "step": "plan+fwd+loss+bwd+allreduce+Adam"},
+            "step_flops_model": {"algorithmic_gflop_per_bar": round(fpb / 1e9, 3),
+                                 "achieved_TFLOP/s_per_gpu": round(value * fpb / 1e12 / world, 2),
+                                 "frac_of_fp32_mfma_peak": round(value * fpb / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4)},
+            "losses": {k: round(v, 5) for k, v in losses.items()},
+            "roofline": roof, "roofline_segreduce": roof_seg,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_subprocess(cfg)
+            if line["cpu_baseline"].get("value"):
+                line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,32 @@ from ._lib import PLAN_FIELDS, HipExtensionError, call, plan_layout, ptr, stream
 
 F32, I32, I64, U8, F64 = torch.float32, torch.int32, torch.int64, torch.uint8, torch.float64
 
+# Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline
+# figures): PROF = {"kernel class": [(start_event, end_event, algorithmic_work), ...]} or None.
+PROF = None
+
+
+def _prof_begin(name: str):
+    if PROF is None:
+        return None
+    PROF.setdefault(name, [])
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(name: str, e0, work: float):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROF[name].append((e0, e1, work))
+
+
+def gemm_class(transA: bool, transB: bool, M: int, N: int) -> str:
+    """Kernel instance a GEMM call maps to (same rule as pm_gemm_f32): tile size and operand layout."""
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 192
+    return f"gemm_{'T' if transA else 'N'}{'T' if transB else 'N'}_{128 if big else 64}"
+
 
 def _chk(t: Optional[torch.Tensor], dtype, name: str, allow_none=False):
     if t is None:
@@ -108,8 +134,10 @@ def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int,
     _chk(x, F32, "x"); _chk(T, F32, "T")
     N, d = x.shape
     A = out if out is not None else torch.empty(N, 7 * d, dtype=F32, device=x.device)
+    e0 = _prof_begin("segreduce_fwd")
     call("pm_segreduce_fwd", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, float(dropout_p),
          seed & 0xFFFFFFFF, layer_uid, ptr(A), stream())
+    _prof_end("segreduce_fwd", e0, 4.0 * d * N * (1 + C.N_EDGE_TYPES) + 12.0 * plan.E)   # algorithmic HBM bytes
     return A
 
 
@@ -130,8 +158,11 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=Non
     """out[M,N] (=|+=) op(A) op(B) (+bias)(relu); A/B/out may be views with an element offset
     (pass the sliced tensor: its data_ptr() carries the offset) and explicit leading dimensions."""
     flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0)
+    cls = gemm_class(transA, transB, M, N) if PROF is not None else ""
+    e0 = _prof_begin(cls)
     call("pm_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
          flags, split_k, ptr(rowmap), rows_per_entry, ptr(dyn_entries), stream())
+    _prof_end(cls, e0, 2.0 * M * N * K)                                                  # algorithmic flops
     return out
 
 

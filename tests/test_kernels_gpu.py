@@ -230,7 +230,7 @@ def test_elementwise_helpers():
     rows = torch.tensor([5, 9, 60, 61, 3], dtype=torch.int32, device=DEV)
     cnt = torch.tensor([4], dtype=torch.int32, device=DEV)
     out = torch.zeros(20, device=DEV)
-    ops.colsum_rows_acc(a.view(-1)[7:], 20, 33 * 10, rows, 10, cnt, 5, out)       # 100 entries of 10 rows, offset view
+    ops.colsum_rows_acc(a.view(-1)[7:], 20, 33, rows, 10, cnt, 5, out)            # 100 entries of 10 rows, offset view
     want = a.view(100, 10, 33)[rows[:4].long(), :, 7:27].double().sum((0, 1))
     assert rel_err(out, want) < 1e-5
     mu, lv, eps = torch.randn(64, 32, device=DEV), torch.randn(64, 32, device=DEV), torch.randn(64, 32, device=DEV)

@@ -173,7 +173,7 @@ def main():
         dom = max(gemm_keys, key=lambda k: gst[k]["total_ms"])
         ds = gst[dom]
         tf = ds["work"] / (ds["total_ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[-3:]},{dom[-3:]},{dom[5:7]}> (v_mfma_f32_32x32x2_f32)",
+        roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[8:]},{dom[5:7]}> (v_mfma_f32_32x32x2_f32)",
                 "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                 "launches_per_step": ds["launches"] / args.steps, "avg_launch_us": round(ds["avg_us"], 2),

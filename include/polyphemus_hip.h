@@ -112,6 +112,9 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] *
  *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
  *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
 enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2 };
+/* tile configuration pm_gemm_f32 picks for a shape: 0 = 64x64, 1 = 128x128, 2 = 64x256, 3 = 256x64 (host only) */
+int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K);
+int pm_gemm_force_config(int32_t cfg); /* -1 = automatic (default); 0..3 pins a configuration (A/B timing) */
 int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
                 const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
                 int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
@@ -122,15 +125,17 @@ int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const f
  * Tensors are viewed as [O, C, I] (row-major [M,C]: O=M, I=1; NCHW: O=G, I=H*W). */
 int pm_bn_stats(const float* x, int32_t O, int32_t C, int32_t I, float* mean /* [C] */,
                 float* var /* [C] biased */, float* running_mean /* NULL or [C], updated */,
-                float* running_var, float momentum, double* scratch /* [64*2*C] */, pm_stream_t stream);
+                float* running_var, float momentum, double* scratch /* [PM_BN_SCRATCH(C)] */, pm_stream_t stream);
 int pm_bn_apply(const float* x, int32_t O, int32_t C, int32_t I, const float* mean, const float* var,
                 float eps, const float* gamma, const float* beta, const float* residual /* or NULL */,
                 int relu, float* y, pm_stream_t stream);
-/* dx = BN'(du), du = dy * [relu ? bn(x) > 0 : 1]; dgamma/dbeta accumulate. */
+/* dx = BN'(du), du = dy * [relu ? bn(x) > 0 : 1]; dgamma/dbeta accumulate; dbias_pre (optional) += column sums of dx,
+ * i.e. the gradient of a bias added right in front of this BatchNorm (GCL.bias, model.py:119 + :203). */
 int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
               const float* var, float eps, const float* gamma, const float* beta, int relu,
-              float* dgamma /* += */, float* dbeta /* += */, float* dx, double* scratch /* [64*2*C+2*C] */,
-              pm_stream_t stream);
+              float* dgamma /* += */, float* dbeta /* += */, float* dbias_pre /* NULL or += */, float* dx,
+              double* scratch /* [PM_BN_SCRATCH(C)] */, pm_stream_t stream);
+#define PM_BN_SCRATCH(C) (256 * 3 * (C) + 4 * (C))
 
 /* ------------------------------------------------------------------ element-wise helpers */
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
@@ -218,6 +223,53 @@ int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 
 /* Counter-based dropout mask shared by device code and the oracle (host-callable). */
 uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel);
+
+/* ------------------------------------------------------------------ native training step
+ * The whole of `PolyphemusTrainer.train`'s inner iteration (training.py:137-166) issued from C++:
+ * ~330 kernel launches per step with no interpreter between them.  The model is described by
+ * offsets (in floats) into the caller's flat parameter / buffer / gradient arrays, named after the
+ * reference's modules; activations live in a caller-provided workspace arena.
+ * Three calls so that the data-parallel gradient buckets can be exchanged as soon as they are final:
+ *   pm_vae_step_forward  : plan -> encoder -> reparam -> decoder -> losses (+ d loss / d logits)
+ *   pm_vae_step_backward_decoder : decoder gradients are final afterwards
+ *   pm_vae_step_backward_encoder : encoder gradients are final afterwards
+ * `state` is a caller-owned HOST blob of pm_vae_step_state_bytes() that carries the saved-activation
+ * pointers between the calls.  Training mode only (batch statistics, running stats updated). */
+#define PM_MAX_LAYERS 16
+typedef struct PmLin { int64_t w, b; } PmLin;              /* offsets into params (and grads)            */
+typedef struct PmBn { int64_t w, b, rm, rv; } PmBn;        /* w,b: params; rm,rv: running stats in buffers */
+typedef struct PmGcn {
+  int64_t nn_w, nn_b;                                       /* shared edge network Linear(32 -> d)          */
+  int64_t weight[PM_MAX_LAYERS];                            /* [6,d,d] immediately followed by root [d,d]   */
+  int64_t bias[PM_MAX_LAYERS];
+  PmBn norm[PM_MAX_LAYERS];
+} PmGcn;
+typedef struct PmVaeLayout {
+  int32_t d, n_bars, n_layers, reserved;
+  /* encoder (model.py:420-483) */
+  PmLin enc_conv0; PmBn enc_bn1; PmLin enc_conv4; PmBn enc_bn5; PmLin enc_lin1, enc_lin4, enc_s_bars;
+  PmLin enc_pitch_nd, enc_pitch_d, enc_dur; PmBn enc_bn_nd, enc_bn_d, enc_bn_dur; PmLin enc_chord;
+  PmGcn enc_gcn; PmLin enc_gate; PmBn enc_gate_bn; PmLin enc_c_bars;
+  PmLin enc_merge; PmBn enc_bn_merge; PmLin enc_mu, enc_lv;
+  /* decoder (model.py:486-655) */
+  PmLin dec_lin; PmBn dec_bn; PmLin dec_s_bars, dec_s_lin1, dec_s_lin4, dec_conv1; PmBn dec_bn2; PmLin dec_conv4;
+  PmLin dec_c_bars; PmGcn dec_gcn; PmLin dec_chord, dec_pitch_d, dec_pitch_nd, dec_dur;
+} PmVaeLayout;
+typedef struct PmBatch {                                    /* device pointers of one collated batch          */
+  const int64_t* edge_index; const int32_t* edge_type; const int32_t* edge_dist;
+  const int64_t* bars; const int64_t* batch; const uint8_t* is_drum; const int32_t* tokens; const float* s_tensor;
+  int32_t N, E, G, B;
+} PmBatch;
+int64_t pm_vae_layout_bytes(void);
+int64_t pm_vae_step_state_bytes(void);
+int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B);
+int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,
+                        const PmBatch* batch, int32_t* plan, const float* eps /* [B,d] */, float msg_dropout,
+                        uint32_t seed_enc, uint32_t seed_dec, float beta, int structure_loss_on_logits,
+                        void* workspace, int64_t workspace_bytes, void* state, double* losses /* [4] dev */,
+                        pm_stream_t stream);
+int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
+int pm_vae_step_backward_encoder(void* state, pm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -28,9 +28,11 @@ _SIGS = {
     "pm_segreduce_fwd": "pppiiiifuups",
     "pm_segreduce_bwd": "pppppiiiifuupps",
     "pm_gemm_f32": "iiiiipipipipiipips",
+    "pm_gemm_config": "iiii",
+    "pm_gemm_force_config": "i",
     "pm_bn_stats": "piiippppfps",
     "pm_bn_apply": "piiippfpppips",
-    "pm_bn_bwd": "ppiiippfppipppps",
+    "pm_bn_bwd": "ppiiippfppippppps",
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",
     "pm_colsum_acc": "piiips",
@@ -55,9 +57,15 @@ _SIGS = {
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
     "pm_adam_step": "pppplffffifs",
+    "pm_vae_step_workspace_bytes": "piiii",
+    "pm_vae_step_forward": "pppppppfuufiplpps",
+    "pm_vae_step_backward_decoder": "ps",
+    "pm_vae_step_backward_encoder": "ps",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p}
-EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash"])
+_RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes"}
+EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
+                                 "pm_vae_step_state_bytes"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -78,7 +86,9 @@ def lib() -> C.CDLL:
         for name, sig in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = [_CT[c] for c in sig]
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name in _RET64 else C.c_int
+        L.pm_vae_layout_bytes.restype = C.c_int64
+        L.pm_vae_step_state_bytes.restype = C.c_int64
         L.pm_abi_version.restype = C.c_int
         L.pm_build_info.restype = C.c_char_p
         L.pm_dropout_hash.argtypes = [C.c_uint32] * 4

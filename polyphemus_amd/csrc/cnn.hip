@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_bwd_data(const float* __restric
     dx[i] = acc;
   }
 }
-// one workgroup per (co, ci): dw[co,ci,:,:] += sum_{g,h,w} dy * x_shifted ; db[co] += sum dy (ci == 0)
+// grid = (co*ci, g-chunks): dw[co,ci,:,:] += sum_{g,h,w} dy * x_shifted ; db[co] += sum dy (ci == 0).
+// Each workgroup reduces a slice of the bars in fp64 and adds its 9 (+1) partials with float atomics.
 __global__ void __launch_bounds__(256) k_conv3x3_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
                                                             int G, int Ci, int Co, int H, int W, int up4, float* dw,
                                                             float* db) {
@@ -73,9 +74,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_bwd_weight(const float* __restr
   const int co = blockIdx.x / Ci, ci = blockIdx.x % Ci;
   const int Win = up4 ? W / 4 : W;
   double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t total = (int64_t)G * H * W;
+  const int gper = (G + gridDim.y - 1) / gridDim.y;
+  const int g0 = blockIdx.y * gper, g1 = min(G, g0 + gper);
+  const int64_t total = (int64_t)(g1 - g0) * H * W;
   for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
-    const int wq = (int)(i % W), h = (int)((i / W) % H), g = (int)(i / ((int64_t)W * H));
+    const int wq = (int)(i % W), h = (int)((i / W) % H), g = g0 + (int)(i / ((int64_t)W * H));
     const float d = dy[((int64_t)g * Co + co) * H * W + h * W + wq];
     const float* xp = x + ((int64_t)g * Ci + ci) * H * Win;
     acc[9] += d;
@@ -99,8 +102,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_bwd_weight(const float* __restr
   __syncthreads();
   if (threadIdx.x < 10) {
     const double s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-    if (threadIdx.x < 9) dw[((int64_t)co * Ci + ci) * 9 + threadIdx.x] += (float)s;
-    else if (ci == 0 && db) db[co] += (float)s;
+    if (threadIdx.x < 9) atomicAdd(&dw[((int64_t)co * Ci + ci) * 9 + threadIdx.x], (float)s);
+    else if (ci == 0 && db) atomicAdd(&db[co], (float)s);
   }
 }
 static inline int cgrid(int64_t n) { int64_t g = pm_cdiv(n, 256); return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }
@@ -122,8 +125,11 @@ extern "C" int pm_conv3x3_bwd_data(const float* dy, const float* w, int32_t G, i
 extern "C" int pm_conv3x3_bwd_weight(const float* x, const float* dy, int32_t G, int32_t Ci, int32_t Co, int32_t H,
                                      int32_t W, int up4, float* dw, float* db, pm_stream_t stream) {
   if (!x || !dy || !dw || G <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || (up4 && (W & 3))) return PM_E_INVALID;
-  hipLaunchKernelGGL(k_conv3x3_bwd_weight, dim3(Co * Ci), dim3(256), 0, (hipStream_t)stream, x, dy, G, Ci, Co, H, W,
-                     up4, dw, db);
+  int chunks = (int)pm_cdiv(1024, Co * Ci);                       // ~1k workgroups in total
+  if (chunks > G) chunks = G;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(k_conv3x3_bwd_weight, dim3(Co * Ci, chunks), dim3(256), 0, (hipStream_t)stream, x, dy, G, Ci, Co,
+                     H, W, up4, dw, db);
   return pm_check_launch();
 }
 

@@ -122,14 +122,32 @@ __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restri
   const int* list = group_list + (grp == 0 ? 0 : N);
   const int64_t rows = (int64_t)cnt * PM_N_SLOTS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // PAD is the token of >= 10 of the 15 slots of every node: its rows are summed in registers per wave and
+  // hit the LDS row once, instead of serialising thousands of ds_add_f32 on one address.
+  const int pad = kind == 0 ? 130 : 98;
+  float2 pacc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // channels lane*2 + 128*j  (d/2 <= 512)
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const int n = list[row / PM_N_SLOTS], s = (int)(row % PM_N_SLOTS) + 1;
     const int v = tok[((int64_t)n * 16 + s) * 2 + kind];
     const float* src = dX + ((int64_t)n * PM_N_SLOTS + (s - 1)) * d + kind * dh;
-    for (int c = lane; c < dh; c += 64) {
-      const float g = src[c];
-      if (g != 0.f) atomicAdd(&sS[v * dh + c], g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane * 2 + 128 * j;
+      if (c >= dh) break;
+      const float2 g = *reinterpret_cast<const float2*>(src + c);
+      if (v == pad) { pacc[j].x += g.x; pacc[j].y += g.y; }
+      else {
+        if (g.x != 0.f) atomicAdd(&sS[v * dh + c], g.x);
+        if (g.y != 0.f) atomicAdd(&sS[v * dh + c + 1], g.y);
+      }
     }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = lane * 2 + 128 * j;
+    if (c >= dh) break;
+    if (pacc[j].x != 0.f) atomicAdd(&sS[pad * dh + c], pacc[j].x);
+    if (pacc[j].y != 0.f) atomicAdd(&sS[pad * dh + c + 1], pacc[j].y);
   }
   __syncthreads();
   float* out = S + (int64_t)t * EMB_V * dh;

@@ -5,111 +5,139 @@
 // bf16 MFMA cannot hold the 1e-4 parity bar through 16 BatchNorm'd layers, so operands stay fp32
 // (157 TFLOP/s peak, MI355X_MICROARCH §Matrix cores).
 //
-// Tiling: 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (128x128 or 64x64), BK = 16.
-// LDS tiles are k-major ([BK][BM+4]) so an MFMA operand read is 32 consecutive floats per half-wave
-// (conflict-free ds_read_b32); global loads are staged through registers one tile ahead
-// (double-buffered LDS, one barrier per k-tile).  The gathered dimension may be indirect
-// (row map) for the drum / non-drum routing of the content decoder (model.py:552-576).
+// One kernel template, four tile configurations (all 64-lane waves, 32x32 MFMA tiles per wave):
+//   C0  64x64x16   4 waves (2x2)  small problems
+//   C1 128x128x16  4 waves (2x2)  wide outputs (N > 256): many tiles per CU
+//   C2  64x256x32  8 waves (2x4)  N <= 256 (every GCL / chord GEMM): the streamed operand (the node
+//                                 dimension, 16 k rows) is read from HBM exactly once and 8 waves
+//                                 per CU keep 2 waves per SIMD with only ~256 workgroups
+//   C3 256x64x32   8 waves (4x2)  the transposed situation (M <= 256, wide N: weight gradients)
+// LDS tiles are k-major so an MFMA operand read is 32 consecutive floats per half-wave
+// (conflict-free ds_read_b32); global loads are staged through registers one k-tile ahead
+// (double-buffered LDS, one barrier per k-tile).  Workgroup ids are remapped so that tiles sharing
+// a row panel run on the same XCD (shared L2).  The gathered dimension may be indirect (row map +
+// device-side count) for the drum / non-drum routing of the content decoder (model.py:552-576).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define GEMM_BK 16
-#define GEMM_THREADS 256
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias;
   const int32_t* rowmap; const int32_t* dyn_entries;
-  int M, N, K, lda, ldb, ldc, rpe, flags, kper;
+  int M, N, K, lda, ldb, ldc, rpe, flags, kper, ntm, ntn;
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
   return map ? (int64_t)map[r / rpe] * rpe + (r % rpe) : (int64_t)r;
 }
 
-// Stage one operand tile (R rows x BK k) into registers.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define PM_OOB ((int)0x80000000)     // byte offset >= num_records: the buffer load returns 0, no branch, no fault
+
+// Stage one operand tile (R rows x BK k) through registers into its k-major LDS image S[k][r].
 //  KC = true : stored k-contiguous, element (r,k) at P[row(r)*ld + k]   (A when !transA, B when transB)
 //  KC = false: stored r-contiguous, element (r,k) at P[row(k)*ld + r]   (A when transA, B when !transB)
-// `gather` says whether the row map applies to this operand's stored rows.
-template <int R, bool KC, bool VEC>
+// Loads are raw buffer loads (32-bit byte offsets, hardware range check): out-of-tile elements get the
+// offset PM_OOB and read as 0, so the k-loop has no predicated branches and no early s_waitcnt, and the
+// prefetch of tile t+1 stays in flight behind the MFMAs of tile t.
+template <int R, int BK, int THREADS, bool KC, bool VEC>
 struct TileStage {
-  static constexpr int NV = VEC ? (R * GEMM_BK / 4) / GEMM_THREADS : 0;
-  static constexpr int NS = VEC ? 0 : (R * GEMM_BK) / GEMM_THREADS;
-  float4 v[NV > 0 ? NV : 1];
-  float s[NS > 0 ? NS : 1];
+  static constexpr int NV = VEC ? (R * BK / 4) / THREADS : 0;
+  static constexpr int NS = VEC ? 0 : (R * BK) / THREADS;
+  static constexpr int NE = VEC ? NV : NS;
+  static constexpr int LD = KC ? R + 1 : R + 4;      // KC: transposing scalar stores spread over banks; else 16-B rows
+  static_assert(!VEC || (R * BK / 4) % THREADS == 0, "tile does not divide over the workgroup");
+  u32x4 v[NV > 0 ? NV : 1];
+  unsigned s[NS > 0 ? NS : 1];
+  int base[NE];                                       // tile-invariant byte offset of each element, or PM_OOB
+  __amdgpu_buffer_rsrc_t rsrc;
+  const int32_t* map;
+  int rpe, ld;
 
-  __device__ inline void load(const float* __restrict__ P, int ld, int r0, int rmax, int k0, int kmax,
-                              const int32_t* map, int rpe) {
-    if (VEC) {
+  __device__ inline void init(const float* P, int ld_, int r0, int rmax, const int32_t* map_, int rpe_) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, PM_OOB, 0x00020000);
+    map = map_; rpe = rpe_; ld = ld_;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int f = threadIdx.x + j * GEMM_THREADS;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KC) {
-          const int r = r0 + f / (GEMM_BK / 4), k = k0 + (f % (GEMM_BK / 4)) * 4;
-          if (r < rmax && k < kmax) t = *reinterpret_cast<const float4*>(P + map_row(map, rpe, r) * ld + k);
-        } else {
-          const int k = k0 + f / (R / 4), r = r0 + (f % (R / 4)) * 4;
-          if (r < rmax && k < kmax) t = *reinterpret_cast<const float4*>(P + map_row(map, rpe, k) * ld + r);
-        }
-        v[j] = t;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int e = threadIdx.x + j * GEMM_THREADS;
-        float t = 0.f;
-        if (KC) {
-          const int r = r0 + e / GEMM_BK, k = k0 + e % GEMM_BK;
-          if (r < rmax && k < kmax) t = P[map_row(map, rpe, r) * ld + k];
-        } else {
-          const int k = k0 + e / R, r = r0 + e % R;
-          if (r < rmax && k < kmax) t = P[map_row(map, rpe, k) * ld + r];
-        }
-        s[j] = t;
+    for (int j = 0; j < NE; ++j) {
+      const int f = threadIdx.x + j * THREADS;
+      if (KC) {                                        // row fixed per thread: resolve the row map once
+        const int r = r0 + (VEC ? f / (BK / 4) : f / BK);
+        const int kb = VEC ? (f % (BK / 4)) * 16 : (f % BK) * 4;
+        base[j] = r < rmax ? (int)(map_row(map, rpe, r) * ld * 4) + kb : PM_OOB;
+      } else {
+        const int r = r0 + (VEC ? (f % (R / 4)) * 4 : f % R);
+        base[j] = r < rmax ? r * 4 : PM_OOB;
       }
     }
   }
-  // LDS image: S[k][r], leading dimension R + 4
+  __device__ inline void load(int k0, int kmax) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int f = threadIdx.x + j * THREADS;
+      int off;
+      if (KC) {
+        const int k = k0 + (VEC ? (f % (BK / 4)) * 4 : f % BK);
+        off = (k < kmax && base[j] >= 0) ? base[j] + k0 * 4 : PM_OOB;
+      } else {
+        const int k = k0 + (VEC ? f / (R / 4) : f / R);
+        off = PM_OOB;
+        if (k < kmax && base[j] >= 0) off = base[j] + (int)(map_row(map, rpe, k) * ld * 4);
+      }
+      if (VEC) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      else s[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+    }
+  }
   __device__ inline void store(float* __restrict__ S) const {
-    constexpr int LD = R + 4;
     if (VEC) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const int f = threadIdx.x + j * GEMM_THREADS;
+        const int f = threadIdx.x + j * THREADS;
         if (KC) {
-          const int r = f / (GEMM_BK / 4), k = (f % (GEMM_BK / 4)) * 4;
-          S[(k + 0) * LD + r] = v[j].x; S[(k + 1) * LD + r] = v[j].y;
-          S[(k + 2) * LD + r] = v[j].z; S[(k + 3) * LD + r] = v[j].w;
+          const int r = f / (BK / 4), k = (f % (BK / 4)) * 4;
+          S[(k + 0) * LD + r] = __uint_as_float(v[j].x); S[(k + 1) * LD + r] = __uint_as_float(v[j].y);
+          S[(k + 2) * LD + r] = __uint_as_float(v[j].z); S[(k + 3) * LD + r] = __uint_as_float(v[j].w);
         } else {
           const int k = f / (R / 4), r = (f % (R / 4)) * 4;
-          *reinterpret_cast<float4*>(S + k * LD + r) = v[j];
+          *reinterpret_cast<u32x4*>(S + k * LD + r) = v[j];
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        const int e = threadIdx.x + j * GEMM_THREADS;
-        if (KC) S[(e % GEMM_BK) * LD + e / GEMM_BK] = s[j];
-        else S[(e / R) * LD + e % R] = s[j];
+        const int e = threadIdx.x + j * THREADS;
+        if (KC) S[(e % BK) * LD + e / BK] = __uint_as_float(s[j]);
+        else S[(e / R) * LD + e % R] = __uint_as_float(s[j]);
       }
     }
   }
 };
 
-template <int BM, int BN, bool TA, bool TB, bool VA, bool VB>
-__global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[2][GEMM_BK * LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GEMM_BK * LDB_S];
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB>
+__global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
+  constexpr int THREADS = 64 * WVM * WVN;
+  constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
+  using StA = TileStage<BM, BK, THREADS, !TA, VA>;
+  using StB = TileStage<BN, BK, THREADS, TB, VB>;
+  constexpr int LDA_S = StA::LD, LDB_S = StB::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const As0 = smem;                              // two A buffers, then two B buffers
+  float* const Bs0 = smem + 2 * BK * LDA_S;
 
   int M = g.M, K = g.K;
   if (g.dyn_entries) {                       // data-dependent size of the gathered dimension, read on device
     const int n = *g.dyn_entries * g.rpe;
     if (TA) K = n < K ? n : K; else M = n < M ? n : M;
   }
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
+  // contiguous run of tiles; tiles of one row panel (n fastest) then share the panel through one L2.
+  const int nwg = g.ntm * g.ntn;
+  int t = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN;
   if (m0 >= M) return;
   const int kbeg = blockIdx.z * g.kper;
   int kend = kbeg + g.kper;
@@ -117,15 +145,15 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   if (kbeg >= kend) return;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WVN, wc = wave % WVN;
   const int li = lane & 31, lh = lane >> 5;
 
   // !TA: A k-contiguous, rows = M (gathered).  TA: A r-contiguous, stored rows = K (gathered).
   // TB : B k-contiguous (stored [N,K]), never gathered.  !TB: B stored [K,N]; its K rows are gathered iff TA.
   const int32_t* mapA = g.rowmap;
   const int32_t* mapB = (TA && !TB) ? g.rowmap : nullptr;
-  TileStage<BM, !TA, VA> sa;
-  TileStage<BN, TB, VB> sb;
+  StA sa;
+  StB sb;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -135,37 +163,49 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  sa.load(g.A, g.lda, m0, M, kbeg, kend, mapA, g.rpe);
-  sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, mapB, g.rpe);
-  sa.store(As[0]);
-  sb.store(Bs[0]);
+  sa.init(g.A, g.lda, m0, M, mapA, g.rpe);
+  sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe);
+  sa.load(kbeg, kend);
+  sb.load(kbeg, kend);
+  sa.store(As0);
+  sb.store(Bs0);
   __syncthreads();
 
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-    const bool more = k0 + GEMM_BK < kend;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
     if (more) {
-      sa.load(g.A, g.lda, m0, M, k0 + GEMM_BK, kend, mapA, g.rpe);
-      sb.load(g.B, g.ldb, n0, g.N, k0 + GEMM_BK, kend, mapB, g.rpe);
+      sa.load(k0 + BK, kend);
+      sb.load(k0 + BK, kend);
     }
-    const float* as = As[buf] + wr * WM + li;
-    const float* bs = Bs[buf] + wc * WN + li;
+    const float* as = As0 + buf * (BK * LDA_S) + wr * WM + li + lh * LDA_S;
+    const float* bs = Bs0 + buf * (BK * LDB_S) + wc * WN + li + lh * LDB_S;
+    // fragments of step kk+2 are read while the MFMAs of step kk run (explicit LDS software pipeline)
+    float a[2][TM], b[2][TN];
 #pragma unroll
-    for (int kk = 0; kk < GEMM_BK; kk += 2) {
-      float a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(kk + lh) * LDA_S + i * 32];
+    for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + lh) * LDB_S + j * 32];
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[nxt][i] = as[(kk + 2) * LDA_S + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[nxt][j] = bs[(kk + 2) * LDB_S + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
-      sa.store(As[buf ^ 1]);
-      sb.store(Bs[buf ^ 1]);
+      sa.store(As0 + (buf ^ 1) * (BK * LDA_S));
+      sb.store(Bs0 + (buf ^ 1) * (BK * LDB_S));
     }
     __syncthreads();
     buf ^= 1;
@@ -201,19 +241,52 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
   }
 }
 
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB>
+static void launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
+  using StA = TileStage<BM, BK, 64 * WVM * WVN, !TA, VA>;
+  using StB = TileStage<BN, BK, 64 * WVM * WVN, TB, VB>;
+  const size_t lds = sizeof(float) * 2 * BK * (StA::LD + StB::LD);
+  auto kern = k_gemm<BM, BN, BK, WVM, WVN, TA, TB, VA, VB>;
+  static bool attr_done = false;             // > 64 KiB of dynamic LDS needs the attribute (once per instantiation)
+  if (lds > 64 * 1024 && !attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, g);
+}
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB>
 static void launch_v(bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
-  if (va && vb) hipLaunchKernelGGL((k_gemm<BM, BN, TA, TB, true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
-  else if (va) hipLaunchKernelGGL((k_gemm<BM, BN, TA, TB, true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-  else if (vb) hipLaunchKernelGGL((k_gemm<BM, BN, TA, TB, false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
-  else hipLaunchKernelGGL((k_gemm<BM, BN, TA, TB, false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+  if (va && vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true>(grid, st, g);
+  else if (va) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, false>(grid, st, g);
+  else if (vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, true>(grid, st, g);
+  else launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, false>(grid, st, g);
 }
-template <int BM, int BN>
+template <int BM, int BN, int BK, int WVM, int WVN>
 static void launch_t(int ta, int tb, bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
-  if (!ta && !tb) launch_v<BM, BN, false, false>(va, vb, grid, st, g);
-  else if (!ta && tb) launch_v<BM, BN, false, true>(va, vb, grid, st, g);
-  else launch_v<BM, BN, true, false>(va, vb, grid, st, g);
+  if (!ta && !tb) launch_v<BM, BN, BK, WVM, WVN, false, false>(va, vb, grid, st, g);
+  else if (!ta && tb) launch_v<BM, BN, BK, WVM, WVN, false, true>(va, vb, grid, st, g);
+  else launch_v<BM, BN, BK, WVM, WVN, true, false>(va, vb, grid, st, g);
 }
+
+static const int CFG_BM[4] = {64, 128, 64, 256}, CFG_BN[4] = {64, 128, 256, 64}, CFG_BK[4] = {16, 16, 32, 32};
+
+// Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
+static int g_forced_cfg = -1;
+extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && cfg <= 3) ? cfg : -1; return PM_OK; }
+static int pick_config(int transA, int M, int N, int K) {
+  if (g_forced_cfg >= 0) return g_forced_cfg;
+  // Measured on MI355X (tools/bench_gemm.py, shapes of the training step, interleaved A/B in one process):
+  //  - NN / NT (the node dimension is M): 64x64 tiles win or tie everywhere (102-113 TFLOP/s): 4 workgroups per
+  //    CU = 4 waves per SIMD hide the LDS/barrier latency; the panels they re-read sit in L2 / Infinity Cache.
+  //  - TN (weight gradients, K = node dimension, split-K): 128x128 tiles (100-108 TFLOP/s): both operands are
+  //    staged with plain 16-byte LDS rows and 4x fewer atomics leave the workgroup.
+  //  The 8-wave 64x256 / 256x64 shapes (operand streamed exactly once) are 5-20 % slower at these sizes.
+  (void)K;
+  if (transA) return ((int64_t)M * N >= 128 * 128 * 2) ? 1 : 0;
+  return 0;
+}
+
+extern "C" int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K) { return pick_config(transA, M, N, K); }
 
 extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
                            const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
@@ -222,32 +295,40 @@ extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return PM_E_INVALID;
   if (transA && transB) return PM_E_UNSUPPORTED;
   if ((rowmap || dyn_entries) && rows_per_entry <= 0) return PM_E_INVALID;
+  // operands are addressed with 32-bit byte offsets (buffer loads): each must span < 2 GiB
+  if (!rowmap && ((int64_t)(transA ? K : M) * lda * 4 >= ((int64_t)1 << 31) ||
+                  (int64_t)(transB ? N : K) * ldb * 4 >= ((int64_t)1 << 31))) return PM_E_UNSUPPORTED;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.rowmap = rowmap; g.dyn_entries = dyn_entries;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.rpe = rows_per_entry > 0 ? rows_per_entry : 1; g.flags = flags;
-  const bool small = (pm_cdiv(M, 128) * pm_cdiv(N, 128)) < 192;       // < ~1 block per CU: use 64x64 tiles
-  const int BM = small ? 64 : 128, BN = BM;
-  const int64_t tiles = pm_cdiv(M, BM) * pm_cdiv(N, BN);
+  const int cfg = pick_config(transA, M, N, K);
+  const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
+  g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
+  const int64_t tiles = (int64_t)g.ntm * g.ntn;
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
-    if (transA && tiles < 512) {
-      split_k = (int)(1024 / tiles);
-      const int maxs = (int)pm_cdiv(K, 8 * GEMM_BK);
+    if (transA && tiles < 384) {
+      split_k = (int)(512 / tiles);
+      const int maxs = (int)pm_cdiv(K, 8 * BK);
       if (split_k > maxs) split_k = maxs;
       if (split_k < 1) split_k = 1;
     }
   }
   if (split_k > 1 && ((flags & PM_GEMM_RELU) || !(flags & PM_GEMM_ACCUM))) return PM_E_INVALID;  // needs += semantics
-  int kper = (int)pm_cdiv(pm_cdiv(K, split_k), GEMM_BK) * GEMM_BK;
+  const int kper = (int)pm_cdiv(pm_cdiv(K, split_k), BK) * BK;
   g.kper = kper;
   split_k = (int)pm_cdiv(K, kper);
   // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
   const bool va = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0);
   const bool vb = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0);
-  dim3 grid((unsigned)pm_cdiv(N, BN), (unsigned)pm_cdiv(M, BM), (unsigned)split_k);
+  dim3 grid((unsigned)tiles, 1, (unsigned)split_k);
   hipStream_t st = (hipStream_t)stream;
-  if (small) launch_t<64, 64>(transA, transB, va, vb, grid, st, g);
-  else launch_t<128, 128>(transA, transB, va, vb, grid, st, g);
+  switch (cfg) {
+    case 0: launch_t<64, 64, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 1: launch_t<128, 128, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 2: launch_t<64, 256, 32, 2, 4>(transA, transB, va, vb, grid, st, g); break;
+    default: launch_t<256, 64, 32, 4, 2>(transA, transB, va, vb, grid, st, g); break;
+  }
   return pm_check_launch();
 }

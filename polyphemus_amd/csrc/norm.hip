@@ -8,34 +8,37 @@
 // fp64 so that var = E[x^2] - E[x]^2 keeps fp32 parity.
 #include "common.h"
 
-#define BN_MAX_CHUNKS 64
+#define BN_MAX_CHUNKS 256
+#define BN_NACC 3          /* accumulators per column: stats use 2, backward uses 3 */
 
-// MODE 0: (x, x*x)      MODE 1: (du, du*xhat) with du = dy * [relu ? bn(x) > 0 : 1]
+// MODE 0: (x, x*x)      MODE 1: (du, du*xhat, xhat) with du = dy * [relu ? bn(x) > 0 : 1]
 struct BnCtx {
   const float* mean; const float* var; const float* gamma; const float* beta; float eps; int relu;
 };
 template <int MODE>
-__device__ static inline void bn_pair(float xv, float dyv, float m, float rstd, float ga, float be, int relu,
-                                      double& a, double& b) {
+__device__ static inline void bn_acc(float xv, float dyv, float m, float rstd, float ga, float be, int relu,
+                                     double& a, double& b, double& c) {
   if (MODE == 0) { a += (double)xv; b += (double)xv * (double)xv; }
   else {
     const float xh = (xv - m) * rstd;
     float du = dyv;
     if (relu && !(xh * ga + be > 0.f)) du = 0.f;
-    a += (double)du; b += (double)du * (double)xh;
+    a += (double)du; b += (double)du * (double)xh; c += (double)xh;
   }
 }
 
-// fast path: I == 1, C % 4 == 0.  grid = (ceil(C/256), nchunk), 4 waves split the rows of a chunk.
+// fast path: I == 1, C % 4 == 0.  grid = (ceil(C/256), nchunk); the 4 waves of a workgroup split the rows of
+// its chunk, lanes own 4 consecutive columns (float4 loads, 1 KiB per wave-instruction at C = 256).
+// partial layout: [chunk][BN_NACC][C] doubles.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_colreduce_rows(const float* __restrict__ x, const float* __restrict__ dy,
                                                         int O, int C, BnCtx ctx, int rows_per_chunk,
                                                         double* __restrict__ partial) {
-  __shared__ double sh[4][64][8];
+  __shared__ double sh[4][64][12];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
   const bool ok = c < C;
-  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float m[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
   if (MODE == 1 && ok) {
 #pragma unroll
@@ -52,55 +55,74 @@ __global__ void __launch_bounds__(256) k_colreduce_rows(const float* __restrict_
       const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * C + c);
       float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (MODE == 1) dv = *reinterpret_cast<const float4*>(dy + (int64_t)r * C + c);
-      bn_pair<MODE>(xv.x, dv.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4]);
-      bn_pair<MODE>(xv.y, dv.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5]);
-      bn_pair<MODE>(xv.z, dv.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6]);
-      bn_pair<MODE>(xv.w, dv.w, m[3], rs[3], ga[3], be[3], ctx.relu, acc[3], acc[7]);
+      bn_acc<MODE>(xv.x, dv.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4], acc[8]);
+      bn_acc<MODE>(xv.y, dv.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5], acc[9]);
+      bn_acc<MODE>(xv.z, dv.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6], acc[10]);
+      bn_acc<MODE>(xv.w, dv.w, m[3], rs[3], ga[3], be[3], ctx.relu, acc[3], acc[7], acc[11]);
     }
   }
+  constexpr int NA = MODE == 0 ? 8 : 12;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) sh[wave][lane][j] = acc[j];
+  for (int j = 0; j < NA; ++j) sh[wave][lane][j] = acc[j];
   __syncthreads();
   if (wave == 0 && ok) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NA; ++j) {
       const double s = sh[0][lane][j] + sh[1][lane][j] + sh[2][lane][j] + sh[3][lane][j];
-      partial[((int64_t)blockIdx.y * 2 + (j >> 2)) * C + c + (j & 3)] = s;
+      partial[((int64_t)blockIdx.y * BN_NACC + (j >> 2)) * C + c + (j & 3)] = s;
     }
   }
 }
 
-// generic path: one workgroup per channel, any I (NCHW) or C (e.g. the 1-channel gate).
+// generic path: any I (NCHW) or C (e.g. the 1-channel gate).  grid = (C, nchunk): a workgroup reduces one slice of
+// the (o, i) index space of one channel.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_colreduce_chan(const float* __restrict__ x, const float* __restrict__ dy,
-                                                        int O, int C, int I, BnCtx ctx, double* __restrict__ partial) {
-  __shared__ double sh[2][4];
+                                                        int O, int C, int I, BnCtx ctx, int64_t per_chunk,
+                                                        double* __restrict__ partial) {
+  __shared__ double sh[3][4];
   const int c = blockIdx.x;
   float m = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
   if (MODE == 1) { m = ctx.mean[c]; rs = rsqrtf(ctx.var[c] + ctx.eps); ga = ctx.gamma[c]; be = ctx.beta[c]; }
-  double a = 0, b = 0;
+  double a = 0, b = 0, cc = 0;
   const int64_t total = (int64_t)O * I;
-  for (int64_t j = threadIdx.x; j < total; j += blockDim.x) {
+  const int64_t j0 = (int64_t)blockIdx.y * per_chunk;
+  int64_t j1 = j0 + per_chunk;
+  if (j1 > total) j1 = total;
+  for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
     const int64_t idx = ((j / I) * C + c) * I + (j % I);
-    bn_pair<MODE>(x[idx], MODE == 1 ? dy[idx] : 0.f, m, rs, ga, be, ctx.relu, a, b);
+    bn_acc<MODE>(x[idx], MODE == 1 ? dy[idx] : 0.f, m, rs, ga, be, ctx.relu, a, b, cc);
   }
-  a = pm_wave_sum_d(a); b = pm_wave_sum_d(b);
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  a = pm_wave_sum_d(a); b = pm_wave_sum_d(b); cc = pm_wave_sum_d(cc);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; sh[2][threadIdx.x >> 6] = cc; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    partial[c] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    partial[C + c] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-  }
+  if (threadIdx.x < 3)
+    partial[((int64_t)blockIdx.y * BN_NACC + threadIdx.x) * C + c] =
+        sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
-__global__ void k_bn_finalize_stats(const double* __restrict__ partial, int nchunk, int C, double count, float* mean,
-                                    float* var, float* rmean, float* rvar, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0;
-  for (int k = 0; k < nchunk; ++k) { s0 += partial[((int64_t)k * 2) * C + c]; s1 += partial[((int64_t)k * 2 + 1) * C + c]; }
-  const double mu = s0 / count;
-  double v = s1 / count - mu * mu;
+// Sum the chunk partials of 64 columns with 4 waves (wave w takes chunks w, w+4, ...), then finish.
+__device__ static inline void sum_chunks(const double* __restrict__ partial, int nchunk, int C, int c, int nacc,
+                                         double (*sh)[64][BN_NACC], double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s[BN_NACC] = {0, 0, 0};
+  if (c < C)
+    for (int k = wave; k < nchunk; k += 4)
+      for (int a = 0; a < nacc; ++a) s[a] += partial[((int64_t)k * BN_NACC + a) * C + c];
+  for (int a = 0; a < BN_NACC; ++a) sh[wave][lane][a] = s[a];
+  __syncthreads();
+  for (int a = 0; a < BN_NACC; ++a) out[a] = sh[0][lane][a] + sh[1][lane][a] + sh[2][lane][a] + sh[3][lane][a];
+}
+__global__ void __launch_bounds__(256) k_bn_finalize_stats(const double* __restrict__ partial, int nchunk, int C,
+                                                           double count, float* mean, float* var, float* rmean,
+                                                           float* rvar, float momentum) {
+  __shared__ double sh[4][64][BN_NACC];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s[BN_NACC];
+  sum_chunks(partial, nchunk, C, c, 2, sh, s);
+  if (threadIdx.x >= 64 || c >= C) return;
+  const double mu = s[0] / count;
+  double v = s[1] / count - mu * mu;
   if (v < 0) v = 0;
   mean[c] = (float)mu;
   var[c] = (float)v;
@@ -110,23 +132,33 @@ __global__ void k_bn_finalize_stats(const double* __restrict__ partial, int nchu
     rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
   }
 }
-__global__ void k_bn_finalize_bwd(const double* __restrict__ partial, int nchunk, int C, double count, float* dgamma,
-                                  float* dbeta, double* means) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0;
-  for (int k = 0; k < nchunk; ++k) { s0 += partial[((int64_t)k * 2) * C + c]; s1 += partial[((int64_t)k * 2 + 1) * C + c]; }
-  if (dbeta) dbeta[c] += (float)s0;
-  if (dgamma) dgamma[c] += (float)s1;
-  means[c] = s0 / count;
-  means[C + c] = s1 / count;
+// dgamma += sum(du*xhat); dbeta += sum(du); means = the two batch means of the backward formula;
+// dbias_pre += sum_rows dx = gamma*rstd*(sum(du) - count*mean(du) - mean(du*xhat)*sum(xhat))   (the gradient of a bias
+// added in front of this BatchNorm: analytically zero, evaluated here in fp64 instead of a separate column-sum pass)
+__global__ void __launch_bounds__(256) k_bn_finalize_bwd(const double* __restrict__ partial, int nchunk, int C,
+                                                         double count, BnCtx ctx, float* dgamma, float* dbeta,
+                                                         float* dbias_pre, double* means) {
+  __shared__ double sh[4][64][BN_NACC];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s[BN_NACC];
+  sum_chunks(partial, nchunk, C, c, 3, sh, s);
+  if (threadIdx.x >= 64 || c >= C) return;
+  if (dbeta) dbeta[c] += (float)s[0];
+  if (dgamma) dgamma[c] += (float)s[1];
+  const double m0 = s[0] / count, m1 = s[1] / count;
+  means[c] = m0;
+  means[C + c] = m1;
+  if (dbias_pre) {
+    const double rstd = 1.0 / sqrt((double)ctx.var[c] + (double)ctx.eps);
+    dbias_pre[c] += (float)((double)ctx.gamma[c] * rstd * ((s[0] - count * m0) - m1 * s[2]));
+  }
 }
 
 template <int MODE>
 static int run_reduce(const float* x, const float* dy, int O, int C, int I, BnCtx ctx, double* partial, int* nchunk,
                       hipStream_t st) {
   if (I == 1 && (C % 4) == 0 && ((uintptr_t)x % 16) == 0 && (MODE == 0 || ((uintptr_t)dy % 16) == 0)) {
-    int nc = (int)pm_cdiv(O, 64);
+    int nc = (int)pm_cdiv(O, 32);
     if (nc > BN_MAX_CHUNKS) nc = BN_MAX_CHUNKS;
     if (nc < 1) nc = 1;
     const int rpc = (int)pm_cdiv(O, nc);
@@ -135,8 +167,15 @@ static int run_reduce(const float* x, const float* dy, int O, int C, int I, BnCt
                        partial);
     *nchunk = nc;
   } else {
-    hipLaunchKernelGGL((k_colreduce_chan<MODE>), dim3(C), dim3(256), 0, st, x, dy, O, C, I, ctx, partial);
-    *nchunk = 1;
+    const int64_t total = (int64_t)O * I;
+    int nc = (int)pm_cdiv(total, 2048);
+    const int cap = C >= 64 ? 8 : (C >= 8 ? 32 : BN_MAX_CHUNKS);
+    if (nc > cap) nc = cap;
+    if (nc < 1) nc = 1;
+    const int64_t per = pm_cdiv(total, nc);
+    nc = (int)pm_cdiv(total, per);
+    hipLaunchKernelGGL((k_colreduce_chan<MODE>), dim3(C, nc), dim3(256), 0, st, x, dy, O, C, I, ctx, per, partial);
+    *nchunk = nc;
   }
   return PM_OK;
 }
@@ -149,7 +188,7 @@ extern "C" int pm_bn_stats(const float* x, int32_t O, int32_t C, int32_t I, floa
   BnCtx ctx = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
   int nchunk = 1;
   run_reduce<0>(x, nullptr, O, C, I, ctx, scratch, &nchunk, st);
-  hipLaunchKernelGGL(k_bn_finalize_stats, dim3(pm_cdiv(C, 128)), dim3(128), 0, st, scratch, nchunk, C,
+  hipLaunchKernelGGL(k_bn_finalize_stats, dim3(pm_cdiv(C, 64)), dim3(256), 0, st, scratch, nchunk, C,
                      (double)O * (double)I, mean, var, running_mean, running_var, momentum);
   return pm_check_launch();
 }
@@ -217,16 +256,16 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
 }
 extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
                          const float* var, float eps, const float* gamma, const float* beta, int relu, float* dgamma,
-                         float* dbeta, float* dx, double* scratch, pm_stream_t stream) {
+                         float* dbeta, float* dbias_pre, float* dx, double* scratch, pm_stream_t stream) {
   if (!x || !dy || !mean || !var || !gamma || !beta || !dx || !scratch || O <= 0 || C <= 0 || I <= 0)
     return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   BnCtx ctx = {mean, var, gamma, beta, eps, relu};
   int nchunk = 1;
   run_reduce<1>(x, dy, O, C, I, ctx, scratch, &nchunk, st);
-  double* means = scratch + (int64_t)BN_MAX_CHUNKS * 2 * C;
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(pm_cdiv(C, 128)), dim3(128), 0, st, scratch, nchunk, C,
-                     (double)O * (double)I, dgamma, dbeta, means);
+  double* means = scratch + (int64_t)BN_MAX_CHUNKS * BN_NACC * C;
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(pm_cdiv(C, 64)), dim3(256), 0, st, scratch, nchunk, C,
+                     (double)O * (double)I, ctx, dgamma, dbeta, dbias_pre, means);
   const int64_t n = (int64_t)O * C * I;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n)), dim3(256), 0, st, x, dy, n, C, I, ctx, means, dx);
   return pm_check_launch();

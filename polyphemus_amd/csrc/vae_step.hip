@@ -1,0 +1,416 @@
+// vae_step.hip — the training step of the graph-VAE issued from C++ (no interpreter between launches).
+//
+// Reference: one iteration of PolyphemusTrainer.train (training.py:137-166) = VAE.forward
+// (model.py:665-678) + _losses (training.py:298-347) + backward.  The kernel sequence is the one of
+// polyphemus_amd/engine.py (the Python orchestration used by the autograd drop-in path); this file
+// is its native twin for the fused trainer: ~330 launches per step cost ~1 ms of host time here
+// against ~17 ms through Python/ctypes, which was the step's bottleneck once the kernels were fast.
+//
+// Activations are carved from a caller-provided arena (pure function of the shapes, so the same
+// arena is reused every step and the sequence is hipGraph-capturable).
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+struct Arena {
+  char* base; size_t cap, used; bool overflow;
+  void* take(size_t bytes) {
+    const size_t a = (used + 255) & ~size_t(255);
+    used = a + bytes;
+    if (!base) return nullptr;                 // measuring pass
+    if (used > cap) { overflow = true; return base; }
+    return base + a;
+  }
+  float* f(size_t n) { return (float*)take(n * sizeof(float)); }
+  double* dbl(size_t n) { return (double*)take(n * sizeof(double)); }
+};
+
+struct GcnSaved {
+  float* T; float* x[PM_MAX_LAYERS + 1]; float* A[PM_MAX_LAYERS]; float* h[PM_MAX_LAYERS];
+  float* mean[PM_MAX_LAYERS]; float* var[PM_MAX_LAYERS];
+  uint32_t seed, uid0; float p;
+};
+
+struct StepState {
+  uint64_t magic;
+  PmVaeLayout lay;
+  const float* P; float* Bf; float* G;
+  PmBatch bt; const int32_t* plan; const float* eps;
+  Arena ar;
+  double* bn_scratch; double* losses;
+  float beta; int fix_structure;
+  // encoder
+  float *c0, *a0, *m0, *v0, *p0, *c1, *a1, *m1, *v1, *h1, *h2, *zcat;
+  float *emb_stats, *X, *x0; GcnSaved eg; float *g, *gm, *gv, *alpha, *pooled;
+  float *m, *mm, *mv, *zg, *mu, *lv, *z;
+  // decoder
+  float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
+  // loss gradients
+  float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
+  int rc;
+};
+constexpr uint64_t kMagic = 0x504d5354455031ULL;
+
+struct Ctx {
+  StepState* s; hipStream_t st; int rc;
+  int N, E, Gn, B, d, nb, L;
+  const float* P; float* G; float* Bf;
+  void chk(int r) { if (r != PM_OK && rc == PM_OK) rc = r; }
+};
+
+// y[M, Nout] = x @ W^T + b      (x: leading dim lda, y: leading dim ldc)
+void lin(Ctx& c, const float* x, PmLin l, int M, int Nout, int Kin, float* y, bool relu, int lda = 0, int ldc = 0) {
+  c.chk(pm_gemm_f32(0, 1, M, Nout, Kin, x, lda ? lda : Kin, c.P + l.w, Kin, y, ldc ? ldc : Nout, c.P + l.b,
+                    relu ? PM_GEMM_RELU : 0, 1, nullptr, 0, nullptr, c.st));
+}
+// dW += dy^T x ; db += colsum(dy) ; dx = dy @ W
+void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, int Kin, float* dx, int lddy = 0,
+             int ldx = 0, int lddx = 0, bool want_bias = true) {
+  lddy = lddy ? lddy : Nout;
+  c.chk(pm_gemm_f32(1, 0, Nout, Kin, M, dy, lddy, x, ldx ? ldx : Kin, c.G + l.w, Kin, nullptr, PM_GEMM_ACCUM, 0,
+                    nullptr, 0, nullptr, c.st));
+  if (want_bias) c.chk(pm_colsum_acc(dy, M, Nout, lddy, c.G + l.b, c.st));
+  if (dx) c.chk(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr, 0, 1, nullptr,
+                            0, nullptr, c.st));
+}
+// training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
+void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
+            float* var) {
+  c.chk(pm_bn_stats(x, O, C, I, mean, var, c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.s->bn_scratch, c.st));
+  c.chk(pm_bn_apply(x, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, res, relu ? 1 : 0, y, c.st));
+}
+void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn bn, const float* mean, const float* var,
+            bool relu, float* dx, float* dbias_pre = nullptr) {
+  c.chk(pm_bn_bwd(x, dy, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, relu ? 1 : 0, c.G + bn.w, c.G + bn.b,
+                  dbias_pre, dx, c.s->bn_scratch, c.st));
+}
+
+// GCN.forward (model.py:190-208): L x { A = segreduce(x); h = A @ [W;root] + b; x' = x + relu(BN(h)) }
+float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t seed, uint32_t uid0, float p) {
+  Arena& ar = c.s->ar;
+  const int N = c.N, d = c.d;
+  sv.T = ar.f((size_t)PM_N_DIST * d);
+  sv.seed = seed; sv.uid0 = uid0; sv.p = p;
+  if (ar.base) c.chk(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
+  sv.x[0] = x0;
+  for (int i = 0; i < c.L; ++i) {
+    sv.A[i] = ar.f((size_t)N * 7 * d); sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
+    sv.mean[i] = ar.f(d); sv.var[i] = ar.f(d);
+    if (!ar.base) continue;
+    c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, sv.A[i], c.st));
+    c.chk(pm_gemm_f32(0, 0, N, d, 7 * d, sv.A[i], 7 * d, c.P + g.weight[i], d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr,
+                      0, nullptr, c.st));
+    bn_fwd(c, sv.h[i], N, d, 1, g.norm[i], true, sv.x[i], sv.x[i + 1], sv.mean[i], sv.var[i]);
+  }
+  return sv.x[c.L];
+}
+// returns d loss / d x0 ; dx_in is d loss / d x_L (overwritten scratch chain inside the arena)
+float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
+  Arena& ar = c.s->ar;
+  const int N = c.N, d = c.d;
+  float* dT = ar.f((size_t)PM_N_DIST * d);
+  float* dh = ar.f((size_t)N * d);
+  float* dA = ar.f((size_t)N * 7 * d);
+  float* dxa = ar.f((size_t)N * d);
+  float* dxb = ar.f((size_t)N * d);
+  hipMemsetAsync(dT, 0, sizeof(float) * PM_N_DIST * d, c.st);
+  for (int i = c.L - 1; i >= 0; --i) {
+    bn_bwd(c, sv.h[i], dx, N, d, 1, g.norm[i], sv.mean[i], sv.var[i], true, dh, c.G + g.bias[i]);
+    c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, c.P + g.weight[i], d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
+    c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, c.G + g.weight[i], d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0,
+                      nullptr, c.st));
+    float* out = (dx == dxa) ? dxb : dxa;
+    c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, out, dT, c.st));
+    dx = out;
+  }
+  c.chk(pm_edge_table_bwd(dT, d, c.G + g.nn_w, c.G + g.nn_b, c.st));
+  return dx;
+}
+
+Ctx make_ctx(StepState* s, hipStream_t st) {
+  Ctx c;
+  c.s = s; c.st = st; c.rc = PM_OK;
+  c.N = s->bt.N; c.E = s->bt.E; c.Gn = s->bt.G; c.B = s->bt.B;
+  c.d = s->lay.d; c.nb = s->lay.n_bars; c.L = s->lay.n_layers;
+  c.P = s->P; c.G = s->G; c.Bf = s->Bf;
+  return c;
+}
+
+// The forward pass + losses; with ar.base == nullptr it only measures the arena.
+void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
+  StepState& s = *c.s;
+  Arena& ar = s.ar;
+  const PmVaeLayout& Y = s.lay;
+  const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
+  const bool run = ar.base != nullptr;
+  PmPlanView pv;
+  if (run) pv = pm_plan_view(s.plan, N, c.E, Gn);
+  s.bn_scratch = ar.dbl((size_t)PM_BN_SCRATCH(2 * d > 16 ? 2 * d : 16));
+  // ---------------- structure encoder (model.py:211-256,434-445)
+  s.zcat = ar.f((size_t)B * 2 * d);
+  s.c0 = ar.f((size_t)Gn * 8 * 128); s.a0 = ar.f((size_t)Gn * 8 * 128); s.m0 = ar.f(8); s.v0 = ar.f(8);
+  s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
+  s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.f((size_t)Gn * d);
+  if (run) {
+    c.chk(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
+    bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
+    c.chk(pm_maxpool4_fwd(s.a0, (int64_t)Gn * 8 * 32, s.p0, c.st));
+    c.chk(pm_conv3x3_fwd(s.p0, c.P + Y.enc_conv4.w, c.P + Y.enc_conv4.b, Gn, 8, 16, 4, 8, 0, s.c1, c.st));
+    bn_fwd(c, s.c1, Gn, 16, 32, Y.enc_bn5, true, nullptr, s.a1, s.m1, s.v1);
+    lin(c, s.a1, Y.enc_lin1, Gn, d, 512, s.h1, true);
+    lin(c, s.h1, Y.enc_lin4, Gn, d, d, s.h2, false);
+    lin(c, s.h2, Y.enc_s_bars, B, d, nb * d, s.zcat + d, false, nb * d, 2 * d);           // z_s = zcat[:, d:]
+  }
+  // ---------------- content encoder (model.py:344-417)
+  float* tables = ar.f((size_t)4 * PM_N_PITCH * dh);
+  s.emb_stats = ar.f((size_t)4 * 2 * dh);
+  s.X = ar.f((size_t)N * PM_N_SLOTS * d);
+  s.x0 = ar.f((size_t)N * d);
+  if (run) {
+    c.chk(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
+                          c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_d.b,
+                          c.P + Y.enc_bn_nd.w, c.P + Y.enc_bn_nd.b, c.P + Y.enc_bn_dur.w, c.P + Y.enc_bn_dur.b,
+                          c.Bf + Y.enc_bn_d.rm, c.Bf + Y.enc_bn_d.rv, c.Bf + Y.enc_bn_nd.rm, c.Bf + Y.enc_bn_nd.rv,
+                          c.Bf + Y.enc_bn_dur.rm, c.Bf + Y.enc_bn_dur.rv, pv.tok_hist, d, 1, 1e-5f, 0.1f, tables,
+                          s.emb_stats, c.st));
+    c.chk(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, s.X, c.st));
+    lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
+  }
+  float* xL = gcn_forward(c, s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
+  s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);
+  if (run) {
+    c.chk(pm_gate_fwd(xL, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
+    c.chk(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, s.bn_scratch, c.st));
+    c.chk(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
+                          s.alpha, s.pooled, c.st));
+    lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);            // z_c = zcat[:, :d]
+  }
+  // ---------------- merge + heads (model.py:472-481), reparametrisation (model.py:671-673)
+  s.m = ar.f((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
+  s.mu = ar.f((size_t)B * d); s.lv = ar.f((size_t)B * d); s.z = ar.f((size_t)B * d);
+  if (run) {
+    lin(c, s.zcat, Y.enc_merge, B, d, 2 * d, s.m, false);
+    bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
+    lin(c, s.zg, Y.enc_mu, B, d, d, s.mu, false);
+    lin(c, s.zg, Y.enc_lv, B, d, d, s.lv, false);
+    c.chk(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
+  }
+  // ---------------- decoder (model.py:634-655)
+  s.zd = ar.f((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
+  s.sb = ar.f((size_t)Gn * d); s.u1 = ar.f((size_t)Gn * d); s.u2 = ar.f((size_t)Gn * 512);
+  s.c2 = ar.f((size_t)Gn * 8 * 128); s.a2 = ar.f((size_t)Gn * 8 * 128); s.m2 = ar.f(8); s.v2 = ar.f(8);
+  s.s_logits = ar.f((size_t)Gn * 128); s.cb = ar.f((size_t)Gn * d);
+  float* xd0 = ar.f((size_t)N * d);
+  if (run) {
+    lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
+    bn_fwd(c, s.zd, B, 2 * d, 1, Y.dec_bn, true, nullptr, s.zr, s.dm, s.dv);
+    lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                      // A = zr[:, :d]
+    lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
+    lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
+    c.chk(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
+    bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
+    c.chk(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
+    lin(c, s.zr + d, Y.dec_c_bars, B, nb * d, d, s.cb, false, 2 * d, 0);                  // A = zr[:, d:]
+    c.chk(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
+  }
+  float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
+  const int64_t R = (int64_t)N * PM_N_SLOTS;
+  s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
+  s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
+  s.dmu = ar.f((size_t)B * d); s.dlv = ar.f((size_t)B * d);
+  if (run) {
+    lin(c, xdL, Y.dec_chord, N, PM_N_SLOTS * d, d, s.H, false);
+    // duration logits for every (node, slot) row; pitch logits per drum / non-drum node list (model.py:561-576)
+    c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
+                      c.P + Y.dec_dur.b, 0, 1, nullptr, 0, nullptr, c.st));
+    c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_d.w, dh, s.c_logits, PM_N_TOK,
+                      c.P + Y.dec_pitch_d.b, 0, 1, pv.group_list, PM_N_SLOTS, pv.group_cnt, c.st));
+    c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_nd.w, dh, s.c_logits, PM_N_TOK,
+                      c.P + Y.dec_pitch_nd.b, 0, 1, pv.group_list + N, PM_N_SLOTS, pv.group_cnt + 1, c.st));
+    // ---------------- losses (training.py:298-347) and their gradients w.r.t. the model outputs
+    c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, N, 1.0f, s.dc_logits, s.losses, c.st));
+    hipMemsetAsync(s.dmu, 0, sizeof(float) * B * d, c.st);
+    hipMemsetAsync(s.dlv, 0, sizeof(float) * B * d, c.st);
+    c.chk(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
+    if (s.fix_structure)
+      c.chk(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
+    else      // training.py:307 evaluates the BCE on the target itself: a constant, no gradient (SURVEY B-1)
+      c.chk(pm_bce_logits(s.bt.s_tensor, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, nullptr, s.losses, c.st));
+  }
+}
+
+void backward_decoder(Ctx& c) {
+  StepState& s = *c.s;
+  Arena& ar = s.ar;
+  const PmVaeLayout& Y = s.lay;
+  const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
+  PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
+  const int64_t R = (int64_t)N * PM_N_SLOTS;
+  float* dzr = ar.f((size_t)B * 2 * d);
+  hipMemsetAsync(dzr, 0, sizeof(float) * B * 2 * d, c.st);
+  // ---- content decoder
+  float* dH = ar.f((size_t)R * d);
+  c.chk(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
+                    nullptr, 0, 1, nullptr, 0, nullptr, c.st));
+  c.chk(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
+                    nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
+  c.chk(pm_colsum_acc(s.dc_logits + PM_N_PITCH, (int)R, PM_N_DUR, PM_N_TOK, c.G + Y.dec_dur.b, c.st));
+  const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
+  for (int g = 0; g < 2; ++g) {
+    const int32_t* lst = pv.group_list + (g ? N : 0);
+    const int32_t* cnt = pv.group_cnt + g;
+    c.chk(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
+                      PM_N_SLOTS, cnt, c.st));
+    c.chk(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
+                      PM_GEMM_ACCUM, 0, lst, PM_N_SLOTS, cnt, c.st));
+    c.chk(pm_colsum_rows_acc(s.dc_logits, PM_N_PITCH, PM_N_TOK, lst, PM_N_SLOTS, cnt, N, c.G + pit[g].b, c.st));
+  }
+  float* dxL = ar.f((size_t)N * d);
+  lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, PM_N_SLOTS * d, d, dxL);
+  float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
+  float* dcb = ar.f((size_t)Gn * d);
+  c.chk(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
+  lin_bwd(c, dcb, s.zr + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d);
+  // ---- structure decoder (only when the structure loss reaches the logits)
+  if (s.fix_structure) {
+    float* da2 = ar.f((size_t)Gn * 8 * 128); float* dc2 = ar.f((size_t)Gn * 8 * 128);
+    float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.f((size_t)Gn * d); float* dsb = ar.f((size_t)Gn * d);
+    c.chk(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
+    c.chk(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
+    bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
+    c.chk(pm_conv3x3_bwd_weight(s.u2, dc2, Gn, 16, 8, 4, 32, 1, c.G + Y.dec_conv1.w, c.G + Y.dec_conv1.b, c.st));
+    c.chk(pm_conv3x3_bwd_data(dc2, c.P + Y.dec_conv1.w, Gn, 16, 8, 4, 32, 1, du2, c.st));
+    c.chk(pm_relu_bwd(du2, s.u2, (int64_t)Gn * 512, du2, c.st));
+    lin_bwd(c, du2, s.u1, Y.dec_s_lin4, Gn, 512, d, du1);
+    c.chk(pm_relu_bwd(du1, s.u1, (int64_t)Gn * d, du1, c.st));
+    lin_bwd(c, du1, s.sb, Y.dec_s_lin1, Gn, d, d, dsb);
+    lin_bwd(c, dsb, s.zr, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
+  }
+  float* dzd = ar.f((size_t)B * 2 * d);
+  bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
+  s.dz = ar.f((size_t)B * d);
+  lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz);
+  c.chk(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
+}
+
+void backward_encoder(Ctx& c) {
+  StepState& s = *c.s;
+  Arena& ar = s.ar;
+  const PmVaeLayout& Y = s.lay;
+  const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
+  float* dzg = ar.f((size_t)B * d); float* dzg2 = ar.f((size_t)B * d);
+  lin_bwd(c, s.dmu, s.zg, Y.enc_mu, B, d, d, dzg);
+  lin_bwd(c, s.dlv, s.zg, Y.enc_lv, B, d, d, dzg2);
+  c.chk(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
+  float* dm = ar.f((size_t)B * d);
+  bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
+  float* dzcat = ar.f((size_t)B * 2 * d);
+  lin_bwd(c, dm, s.zcat, Y.enc_merge, B, d, 2 * d, dzcat);
+  // ---- content branch (z_c = zcat[:, :d])
+  float* dpooled = ar.f((size_t)Gn * d);
+  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d);
+  float* dxL = ar.f((size_t)N * d);
+  float* pscr = ar.f((size_t)3 * N + 8);
+  c.chk(pm_attnpool_bwd(s.eg.x[c.L], s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, s.alpha, dpooled, c.P + Y.enc_gate.w,
+                        s.plan, N, c.E, Gn, d, dxL, c.G + Y.enc_gate.w, c.G + Y.enc_gate.b, c.G + Y.enc_gate_bn.w,
+                        c.G + Y.enc_gate_bn.b, pscr, c.st));
+  float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
+  c.chk(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
+  float* dX = ar.f((size_t)N * PM_N_SLOTS * d);
+  lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
+  float* S = ar.f((size_t)4 * PM_N_PITCH * dh);
+  c.chk(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, c.st));
+  PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
+  c.chk(pm_embed_tables_bwd(S, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
+                            c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_nd.w,
+                            c.P + Y.enc_bn_dur.w, s.emb_stats, pv.tok_hist, d, 1e-5f, c.G + Y.enc_pitch_d.w,
+                            c.G + Y.enc_pitch_d.b, c.G + Y.enc_pitch_nd.w, c.G + Y.enc_pitch_nd.b, c.G + Y.enc_dur.w,
+                            c.G + Y.enc_dur.b, c.G + Y.enc_bn_d.w, c.G + Y.enc_bn_d.b, c.G + Y.enc_bn_nd.w,
+                            c.G + Y.enc_bn_nd.b, c.G + Y.enc_bn_dur.w, c.G + Y.enc_bn_dur.b, c.st));
+  // ---- structure branch (z_s = zcat[:, d:])
+  float* dh2 = ar.f((size_t)Gn * d); float* dh1 = ar.f((size_t)Gn * d); float* da1 = ar.f((size_t)Gn * 512);
+  float* dc1 = ar.f((size_t)Gn * 512); float* dp0 = ar.f((size_t)Gn * 8 * 32); float* da0 = ar.f((size_t)Gn * 8 * 128);
+  float* dc0 = ar.f((size_t)Gn * 8 * 128);
+  lin_bwd(c, dzcat + d, s.h2, Y.enc_s_bars, B, d, nb * d, dh2, 2 * d, nb * d, nb * d);
+  lin_bwd(c, dh2, s.h1, Y.enc_lin4, Gn, d, d, dh1);
+  c.chk(pm_relu_bwd(dh1, s.h1, (int64_t)Gn * d, dh1, c.st));
+  lin_bwd(c, dh1, s.a1, Y.enc_lin1, Gn, d, 512, da1);
+  bn_bwd(c, s.c1, da1, Gn, 16, 32, Y.enc_bn5, s.m1, s.v1, true, dc1);
+  c.chk(pm_conv3x3_bwd_weight(s.p0, dc1, Gn, 8, 16, 4, 8, 0, c.G + Y.enc_conv4.w, c.G + Y.enc_conv4.b, c.st));
+  c.chk(pm_conv3x3_bwd_data(dc1, c.P + Y.enc_conv4.w, Gn, 8, 16, 4, 8, 0, dp0, c.st));
+  c.chk(pm_maxpool4_bwd(s.a0, dp0, (int64_t)Gn * 8 * 32, da0, c.st));
+  bn_bwd(c, s.c0, da0, Gn, 8, 128, Y.enc_bn1, s.m0, s.v0, true, dc0);
+  c.chk(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
+}
+
+// arena use of the two backward passes, measured with a null base
+void measure_backward(Ctx& c) {
+  // mirrors the ar.f() calls of backward_decoder / backward_encoder / gcn_backward (x2)
+  Arena& ar = c.s->ar;
+  const size_t N = c.N, Gn = c.Gn, B = c.B, d = c.d, dh = d / 2, R = N * PM_N_SLOTS;
+  size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d) + Gn * d +
+                  (Gn * 8 * 128 * 2 + Gn * 512 + 2 * Gn * d) + B * 2 * d + B * d +
+                  2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + N * PM_N_SLOTS * d + 4 * PM_N_PITCH * dh +
+                  (2 * Gn * d + 2 * Gn * 512 + Gn * 8 * 32 + 2 * Gn * 8 * 128);
+  ar.take(floats * sizeof(float) + 64 * 256);    // + alignment slack of the ~60 carve-outs
+}
+
+}  // namespace
+
+extern "C" int64_t pm_vae_layout_bytes(void) { return (int64_t)sizeof(PmVaeLayout); }
+extern "C" int64_t pm_vae_step_state_bytes(void) { return (int64_t)sizeof(StepState); }
+
+extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B) {
+  if (!lay || N <= 0 || E <= 0 || G <= 0 || B <= 0 || lay->n_layers > PM_MAX_LAYERS) return -1;
+  StepState s;
+  memset(&s, 0, sizeof(s));
+  s.lay = *lay; s.bt.N = N; s.bt.E = E; s.bt.G = G; s.bt.B = B;
+  s.ar.base = nullptr; s.ar.cap = 0; s.ar.used = 0;
+  Ctx c = make_ctx(&s, nullptr);
+  forward(c, 0.f, 0, 0);
+  measure_backward(c);
+  return (int64_t)s.ar.used + 4096;
+}
+
+extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,
+                                   const PmBatch* batch, int32_t* plan, const float* eps, float msg_dropout,
+                                   uint32_t seed_enc, uint32_t seed_dec, float beta, int structure_loss_on_logits,
+                                   void* workspace, int64_t workspace_bytes, void* state, double* losses,
+                                   pm_stream_t stream) {
+  if (!lay || !params || !buffers || !grads || !batch || !plan || !eps || !workspace || !state || !losses)
+    return PM_E_INVALID;
+  if (lay->n_layers > PM_MAX_LAYERS || lay->n_layers <= 0 || (lay->d & 7) || batch->G != batch->B * lay->n_bars)
+    return PM_E_INVALID;
+  StepState* s = (StepState*)state;
+  memset(s, 0, sizeof(*s));
+  s->magic = kMagic; s->lay = *lay; s->P = params; s->Bf = buffers; s->G = grads; s->bt = *batch; s->plan = plan;
+  s->eps = eps; s->losses = losses; s->beta = beta; s->fix_structure = structure_loss_on_logits;
+  s->ar.base = (char*)workspace; s->ar.cap = (size_t)workspace_bytes; s->ar.used = 0; s->ar.overflow = false;
+  hipStream_t st = (hipStream_t)stream;
+  Ctx c = make_ctx(s, st);
+  c.chk(pm_plan_build(batch->edge_index, batch->edge_type, batch->edge_dist, batch->bars, batch->batch, batch->is_drum,
+                      batch->tokens, lay->n_bars, batch->N, batch->E, batch->G, plan, stream));
+  forward(c, msg_dropout, seed_enc, seed_dec);
+  if (s->ar.overflow) return PM_E_INVALID;
+  s->rc = c.rc;
+  return c.rc;
+}
+extern "C" int pm_vae_step_backward_decoder(void* state, pm_stream_t stream) {
+  StepState* s = (StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK) return PM_E_INVALID;
+  Ctx c = make_ctx(s, (hipStream_t)stream);
+  backward_decoder(c);
+  if (s->ar.overflow) return PM_E_INVALID;
+  s->rc = c.rc;
+  return c.rc;
+}
+extern "C" int pm_vae_step_backward_encoder(void* state, pm_stream_t stream) {
+  StepState* s = (StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK) return PM_E_INVALID;
+  Ctx c = make_ctx(s, (hipStream_t)stream);
+  backward_encoder(c);
+  if (s->ar.overflow) return PM_E_INVALID;
+  s->rc = c.rc;
+  return c.rc;
+}

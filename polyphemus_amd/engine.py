@@ -76,9 +76,9 @@ class Engine:
         y = ops.bn_apply(x, O, Cn, I, mean, var, self.T[key + ".weight"], self.T[key + ".bias"], EPS, residual, relu)
         return y, mean, var
 
-    def bn_back(self, x, dy, key, O, Cn, I, mean, var, relu, G):
+    def bn_back(self, x, dy, key, O, Cn, I, mean, var, relu, G, dbias_pre=None):
         return ops.bn_bwd(x, dy, O, Cn, I, mean, var, self.T[key + ".weight"], self.T[key + ".bias"],
-                          G[key + ".weight"], G[key + ".bias"], EPS, relu)
+                          G[key + ".weight"], G[key + ".bias"], EPS, relu, dbias_pre=dbias_pre)
 
     # ------------------------------------------------------------------ GCN (model.py:167-208)
     def gcn_forward(self, x, plan, key, training, seed, uid0):
@@ -104,8 +104,8 @@ class Engine:
         for i in reversed(range(self.L)):
             lk = f"{key}.layers.{i}"
             x, A, h, mean, var = sv["layers"][i]
-            dh = self.bn_back(h, dx, f"{key}.norm_layers.{i}.module", N, d, 1, mean, var, True, G)
-            ops.colsum_acc(dh, N, d, d, G[lk + ".bias"])
+            dh = self.bn_back(h, dx, f"{key}.norm_layers.{i}.module", N, d, 1, mean, var, True, G,
+                              dbias_pre=G[lk + ".bias"])          # GCL.bias sits right in front of the BatchNorm
             dA = torch.empty(N, 7 * d, dtype=F32, device=dx.device)
             ops.gemm(dh, self.T[lk + ".weight"], dA, N, 7 * d, d, d, d, 7 * d, transB=True)
             ops.gemm(A, dh, G[lk + ".weight"], 7 * d, d, N, 7 * d, d, d, transA=True, accum=True, split_k=0)

@@ -366,6 +366,7 @@ class VAE(nn.Module):
                 b.data = bflat[boffs[n]:boffs[n] + b.numel()].view(b.shape)
         self.__dict__["flat_params"], self.__dict__["flat_buffers"] = flat, bflat
         self.__dict__["_offsets"], self.__dict__["_param_names"] = offs, [n for n, _ in named]
+        self.__dict__["_buf_offsets"] = boffs
         tensors = {n: p for n, p in named}
         tensors.update({n: b for n, b in self.named_buffers()})
         for k in list(tensors):                        # shared edge network: alias layers.{i}.nn.* -> layers.0.nn.*

@@ -36,10 +36,13 @@ def _prof_end(name: str, e0, work: float):
         PROF[name].append((e0, e1, work))
 
 
-def gemm_class(transA: bool, transB: bool, M: int, N: int) -> str:
-    """Kernel instance a GEMM call maps to (same rule as pm_gemm_f32): tile size and operand layout."""
-    big = ((M + 127) // 128) * ((N + 127) // 128) >= 192
-    return f"gemm_{'T' if transA else 'N'}{'T' if transB else 'N'}_{128 if big else 64}"
+_GEMM_TILES = ("64x64", "128x128", "64x256", "256x64")
+
+
+def gemm_class(transA: bool, transB: bool, M: int, N: int, K: int) -> str:
+    """Kernel instance a GEMM call maps to (asks the library which tile configuration it picks)."""
+    from ._lib import lib
+    return f"gemm_{'T' if transA else 'N'}{'T' if transB else 'N'}_{_GEMM_TILES[lib().pm_gemm_config(int(transA), M, N, K)]}"
 
 
 def _chk(t: Optional[torch.Tensor], dtype, name: str, allow_none=False):
@@ -158,7 +161,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=Non
     """out[M,N] (=|+=) op(A) op(B) (+bias)(relu); A/B/out may be views with an element offset
     (pass the sliced tensor: its data_ptr() carries the offset) and explicit leading dimensions."""
     flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0)
-    cls = gemm_class(transA, transB, M, N) if PROF is not None else ""
+    cls = gemm_class(transA, transB, M, N, K) if PROF is not None else ""
     e0 = _prof_begin(cls)
     call("pm_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
          flags, split_k, ptr(rowmap), rows_per_entry, ptr(dyn_entries), stream())
@@ -175,7 +178,7 @@ def linear(x, weight, bias=None, relu=False, out=None):
 
 
 def bn_scratch(C_: int, device) -> torch.Tensor:
-    return torch.empty(64 * 2 * C_ + 2 * C_, dtype=F64, device=device)
+    return torch.empty(256 * 3 * C_ + 4 * C_, dtype=F64, device=device)          # PM_BN_SCRATCH(C)
 
 
 def bn_stats(x, O, C_, I, running_mean=None, running_var=None, momentum=0.1, scratch=None):
@@ -194,11 +197,12 @@ def bn_apply(x, O, C_, I, mean, var, gamma, beta, eps=1e-5, residual=None, relu=
     return y
 
 
-def bn_bwd(x, dy, O, C_, I, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, relu=False, out=None, scratch=None):
+def bn_bwd(x, dy, O, C_, I, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, relu=False, out=None, scratch=None,
+           dbias_pre=None):
     dx = out if out is not None else torch.empty_like(x)
     scratch = scratch if scratch is not None else bn_scratch(C_, x.device)
     call("pm_bn_bwd", ptr(x), ptr(dy), O, C_, I, ptr(mean), ptr(var), eps, ptr(gamma), ptr(beta), int(relu),
-         ptr(dgamma), ptr(dbeta), ptr(dx), ptr(scratch), stream())
+         ptr(dgamma), ptr(dbeta), ptr(dbias_pre), ptr(dx), ptr(scratch), stream())
     return dx
 
 

@@ -9,19 +9,28 @@ but without autograd bookkeeping and without the reference's 7 `.item()` host sy
     -> [data parallel: RCCL all-reduce of the flat gradient, two buckets overlapped with the
         encoder backward] -> fused Adam on the flat parameter buffer
 
+Two orchestrations of the SAME kernels:
+  * native (default): three C calls (`pm_vae_step_forward`, `..._backward_decoder`,
+    `..._backward_encoder`, csrc/vae_step.hip) issue the ~330 launches of a step from C++;
+  * python (`native=False`): the same sequence through `engine.Engine` (the executable
+    specification the autograd drop-in path uses); kept for cross-checking.
+
 Reference quirks reproduced by default: the structure BCE is evaluated on the
 target (no gradient reaches the structure decoder, B-1), beta stays 0 (B-3), message dropout
 p = 0.1 is always on in training (B-2).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, Optional
 
 import torch
 
 from . import ops
+from ._lib import call, lib, plan_layout, ptr, stream, PLAN_FIELDS
 from .model import VAE, prepare_graph
+from .native import build_layout, make_batch
 from .parallel import GradBuckets, broadcast_
 
 
@@ -42,14 +51,17 @@ class ExpDecayLR:
 
 class HipTrainer:
     def __init__(self, vae: VAE, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler: Optional[dict] = None,
-                 structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None):
+                 structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None, native: bool = True):
         self.vae = vae
         self.lr, self.betas, self.eps = lr, betas, eps
         self.sched = ExpDecayLR(**lr_scheduler) if lr_scheduler else None
         self.fix_structure_loss = structure_loss_on_logits
         self.beta = beta
         self.pg = process_group
+        self.native = native
         flat = vae.flat_params
+        if not flat.is_cuda:
+            raise RuntimeError("HipTrainer needs the model on the GPU (vae.to('cuda')) before it is built")
         self.grads = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
@@ -69,21 +81,82 @@ class HipTrainer:
         self.buckets = GradBuckets(self.grads, [dec_lo], process_group)  # bucket 0 encoder, bucket 1 decoder
         self.world = self.buckets.world
         broadcast_([vae.flat_params, vae.flat_buffers], 0, process_group)
+        # native step plumbing
+        self._layout = build_layout(vae)
+        self._flat_ptr = flat.data_ptr()
+        self._state = ctypes.create_string_buffer(int(lib().pm_vae_step_state_bytes()))
+        self._ws: Optional[torch.Tensor] = None
+        self._plan_buf: Optional[torch.Tensor] = None
+        sd = dict(vae.named_buffers())
+        emb = {"encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur"}
+        self._nbt = [b for n, b in sd.items() if n.endswith("num_batches_tracked") and n.rsplit(".", 1)[0] not in emb]
+        self._nbt_emb = [sd[k + ".num_batches_tracked"] for k in
+                         ("encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur")]
 
     # ------------------------------------------------------------------------------------------
-    def train_step(self, graph, eps: Optional[torch.Tensor] = None):
-        """One optimizer step on `graph` (device batch).  Returns the device tensor
-        [pitch, dur, structure, kld] of loss values (float64, no host sync)."""
+    def _prep_inputs(self, graph):
+        """Compact device inputs of a batch (token ids, edge ids) — converted once and cached on the graph."""
+        c = graph.__dict__.get("_pm_inputs") if hasattr(graph, "__dict__") else None
+        if c is None:
+            has = lambda k: k in getattr(graph, "__dict__", {}) or (hasattr(graph, "keys") and k in graph.keys())
+            if has("edge_type") and has("edge_dist"):
+                et, ed = graph.edge_type.to(torch.int32).contiguous(), graph.edge_dist.to(torch.int32).contiguous()
+            else:
+                et, ed = ops.edge_attrs_to_ids(graph.edge_attrs.float().contiguous())
+            tok = graph.tokens.to(torch.int32).contiguous() if has("tokens") else ops.tokens_from_onehot(
+                graph.c_tensor.float().contiguous())
+            drum = graph.is_drum.contiguous()
+            drum = drum.view(torch.uint8) if drum.dtype == torch.bool else drum
+            c = (et, ed, tok, drum)
+            try:
+                graph.__dict__["_pm_inputs"] = c
+            except Exception:
+                pass
+        return c
+
+    def _native_forward_backward(self, graph, eps):
+        vae = self.vae
+        L = lib()
+        et, ed, tok, drum = self._prep_inputs(graph)
+        s_tensor = graph.s_tensor
+        if s_tensor.dtype != torch.float32 or not s_tensor.is_contiguous():
+            s_tensor = s_tensor.float().contiguous()
+        bt = make_batch(graph, tok, drum, et, ed)
+        bt.s_tensor = s_tensor.data_ptr()
+        bt.B = bt.G // vae.cfg["n_bars"]
+        need = int(L.pm_vae_step_workspace_bytes(ctypes.byref(self._layout), bt.N, bt.E, bt.G, bt.B))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.grads.device)
+        off = plan_layout(bt.N, bt.E, bt.G)
+        if self._plan_buf is None or self._plan_buf.numel() < off[-1]:
+            self._plan_buf = torch.empty(off[-1], dtype=torch.int32, device=self.grads.device)
+        if eps is None:
+            eps = torch.randn(bt.B, vae.cfg["d"], device=self.grads.device)
+        st = stream()
+        call("pm_vae_step_forward", ctypes.addressof(self._layout), ptr(vae.flat_params), ptr(vae.flat_buffers),
+             ptr(self.grads), ctypes.addressof(bt), ptr(self._plan_buf), ptr(eps), float(vae.msg_dropout),
+             vae._next_seed(), vae._next_seed(), float(self.beta), int(self.fix_structure_loss), ptr(self._ws),
+             self._ws.numel(), ctypes.addressof(self._state), ptr(self.loss_buf), st)
+        state = ctypes.addressof(self._state)
+        call("pm_vae_step_backward_decoder", state, st)
+        self.buckets.launch(1)                               # decoder gradients: overlapped with the encoder backward
+        call("pm_vae_step_backward_encoder", state, st)
+        self.buckets.launch(0)                               # encoder gradients
+        # num_batches_tracked (int64 bookkeeping of nn.BatchNorm): +1 per forward; the embedding norms only
+        # when their group is non-empty, bn_dur once per non-empty group (model.py:362,375)
+        torch._foreach_add_(self._nbt, 1)
+        i = PLAN_FIELDS.index("group_cnt")
+        has = (self._plan_buf[off[i]:off[i] + 2] > 0).to(torch.int64)
+        self._nbt_emb[0] += has[0]
+        self._nbt_emb[1] += has[1]
+        self._nbt_emb[2] += has[0] + has[1]
+        return self.loss_buf
+
+    def _python_forward_backward(self, graph, eps):
         vae, eng = self.vae, self.vae.engine
-        if not vae.training:
-            raise RuntimeError("train_step needs vae.train()")
-        vae._check_flat()
-        if self.grads.data_ptr() == 0 or self.grads.device != vae.flat_params.device:
-            raise RuntimeError("trainer was built before the model was moved; rebuild it")
         eng.msg_dropout = vae.msg_dropout
         graph.__dict__.pop("_pm_plan", None)                 # the plan is part of the step (new batch every step)
         plan = prepare_graph(graph, vae.cfg["n_bars"])
-        self.grads.zero_()
         G = self._G
         s_tensor = graph.s_tensor.float().contiguous()
         mu, lv, esv = eng.encoder_forward(plan, s_tensor, True, vae._next_seed())
@@ -91,7 +164,6 @@ class HipTrainer:
             eps = torch.randn_like(mu)
         z = ops.reparam_fwd(mu, lv, eps)
         s_logits, c_logits, dsv = eng.decoder_forward(plan, z, True, vae._next_seed())
-        # ---- loss (training.py:298-347) with gradients w.r.t. the logits
         out, dc = ops.content_ce(c_logits, plan, grad_scale=1.0, want_grad=True, out=self.loss_buf)
         dmu, dlv = torch.zeros_like(mu), torch.zeros_like(lv)
         ops.kld(mu, lv, out, beta=self.beta, dmu=dmu, dlog_var=dlv)
@@ -101,12 +173,25 @@ class HipTrainer:
         else:                                                # training.py:307: BCE of the target against itself
             ops.bce_logits(s_tensor.reshape(-1), s_tensor.reshape(-1), out, 1.0, want_grad=False)
             ds = None
-        # ---- backward
         dz = eng.decoder_backward(dsv, ds, dc, G)
-        self.buckets.launch(1)                               # decoder gradients: overlapped with the encoder backward
+        self.buckets.launch(1)
         ops.reparam_bwd(dz, lv, eps, dmu, dlv)
         eng.encoder_backward(esv, dmu, dlv, G)
-        self.buckets.launch(0)                               # encoder gradients
+        self.buckets.launch(0)
+        return out
+
+    def train_step(self, graph, eps: Optional[torch.Tensor] = None):
+        """One optimizer step on `graph` (device batch).  Returns the device tensor
+        [pitch, dur, structure, kld] of loss values (float64, no host sync)."""
+        vae = self.vae
+        if not vae.training:
+            raise RuntimeError("train_step needs vae.train()")
+        if vae.flat_params.data_ptr() != self._flat_ptr:
+            raise RuntimeError("the model's flat parameter buffer moved after the trainer was built; rebuild it")
+        if not vae.cfg["batch_norm"] or vae.cfg["dropout"] != 0:
+            raise NotImplementedError("HIP path: needs batch_norm=True and cfg dropout == 0 (training.json)")
+        self.grads.zero_()
+        out = (self._native_forward_backward if self.native else self._python_forward_backward)(graph, eps)
         mean_scale = self.buckets.wait()
         # ---- optimizer (training.py:160-172)
         self.step_count += 1

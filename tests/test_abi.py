@@ -17,7 +17,7 @@ def header_prototypes():
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
-    for m in re.finditer(r"\b(int|uint32_t|const char\*)\s+(pm_\w+)\s*\(([^;{]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|int64_t|uint32_t|const char\*)\s+(pm_\w+)\s*\(([^;{]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         codes = ""
         for a in [x.strip() for x in args.split(",")]:

@@ -141,16 +141,26 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    import ctypes
+    from polyphemus_amd._lib import lib
+    L = lib()
     for _ in range(args.warmup):
         trainer.train_step(batch)
-    ops.PROF = {}
+    # HIP events around every GEMM / segment-reduce launch of the timed region (in-library, on the launch stream)
+    L.pm_prof_begin(args.steps * 200)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.train_step(batch)
     sync()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROF = ops.PROF, None
+    NCLS = 14
+    ms_a, work_a, cnt_a = (ctypes.c_double * NCLS)(), (ctypes.c_double * NCLS)(), (ctypes.c_int64 * NCLS)()
+    L.pm_prof_end(ctypes.cast(ms_a, ctypes.c_void_p), ctypes.cast(work_a, ctypes.c_void_p), ctypes.cast(cnt_a, ctypes.c_void_p))
+    tiles, lay = ("64x64", "128x128", "64x256", "256x64"), ("NN", "NT", "TN")
+    names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(12)] + ["segreduce_fwd", "segreduce_bwd"]
+    gst = {names[c]: dict(launches=int(cnt_a[c]), total_ms=ms_a[c], avg_us=1e3 * ms_a[c] / cnt_a[c], work=work_a[c])
+           for c in range(NCLS) if cnt_a[c] > 0}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot_nodes = torch.tensor([float(n_nodes), float(G)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -159,24 +169,19 @@ def main():
     elapsed = float(t.item())
     losses = trainer.losses_dict(out)
 
-    def kernel_stats(name):
-        recs = prof[name]
-        if not recs:
-            return None
-        ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        work = sum(w for _, _, w in recs)
-        return dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), work=work)
-
     if rank == 0:
-        gst = {k: kernel_stats(k) for k in prof}
-        gemm_keys = [k for k in gst if k.startswith("gemm") and gst[k]]
+        gemm_keys = [k for k in gst if k.startswith("gemm")]
         dom = max(gemm_keys, key=lambda k: gst[k]["total_ms"])
         ds = gst[dom]
         tf = ds["work"] / (ds["total_ms"] * 1e-3) / 1e12
+        gemm_ms = sum(gst[k]["total_ms"] for k in gemm_keys)
+        gemm_tf = sum(gst[k]["work"] for k in gemm_keys) / (gemm_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[8:]},{dom[5:7]}> (v_mfma_f32_32x32x2_f32)",
                 "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                 "launches_per_step": ds["launches"] / args.steps, "avg_launch_us": round(ds["avg_us"], 2),
+                "algorithmic_gflop_per_launch": round(ds["work"] / ds["launches"] / 1e9, 3),
+                "all_gemm": {"TFLOP/s": round(gemm_tf, 2), "ms_per_step": round(gemm_ms / args.steps, 3)},
                 "other_gemm_classes": {k: {"TFLOP/s": round(gst[k]["work"] / (gst[k]["total_ms"] * 1e-3) / 1e12, 2),
                                            "avg_us": round(gst[k]["avg_us"], 2),
                                            "launches_per_step": gst[k]["launches"] / args.steps}
@@ -187,6 +192,10 @@ def main():
                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
                     "launches_per_step": ss["launches"] / args.steps, "avg_launch_us": round(ss["avg_us"], 2),
                     "algorithmic_bytes_per_launch": ss["work"] / ss["launches"]}
+        sb = gst.get("segreduce_bwd")
+        if sb:
+            roof_seg["backward"] = {"GB/s": round(sb["work"] / (sb["total_ms"] * 1e-3) / 1e9, 1),
+                                    "avg_launch_us": round(sb["avg_us"], 2)}
         bars_total = float(tot_nodes[1].item())
         value = bars_total * args.steps / elapsed
         fpb = flops_per_bar(float(tot_nodes[0].item()), bars_total, args.d, args.layers)

@@ -224,6 +224,14 @@ int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 /* Counter-based dropout mask shared by device code and the oracle (host-callable). */
 uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel);
 
+/* ------------------------------------------------------------------ launch-duration profiler (bench.py roofline)
+ * HIP events around every GEMM / segment-reduce launch while enabled; pm_prof_end sums the durations per class:
+ * classes 0..11 = GEMM tile configuration * 3 + {0 NN, 1 NT, 2 TN}; 12 = segment-reduce forward; 13 = backward.
+ * `work` = algorithmic flops (GEMM) or algorithmic HBM bytes (segment-reduce) of the launches. */
+enum { PM_PROF_NCLASS_PUBLIC = 14 };
+int pm_prof_begin(int32_t max_events);
+int pm_prof_end(double* ms /* [14] host */, double* work /* [14] host */, int64_t* count /* [14] host */);
+
 /* ------------------------------------------------------------------ native training step
  * The whole of `PolyphemusTrainer.train`'s inner iteration (training.py:137-166) issued from C++:
  * ~330 kernel launches per step with no interpreter between them.  The model is described by

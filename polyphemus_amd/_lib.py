@@ -57,6 +57,8 @@ _SIGS = {
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
     "pm_adam_step": "pppplffffifs",
+    "pm_prof_begin": "i",
+    "pm_prof_end": "ppp",
     "pm_vae_step_workspace_bytes": "piiii",
     "pm_vae_step_forward": "pppppppfuufiplpps",
     "pm_vae_step_backward_decoder": "ps",

@@ -18,6 +18,7 @@
 // a row panel run on the same XCD (shared L2).  The gathered dimension may be indirect (row map +
 // device-side count) for the drum / non-drum routing of the content decoder (model.py:552-576).
 #include "common.h"
+#include "prof.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -324,11 +325,48 @@ extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t
   const bool vb = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0);
   dim3 grid((unsigned)tiles, 1, (unsigned)split_k);
   hipStream_t st = (hipStream_t)stream;
+  const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), 2.0 * M * N * K);
   switch (cfg) {
     case 0: launch_t<64, 64, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
     case 1: launch_t<128, 128, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
     case 2: launch_t<64, 256, 32, 2, 4>(transA, transB, va, vb, grid, st, g); break;
     default: launch_t<256, 64, 32, 4, 2>(transA, transB, va, vb, grid, st, g); break;
   }
+  pm_prof_close(st, pe);
   return pm_check_launch();
+}
+
+// ---------------------------------------------------------------- launch-duration profiler (see prof.h)
+PmProfState g_pm_prof = {false, 0, 0, nullptr};
+
+extern "C" int pm_prof_begin(int32_t max_events) {
+  PmProfState& p = g_pm_prof;
+  if (max_events <= 0) return PM_E_INVALID;
+  if (p.cap < max_events) {
+    PmProfEvent* ev = (PmProfEvent*)realloc(p.ev, sizeof(PmProfEvent) * max_events);
+    if (!ev) return PM_E_INVALID;
+    p.ev = ev;
+    for (int i = p.cap; i < max_events; ++i) {
+      if (hipEventCreate(&p.ev[i].a) != hipSuccess || hipEventCreate(&p.ev[i].b) != hipSuccess) return PM_E_LAUNCH;
+    }
+    p.cap = max_events;
+  }
+  p.n = 0;
+  p.on = true;
+  return PM_OK;
+}
+// Stops recording, waits for the recorded events and sums them per class: ms[c], work[c], count[c] (c < PM_PROF_NCLASS).
+extern "C" int pm_prof_end(double* ms, double* work, int64_t* count) {
+  PmProfState& p = g_pm_prof;
+  p.on = false;
+  if (!ms || !work || !count) return PM_E_INVALID;
+  for (int c = 0; c < PM_PROF_NCLASS; ++c) { ms[c] = 0; work[c] = 0; count[c] = 0; }
+  for (int i = 0; i < p.n; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(p.ev[i].b) != hipSuccess || hipEventElapsedTime(&t, p.ev[i].a, p.ev[i].b) != hipSuccess)
+      return PM_E_LAUNCH;
+    ms[p.ev[i].cls] += t; work[p.ev[i].cls] += p.ev[i].work; count[p.ev[i].cls] += 1;
+  }
+  p.n = 0;
+  return PM_OK;
 }

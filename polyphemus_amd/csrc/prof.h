@@ -1,0 +1,28 @@
+// prof.h — optional per-launch HIP-event timing of the kernel classes the roofline figures are quoted on
+// (bench.py: `roofline.achieved` = algorithmic work / measured launch duration, live in the timed region).
+// Disabled by default: the launch path then costs one predictable branch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum {
+  PM_PROF_GEMM0 = 0,            // 12 GEMM classes: tile config (0..3) * 3 + {NN, NT, TN}
+  PM_PROF_SEGREDUCE_FWD = 12,
+  PM_PROF_SEGREDUCE_BWD = 13,
+  PM_PROF_NCLASS = 14
+};
+struct PmProfEvent { hipEvent_t a, b; int cls; double work; };
+struct PmProfState { bool on; int n, cap; PmProfEvent* ev; };
+extern PmProfState g_pm_prof;
+
+static inline int pm_prof_open(hipStream_t st, int cls, double work) {
+  PmProfState& p = g_pm_prof;
+  if (!p.on || p.n >= p.cap) return -1;
+  const int i = p.n++;
+  p.ev[i].cls = cls; p.ev[i].work = work;
+  hipEventRecord(p.ev[i].a, st);
+  return i;
+}
+static inline void pm_prof_close(hipStream_t st, int i) {
+  if (i >= 0) hipEventRecord(g_pm_prof.ev[i].b, st);
+}

@@ -12,6 +12,7 @@
 // Algorithmic HBM bytes: forward 4*d*N*(1+R) + 12*E (+4*d*N for the root copy
 // this kernel also writes), backward 4*d*N*(R+1) + 12*E + 4*32*d.
 #include "common.h"
+#include "prof.h"
 
 extern "C" uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel) {
   return pm_elem_hash(pm_edge_key(seed, layer_uid, eid), channel) >> 8;
@@ -122,10 +123,12 @@ extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* p
   hipLaunchKernelGGL((k_segreduce_fwd<NV, DR>), grid, block, 0, st, x, T, pv.rowptr, pv.csr_src, pv.csr_dist,       \
                      pv.csr_eid, N, d, seed, layer_uid, thresh, scale, A)
   const int nv = (int)pm_cdiv(d, 256);
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_FWD, 4.0 * d * (double)N * (1 + PM_N_REL) + 12.0 * E);
   if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
   else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
   else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
 #undef LAUNCH
+  pm_prof_close(st, pe);
   return pm_check_launch();
 }
 
@@ -225,9 +228,11 @@ extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA,
   hipLaunchKernelGGL((k_segreduce_bwd<NV, DR>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,          \
                      pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, dx, dT)
   const int nv = (int)pm_cdiv(d, 256);
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * (PM_N_REL + 1) + 12.0 * E + 128.0 * d);
   if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
   else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
   else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
 #undef LAUNCH
+  pm_prof_close(st, pe);
   return pm_check_launch();
 }

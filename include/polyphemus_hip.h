@@ -65,9 +65,11 @@ enum {
   PM_PLAN_NODE_BAR,     /* [N] distinct bar id = bars + n_bars*batch (model.py:403) */
   PM_PLAN_BAR_PTR,      /* [G+1] node offsets of each bar                         */
   PM_PLAN_GROUP_LIST,   /* [2N] drum nodes (ascending) in [0,n_drum); non-drum nodes in [N, N+n_non_drum) */
-  PM_PLAN_GROUP_CNT,    /* [4] {n_drum, n_non_drum, 0, 0}                         */
+  PM_PLAN_GROUP_CNT,    /* [4] {n_drum, n_non_drum, 15*n_drum, 15*n_non_drum}     */
   PM_PLAN_TOK_HIST,     /* [4][131] token counts over slots 1..15:
                            0 drum pitch, 1 non-drum pitch, 2 drum dur, 3 non-drum dur */
+  PM_PLAN_ROW_LIST,     /* [2*15N] (node, slot) rows = node*15 + slot of the drum nodes in [0, 15 n_drum),
+                           of the non-drum nodes from 15N on: row maps of the un-embedding GEMMs */
   PM_PLAN_SCRATCH,      /* cursors + scan partials                                */
   PM_PLAN_NFIELDS
 };
@@ -208,9 +210,12 @@ int pm_maxpool4_bwd(const float* x, const float* dy, int64_t n_out, float* dx, p
  * Fused softmax cross-entropy of the pitch (131, ignore 130) and duration (99, ignore 98)
  * logits with their gradient, KL divergence, and the structure BCE.  `out` receives
  * {pitch, dur, structure, kld} (float64[4], zeroed by the call). */
+/* db_* (optional, all or none, need d_logits): += column sums of d_logits over the drum rows / non-drum rows
+ * (pitch block) and all rows (duration block) = gradients of the three un-embedding biases (model.py:561-567). */
 int pm_content_ce(const float* c_logits /* [N,15,230] */, const int32_t* tokens /* [N,16,2] */,
-                  const int32_t* tok_hist, int32_t N, float grad_scale, float* d_logits /* or NULL */, double* out,
-                  pm_stream_t stream);
+                  const int32_t* tok_hist, const uint8_t* is_drum /* [N] or NULL */, int32_t N, float grad_scale,
+                  float* d_logits /* or NULL */, float* db_pitch_drum /* [131] or NULL */,
+                  float* db_pitch_nd /* [131] */, float* db_dur /* [99] */, double* out, pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
            float* dlog_var, double* out, pm_stream_t stream);
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpolyphemus_hip.so")
 
 PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", "csc_reldist", "csc_eid",
-               "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "scratch"]
+               "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "row_list", "scratch"]
 
 # argument codes: p = device pointer, i = int32, l = int64, f = float, u = uint32, s = stream
 _SIGS = {
@@ -53,7 +53,7 @@ _SIGS = {
     "pm_conv3x3_bwd_weight": "ppiiiiiipps",
     "pm_maxpool4_fwd": "plps",
     "pm_maxpool4_bwd": "pplps",
-    "pm_content_ce": "pppifpps",
+    "pm_content_ce": "ppppifppppps",
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
     "pm_adam_step": "pppplffffifs",

@@ -19,7 +19,7 @@ struct PmPlanView {
   const int32_t* rowptr; const int32_t* csr_src; const int32_t* csr_dist; const int32_t* csr_eid;
   const int32_t* colptr; const int32_t* csc_dst; const int32_t* csc_reldist; const int32_t* csc_eid;
   const float* csc_invcnt; const int32_t* node_bar; const int32_t* bar_ptr; const int32_t* group_list;
-  const int32_t* group_cnt; const int32_t* tok_hist;
+  const int32_t* group_cnt; const int32_t* tok_hist; const int32_t* row_list;
 };
 void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off);
 static inline PmPlanView pm_plan_view(const int32_t* plan, int32_t N, int32_t E, int32_t G) {
@@ -34,6 +34,7 @@ static inline PmPlanView pm_plan_view(const int32_t* plan, int32_t N, int32_t E,
   v.node_bar = plan + o[PM_PLAN_NODE_BAR]; v.bar_ptr = plan + o[PM_PLAN_BAR_PTR];
   v.group_list = plan + o[PM_PLAN_GROUP_LIST]; v.group_cnt = plan + o[PM_PLAN_GROUP_CNT];
   v.tok_hist = plan + o[PM_PLAN_TOK_HIST];
+  v.row_list = plan + o[PM_PLAN_ROW_LIST];
   return v;
 }
 

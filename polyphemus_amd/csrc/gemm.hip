@@ -30,7 +30,7 @@ struct GemmArgs {
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
-  return map ? (int64_t)map[r / rpe] * rpe + (r % rpe) : (int64_t)r;
+  return map ? (rpe == 1 ? (int64_t)map[r] : (int64_t)map[r / rpe] * rpe + (r % rpe)) : (int64_t)r;
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -52,6 +52,7 @@ struct TileStage {
   u32x4 v[NV > 0 ? NV : 1];
   unsigned s[NS > 0 ? NS : 1];
   int base[NE];                                       // tile-invariant byte offset of each element, or PM_OOB
+  int krow[NE];                                       // !KC + row map: physical row of the next tile's k (prefetched)
   __amdgpu_buffer_rsrc_t rsrc;
   const int32_t* map;
   int rpe, ld;
@@ -82,11 +83,27 @@ struct TileStage {
         off = (k < kmax && base[j] >= 0) ? base[j] + k0 * 4 : PM_OOB;
       } else {
         const int k = k0 + (VEC ? f / (R / 4) : f / R);
-        off = PM_OOB;
-        if (k < kmax && base[j] >= 0) off = base[j] + (int)(map_row(map, rpe, k) * ld * 4);
+        // gathered K rows: the row-map entry of THIS tile was fetched while the previous tile was being
+        // multiplied (krow), so no index load sits between the MFMAs and the data load
+        const int prow = map ? krow[j] : k;
+        off = (k < kmax && base[j] >= 0) ? base[j] + prow * (ld * 4) : PM_OOB;
+        if (map) {
+          const int kn = k + BK;
+          krow[j] = kn < kmax ? (rpe == 1 ? map[kn] : map[kn / rpe] * rpe + kn % rpe) : 0;
+        }
       }
       if (VEC) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
       else s[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+    }
+  }
+  // first tile of a gathered-K operand: resolve its row-map entries up front
+  __device__ inline void prime(int k0, int kmax) {
+    if (KC || !map) return;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int f = threadIdx.x + j * THREADS;
+      const int k = k0 + (VEC ? f / (R / 4) : f / R);
+      krow[j] = k < kmax ? (rpe == 1 ? map[k] : map[k / rpe] * rpe + k % rpe) : 0;
     }
   }
   __device__ inline void store(float* __restrict__ S) const {
@@ -166,6 +183,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
 
   sa.init(g.A, g.lda, m0, M, mapA, g.rpe);
   sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe);
+  sa.prime(kbeg, kend);
+  sb.prime(kbeg, kend);
   sa.load(kbeg, kend);
   sb.load(kbeg, kend);
   sa.store(As0);

@@ -7,16 +7,23 @@
 #include "common.h"
 
 // one wave per (node, slot) row.  out[0] += pitch CE / n_valid_pitch, out[1] += dur CE / n_valid_dur.
+// Optionally also the gradients of the three un-embedding biases (column sums of d_logits over the drum rows,
+// the non-drum rows and all rows: model.py:561-567), accumulated in registers while the rows stream by.
 __global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ logits, const int* __restrict__ tok,
-                                                    const int* __restrict__ hist, int64_t rows, float grad_scale,
-                                                    float* __restrict__ dlogits, double* __restrict__ out) {
+                                                    const int* __restrict__ hist, const uint8_t* __restrict__ is_drum,
+                                                    int64_t rows, float grad_scale, float* __restrict__ dlogits,
+                                                    float* db_pitch_d, float* db_pitch_nd, float* db_dur,
+                                                    double* __restrict__ out) {
   __shared__ double sh[2][4];
+  __shared__ float sb[4][2][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // valid rows = all rows - PAD rows (token histogram of the plan: tables 0/1 pitch, 2/3 duration)
   const double np = (double)rows - (double)(hist[0 * PM_N_PITCH + 130] + hist[1 * PM_N_PITCH + 130]);
   const double nd = (double)rows - (double)(hist[2 * PM_N_PITCH + 98] + hist[3 * PM_N_PITCH + 98]);
   const float inv_p = (float)(1.0 / np), inv_d = (float)(1.0 / nd);
+  const bool want_b = db_pitch_d != nullptr && dlogits != nullptr;
   double lp = 0, ld = 0;
+  float bacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // [drum?][column lane + 64 j]
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const int n = (int)(row / PM_N_SLOTS), s = (int)(row % PM_N_SLOTS) + 1;
     const int tp = tok[((int64_t)n * 16 + s) * 2], td = tok[((int64_t)n * 16 + s) * 2 + 1];
@@ -46,30 +53,50 @@ __global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ lo
     if (dlogits) {
       float* g = dlogits + row * PM_N_TOK;
       const float kp = vp ? grad_scale * inv_p : 0.f, kd = vd ? grad_scale * inv_d : 0.f;
+      const int grp = want_b ? (is_drum[n] ? 1 : 0) : 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = lane + j * 64;
-        if (c < PM_N_PITCH) g[c] = kp * (e[j] / sp - (c == tp ? 1.f : 0.f));
-        else if (c < PM_N_TOK) g[c] = kd * (e[j] / sd - (c - PM_N_PITCH == td ? 1.f : 0.f));
+        float gv = 0.f;
+        if (c < PM_N_PITCH) gv = kp * (e[j] / sp - (c == tp ? 1.f : 0.f));
+        else if (c < PM_N_TOK) gv = kd * (e[j] / sd - (c - PM_N_PITCH == td ? 1.f : 0.f));
+        if (c < PM_N_TOK) g[c] = gv;
+        if (grp) bacc[1][j] += gv; else bacc[0][j] += gv;
       }
     }
   }
   if (lane == 0) { sh[0][wave] = lp; sh[1][wave] = ld; }
+  if (want_b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sb[wave][0][lane + 64 * j] = bacc[0][j]; sb[wave][1][lane + 64 * j] = bacc[1][j]; }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(&out[0], (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / np);
     atomicAdd(&out[1], (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / nd);
   }
+  if (want_b && threadIdx.x < PM_N_TOK) {
+    const int c = threadIdx.x;
+    const float nd_sum = sb[0][0][c] + sb[1][0][c] + sb[2][0][c] + sb[3][0][c];
+    const float d_sum = sb[0][1][c] + sb[1][1][c] + sb[2][1][c] + sb[3][1][c];
+    if (c < PM_N_PITCH) {
+      if (d_sum != 0.f) atomicAdd(&db_pitch_d[c], d_sum);
+      if (nd_sum != 0.f) atomicAdd(&db_pitch_nd[c], nd_sum);
+    } else if (nd_sum + d_sum != 0.f) atomicAdd(&db_dur[c - PM_N_PITCH], nd_sum + d_sum);
+  }
 }
-extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist, int32_t N,
-                             float grad_scale, float* d_logits, double* out, pm_stream_t stream) {
+extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist,
+                             const uint8_t* is_drum, int32_t N, float grad_scale, float* d_logits, float* db_pitch_drum,
+                             float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream) {
   if (!c_logits || !tokens || !tok_hist || !out || N <= 0) return PM_E_INVALID;
+  if (db_pitch_drum && (!db_pitch_nd || !db_dur || !is_drum || !d_logits)) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(out, 0, 2 * sizeof(double), st);
   const int64_t rows = (int64_t)N * PM_N_SLOTS;
   int nb = (int)pm_cdiv(rows, 4 * 8);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(256), 0, st, c_logits, tokens, tok_hist, rows, grad_scale, d_logits, out);
+  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(256), 0, st, c_logits, tokens, tok_hist, is_drum, rows, grad_scale,
+                     d_logits, db_pitch_drum, db_pitch_nd, db_dur, out);
   return pm_check_launch();
 }
 

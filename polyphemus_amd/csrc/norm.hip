@@ -101,22 +101,28 @@ __global__ void __launch_bounds__(256) k_colreduce_chan(const float* __restrict_
         sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
-// Sum the chunk partials of 64 columns with 4 waves (wave w takes chunks w, w+4, ...), then finish.
+// Sum the chunk partials of 64 columns with the 16 waves of a 1024-thread workgroup (wave w takes chunks
+// w, w+16, ...: at most 16 dependent L2 round trips per thread), then combine through LDS.
+#define BN_FIN_WAVES 16
 __device__ static inline void sum_chunks(const double* __restrict__ partial, int nchunk, int C, int c, int nacc,
                                          double (*sh)[64][BN_NACC], double* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double s[BN_NACC] = {0, 0, 0};
   if (c < C)
-    for (int k = wave; k < nchunk; k += 4)
+    for (int k = wave; k < nchunk; k += BN_FIN_WAVES)
       for (int a = 0; a < nacc; ++a) s[a] += partial[((int64_t)k * BN_NACC + a) * C + c];
   for (int a = 0; a < BN_NACC; ++a) sh[wave][lane][a] = s[a];
   __syncthreads();
-  for (int a = 0; a < BN_NACC; ++a) out[a] = sh[0][lane][a] + sh[1][lane][a] + sh[2][lane][a] + sh[3][lane][a];
+  for (int a = 0; a < BN_NACC; ++a) {
+    double t = 0;
+    for (int w = 0; w < BN_FIN_WAVES; ++w) t += sh[w][lane][a];
+    out[a] = t;
+  }
 }
-__global__ void __launch_bounds__(256) k_bn_finalize_stats(const double* __restrict__ partial, int nchunk, int C,
+__global__ void __launch_bounds__(1024) k_bn_finalize_stats(const double* __restrict__ partial, int nchunk, int C,
                                                            double count, float* mean, float* var, float* rmean,
                                                            float* rvar, float momentum) {
-  __shared__ double sh[4][64][BN_NACC];
+  __shared__ double sh[BN_FIN_WAVES][64][BN_NACC];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s[BN_NACC];
   sum_chunks(partial, nchunk, C, c, 2, sh, s);
@@ -135,10 +141,10 @@ __global__ void __launch_bounds__(256) k_bn_finalize_stats(const double* __restr
 // dgamma += sum(du*xhat); dbeta += sum(du); means = the two batch means of the backward formula;
 // dbias_pre += sum_rows dx = gamma*rstd*(sum(du) - count*mean(du) - mean(du*xhat)*sum(xhat))   (the gradient of a bias
 // added in front of this BatchNorm: analytically zero, evaluated here in fp64 instead of a separate column-sum pass)
-__global__ void __launch_bounds__(256) k_bn_finalize_bwd(const double* __restrict__ partial, int nchunk, int C,
+__global__ void __launch_bounds__(1024) k_bn_finalize_bwd(const double* __restrict__ partial, int nchunk, int C,
                                                          double count, BnCtx ctx, float* dgamma, float* dbeta,
                                                          float* dbias_pre, double* means) {
-  __shared__ double sh[4][64][BN_NACC];
+  __shared__ double sh[BN_FIN_WAVES][64][BN_NACC];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s[BN_NACC];
   sum_chunks(partial, nchunk, C, c, 3, sh, s);
@@ -188,7 +194,7 @@ extern "C" int pm_bn_stats(const float* x, int32_t O, int32_t C, int32_t I, floa
   BnCtx ctx = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
   int nchunk = 1;
   run_reduce<0>(x, nullptr, O, C, I, ctx, scratch, &nchunk, st);
-  hipLaunchKernelGGL(k_bn_finalize_stats, dim3(pm_cdiv(C, 64)), dim3(256), 0, st, scratch, nchunk, C,
+  hipLaunchKernelGGL(k_bn_finalize_stats, dim3(pm_cdiv(C, 64)), dim3(1024), 0, st, scratch, nchunk, C,
                      (double)O * (double)I, mean, var, running_mean, running_var, momentum);
   return pm_check_launch();
 }
@@ -264,7 +270,7 @@ extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, 
   int nchunk = 1;
   run_reduce<1>(x, dy, O, C, I, ctx, scratch, &nchunk, st);
   double* means = scratch + (int64_t)BN_MAX_CHUNKS * BN_NACC * C;
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(pm_cdiv(C, 64)), dim3(256), 0, st, scratch, nchunk, C,
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(pm_cdiv(C, 64)), dim3(1024), 0, st, scratch, nchunk, C,
                      (double)O * (double)I, ctx, dgamma, dbeta, dbias_pre, means);
   const int64_t n = (int64_t)O * C * I;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n)), dim3(256), 0, st, x, dy, n, C, I, ctx, means, dx);

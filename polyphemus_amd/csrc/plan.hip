@@ -13,7 +13,7 @@ void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   sz[PM_PLAN_COLPTR] = (int64_t)N + 1;
   sz[PM_PLAN_CSC_DST] = E; sz[PM_PLAN_CSC_RELDIST] = E; sz[PM_PLAN_CSC_EID] = E; sz[PM_PLAN_CSC_INVCNT] = E;
   sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = 2 * (int64_t)N;
-  sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH;
+  sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH; sz[PM_PLAN_ROW_LIST] = 2 * (int64_t)N * PM_N_SLOTS;
   // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums
   sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;
   int64_t o = 0;
@@ -169,11 +169,17 @@ __global__ void k_finish_csc(const int64_t* __restrict__ ei, const int32_t* __re
   }
 }
 __global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int* list,
-                             int* cnt) {
+                             int* rows, int* cnt) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n == 0) { cnt[0] = pos[N]; cnt[1] = N - pos[N]; cnt[2] = 0; cnt[3] = 0; }
+  if (n == 0) {
+    cnt[0] = pos[N]; cnt[1] = N - pos[N];
+    cnt[2] = PM_N_SLOTS * pos[N]; cnt[3] = PM_N_SLOTS * (N - pos[N]);
+  }
   if (n >= N) return;
-  if (is_drum[n]) list[pos[n]] = n; else list[N + (n - pos[n])] = n;   // non-drum list starts at N
+  const int slot = is_drum[n] ? pos[n] : N + (n - pos[n]);             // non-drum lists start at N (15 N for rows)
+  list[slot] = n;
+#pragma unroll
+  for (int s = 0; s < PM_N_SLOTS; ++s) rows[slot * PM_N_SLOTS + s] = n * PM_N_SLOTS + s;
 }
 
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
@@ -195,7 +201,7 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   hipMemsetAsync(rowptr, 0, sizeof(int) * ((int64_t)N * PM_N_REL + 1), st);
   hipMemsetAsync(colptr, 0, sizeof(int) * ((int64_t)N + 1), st);
   hipMemsetAsync(barptr, 0, sizeof(int) * ((int64_t)G + 1), st);
-  hipMemsetAsync(plan + o[PM_PLAN_GROUP_CNT], 0, sizeof(int) * (o[PM_PLAN_SCRATCH] - o[PM_PLAN_GROUP_CNT]), st);
+  hipMemsetAsync(plan + o[PM_PLAN_GROUP_CNT], 0, sizeof(int) * (o[PM_PLAN_ROW_LIST] - o[PM_PLAN_GROUP_CNT]), st);
   hipMemsetAsync(cur_in, 0, sizeof(int) * ((int64_t)N * PM_N_REL + N + N + 1), st);
   const int T = 256;
   hipLaunchKernelGGL(k_count_edges, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr);
@@ -219,7 +225,7 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
                      colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
                      reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
   hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N,
-                     plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_GROUP_CNT]);
+                     plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_ROW_LIST], plan + o[PM_PLAN_GROUP_CNT]);
   return pm_check_launch();
 }
 

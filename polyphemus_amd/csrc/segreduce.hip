@@ -218,7 +218,7 @@ extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA,
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
   int nblk = (int)pm_cdiv(N, 4);
-  if (nblk > 512) nblk = 512;
+  if (nblk > 1536) nblk = 1536;       // enough waves in flight to hide the dependent colptr -> edge -> row gathers
   const dim3 grid(nblk), block(256);
   const size_t lds = sizeof(float) * PM_N_DIST * d;
   const bool drop = dropout_p > 0.f;

@@ -225,11 +225,13 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
                       c.P + Y.dec_dur.b, 0, 1, nullptr, 0, nullptr, c.st));
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_d.w, dh, s.c_logits, PM_N_TOK,
-                      c.P + Y.dec_pitch_d.b, 0, 1, pv.group_list, PM_N_SLOTS, pv.group_cnt, c.st));
+                      c.P + Y.dec_pitch_d.b, 0, 1, pv.row_list, 1, pv.group_cnt + 2, c.st));
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_nd.w, dh, s.c_logits, PM_N_TOK,
-                      c.P + Y.dec_pitch_nd.b, 0, 1, pv.group_list + N, PM_N_SLOTS, pv.group_cnt + 1, c.st));
+                      c.P + Y.dec_pitch_nd.b, 0, 1, pv.row_list + (int64_t)N * PM_N_SLOTS, 1, pv.group_cnt + 3, c.st));
     // ---------------- losses (training.py:298-347) and their gradients w.r.t. the model outputs
-    c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, N, 1.0f, s.dc_logits, s.losses, c.st));
+    // (also accumulates the three un-embedding bias gradients: column sums of d_logits per node group)
+    c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, 1.0f, s.dc_logits, c.G + Y.dec_pitch_d.b,
+                        c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     hipMemsetAsync(s.dmu, 0, sizeof(float) * B * d, c.st);
     hipMemsetAsync(s.dlv, 0, sizeof(float) * B * d, c.st);
     c.chk(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
@@ -255,16 +257,14 @@ void backward_decoder(Ctx& c) {
                     nullptr, 0, 1, nullptr, 0, nullptr, c.st));
   c.chk(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
                     nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
-  c.chk(pm_colsum_acc(s.dc_logits + PM_N_PITCH, (int)R, PM_N_DUR, PM_N_TOK, c.G + Y.dec_dur.b, c.st));
   const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
   for (int g = 0; g < 2; ++g) {
-    const int32_t* lst = pv.group_list + (g ? N : 0);
-    const int32_t* cnt = pv.group_cnt + g;
+    const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);   // (node, slot) rows of the group
+    const int32_t* cnt = pv.group_cnt + 2 + g;
     c.chk(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
-                      PM_N_SLOTS, cnt, c.st));
+                      1, cnt, c.st));
     c.chk(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
-                      PM_GEMM_ACCUM, 0, lst, PM_N_SLOTS, cnt, c.st));
-    c.chk(pm_colsum_rows_acc(s.dc_logits, PM_N_PITCH, PM_N_TOK, lst, PM_N_SLOTS, cnt, N, c.G + pit[g].b, c.st));
+                      PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
   lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, PM_N_SLOTS * d, d, dxL);

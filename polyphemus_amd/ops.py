@@ -86,7 +86,17 @@ class Plan:
         return self.field("group_list")[self.N:2 * self.N]
 
     @property
+    def drum_rows(self) -> torch.Tensor:
+        """(node, slot) rows node*15+slot of the drum nodes (first 15*n_drum entries are live)."""
+        return self.field("row_list")[:self.N * C.N_SLOTS]
+
+    @property
+    def nondrum_rows(self) -> torch.Tensor:
+        return self.field("row_list")[self.N * C.N_SLOTS:2 * self.N * C.N_SLOTS]
+
+    @property
     def group_cnt(self) -> torch.Tensor:
+        """[n_drum, n_non_drum, 15*n_drum, 15*n_non_drum] (device)."""
         return self.field("group_cnt")
 
 
@@ -306,12 +316,15 @@ def maxpool4_bwd(x, dy):
     return dx
 
 
-def content_ce(c_logits, plan: Plan, grad_scale=1.0, want_grad=True, out=None):
+def content_ce(c_logits, plan: Plan, grad_scale=1.0, want_grad=True, out=None, dbias=None):
+    """dbias = (d_bias_pitch_drum [131], d_bias_pitch_non_drum [131], d_bias_dur [99]) accumulates the
+    un-embedding bias gradients inside the same pass (needs want_grad)."""
     N = c_logits.shape[0]
     out = out if out is not None else torch.empty(4, dtype=F64, device=c_logits.device)
     dl = torch.empty_like(c_logits) if want_grad else None
-    call("pm_content_ce", ptr(c_logits), ptr(plan.tokens), ptr(plan.tok_hist), N, grad_scale, ptr(dl), ptr(out),
-         stream())
+    b = dbias if dbias is not None else (None, None, None)
+    call("pm_content_ce", ptr(c_logits), ptr(plan.tokens), ptr(plan.tok_hist), ptr(plan.is_drum), N, grad_scale,
+         ptr(dl), ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(out), stream())
     return out, dl
 
 

@@ -119,12 +119,12 @@ def main():
     from polyphemus_amd.synthetic import synthetic_batch
     from polyphemus_amd.trainer import HipTrainer
 
-    rank, local, world = parallel.init_from_env("nccl")
+    rank, local, world = parallel.init_from_env(os.environ.get("PM_DIST_BACKEND", "nccl"))
     if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())     # (PM_DIST_BACKEND=gloo: ranks may share a GPU)
     torch.cuda.set_device(dev)
     cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=args.layers, d=args.d, n_bars=args.n_bars, resolution=8)
 
@@ -157,7 +157,7 @@ def main():
     NCLS = 14
     ms_a, work_a, cnt_a = (ctypes.c_double * NCLS)(), (ctypes.c_double * NCLS)(), (ctypes.c_int64 * NCLS)()
     L.pm_prof_end(ctypes.cast(ms_a, ctypes.c_void_p), ctypes.cast(work_a, ctypes.c_void_p), ctypes.cast(cnt_a, ctypes.c_void_p))
-    tiles, lay = ("64x64", "128x128", "64x256", "256x64"), ("NN", "NT", "TN")
+    tiles, lay = ("64x64x16", "128x128x16", "64x64x32", "128x128x32"), ("NN", "NT", "TN")
     names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(12)] + ["segreduce_fwd", "segreduce_bwd"]
     gst = {names[c]: dict(launches=int(cnt_a[c]), total_ms=ms_a[c], avg_us=1e3 * ms_a[c] / cnt_a[c], work=work_a[c])
            for c in range(NCLS) if cnt_a[c] > 0}

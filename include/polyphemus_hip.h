@@ -114,7 +114,7 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] *
  *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
  *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
 enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2 };
-/* tile configuration pm_gemm_f32 picks for a shape: 0 = 64x64, 1 = 128x128, 2 = 64x256, 3 = 256x64 (host only) */
+/* tile configuration pm_gemm_f32 picks for a shape: 0 = 64x64x16, 1 = 128x128x16, 2 = 64x64x32, 3 = 128x128x32 (host only) */
 int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K);
 int pm_gemm_force_config(int32_t cfg); /* -1 = automatic (default); 0..3 pins a configuration (A/B timing) */
 int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,

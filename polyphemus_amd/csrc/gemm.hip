@@ -7,11 +7,9 @@
 //
 // One kernel template, four tile configurations (all 64-lane waves, 32x32 MFMA tiles per wave):
 //   C0  64x64x16   4 waves (2x2)  small problems
-//   C1 128x128x16  4 waves (2x2)  wide outputs (N > 256): many tiles per CU
-//   C2  64x256x32  8 waves (2x4)  N <= 256 (every GCL / chord GEMM): the streamed operand (the node
-//                                 dimension, 16 k rows) is read from HBM exactly once and 8 waves
-//                                 per CU keep 2 waves per SIMD with only ~256 workgroups
-//   C3 256x64x32   8 waves (4x2)  the transposed situation (M <= 256, wide N: weight gradients)
+//   C1 128x128x16  4 waves (2x2)  weight gradients (transposed A, split-K)
+//   C2  64x64x32   4 waves (2x2)  long K (>= 1024): half the barriers per flop
+//   C3 128x128x32  4 waves (2x2)  (kept for A/B timing)
 // LDS tiles are k-major so an MFMA operand read is 32 consecutive floats per half-wave
 // (conflict-free ds_read_b32); global loads are staged through registers one k-tile ahead
 // (double-buffered LDS, one barrier per k-tile).  Workgroup ids are remapped so that tiles sharing
@@ -288,7 +286,7 @@ static void launch_t(int ta, int tb, bool va, bool vb, dim3 grid, hipStream_t st
   else launch_v<BM, BN, BK, WVM, WVN, true, false>(va, vb, grid, st, g);
 }
 
-static const int CFG_BM[4] = {64, 128, 64, 256}, CFG_BN[4] = {64, 128, 256, 64}, CFG_BK[4] = {16, 16, 32, 32};
+static const int CFG_BM[4] = {64, 128, 64, 128}, CFG_BN[4] = {64, 128, 64, 128}, CFG_BK[4] = {16, 16, 32, 32};
 
 // Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
 static int g_forced_cfg = -1;
@@ -296,14 +294,15 @@ extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && c
 static int pick_config(int transA, int M, int N, int K) {
   if (g_forced_cfg >= 0) return g_forced_cfg;
   // Measured on MI355X (tools/bench_gemm.py, shapes of the training step, interleaved A/B in one process):
-  //  - NN / NT (the node dimension is M): 64x64 tiles win or tie everywhere (102-113 TFLOP/s): 4 workgroups per
-  //    CU = 4 waves per SIMD hide the LDS/barrier latency; the panels they re-read sit in L2 / Infinity Cache.
-  //  - TN (weight gradients, K = node dimension, split-K): 128x128 tiles (100-108 TFLOP/s): both operands are
+  //  - NN / NT (the node dimension is M): 64x64 tiles win or tie everywhere: 4 workgroups per CU = 4 waves per
+  //    SIMD hide the LDS / barrier latency; the panels they re-read sit in L2 / Infinity Cache.  With a long K
+  //    (>= 1024: GCL forward, chord encoder, d(x_L)) BK = 32 halves the barriers per flop: 107-119 TFLOP/s
+  //    against 102-112; with K = d = 256 the BK = 16 variant stays ahead (110-114 against 106-108).
+  //  - TN (weight gradients, K = node dimension, split-K): 128x128 tiles (98-108 TFLOP/s): both operands are
   //    staged with plain 16-byte LDS rows and 4x fewer atomics leave the workgroup.
-  //  The 8-wave 64x256 / 256x64 shapes (operand streamed exactly once) are 5-20 % slower at these sizes.
-  (void)K;
+  //  8-wave 64x256 / 256x64 shapes (operand streamed exactly once) measured 5-20 % slower at these sizes.
   if (transA) return ((int64_t)M * N >= 128 * 128 * 2) ? 1 : 0;
-  return 0;
+  return K >= 1024 ? 2 : 0;
 }
 
 extern "C" int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K) { return pick_config(transA, M, N, K); }
@@ -348,8 +347,8 @@ extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t
   switch (cfg) {
     case 0: launch_t<64, 64, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
     case 1: launch_t<128, 128, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
-    case 2: launch_t<64, 256, 32, 2, 4>(transA, transB, va, vb, grid, st, g); break;
-    default: launch_t<256, 64, 32, 4, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 2: launch_t<64, 64, 32, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    default: launch_t<128, 128, 32, 2, 2>(transA, transB, va, vb, grid, st, g); break;
   }
   pm_prof_close(st, pe);
   return pm_check_launch();

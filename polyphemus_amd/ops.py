@@ -36,7 +36,7 @@ def _prof_end(name: str, e0, work: float):
         PROF[name].append((e0, e1, work))
 
 
-_GEMM_TILES = ("64x64", "128x128", "64x256", "256x64")
+_GEMM_TILES = ("64x64x16", "128x128x16", "64x64x32", "128x128x32")
 
 
 def gemm_class(transA: bool, transB: bool, M: int, N: int, K: int) -> str:

@@ -78,7 +78,11 @@ int pm_plan_build(const int64_t* edge_index /* [2,E] row0=src,row1=dst (data.py:
                   const int32_t* edge_type /* [E] 0..5 */, const int32_t* edge_dist /* [E] 0..31 */,
                   const int64_t* bars /* [N] */, const int64_t* batch /* [N] */,
                   const uint8_t* is_drum /* [N] */, const int32_t* tokens /* [N,16,2] */,
-                  int32_t n_bars, int32_t N, int32_t E, int32_t G, int32_t* plan, pm_stream_t stream);
+                  int32_t n_bars, int32_t n_slots /* active token slots S, 1..15 (see below); 15 = all */,
+                  int32_t N, int32_t E, int32_t G, int32_t* plan, pm_stream_t stream);
+/* Active slots: slot s >= S holds the PAD token in EVERY node of the batch (S = longest chord + EOS, known
+ * to the host that built the batch).  PAD rows carry no loss (ignore_index) and an identical embedding, so the
+ * token-level tensors of the fused step are [N, S, .] instead of [N, 15, .]; results are unchanged. */
 /* Reference-format inputs -> compact ids (the reference feeds one-hots, data.py:179-182,235-268). */
 int pm_edge_attrs_to_ids(const float* edge_attrs /* [E,33] */, int32_t E, int32_t* edge_type,
                          int32_t* edge_dist, pm_stream_t stream);
@@ -163,10 +167,19 @@ int pm_embed_tables(const float* w_pitch_drum /* [d/2,131] */, const float* b_pi
                     float* tables /* [4][131][d/2] normalised */, float* stats /* [4][2][d/2] mean,var */,
                     pm_stream_t stream);
 int pm_embed_gather(const float* tables, const int32_t* tokens /* [N,16,2] */, const uint8_t* is_drum,
-                    int32_t N, int32_t d, float* X /* [N,15,d] */, pm_stream_t stream);
-int pm_embed_bwd_scatter(const float* dX /* [N,15,d] */, const int32_t* tokens, const int32_t* plan, int32_t N,
-                         int32_t E, int32_t G, int32_t d, float* S /* [4][131][d/2], zeroed by the call */,
-                         pm_stream_t stream);
+                    int32_t N, int32_t d, int32_t n_slots, float* X /* [N,S,d] */, pm_stream_t stream);
+int pm_embed_bwd_scatter(const float* dX /* [N,S,d] */, const int32_t* tokens, const int32_t* plan, int32_t N,
+                         int32_t E, int32_t G, int32_t d, int32_t n_slots,
+                         float* S /* [4][131][d/2], zeroed by the call */, pm_stream_t stream);
+/* PAD tail of the chord encoder when n_slots < 15 (model.py:381-390): forward adds the constant contribution of the
+ * all-PAD slots (+ the Linear bias) per node group and applies the ReLU in place; backward adds the tail's exact
+ * gradients to chord_encoder.weight[:, S*d:] and to the PAD rows of the token sums. */
+int pm_chord_pad_fwd(const float* tables, const float* chord_w /* [d,15d] */, const float* chord_b,
+                     const uint8_t* is_drum, int32_t N, int32_t d, int32_t n_slots, float* cvec /* [2][d] scratch */,
+                     float* y /* [N,d] in place */, pm_stream_t stream);
+int pm_chord_pad_bwd(const float* dy /* [N,d] */, const uint8_t* is_drum, int32_t N, int32_t d, int32_t n_slots,
+                     const float* tables, const float* chord_w, float* gsum /* [2][d] scratch */,
+                     float* d_chord_w /* += */, float* S /* token sums, += */, pm_stream_t stream);
 int pm_embed_tables_bwd(const float* S, const float* w_pitch_drum, const float* b_pitch_drum,
                         const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur, const float* b_dur,
                         const float* bn_drum_g, const float* bn_nd_g, const float* bn_dur_g, const float* stats,
@@ -213,7 +226,8 @@ int pm_maxpool4_bwd(const float* x, const float* dy, int64_t n_out, float* dx, p
 /* db_* (optional, all or none, need d_logits): += column sums of d_logits over the drum rows / non-drum rows
  * (pitch block) and all rows (duration block) = gradients of the three un-embedding biases (model.py:561-567). */
 int pm_content_ce(const float* c_logits /* [N,15,230] */, const int32_t* tokens /* [N,16,2] */,
-                  const int32_t* tok_hist, const uint8_t* is_drum /* [N] or NULL */, int32_t N, float grad_scale,
+                  const int32_t* tok_hist, const uint8_t* is_drum /* [N] or NULL */, int32_t N,
+                  int32_t n_slots /* c_logits is [N,S,230] */, float grad_scale,
                   float* d_logits /* or NULL */, float* db_pitch_drum /* [131] or NULL */,
                   float* db_pitch_nd /* [131] */, float* db_dur /* [99] */, double* out, pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
@@ -272,10 +286,12 @@ typedef struct PmBatch {                                    /* device pointers o
   const int64_t* edge_index; const int32_t* edge_type; const int32_t* edge_dist;
   const int64_t* bars; const int64_t* batch; const uint8_t* is_drum; const int32_t* tokens; const float* s_tensor;
   int32_t N, E, G, B;
+  int32_t n_slots, reserved;                                /* active token slots S (1..15), see pm_plan_build */
 } PmBatch;
 int64_t pm_vae_layout_bytes(void);
 int64_t pm_vae_step_state_bytes(void);
-int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B);
+int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B,
+                                    int32_t n_slots);
 int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,
                         const PmBatch* batch, int32_t* plan, const float* eps /* [B,d] */, float msg_dropout,
                         uint32_t seed_enc, uint32_t seed_dec, float beta, int structure_loss_on_logits,

@@ -20,7 +20,7 @@ PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", 
 # argument codes: p = device pointer, i = int32, l = int64, f = float, u = uint32, s = stream
 _SIGS = {
     "pm_plan_layout": "iiip",
-    "pm_plan_build": "pppppppiiiips",
+    "pm_plan_build": "pppppppiiiiips",
     "pm_edge_attrs_to_ids": "pipps",
     "pm_tokens_from_onehot": "pips",
     "pm_edge_table": "ppips",
@@ -40,8 +40,10 @@ _SIGS = {
     "pm_reparam_fwd": "ppplps",
     "pm_reparam_bwd": "ppplpps",
     "pm_embed_tables": "pppppppppppppppppppiiffpps",
-    "pm_embed_gather": "pppiips",
-    "pm_embed_bwd_scatter": "pppiiiips",
+    "pm_embed_gather": "pppiiips",
+    "pm_chord_pad_fwd": "ppppiiipps",
+    "pm_chord_pad_bwd": "ppiiippppps",
+    "pm_embed_bwd_scatter": "pppiiiiips",
     "pm_embed_tables_bwd": "ppppppppppppifpppppppppppps",
     "pm_gate_fwd": "pppiips",
     "pm_attnpool_fwd": "ppppfpppiiiipps",
@@ -53,13 +55,13 @@ _SIGS = {
     "pm_conv3x3_bwd_weight": "ppiiiiiipps",
     "pm_maxpool4_fwd": "plps",
     "pm_maxpool4_bwd": "pplps",
-    "pm_content_ce": "ppppifppppps",
+    "pm_content_ce": "ppppiifppppps",
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
     "pm_adam_step": "pppplffffifs",
     "pm_prof_begin": "i",
     "pm_prof_end": "ppp",
-    "pm_vae_step_workspace_bytes": "piiii",
+    "pm_vae_step_workspace_bytes": "piiiii",
     "pm_vae_step_forward": "pppppppfuufiplpps",
     "pm_vae_step_backward_decoder": "ps",
     "pm_vae_step_backward_encoder": "ps",

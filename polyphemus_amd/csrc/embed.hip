@@ -80,11 +80,11 @@ extern "C" int pm_embed_tables(const float* w_pd, const float* b_pd, const float
 // one wave per (node, slot): d floats = [pitch half | duration half], float4 per lane
 __global__ void __launch_bounds__(256) k_embed_gather(const float* __restrict__ tables, const int* __restrict__ tok,
                                                       const uint8_t* __restrict__ is_drum, int64_t rows, int d,
-                                                      float* __restrict__ X) {
+                                                      int S, float* __restrict__ X) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63, dh = d / 2;
-  const int n = (int)(row / PM_N_SLOTS), s = (int)(row % PM_N_SLOTS) + 1;     // SOS slot dropped (model.py:349)
+  const int n = (int)(row / S), s = (int)(row % S) + 1;                       // SOS slot dropped (model.py:349)
   const int grp = is_drum[n] ? 0 : 1;
   const int p = tok[((int64_t)n * 16 + s) * 2], du = tok[((int64_t)n * 16 + s) * 2 + 1];
   const float* tp = tables + ((int64_t)grp * EMB_V + p) * dh;
@@ -96,11 +96,12 @@ __global__ void __launch_bounds__(256) k_embed_gather(const float* __restrict__ 
   }
 }
 extern "C" int pm_embed_gather(const float* tables, const int32_t* tokens, const uint8_t* is_drum, int32_t N, int32_t d,
-                               float* X, pm_stream_t stream) {
-  if (!tables || !tokens || !is_drum || !X || N <= 0 || d <= 0 || (d & 7)) return PM_E_INVALID;
-  const int64_t rows = (int64_t)N * PM_N_SLOTS;
+                               int32_t n_slots, float* X, pm_stream_t stream) {
+  if (!tables || !tokens || !is_drum || !X || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
+    return PM_E_INVALID;
+  const int64_t rows = (int64_t)N * n_slots;
   hipLaunchKernelGGL(k_embed_gather, dim3(pm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, tables, tokens,
-                     is_drum, rows, d, X);
+                     is_drum, rows, d, n_slots, X);
   return pm_check_launch();
 }
 
@@ -111,7 +112,7 @@ extern "C" int pm_embed_gather(const float* tables, const int32_t* tokens, const
 __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restrict__ dX, const int* __restrict__ tok,
                                                            const int* __restrict__ group_list,
                                                            const int* __restrict__ group_cnt, int N, int d,
-                                                           float* __restrict__ S) {
+                                                           int NS, float* __restrict__ S) {
   extern __shared__ __attribute__((aligned(16))) float sS[];
   const int t = blockIdx.y, grp = t & 1, kind = t >> 1, dh = d / 2;
   const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
@@ -120,16 +121,16 @@ __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restri
   const int nd = group_cnt[0];
   const int cnt = grp == 0 ? nd : group_cnt[1];
   const int* list = group_list + (grp == 0 ? 0 : N);
-  const int64_t rows = (int64_t)cnt * PM_N_SLOTS;
+  const int64_t rows = (int64_t)cnt * NS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // PAD is the token of >= 10 of the 15 slots of every node: its rows are summed in registers per wave and
   // hit the LDS row once, instead of serialising thousands of ds_add_f32 on one address.
   const int pad = kind == 0 ? 130 : 98;
   float2 pacc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // channels lane*2 + 128*j  (d/2 <= 512)
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int n = list[row / PM_N_SLOTS], s = (int)(row % PM_N_SLOTS) + 1;
+    const int n = list[row / NS], s = (int)(row % NS) + 1;
     const int v = tok[((int64_t)n * 16 + s) * 2 + kind];
-    const float* src = dX + ((int64_t)n * PM_N_SLOTS + (s - 1)) * d + kind * dh;
+    const float* src = dX + ((int64_t)n * NS + (s - 1)) * d + kind * dh;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = lane * 2 + 128 * j;
@@ -157,8 +158,9 @@ __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restri
   }
 }
 extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E,
-                                    int32_t G, int32_t d, float* S, pm_stream_t stream) {
-  if (!dX || !tokens || !plan || !S || N <= 0 || d <= 0 || (d & 7)) return PM_E_INVALID;
+                                    int32_t G, int32_t d, int32_t n_slots, float* S, pm_stream_t stream) {
+  if (!dX || !tokens || !plan || !S || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
+    return PM_E_INVALID;
   const int dh = d / 2;
   const size_t lds = sizeof(float) * EMB_V * dh;
   if (lds > 160 * 1024) return PM_E_UNSUPPORTED;
@@ -168,9 +170,10 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
   if (lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
-  int nb = (int)pm_cdiv((int64_t)N * PM_N_SLOTS, 4 * 64);
+  int nb = (int)pm_cdiv((int64_t)N * n_slots, 4 * 64);
   if (nb > 96) nb = 96;
-  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(256), lds, st, dX, tokens, pv.group_list, pv.group_cnt, N, d, S);
+  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(256), lds, st, dX, tokens, pv.group_list, pv.group_cnt, N, d,
+                     n_slots, S);
   return pm_check_launch();
 }
 
@@ -229,5 +232,118 @@ extern "C" int pm_embed_tables_bwd(const float* S, const float* w_pd, const floa
   const int dh = d / 2;
   hipLaunchKernelGGL(k_embed_tables_bwd, dim3(pm_cdiv(3 * dh, 64)), dim3(64), 0, (hipStream_t)stream, S, P, Gd, stats,
                      tok_hist, dh, eps);
+  return pm_check_launch();
+}
+
+// ---------------------------------------------------------------- PAD tail of the chord encoder
+// Slots beyond the last active one hold the PAD token in every node, so their part of the chord encoder
+//   chord_encoder(X)[n] = sum_s X[n, s, :] @ Wc[:, s-block]^T + b            (model.py:381-386)
+// is one constant vector per node group:  c_g = b + sum_{s >= S} Xpad_g @ Wc[:, s-block]^T,
+// Xpad_g = [Tn_pitch[g][PAD] | Tn_dur[g][PAD]].  The GEMM then runs on the S active slots only and these
+// tiny kernels add the tail (forward) and its exact gradients (backward).
+__device__ static inline float xpad(const float* __restrict__ tables, int g, int c, int dh) {
+  return c < dh ? tables[((int64_t)g * EMB_V + 130) * dh + c] : tables[((int64_t)(2 + g) * EMB_V + 98) * dh + (c - dh)];
+}
+// one wave per (group, output channel): dot of the d*(15-S) tail inputs with the weight row
+__global__ void __launch_bounds__(256) k_chord_pad_fwd(const float* __restrict__ tables, const float* __restrict__ Wc,
+                                                       const float* __restrict__ bc, int d, int S, float* __restrict__ cvec) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= 2 * d) return;
+  const int g = w / d, o = w % d, dh = d / 2;
+  const float* wrow = Wc + (int64_t)o * PM_N_SLOTS * d;
+  float acc = 0.f;
+  for (int i = S * d + lane; i < PM_N_SLOTS * d; i += 64) acc += xpad(tables, g, i % d, dh) * wrow[i];
+  acc = pm_wave_sum(acc);
+  if (lane == 0) cvec[g * d + o] = acc + bc[o];
+}
+// x0 = relu(y + c[group(n)])   (in place)
+__global__ void __launch_bounds__(256) k_group_bias_relu(float* __restrict__ y, const float* __restrict__ cvec,
+                                                         const uint8_t* __restrict__ is_drum, int N, int d) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* c = cvec + (is_drum[n] ? 0 : d);
+  for (int i = (threadIdx.x & 63) * 4; i < d; i += 256) {
+    float4 v = *reinterpret_cast<float4*>(y + (int64_t)n * d + i);
+    const float4 b = *reinterpret_cast<const float4*>(c + i);
+    v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+    *reinterpret_cast<float4*>(y + (int64_t)n * d + i) = v;
+  }
+}
+extern "C" int pm_chord_pad_fwd(const float* tables, const float* Wc, const float* bc, const uint8_t* is_drum, int32_t N,
+                                int32_t d, int32_t n_slots, float* cvec, float* y, pm_stream_t stream) {
+  if (!tables || !Wc || !bc || !is_drum || !cvec || !y || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
+    return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_chord_pad_fwd, dim3(pm_cdiv(2 * d, 4)), dim3(256), 0, st, tables, Wc, bc, d, n_slots, cvec);
+  hipLaunchKernelGGL(k_group_bias_relu, dim3(pm_cdiv(N, 4)), dim3(256), 0, st, y, cvec, is_drum, N, d);
+  return pm_check_launch();
+}
+// gsum[g][o] = sum over the nodes of group g of dy[n][o]
+__global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ dy, const uint8_t* __restrict__ is_drum,
+                                                      int N, int d, int rows_per_chunk, float* gsum) {
+  __shared__ float sh[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > N) r1 = N;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < d)
+    for (int r = r0 + wave; r < r1; r += 4) { const float v = dy[(int64_t)r * d + c]; if (is_drum[r]) a0 += v; else a1 += v; }
+  sh[wave][0][lane] = a0; sh[wave][1][lane] = a1;
+  __syncthreads();
+  if (wave == 0 && c < d) {
+    atomicAdd(&gsum[c], sh[0][0][lane] + sh[1][0][lane] + sh[2][0][lane] + sh[3][0][lane]);
+    atomicAdd(&gsum[d + c], sh[0][1][lane] + sh[1][1][lane] + sh[2][1][lane] + sh[3][1][lane]);
+  }
+}
+// dWc[o, s*d + c] += sum_g gsum[g][o] * Xpad_g[c]   for the tail slots s >= S
+__global__ void __launch_bounds__(256) k_chord_pad_bwd_w(const float* __restrict__ gsum, const float* __restrict__ tables,
+                                                         int d, int S, float* dWc) {
+  const int64_t total = (int64_t)d * (PM_N_SLOTS - S) * d;
+  const int dh = d / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(i / ((int64_t)(PM_N_SLOTS - S) * d)), rem = (int)(i % ((int64_t)(PM_N_SLOTS - S) * d));
+    const int c = rem % d;
+    dWc[(int64_t)o * PM_N_SLOTS * d + (int64_t)S * d + rem] += gsum[o] * xpad(tables, 0, c, dh) + gsum[d + o] * xpad(tables, 1, c, dh);
+  }
+}
+// S[pitch table g][PAD][c] / S[dur table 2+g][PAD][c] += sum_{s >= S} sum_o gsum[g][o] * Wc[o, s*d + c]
+__global__ void __launch_bounds__(256) k_chord_pad_bwd_x(const float* __restrict__ gsum, const float* __restrict__ Wc,
+                                                         int d, int S, float* Stab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * d) return;
+  const int g = i / d, c = i % d, dh = d / 2;
+  float acc = 0.f;
+  for (int o = 0; o < d; ++o) {
+    const float gv = gsum[g * d + o];
+    const float* wrow = Wc + (int64_t)o * PM_N_SLOTS * d + c;
+    float t = 0.f;
+    for (int s = S; s < PM_N_SLOTS; ++s) t += wrow[(int64_t)s * d];
+    acc += gv * t;
+  }
+  if (c < dh) Stab[((int64_t)g * EMB_V + 130) * dh + c] += acc;
+  else Stab[((int64_t)(2 + g) * EMB_V + 98) * dh + (c - dh)] += acc;
+}
+// dy = d loss / d (chord pre-activation) with the ReLU mask applied; Stab = the [4][131][d/2] token sums AFTER
+// pm_embed_bwd_scatter has filled the active slots.
+extern "C" int pm_chord_pad_bwd(const float* dy, const uint8_t* is_drum, int32_t N, int32_t d, int32_t n_slots,
+                                const float* tables, const float* Wc, float* gsum /* [2][d] scratch */, float* dWc,
+                                float* Stab, pm_stream_t stream) {
+  if (!dy || !is_drum || !tables || !Wc || !gsum || !dWc || !Stab || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 ||
+      n_slots > PM_N_SLOTS)
+    return PM_E_INVALID;
+  if (n_slots == PM_N_SLOTS) return PM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(gsum, 0, sizeof(float) * 2 * d, st);
+  int nc = (int)pm_cdiv(N, 128);
+  if (nc > 128) nc = 128;
+  const int rpc = (int)pm_cdiv(N, nc);
+  nc = (int)pm_cdiv(N, rpc);
+  hipLaunchKernelGGL(k_group_colsum, dim3(pm_cdiv(d, 64), nc), dim3(256), 0, st, dy, is_drum, N, d, rpc, gsum);
+  const int64_t total = (int64_t)d * (PM_N_SLOTS - n_slots) * d;
+  hipLaunchKernelGGL(k_chord_pad_bwd_w, dim3((unsigned)(pm_cdiv(total, 256) > 2048 ? 2048 : pm_cdiv(total, 256))), dim3(256), 0,
+                     st, gsum, tables, d, n_slots, dWc);
+  hipLaunchKernelGGL(k_chord_pad_bwd_x, dim3(pm_cdiv(2 * d, 64)), dim3(64), 0, st, gsum, Wc, d, n_slots, Stab);
   return pm_check_launch();
 }

@@ -11,21 +11,23 @@
 // the non-drum rows and all rows: model.py:561-567), accumulated in registers while the rows stream by.
 __global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ logits, const int* __restrict__ tok,
                                                     const int* __restrict__ hist, const uint8_t* __restrict__ is_drum,
-                                                    int64_t rows, float grad_scale, float* __restrict__ dlogits,
+                                                    int64_t rows, int S, float grad_scale, float* __restrict__ dlogits,
                                                     float* db_pitch_d, float* db_pitch_nd, float* db_dur,
                                                     double* __restrict__ out) {
   __shared__ double sh[2][4];
   __shared__ float sb[4][2][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // valid rows = all rows - PAD rows (token histogram of the plan: tables 0/1 pitch, 2/3 duration)
-  const double np = (double)rows - (double)(hist[0 * PM_N_PITCH + 130] + hist[1 * PM_N_PITCH + 130]);
-  const double nd = (double)rows - (double)(hist[2 * PM_N_PITCH + 98] + hist[3 * PM_N_PITCH + 98]);
+  // valid rows = all (node, slot 1..15) rows - PAD rows (token histogram of the plan: tables 0/1 pitch, 2/3 dur);
+  // only the first S slots are present in `logits` (the others are PAD in every node and contribute nothing)
+  const double rows15 = (double)(rows / S) * PM_N_SLOTS;
+  const double np = rows15 - (double)(hist[0 * PM_N_PITCH + 130] + hist[1 * PM_N_PITCH + 130]);
+  const double nd = rows15 - (double)(hist[2 * PM_N_PITCH + 98] + hist[3 * PM_N_PITCH + 98]);
   const float inv_p = (float)(1.0 / np), inv_d = (float)(1.0 / nd);
   const bool want_b = db_pitch_d != nullptr && dlogits != nullptr;
   double lp = 0, ld = 0;
   float bacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // [drum?][column lane + 64 j]
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int n = (int)(row / PM_N_SLOTS), s = (int)(row % PM_N_SLOTS) + 1;
+    const int n = (int)(row / S), s = (int)(row % S) + 1;
     const int tp = tok[((int64_t)n * 16 + s) * 2], td = tok[((int64_t)n * 16 + s) * 2 + 1];
     const float* r = logits + row * PM_N_TOK;
     float v[4];                                               // lanes cover 230 = 3 full passes + 38
@@ -86,16 +88,16 @@ __global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ lo
   }
 }
 extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist,
-                             const uint8_t* is_drum, int32_t N, float grad_scale, float* d_logits, float* db_pitch_drum,
-                             float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream) {
-  if (!c_logits || !tokens || !tok_hist || !out || N <= 0) return PM_E_INVALID;
+                             const uint8_t* is_drum, int32_t N, int32_t n_slots, float grad_scale, float* d_logits,
+                             float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream) {
+  if (!c_logits || !tokens || !tok_hist || !out || N <= 0 || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   if (db_pitch_drum && (!db_pitch_nd || !db_dur || !is_drum || !d_logits)) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(out, 0, 2 * sizeof(double), st);
-  const int64_t rows = (int64_t)N * PM_N_SLOTS;
+  const int64_t rows = (int64_t)N * n_slots;
   int nb = (int)pm_cdiv(rows, 4 * 8);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(256), 0, st, c_logits, tokens, tok_hist, is_drum, rows, grad_scale,
+  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(256), 0, st, c_logits, tokens, tok_hist, is_drum, rows, n_slots, grad_scale,
                      d_logits, db_pitch_drum, db_pitch_nd, db_dur, out);
   return pm_check_launch();
 }

@@ -168,24 +168,26 @@ __global__ void k_finish_csc(const int64_t* __restrict__ ei, const int32_t* __re
     csc_invcnt[p] = 1.0f / (float)(cnt > 1 ? cnt : 1);                      // scatter 'mean': sum / clamp(count, 1)
   }
 }
-__global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int* list,
+__global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int S, int* list,
                              int* rows, int* cnt) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n == 0) {
     cnt[0] = pos[N]; cnt[1] = N - pos[N];
-    cnt[2] = PM_N_SLOTS * pos[N]; cnt[3] = PM_N_SLOTS * (N - pos[N]);
+    cnt[2] = S * pos[N]; cnt[3] = S * (N - pos[N]);
   }
   if (n >= N) return;
-  const int slot = is_drum[n] ? pos[n] : N + (n - pos[n]);             // non-drum lists start at N (15 N for rows)
-  list[slot] = n;
-#pragma unroll
-  for (int s = 0; s < PM_N_SLOTS; ++s) rows[slot * PM_N_SLOTS + s] = n * PM_N_SLOTS + s;
+  const bool dr = is_drum[n] != 0;
+  const int j = dr ? pos[n] : n - pos[n];
+  list[dr ? j : N + j] = n;                                            // non-drum node list starts at N
+  int* r = rows + (dr ? 0 : (int64_t)N * PM_N_SLOTS) + (int64_t)j * S;  // non-drum row list starts at 15 N
+  for (int s = 0; s < S; ++s) r[s] = n * S + s;                        // rows of the [N, S, .] head tensors
 }
 
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
                              const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
-                             const int32_t* tokens, int32_t n_bars, int32_t N, int32_t E, int32_t G, int32_t* plan,
-                             pm_stream_t stream) {
+                             const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
+                             int32_t* plan, pm_stream_t stream) {
+  if (n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   if (!edge_index || !edge_type || !edge_dist || !bars || !batch || !is_drum || !plan || N <= 0 || E <= 0 || G <= 0)
     return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -224,7 +226,7 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   hipLaunchKernelGGL(k_finish_csc, dim3(pm_cdiv(N, T)), dim3(T), 0, st, edge_index, edge_type, edge_dist, E, N, rowptr,
                      colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
                      reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
-  hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N,
+  hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N, n_slots,
                      plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_ROW_LIST], plan + o[PM_PLAN_GROUP_CNT]);
   return pm_check_launch();
 }

@@ -42,7 +42,7 @@ struct StepState {
   float beta; int fix_structure;
   // encoder
   float *c0, *a0, *m0, *v0, *p0, *c1, *a1, *m1, *v1, *h1, *h2, *zcat;
-  float *emb_stats, *X, *x0; GcnSaved eg; float *g, *gm, *gv, *alpha, *pooled;
+  float *emb_stats, *X, *x0, *tables, *cvec; GcnSaved eg; float *g, *gm, *gv, *alpha, *pooled;
   float *m, *mm, *mv, *zg, *mu, *lv, *z;
   // decoder
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
@@ -54,7 +54,7 @@ constexpr uint64_t kMagic = 0x504d5354455031ULL;
 
 struct Ctx {
   StepState* s; hipStream_t st; int rc;
-  int N, E, Gn, B, d, nb, L;
+  int N, E, Gn, B, d, nb, L, S;          // S = active token slots (1..15)
   const float* P; float* G; float* Bf;
   void chk(int r) { if (r != PM_OK && rc == PM_OK) rc = r; }
 };
@@ -133,6 +133,7 @@ Ctx make_ctx(StepState* s, hipStream_t st) {
   c.s = s; c.st = st; c.rc = PM_OK;
   c.N = s->bt.N; c.E = s->bt.E; c.Gn = s->bt.G; c.B = s->bt.B;
   c.d = s->lay.d; c.nb = s->lay.n_bars; c.L = s->lay.n_layers;
+  c.S = s->bt.n_slots;
   c.P = s->P; c.G = s->G; c.Bf = s->Bf;
   return c;
 }
@@ -165,8 +166,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   // ---------------- content encoder (model.py:344-417)
   float* tables = ar.f((size_t)4 * PM_N_PITCH * dh);
   s.emb_stats = ar.f((size_t)4 * 2 * dh);
-  s.X = ar.f((size_t)N * PM_N_SLOTS * d);
+  const int S = c.S;                                   // token-level tensors are [N, S, .] (active slots only)
+  s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
+  s.tables = tables; s.cvec = ar.f((size_t)2 * d);
   if (run) {
     c.chk(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                           c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_d.b,
@@ -174,8 +177,13 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                           c.Bf + Y.enc_bn_d.rm, c.Bf + Y.enc_bn_d.rv, c.Bf + Y.enc_bn_nd.rm, c.Bf + Y.enc_bn_nd.rv,
                           c.Bf + Y.enc_bn_dur.rm, c.Bf + Y.enc_bn_dur.rv, pv.tok_hist, d, 1, 1e-5f, 0.1f, tables,
                           s.emb_stats, c.st));
-    c.chk(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, s.X, c.st));
-    lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
+    c.chk(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
+    if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
+    else {             // x0 = relu(X[:, :S] @ Wc[:, :S*d]^T + (bias + all-PAD tail slots, one vector per node group))
+      c.chk(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
+                        nullptr, 0, nullptr, c.st));
+      c.chk(pm_chord_pad_fwd(tables, c.P + Y.enc_chord.w, c.P + Y.enc_chord.b, s.bt.is_drum, N, d, S, s.cvec, s.x0, c.st));
+    }
   }
   float* xL = gcn_forward(c, s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
   s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);
@@ -215,12 +223,12 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     c.chk(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
   }
   float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
-  const int64_t R = (int64_t)N * PM_N_SLOTS;
+  const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.f((size_t)B * d); s.dlv = ar.f((size_t)B * d);
   if (run) {
-    lin(c, xdL, Y.dec_chord, N, PM_N_SLOTS * d, d, s.H, false);
+    lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);            // rows [0, S*d) of chord_decoder.weight
     // duration logits for every (node, slot) row; pitch logits per drum / non-drum node list (model.py:561-576)
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
                       c.P + Y.dec_dur.b, 0, 1, nullptr, 0, nullptr, c.st));
@@ -230,7 +238,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                       c.P + Y.dec_pitch_nd.b, 0, 1, pv.row_list + (int64_t)N * PM_N_SLOTS, 1, pv.group_cnt + 3, c.st));
     // ---------------- losses (training.py:298-347) and their gradients w.r.t. the model outputs
     // (also accumulates the three un-embedding bias gradients: column sums of d_logits per node group)
-    c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, 1.0f, s.dc_logits, c.G + Y.dec_pitch_d.b,
+    c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.dc_logits, c.G + Y.dec_pitch_d.b,
                         c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     hipMemsetAsync(s.dmu, 0, sizeof(float) * B * d, c.st);
     hipMemsetAsync(s.dlv, 0, sizeof(float) * B * d, c.st);
@@ -248,7 +256,8 @@ void backward_decoder(Ctx& c) {
   const PmVaeLayout& Y = s.lay;
   const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
   PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
-  const int64_t R = (int64_t)N * PM_N_SLOTS;
+  const int S = c.S;
+  const int64_t R = (int64_t)N * S;
   float* dzr = ar.f((size_t)B * 2 * d);
   hipMemsetAsync(dzr, 0, sizeof(float) * B * 2 * d, c.st);
   // ---- content decoder
@@ -267,7 +276,7 @@ void backward_decoder(Ctx& c) {
                       PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
-  lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, PM_N_SLOTS * d, d, dxL);
+  lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);          // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
   float* dcb = ar.f((size_t)Gn * d);
   c.chk(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
@@ -317,12 +326,22 @@ void backward_encoder(Ctx& c) {
                         c.G + Y.enc_gate_bn.b, pscr, c.st));
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
   c.chk(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
-  float* dX = ar.f((size_t)N * PM_N_SLOTS * d);
-  lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
-  float* S = ar.f((size_t)4 * PM_N_PITCH * dh);
-  c.chk(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, c.st));
+  const int S = c.S;
+  float* dX = ar.f((size_t)N * S * d);
+  float* Stab = ar.f((size_t)4 * PM_N_PITCH * dh);
+  float* gsum = ar.f((size_t)2 * d);
+  if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
+  else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
+    c.chk(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
+                      nullptr, 0, nullptr, c.st));
+    c.chk(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
+    c.chk(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
+                      nullptr, c.st));
+  }
+  c.chk(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
+  c.chk(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
   PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
-  c.chk(pm_embed_tables_bwd(S, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
+  c.chk(pm_embed_tables_bwd(Stab, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                             c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_nd.w,
                             c.P + Y.enc_bn_dur.w, s.emb_stats, pv.tok_hist, d, 1e-5f, c.G + Y.enc_pitch_d.w,
                             c.G + Y.enc_pitch_d.b, c.G + Y.enc_pitch_nd.w, c.G + Y.enc_pitch_nd.b, c.G + Y.enc_dur.w,
@@ -348,12 +367,12 @@ void backward_encoder(Ctx& c) {
 void measure_backward(Ctx& c) {
   // mirrors the ar.f() calls of backward_decoder / backward_encoder / gcn_backward (x2)
   Arena& ar = c.s->ar;
-  const size_t N = c.N, Gn = c.Gn, B = c.B, d = c.d, dh = d / 2, R = N * PM_N_SLOTS;
+  const size_t N = c.N, Gn = c.Gn, B = c.B, d = c.d, dh = d / 2, R = N * c.S;
   size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d) + Gn * d +
                   (Gn * 8 * 128 * 2 + Gn * 512 + 2 * Gn * d) + B * 2 * d + B * d +
-                  2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + N * PM_N_SLOTS * d + 4 * PM_N_PITCH * dh +
+                  2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + R * d + 2 * d + 4 * PM_N_PITCH * dh +
                   (2 * Gn * d + 2 * Gn * 512 + Gn * 8 * 32 + 2 * Gn * 8 * 128);
-  ar.take(floats * sizeof(float) + 64 * 256);    // + alignment slack of the ~60 carve-outs
+  ar.take(floats * sizeof(float) + 256 * 256);    // + alignment slack of the ~60 carve-outs
 }
 
 }  // namespace
@@ -361,11 +380,14 @@ void measure_backward(Ctx& c) {
 extern "C" int64_t pm_vae_layout_bytes(void) { return (int64_t)sizeof(PmVaeLayout); }
 extern "C" int64_t pm_vae_step_state_bytes(void) { return (int64_t)sizeof(StepState); }
 
-extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B) {
-  if (!lay || N <= 0 || E <= 0 || G <= 0 || B <= 0 || lay->n_layers > PM_MAX_LAYERS) return -1;
+extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B,
+                                               int32_t n_slots) {
+  if (!lay || N <= 0 || E <= 0 || G <= 0 || B <= 0 || lay->n_layers > PM_MAX_LAYERS || n_slots < 1 ||
+      n_slots > PM_N_SLOTS)
+    return -1;
   StepState s;
   memset(&s, 0, sizeof(s));
-  s.lay = *lay; s.bt.N = N; s.bt.E = E; s.bt.G = G; s.bt.B = B;
+  s.lay = *lay; s.bt.N = N; s.bt.E = E; s.bt.G = G; s.bt.B = B; s.bt.n_slots = n_slots;
   s.ar.base = nullptr; s.ar.cap = 0; s.ar.used = 0;
   Ctx c = make_ctx(&s, nullptr);
   forward(c, 0.f, 0, 0);
@@ -380,7 +402,8 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
                                    pm_stream_t stream) {
   if (!lay || !params || !buffers || !grads || !batch || !plan || !eps || !workspace || !state || !losses)
     return PM_E_INVALID;
-  if (lay->n_layers > PM_MAX_LAYERS || lay->n_layers <= 0 || (lay->d & 7) || batch->G != batch->B * lay->n_bars)
+  if (lay->n_layers > PM_MAX_LAYERS || lay->n_layers <= 0 || (lay->d & 7) || batch->G != batch->B * lay->n_bars ||
+      batch->n_slots < 1 || batch->n_slots > PM_N_SLOTS)
     return PM_E_INVALID;
   StepState* s = (StepState*)state;
   memset(s, 0, sizeof(*s));
@@ -390,7 +413,7 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
   hipStream_t st = (hipStream_t)stream;
   Ctx c = make_ctx(s, st);
   c.chk(pm_plan_build(batch->edge_index, batch->edge_type, batch->edge_dist, batch->bars, batch->batch, batch->is_drum,
-                      batch->tokens, lay->n_bars, batch->N, batch->E, batch->G, plan, stream));
+                      batch->tokens, lay->n_bars, batch->n_slots, batch->N, batch->E, batch->G, plan, stream));
   forward(c, msg_dropout, seed_enc, seed_dec);
   if (s->ar.overflow) return PM_E_INVALID;
   s->rc = c.rc;

@@ -155,7 +155,7 @@ class Engine:
             Tn[k + ".bn_non_drums.num_batches_tracked"] += has[1]
             Tn[k + ".bn_dur.num_batches_tracked"] += has[0] + has[1]
         X = torch.empty(N, C.N_SLOTS * d, dtype=F32, device=dev)
-        call("pm_embed_gather", ptr(tables), ptr(plan.tokens), ptr(plan.is_drum), N, d, ptr(X), stream())
+        call("pm_embed_gather", ptr(tables), ptr(plan.tokens), ptr(plan.is_drum), N, d, C.N_SLOTS, ptr(X), stream())
         x0 = self.lin(X, k + ".chord_encoder", relu=True)
         xL, gsv = self.gcn_forward(x0, plan, k + ".graph_encoder", training, seed, ENC_UID)
         gk = k + ".graph_attention.gate_nn"
@@ -203,7 +203,7 @@ class Engine:
         dX = self.lin_bwd(dx0, sv["X"], k + ".chord_encoder", G)
         dh = d // 2
         S = torch.empty(4, C.N_PITCH_TOKENS, dh, dtype=F32, device=dev)
-        call("pm_embed_bwd_scatter", ptr(dX), ptr(plan.tokens), ptr(plan.buf), N, plan.E, G_, d, ptr(S), stream())
+        call("pm_embed_bwd_scatter", ptr(dX), ptr(plan.tokens), ptr(plan.buf), N, plan.E, G_, d, C.N_SLOTS, ptr(S), stream())
         call("pm_embed_tables_bwd", ptr(S), ptr(Tn[k + ".drums_pitch_emb.weight"]), ptr(Tn[k + ".drums_pitch_emb.bias"]),
              ptr(Tn[k + ".non_drums_pitch_emb.weight"]), ptr(Tn[k + ".non_drums_pitch_emb.bias"]),
              ptr(Tn[k + ".dur_emb.weight"]), ptr(Tn[k + ".dur_emb.bias"]), ptr(Tn[k + ".bn_drums.weight"]),

@@ -169,7 +169,13 @@ def collate_samples(samples: Sequence[dict], n_bars: int) -> BarGraphBatch:
         batch.append(np.full(s["num_nodes"], i, np.int64))
         off += s["num_nodes"]
     cat = lambda k: np.concatenate([s[k] for s in samples])
+    tok = cat("tokens")
+    # active token slots: slot s (1..15) is active if any node holds a non-PAD token there; slots beyond the
+    # last active one are PAD everywhere, which lets the fused step skip them (same losses and gradients)
+    live = (tok[:, 1:, 0] != C.PITCH_PAD) | (tok[:, 1:, 1] != C.DUR_PAD)
+    n_slots = int(np.nonzero(live.any(axis=0))[0].max()) + 1 if live.any() else 1
     return BarGraphBatch(
+        n_slots=n_slots,
         edge_index=torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)])),
         edge_type=torch.from_numpy(cat("etype").astype(np.int32)),
         edge_dist=torch.from_numpy(cat("edist").astype(np.int32)),

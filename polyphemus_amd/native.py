@@ -58,7 +58,8 @@ class PmVaeLayout(C.Structure):
 class PmBatch(C.Structure):
     _fields_ = [("edge_index", C.c_void_p), ("edge_type", C.c_void_p), ("edge_dist", C.c_void_p), ("bars", C.c_void_p),
                 ("batch", C.c_void_p), ("is_drum", C.c_void_p), ("tokens", C.c_void_p), ("s_tensor", C.c_void_p),
-                ("N", C.c_int32), ("E", C.c_int32), ("G", C.c_int32), ("B", C.c_int32)]
+                ("N", C.c_int32), ("E", C.c_int32), ("G", C.c_int32), ("B", C.c_int32), ("n_slots", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 def build_layout(vae) -> PmVaeLayout:
@@ -98,4 +99,5 @@ def make_batch(graph, plan_tokens, is_drum_u8, et, ed) -> PmBatch:
     b.bars, b.batch, b.is_drum = graph.bars.data_ptr(), graph.batch.data_ptr(), is_drum_u8.data_ptr()
     b.tokens, b.s_tensor = plan_tokens.data_ptr(), graph.s_tensor.data_ptr()
     b.N, b.E, b.G = graph.bars.shape[0], graph.edge_index.shape[1], graph.s_tensor.shape[0]
+    b.n_slots = int(getattr(graph, "n_slots", 15) or 15)
     return b

@@ -127,7 +127,7 @@ def plan_build(edge_index, edge_type, edge_dist, bars, batch, is_drum, tokens, n
     off = plan_layout(N, E, G)
     buf = torch.empty(off[-1], dtype=I32, device=bars.device)
     call("pm_plan_build", ptr(edge_index), ptr(edge_type), ptr(edge_dist), ptr(bars), ptr(batch), ptr(is_drum),
-         ptr(tokens), n_bars, N, E, G, ptr(buf), stream())
+         ptr(tokens), n_bars, C.N_SLOTS, N, E, G, ptr(buf), stream())
     return Plan(buf, N, E, G, n_bars, tokens, is_drum)
 
 
@@ -323,7 +323,7 @@ def content_ce(c_logits, plan: Plan, grad_scale=1.0, want_grad=True, out=None, d
     out = out if out is not None else torch.empty(4, dtype=F64, device=c_logits.device)
     dl = torch.empty_like(c_logits) if want_grad else None
     b = dbias if dbias is not None else (None, None, None)
-    call("pm_content_ce", ptr(c_logits), ptr(plan.tokens), ptr(plan.tok_hist), ptr(plan.is_drum), N, grad_scale,
+    call("pm_content_ce", ptr(c_logits), ptr(plan.tokens), ptr(plan.tok_hist), ptr(plan.is_drum), N, C.N_SLOTS, grad_scale,
          ptr(dl), ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(out), stream())
     return out, dl
 

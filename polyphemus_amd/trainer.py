@@ -124,7 +124,7 @@ class HipTrainer:
         bt = make_batch(graph, tok, drum, et, ed)
         bt.s_tensor = s_tensor.data_ptr()
         bt.B = bt.G // vae.cfg["n_bars"]
-        need = int(L.pm_vae_step_workspace_bytes(ctypes.byref(self._layout), bt.N, bt.E, bt.G, bt.B))
+        need = int(L.pm_vae_step_workspace_bytes(ctypes.byref(self._layout), bt.N, bt.E, bt.G, bt.B, bt.n_slots))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.grads.device)
         off = plan_layout(bt.N, bt.E, bt.G)

@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
         assert tr.world == world
         eps = torch.randn(6, CFG["d"], generator=torch.Generator().manual_seed(7 + rank)).cuda()
         tr.train_step(_rank_batch(rank).to("cuda"), eps)
-        q.put((rank, vae.flat_params.detach().cpu(), tr.grads.detach().cpu()))
+        q.put((rank, vae.flat_params.detach().cpu().numpy(), tr.grads.detach().cpu().numpy()))   # by value
     finally:
         dist.destroy_process_group()
 
@@ -54,7 +54,7 @@ def test_two_rank_step_matches_mean_gradient_step():
     res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
-    (_, p0, g0), (_, p1, g1) = res
+    (_, p0, g0), (_, p1, g1) = [(r, torch.from_numpy(a), torch.from_numpy(b)) for r, a, b in res]
     assert torch.equal(p0, p1), "ranks diverged"
     assert torch.equal(g0, g1), "all-reduced gradient differs between ranks"
     # single-process reference: same initial weights (rank 0's), gradient = mean of the two local gradients

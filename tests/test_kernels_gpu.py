@@ -279,7 +279,7 @@ def test_embed_fwd_bwd(small, d, training):
          *[ptr(R32[k]) for k in ("rm_d", "rv_d", "rm_n", "rv_n", "rm_u", "rv_u")], ptr(plan.tok_hist), d, int(training),
          1e-5, 0.1, ptr(tables), ptr(stats), stream())
     X = torch.empty(plan.N, 15, d, device=DEV)
-    call("pm_embed_gather", ptr(tables), ptr(plan.tokens), ptr(plan.is_drum), plan.N, d, ptr(X), stream())
+    call("pm_embed_gather", ptr(tables), ptr(plan.tokens), ptr(plan.is_drum), plan.N, d, 15, ptr(X), stream())
     ref = embed_ref(P64, b, d, training, R64)
     assert rel_err(X, ref.detach()) < 1e-5
     for k in R32:
@@ -289,7 +289,7 @@ def test_embed_fwd_bwd(small, d, training):
     dX = torch.randn_like(X)
     ref.backward(dX.double())
     S = torch.empty(4, 131, dh, device=DEV)
-    call("pm_embed_bwd_scatter", ptr(dX), ptr(plan.tokens), ptr(plan.buf), plan.N, plan.E, plan.G, d, ptr(S), stream())
+    call("pm_embed_bwd_scatter", ptr(dX), ptr(plan.tokens), ptr(plan.buf), plan.N, plan.E, plan.G, d, 15, ptr(S), stream())
     G32 = {k: torch.zeros_like(v) for k, v in P32.items()}
     call("pm_embed_tables_bwd", ptr(S), *[ptr(P32[k]) for k in ("w_pd", "b_pd", "w_pn", "b_pn", "w_du", "b_du", "g_d",
                                                                "g_n", "g_u")], ptr(stats), ptr(plan.tok_hist), d, 1e-5,

@@ -35,7 +35,7 @@ def test_native_step_equals_python_step(B, nb, d, L, fix):
         results.append((losses, {k: v.detach().clone() for k, v in vae.state_dict().items()}, g1))
     (la, sa, ga), (lb, sb, gb) = results
     for k in la[0]:                                            # first step: identical inputs and weights
-        assert abs(la[0][k] - lb[0][k]) <= 1e-9 * max(1.0, abs(lb[0][k])), k
+        assert abs(la[0][k] - lb[0][k]) <= 1e-6 * max(1.0, abs(lb[0][k])), k   # (native: active slots + closed-form PAD tail)
     assert rel_err(ga, gb) < 1e-5
     for x, y in zip(la[1:], lb[1:]):                           # later steps: Adam has amplified atomics-order noise
         for k in x:

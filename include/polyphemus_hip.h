@@ -70,6 +70,9 @@ enum {
                            0 drum pitch, 1 non-drum pitch, 2 drum dur, 3 non-drum dur */
   PM_PLAN_ROW_LIST,     /* [2*15N] (node, slot) rows = node*15 + slot of the drum nodes in [0, 15 n_drum),
                            of the non-drum nodes from 15N on: row maps of the un-embedding GEMMs */
+  PM_PLAN_NODE_TREL,    /* [N] the track relation (0..3) that has in-edges at the node (see pm_segreduce_fwd) */
+  PM_PLAN_TRK_LIST,     /* [4N] nodes grouped by that relation: group t at offset t*N                   */
+  PM_PLAN_TRK_CNT,      /* [8] {4 group sizes, #nodes with in-edges of more than one track relation, 0,0,0} */
   PM_PLAN_SCRATCH,      /* cursors + scan partials                                */
   PM_PLAN_NFIELDS
 };
@@ -99,14 +102,19 @@ int pm_edge_table(const float* nn_weight /* [d,32] */, const float* nn_bias /* [
                   float* T /* [32,d] */, pm_stream_t stream);
 int pm_edge_table_bwd(const float* dT /* [32,d] */, int32_t d, float* d_nn_weight /* += */,
                       float* d_nn_bias /* += */, pm_stream_t stream);
+/* compact != 0: the aggregate is [N,4d] = [track block | onset | next | x].  A node only receives track edges of
+ * ONE track relation (its own track; data.py:36-49,173-176), so three of the four track blocks of every row are
+ * identically zero: the compact form stores the non-zero one (relation PM_PLAN_NODE_TREL[n]) and the GCL GEMM
+ * contracts K = 4d instead of 7d (the track block against weight[node_trel], grouped by relation).  Valid only
+ * when PM_PLAN_TRK_CNT[4] == 0 (true for every graph built by the reference's rules). */
 int pm_segreduce_fwd(const float* x /* [N,d] */, const float* T /* [32,d] */, const int32_t* plan,
                      int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
-                     uint32_t layer_uid, float* A /* [N,7d] */, pm_stream_t stream);
-int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] */,
+                     uint32_t layer_uid, int32_t compact, float* A /* [N,7d] or [N,4d] */, pm_stream_t stream);
+int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] or [N,4d] */,
                      const float* dres /* [N,d] or NULL: added to dx (residual path, model.py:206) */,
                      const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p,
-                     uint32_t seed, uint32_t layer_uid, float* dx /* [N,d] */, float* dT /* [32,d] += */,
-                     pm_stream_t stream);
+                     uint32_t seed, uint32_t layer_uid, int32_t compact, float* dx /* [N,d] */,
+                     float* dT /* [32,d] += */, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ dense contraction (fp32 MFMA)
  * C[M,N] (=|+=) op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU), v_mfma_f32_32x32x2_f32.
@@ -125,6 +133,16 @@ int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const f
                 const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
                 int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
                 pm_stream_t stream);
+/* n_groups independent GEMMs of the same shape bound in ONE launch (blockIdx.y = group): group g uses
+ * A + g*a_stride, B + g*b_stride, C + g*c_stride, bias + g*bias_stride (elements), rowmap + g*map_stride and
+ * dyn_entries + g*dyn_stride.  With a row map and a device-side count per group this is the per-relation
+ * contraction of the compact GCL: h[rows_t] += A'[rows_t, :d] @ weight[t] for the four track relations t. */
+int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                        const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
+                        int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
+                        int32_t n_groups, int64_t a_group_stride, int64_t b_group_stride, int64_t c_group_stride,
+                        int64_t bias_group_stride, int32_t map_group_stride, int32_t dyn_group_stride,
+                        pm_stream_t stream);
 
 /* ------------------------------------------------------------------ batch normalisation
  * nn.BatchNorm1d / BatchNorm2d / PyG BatchNorm (model.py:203,222,228,282,359-375,338,475,638).
@@ -286,7 +304,9 @@ typedef struct PmBatch {                                    /* device pointers o
   const int64_t* edge_index; const int32_t* edge_type; const int32_t* edge_dist;
   const int64_t* bars; const int64_t* batch; const uint8_t* is_drum; const int32_t* tokens; const float* s_tensor;
   int32_t N, E, G, B;
-  int32_t n_slots, reserved;                                /* active token slots S (1..15), see pm_plan_build */
+  int32_t n_slots;                                          /* active token slots S (1..15), see pm_plan_build */
+  int32_t flags;                                            /* bit 0: every node receives edges of at most one track
+                                                               relation (host-verified) -> compact GCL, K = 4d */
 } PmBatch;
 int64_t pm_vae_layout_bytes(void);
 int64_t pm_vae_step_state_bytes(void);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpolyphemus_hip.so")
 
 PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", "csc_reldist", "csc_eid",
-               "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "row_list", "scratch"]
+               "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "row_list", "node_trel", "trk_list", "trk_cnt", "scratch"]
 
 # argument codes: p = device pointer, i = int32, l = int64, f = float, u = uint32, s = stream
 _SIGS = {
@@ -25,9 +25,10 @@ _SIGS = {
     "pm_tokens_from_onehot": "pips",
     "pm_edge_table": "ppips",
     "pm_edge_table_bwd": "pipps",
-    "pm_segreduce_fwd": "pppiiiifuups",
-    "pm_segreduce_bwd": "pppppiiiifuupps",
+    "pm_segreduce_fwd": "pppiiiifuuips",
+    "pm_segreduce_bwd": "pppppiiiifuuipps",
     "pm_gemm_f32": "iiiiipipipipiipips",
+    "pm_gemm_f32_grouped": "iiiiipipipipiipipilllliis",
     "pm_gemm_config": "iiii",
     "pm_gemm_force_config": "i",
     "pm_bn_stats": "piiippppfps",

@@ -20,6 +20,7 @@ struct PmPlanView {
   const int32_t* colptr; const int32_t* csc_dst; const int32_t* csc_reldist; const int32_t* csc_eid;
   const float* csc_invcnt; const int32_t* node_bar; const int32_t* bar_ptr; const int32_t* group_list;
   const int32_t* group_cnt; const int32_t* tok_hist; const int32_t* row_list;
+  const int32_t* node_trel; const int32_t* trk_list; const int32_t* trk_cnt;
 };
 void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off);
 static inline PmPlanView pm_plan_view(const int32_t* plan, int32_t N, int32_t E, int32_t G) {
@@ -35,6 +36,7 @@ static inline PmPlanView pm_plan_view(const int32_t* plan, int32_t N, int32_t E,
   v.group_list = plan + o[PM_PLAN_GROUP_LIST]; v.group_cnt = plan + o[PM_PLAN_GROUP_CNT];
   v.tok_hist = plan + o[PM_PLAN_TOK_HIST];
   v.row_list = plan + o[PM_PLAN_ROW_LIST];
+  v.node_trel = plan + o[PM_PLAN_NODE_TREL]; v.trk_list = plan + o[PM_PLAN_TRK_LIST]; v.trk_cnt = plan + o[PM_PLAN_TRK_CNT];
   return v;
 }
 

@@ -309,21 +309,35 @@ __global__ void __launch_bounds__(256) k_chord_pad_bwd_w(const float* __restrict
   }
 }
 // S[pitch table g][PAD][c] / S[dur table 2+g][PAD][c] += sum_{s >= S} sum_o gsum[g][o] * Wc[o, s*d + c]
+// grid = (d/64, d/16): lanes own 64 consecutive columns c (coalesced weight rows), the 4 waves of a workgroup
+// split 16 output rows o; partial sums meet in LDS and leave with one float atomic per (group, column).
 __global__ void __launch_bounds__(256) k_chord_pad_bwd_x(const float* __restrict__ gsum, const float* __restrict__ Wc,
                                                          int d, int S, float* Stab) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * d) return;
-  const int g = i / d, c = i % d, dh = d / 2;
-  float acc = 0.f;
-  for (int o = 0; o < d; ++o) {
-    const float gv = gsum[g * d + o];
-    const float* wrow = Wc + (int64_t)o * PM_N_SLOTS * d + c;
-    float t = 0.f;
-    for (int s = S; s < PM_N_SLOTS; ++s) t += wrow[(int64_t)s * d];
-    acc += gv * t;
+  __shared__ float sh[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, dh = d / 2;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < d) {
+    for (int o = blockIdx.y * 16 + wave * 4; o < blockIdx.y * 16 + wave * 4 + 4 && o < d; ++o) {
+      const float* wrow = Wc + (int64_t)o * PM_N_SLOTS * d + c;
+      float t = 0.f;
+      for (int s = S; s < PM_N_SLOTS; ++s) t += wrow[(int64_t)s * d];
+      a0 += gsum[o] * t; a1 += gsum[d + o] * t;
+    }
   }
-  if (c < dh) Stab[((int64_t)g * EMB_V + 130) * dh + c] += acc;
-  else Stab[((int64_t)(2 + g) * EMB_V + 98) * dh + (c - dh)] += acc;
+  sh[wave][0][lane] = a0; sh[wave][1][lane] = a1;
+  __syncthreads();
+  if (wave == 0 && c < d) {
+    const float v0 = sh[0][0][lane] + sh[1][0][lane] + sh[2][0][lane] + sh[3][0][lane];
+    const float v1 = sh[0][1][lane] + sh[1][1][lane] + sh[2][1][lane] + sh[3][1][lane];
+    if (c < dh) {
+      atomicAdd(&Stab[((int64_t)0 * EMB_V + 130) * dh + c], v0);
+      atomicAdd(&Stab[((int64_t)1 * EMB_V + 130) * dh + c], v1);
+    } else {
+      atomicAdd(&Stab[((int64_t)2 * EMB_V + 98) * dh + (c - dh)], v0);
+      atomicAdd(&Stab[((int64_t)3 * EMB_V + 98) * dh + (c - dh)], v1);
+    }
+  }
 }
 // dy = d loss / d (chord pre-activation) with the ReLU mask applied; Stab = the [4][131][d/2] token sums AFTER
 // pm_embed_bwd_scatter has filled the active slots.
@@ -344,6 +358,6 @@ extern "C" int pm_chord_pad_bwd(const float* dy, const uint8_t* is_drum, int32_t
   const int64_t total = (int64_t)d * (PM_N_SLOTS - n_slots) * d;
   hipLaunchKernelGGL(k_chord_pad_bwd_w, dim3((unsigned)(pm_cdiv(total, 256) > 2048 ? 2048 : pm_cdiv(total, 256))), dim3(256), 0,
                      st, gsum, tables, d, n_slots, dWc);
-  hipLaunchKernelGGL(k_chord_pad_bwd_x, dim3(pm_cdiv(2 * d, 64)), dim3(64), 0, st, gsum, Wc, d, n_slots, Stab);
+  hipLaunchKernelGGL(k_chord_pad_bwd_x, dim3(pm_cdiv(d, 64), pm_cdiv(d, 16)), dim3(256), 0, st, gsum, Wc, d, n_slots, Stab);
   return pm_check_launch();
 }

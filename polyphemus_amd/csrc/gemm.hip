@@ -25,6 +25,8 @@ struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias;
   const int32_t* rowmap; const int32_t* dyn_entries;
   int M, N, K, lda, ldb, ldc, rpe, flags, kper, ntm, ntn;
+  // grouped launch: blockIdx.y = group; every group has its own operand bases, row-map slice and live count
+  int64_t a_boff, b_boff, c_boff, bias_boff; int map_boff, dyn_boff;
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -140,6 +142,13 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
   float* const As0 = smem;                              // two A buffers, then two B buffers
   float* const Bs0 = smem + 2 * BK * LDA_S;
 
+  if (gridDim.y > 1) {                       // grouped launch (uniform branch): shift everything to this group
+    const int64_t bi = blockIdx.y;
+    g.A += bi * g.a_boff; g.B += bi * g.b_boff; g.C += bi * g.c_boff;
+    if (g.bias) g.bias += bi * g.bias_boff;
+    if (g.rowmap) g.rowmap += bi * g.map_boff;
+    if (g.dyn_entries) g.dyn_entries += bi * g.dyn_boff;
+  }
   int M = g.M, K = g.K;
   if (g.dyn_entries) {                       // data-dependent size of the gathered dimension, read on device
     const int n = *g.dyn_entries * g.rpe;
@@ -307,10 +316,28 @@ static int pick_config(int transA, int M, int N, int K) {
 
 extern "C" int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K) { return pick_config(transA, M, N, K); }
 
+extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                                   const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
+                                   int split_k, const int32_t* rowmap, int32_t rows_per_entry,
+                                   const int32_t* dyn_entries, int32_t n_groups, int64_t a_group_stride,
+                                   int64_t b_group_stride, int64_t c_group_stride, int64_t bias_group_stride,
+                                   int32_t map_group_stride, int32_t dyn_group_stride, pm_stream_t stream);
+
 extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
                            const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
                            int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
                            pm_stream_t stream) {
+  return pm_gemm_f32_grouped(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, split_k, rowmap,
+                             rows_per_entry, dyn_entries, 1, 0, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                                   const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
+                                   int split_k, const int32_t* rowmap, int32_t rows_per_entry,
+                                   const int32_t* dyn_entries, int32_t n_groups, int64_t a_group_stride,
+                                   int64_t b_group_stride, int64_t c_group_stride, int64_t bias_group_stride,
+                                   int32_t map_group_stride, int32_t dyn_group_stride, pm_stream_t stream) {
+  if (n_groups < 1 || n_groups > 65535) return PM_E_INVALID;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return PM_E_INVALID;
   if (transA && transB) return PM_E_UNSUPPORTED;
   if ((rowmap || dyn_entries) && rows_per_entry <= 0) return PM_E_INVALID;
@@ -321,14 +348,16 @@ extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.rowmap = rowmap; g.dyn_entries = dyn_entries;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.rpe = rows_per_entry > 0 ? rows_per_entry : 1; g.flags = flags;
+  g.a_boff = a_group_stride; g.b_boff = b_group_stride; g.c_boff = c_group_stride; g.bias_boff = bias_group_stride;
+  g.map_boff = map_group_stride; g.dyn_boff = dyn_group_stride;
   const int cfg = pick_config(transA, M, N, K);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
-    if (transA && tiles < 384) {
-      split_k = (int)(512 / tiles);
+    if (transA && tiles * n_groups < 384) {
+      split_k = (int)(512 / (tiles * n_groups));
       const int maxs = (int)pm_cdiv(K, 8 * BK);
       if (split_k > maxs) split_k = maxs;
       if (split_k < 1) split_k = 1;
@@ -339,9 +368,9 @@ extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t
   g.kper = kper;
   split_k = (int)pm_cdiv(K, kper);
   // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
-  const bool va = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0);
-  const bool vb = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0);
-  dim3 grid((unsigned)tiles, 1, (unsigned)split_k);
+  const bool va = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (a_group_stride % 4 == 0);
+  const bool vb = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) && (b_group_stride % 4 == 0);
+  dim3 grid((unsigned)tiles, (unsigned)n_groups, (unsigned)split_k);
   hipStream_t st = (hipStream_t)stream;
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), 2.0 * M * N * K);
   switch (cfg) {

@@ -14,8 +14,10 @@ void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   sz[PM_PLAN_CSC_DST] = E; sz[PM_PLAN_CSC_RELDIST] = E; sz[PM_PLAN_CSC_EID] = E; sz[PM_PLAN_CSC_INVCNT] = E;
   sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = 2 * (int64_t)N;
   sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH; sz[PM_PLAN_ROW_LIST] = 2 * (int64_t)N * PM_N_SLOTS;
-  // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums
-  sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;
+  sz[PM_PLAN_NODE_TREL] = N; sz[PM_PLAN_TRK_LIST] = 4 * (int64_t)N; sz[PM_PLAN_TRK_CNT] = 8;
+  // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums | track flags/positions 4 x [N+1]
+  sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64 +
+                        4 * ((int64_t)N + 1);
   int64_t o = 0;
   for (int i = 0; i < PM_PLAN_NFIELDS; ++i) { off[i] = o; o += pm_align4(sz[i]); }
   off[PM_PLAN_NFIELDS] = o;
@@ -183,6 +185,29 @@ __global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restr
   for (int s = 0; s < S; ++s) r[s] = n * S + s;                        // rows of the [N, S, .] head tensors
 }
 
+// Track relation of a node: the (by construction unique) relation r in 0..3 that has in-edges at this node.
+// A node only receives track edges of its own track (data.py:36-49; the fake self-loop of a single-node bar is
+// type 0 and is then the node's only edge, data.py:173-176), so the four track blocks of the GCL aggregate are
+// block-sparse: one non-zero block per node.  cnt[4] counts nodes that violate this (foreign graphs).
+__global__ void k_node_trel(const int* __restrict__ rowptr, int N, int* trel, int* flags4, int* cnt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int t = -1, nrel = 0;
+  for (int r = 0; r < 4; ++r)
+    if (rowptr[n * PM_N_REL + r + 1] > rowptr[n * PM_N_REL + r]) { if (t < 0) t = r; ++nrel; }
+  if (t < 0) t = 0;
+  if (nrel > 1) atomicAdd(&cnt[4], 1);
+  trel[n] = t;
+  for (int r = 0; r < 4; ++r) flags4[(int64_t)r * (N + 1) + n] = (r == t) ? 1 : 0;
+}
+__global__ void k_trk_list(const int* __restrict__ trel, const int* __restrict__ pos4, int N, int* list, int* cnt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < 4) cnt[n] = pos4[(int64_t)n * (N + 1) + N];
+  if (n >= N) return;
+  const int t = trel[n];
+  list[(int64_t)t * N + pos4[(int64_t)t * (N + 1) + n]] = n;
+}
+
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
                              const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
                              const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
@@ -226,6 +251,16 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   hipLaunchKernelGGL(k_finish_csc, dim3(pm_cdiv(N, T)), dim3(T), 0, st, edge_index, edge_type, edge_dist, E, N, rowptr,
                      colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
                      reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
+  {
+    int* flags4 = sums + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;
+    int* tcnt = plan + o[PM_PLAN_TRK_CNT];
+    hipMemsetAsync(tcnt, 0, sizeof(int) * 8, st);
+    hipMemsetAsync(flags4, 0, sizeof(int) * 4 * ((int64_t)N + 1), st);
+    hipLaunchKernelGGL(k_node_trel, dim3(pm_cdiv(N, T)), dim3(T), 0, st, rowptr, N, plan + o[PM_PLAN_NODE_TREL], flags4, tcnt);
+    for (int t = 0; t < 4; ++t) exclusive_scan(flags4 + (int64_t)t * (N + 1), (int64_t)N + 1, sums, st);
+    hipLaunchKernelGGL(k_trk_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, plan + o[PM_PLAN_NODE_TREL], flags4, N,
+                       plan + o[PM_PLAN_TRK_LIST], tcnt);
+  }
   hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N, n_slots,
                      plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_ROW_LIST], plan + o[PM_PLAN_GROUP_CNT]);
   return pm_check_launch();

@@ -54,11 +54,17 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
                                                        const int* __restrict__ rowptr, const int* __restrict__ csr_src,
                                                        const int* __restrict__ csr_dist, const int* __restrict__ csr_eid,
                                                        int N, int d, uint32_t seed, uint32_t layer_uid,
-                                                       uint32_t thresh, float scale, float* __restrict__ A) {
+                                                       uint32_t thresh, float scale, const int* __restrict__ node_trel,
+                                                       float* __restrict__ A) {
   const int lane = threadIdx.x & 63;
   const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (n >= N) return;
-  const int64_t arow = (int64_t)n * 7 * d;
+  // compact layout (node_trel != NULL): A[n] = [track block | onset | next | x], 4 blocks instead of 7 — the
+  // three track blocks a node never receives edges of are identically zero and are not stored
+  const bool compact = node_trel != nullptr;
+  const int trel = compact ? node_trel[n] : -1;
+  const int nblk = compact ? 4 : 7;
+  const int64_t arow = (int64_t)n * nblk * d;
   int c[NV];
   bool ok[NV];
 #pragma unroll
@@ -67,6 +73,8 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
 #pragma unroll 1
   for (int r = 0; r < PM_N_REL; ++r) {
     const int end = rowptr[n * PM_N_REL + r + 1];
+    if (compact && r < 4 && r != trel) { beg = end; continue; }
+    const int blk = compact ? (r < 4 ? 0 : r - 3) : r;
     float4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -96,24 +104,25 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
       float4 o = make_float4(acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv);
-      *reinterpret_cast<float4*>(A + arow + (int64_t)r * d + c[v]) = o;
+      *reinterpret_cast<float4*>(A + arow + (int64_t)blk * d + c[v]) = o;
     }
     beg = end;
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     if (!ok[v]) continue;
-    *reinterpret_cast<float4*>(A + arow + (int64_t)PM_N_REL * d + c[v]) =
+    *reinterpret_cast<float4*>(A + arow + (int64_t)(nblk - 1) * d + c[v]) =
         *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
   }
 }
 
 extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
-                                int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, float* A,
+                                int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact, float* A,
                                 pm_stream_t stream) {
   if (!x || !T || !plan || !A || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f || dropout_p >= 1.f)
     return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
+  const int* trel = compact ? pv.node_trel : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(pm_cdiv(N, 4)), block(256);
   const bool drop = dropout_p > 0.f;
@@ -121,9 +130,9 @@ extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* p
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
 #define LAUNCH(NV, DR)                                                                                              \
   hipLaunchKernelGGL((k_segreduce_fwd<NV, DR>), grid, block, 0, st, x, T, pv.rowptr, pv.csr_src, pv.csr_dist,       \
-                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, A)
+                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, trel, A)
   const int nv = (int)pm_cdiv(d, 256);
-  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_FWD, 4.0 * d * (double)N * (1 + PM_N_REL) + 12.0 * E);
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_FWD, 4.0 * d * (double)N * (1 + (compact ? 3 : PM_N_REL)) + 12.0 * E);
   if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
   else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
   else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
@@ -145,12 +154,13 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
                                                        const int* __restrict__ csc_eid,
                                                        const float* __restrict__ csc_invcnt, int N, int d,
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
-                                                       float* __restrict__ dx, float* __restrict__ dT) {
+                                                       int compact, float* __restrict__ dx, float* __restrict__ dT) {
   extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][d]
   for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) sT[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int nblk = compact ? 4 : 7;
   int c[NV];
   bool ok[NV];
 #pragma unroll
@@ -163,7 +173,7 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
       xv[v] = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
-      acc[v] = *reinterpret_cast<const float4*>(dA + (int64_t)n * 7 * d + (int64_t)PM_N_REL * d + c[v]);
+      acc[v] = *reinterpret_cast<const float4*>(dA + ((int64_t)n * nblk + (nblk - 1)) * d + c[v]);
       if (dres) {
         const float4 rv = *reinterpret_cast<const float4*>(dres + (int64_t)n * d + c[v]);
         acc[v].x += rv.x; acc[v].y += rv.y; acc[v].z += rv.z; acc[v].w += rv.w;
@@ -173,13 +183,14 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
     for (int p = beg; p < end; ++p) {
       const int dst = csc_dst[p], rd = csc_reldist[p];
       const int r = rd & 0xff, dist = rd >> 8;
+      const int blk = compact ? (r < 4 ? 0 : r - 3) : r;     // compact: the one track block a node receives
       const float w = csc_invcnt[p] * scale;
       uint32_t key = 0;
       if (DROP) key = pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[p]);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if (!ok[v]) continue;
-        const float4 g4 = *reinterpret_cast<const float4*>(dA + (int64_t)dst * 7 * d + (int64_t)r * d + c[v]);
+        const float4 g4 = *reinterpret_cast<const float4*>(dA + ((int64_t)dst * nblk + blk) * d + c[v]);
         const float4 tv = *reinterpret_cast<const float4*>(T + dist * d + c[v]);
         float g[4] = {g4.x * w, g4.y * w, g4.z * w, g4.w * w};
         const float xs[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w};
@@ -211,14 +222,14 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
 
 extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
                                 int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
-                                uint32_t layer_uid, float* dx, float* dT, pm_stream_t stream) {
+                                uint32_t layer_uid, int32_t compact, float* dx, float* dT, pm_stream_t stream) {
   if (!x || !T || !dA || !plan || !dx || !dT || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f ||
       dropout_p >= 1.f)
     return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
   int nblk = (int)pm_cdiv(N, 4);
-  if (nblk > 1536) nblk = 1536;       // enough waves in flight to hide the dependent colptr -> edge -> row gathers
+  if (nblk > 768) nblk = 768;         // waves in flight (latency of colptr -> edge -> row gathers) vs table flushes
   const dim3 grid(nblk), block(256);
   const size_t lds = sizeof(float) * PM_N_DIST * d;
   const bool drop = dropout_p > 0.f;
@@ -226,9 +237,9 @@ extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA,
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
 #define LAUNCH(NV, DR)                                                                                               \
   hipLaunchKernelGGL((k_segreduce_bwd<NV, DR>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,          \
-                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, dx, dT)
+                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT)
   const int nv = (int)pm_cdiv(d, 256);
-  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * (PM_N_REL + 1) + 12.0 * E + 128.0 * d);
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 3 : PM_N_REL) + 1) + 12.0 * E + 128.0 * d);
   if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
   else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
   else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }

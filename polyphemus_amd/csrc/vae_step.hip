@@ -55,6 +55,7 @@ constexpr uint64_t kMagic = 0x504d5354455031ULL;
 struct Ctx {
   StepState* s; hipStream_t st; int rc;
   int N, E, Gn, B, d, nb, L, S;          // S = active token slots (1..15)
+  int compact;                           // 1: one track relation per node -> [N,4d] aggregates, K = 4d
   const float* P; float* G; float* Bf;
   void chk(int r) { if (r != PM_OK && rc == PM_OK) rc = r; }
 };
@@ -87,20 +88,36 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
 }
 
 // GCN.forward (model.py:190-208): L x { A = segreduce(x); h = A @ [W;root] + b; x' = x + relu(BN(h)) }
+// Compact mode (c.compact): A is [N,4d] = [track block | onset | next | x] and the contraction is
+//   h = A[:, d:4d] @ [W_4; W_5; root] + b            one GEMM, K = 3d
+//   h[rows_t] += A[rows_t, 0:d] @ W_t   (t = 0..3)   one grouped launch over the four track relations
+// i.e. 8 N d^2 flops instead of 14 N d^2 (the other three track blocks of every row are identically zero).
 float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t seed, uint32_t uid0, float p) {
   Arena& ar = c.s->ar;
-  const int N = c.N, d = c.d;
+  const int N = c.N, d = c.d, nb = c.compact ? 4 : 7;
+  const int64_t dd = (int64_t)d * d;
   sv.T = ar.f((size_t)PM_N_DIST * d);
   sv.seed = seed; sv.uid0 = uid0; sv.p = p;
-  if (ar.base) c.chk(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
+  PmPlanView pv;
+  if (ar.base) {
+    c.chk(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
+    pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
+  }
   sv.x[0] = x0;
   for (int i = 0; i < c.L; ++i) {
-    sv.A[i] = ar.f((size_t)N * 7 * d); sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
+    sv.A[i] = ar.f((size_t)N * nb * d); sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
     sv.mean[i] = ar.f(d); sv.var[i] = ar.f(d);
     if (!ar.base) continue;
-    c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, sv.A[i], c.st));
-    c.chk(pm_gemm_f32(0, 0, N, d, 7 * d, sv.A[i], 7 * d, c.P + g.weight[i], d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr,
-                      0, nullptr, c.st));
+    const float* W = c.P + g.weight[i];
+    c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
+    if (!c.compact) {
+      c.chk(pm_gemm_f32(0, 0, N, d, 7 * d, sv.A[i], 7 * d, W, d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr, 0, nullptr, c.st));
+    } else {
+      c.chk(pm_gemm_f32(0, 0, N, d, 3 * d, sv.A[i] + d, 4 * d, W + 4 * dd, d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr, 0,
+                        nullptr, c.st));
+      c.chk(pm_gemm_f32_grouped(0, 0, N, d, d, sv.A[i], 4 * d, W, d, sv.h[i], d, nullptr, PM_GEMM_ACCUM, 1, pv.trk_list, 1,
+                                pv.trk_cnt, 4, 0, dd, 0, 0, N, 1, c.st));
+    }
     bn_fwd(c, sv.h[i], N, d, 1, g.norm[i], true, sv.x[i], sv.x[i + 1], sv.mean[i], sv.var[i]);
   }
   return sv.x[c.L];
@@ -108,20 +125,36 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
 // returns d loss / d x0 ; dx_in is d loss / d x_L (overwritten scratch chain inside the arena)
 float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   Arena& ar = c.s->ar;
-  const int N = c.N, d = c.d;
+  const int N = c.N, d = c.d, nb = c.compact ? 4 : 7;
+  const int64_t dd = (int64_t)d * d;
   float* dT = ar.f((size_t)PM_N_DIST * d);
   float* dh = ar.f((size_t)N * d);
-  float* dA = ar.f((size_t)N * 7 * d);
+  float* dA = ar.f((size_t)N * nb * d);
   float* dxa = ar.f((size_t)N * d);
   float* dxb = ar.f((size_t)N * d);
+  PmPlanView pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
   hipMemsetAsync(dT, 0, sizeof(float) * PM_N_DIST * d, c.st);
   for (int i = c.L - 1; i >= 0; --i) {
+    const float* W = c.P + g.weight[i];
+    float* dW = c.G + g.weight[i];
     bn_bwd(c, sv.h[i], dx, N, d, 1, g.norm[i], sv.mean[i], sv.var[i], true, dh, c.G + g.bias[i]);
-    c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, c.P + g.weight[i], d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
-    c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, c.G + g.weight[i], d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0,
-                      nullptr, c.st));
+    if (!c.compact) {
+      c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
+      c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
+    } else {
+      // dA[:, d:4d] = dh @ [W_4;W_5;root]^T ; dA[rows_t, 0:d] = dh[rows_t] @ W_t^T
+      c.chk(pm_gemm_f32(0, 1, N, 3 * d, d, dh, d, W + 4 * dd, d, dA + d, 4 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
+      c.chk(pm_gemm_f32_grouped(0, 1, N, d, d, dh, d, W, d, dA, 4 * d, nullptr, 0, 1, pv.trk_list, 1, pv.trk_cnt, 4, 0, dd, 0,
+                                0, N, 1, c.st));
+      // d[W_4;W_5;root] += A[:, d:4d]^T dh ; dW_t += A[rows_t, 0:d]^T dh[rows_t]
+      c.chk(pm_gemm_f32(1, 0, 3 * d, d, N, sv.A[i] + d, 4 * d, dh, d, dW + 4 * dd, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0,
+                        nullptr, c.st));
+      c.chk(pm_gemm_f32_grouped(1, 0, d, d, N, sv.A[i], 4 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, pv.trk_list, 1,
+                                pv.trk_cnt, 4, 0, 0, dd, 0, N, 1, c.st));
+    }
     float* out = (dx == dxa) ? dxb : dxa;
-    c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, out, dT, c.st));
+    c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out, dT,
+                           c.st));
     dx = out;
   }
   c.chk(pm_edge_table_bwd(dT, d, c.G + g.nn_w, c.G + g.nn_b, c.st));
@@ -134,6 +167,7 @@ Ctx make_ctx(StepState* s, hipStream_t st) {
   c.N = s->bt.N; c.E = s->bt.E; c.Gn = s->bt.G; c.B = s->bt.B;
   c.d = s->lay.d; c.nb = s->lay.n_bars; c.L = s->lay.n_layers;
   c.S = s->bt.n_slots;
+  c.compact = (s->bt.flags & 1) ? 1 : 0;
   c.P = s->P; c.G = s->G; c.Bf = s->Bf;
   return c;
 }
@@ -368,7 +402,7 @@ void measure_backward(Ctx& c) {
   // mirrors the ar.f() calls of backward_decoder / backward_encoder / gcn_backward (x2)
   Arena& ar = c.s->ar;
   const size_t N = c.N, Gn = c.Gn, B = c.B, d = c.d, dh = d / 2, R = N * c.S;
-  size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d) + Gn * d +
+  size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d) + Gn * d +   // (7d: upper bound)
                   (Gn * 8 * 128 * 2 + Gn * 512 + 2 * Gn * d) + B * 2 * d + B * d +
                   2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + R * d + 2 * d + 4 * PM_N_PITCH * dh +
                   (2 * Gn * d + 2 * Gn * 512 + Gn * 8 * 32 + 2 * Gn * 8 * 128);
@@ -381,7 +415,7 @@ extern "C" int64_t pm_vae_layout_bytes(void) { return (int64_t)sizeof(PmVaeLayou
 extern "C" int64_t pm_vae_step_state_bytes(void) { return (int64_t)sizeof(StepState); }
 
 extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B,
-                                               int32_t n_slots) {
+                                               int32_t n_slots) {      // sized for the non-compact (7d) aggregates
   if (!lay || N <= 0 || E <= 0 || G <= 0 || B <= 0 || lay->n_layers > PM_MAX_LAYERS || n_slots < 1 ||
       n_slots > PM_N_SLOTS)
     return -1;

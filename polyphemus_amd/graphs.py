@@ -174,8 +174,14 @@ def collate_samples(samples: Sequence[dict], n_bars: int) -> BarGraphBatch:
     # last active one are PAD everywhere, which lets the fused step skip them (same losses and gradients)
     live = (tok[:, 1:, 0] != C.PITCH_PAD) | (tok[:, 1:, 1] != C.DUR_PAD)
     n_slots = int(np.nonzero(live.any(axis=0))[0].max()) + 1 if live.any() else 1
+    # every node receives track edges (types 0..3) of at most ONE relation: true for graphs built by the
+    # reference's rules; verified here because the compact GCL (K = 4d instead of 7d) relies on it
+    et_all, dst_all = cat("etype"), np.concatenate(dst)
+    trk = et_all < C.N_TRACKS
+    pairs = np.unique(np.stack([dst_all[trk], et_all[trk]], 1), axis=0)
+    track_unique = bool(pairs.shape[0] == np.unique(pairs[:, 0]).shape[0])
     return BarGraphBatch(
-        n_slots=n_slots,
+        n_slots=n_slots, track_unique=track_unique,
         edge_index=torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)])),
         edge_type=torch.from_numpy(cat("etype").astype(np.int32)),
         edge_dist=torch.from_numpy(cat("edist").astype(np.int32)),

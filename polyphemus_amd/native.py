@@ -51,7 +51,7 @@ _KIND = {"lin": PmLin, "bn": PmBn, "gcn": PmGcn}
 
 
 class PmVaeLayout(C.Structure):
-    _fields_ = ([("d", C.c_int32), ("n_bars", C.c_int32), ("n_layers", C.c_int32), ("reserved", C.c_int32)] +
+    _fields_ = ([("d", C.c_int32), ("n_bars", C.c_int32), ("n_layers", C.c_int32), ("flags", C.c_int32)] +
                 [(f, _KIND[k]) for f, k, _ in _LAYOUT])
 
 
@@ -59,7 +59,7 @@ class PmBatch(C.Structure):
     _fields_ = [("edge_index", C.c_void_p), ("edge_type", C.c_void_p), ("edge_dist", C.c_void_p), ("bars", C.c_void_p),
                 ("batch", C.c_void_p), ("is_drum", C.c_void_p), ("tokens", C.c_void_p), ("s_tensor", C.c_void_p),
                 ("N", C.c_int32), ("E", C.c_int32), ("G", C.c_int32), ("B", C.c_int32), ("n_slots", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 def build_layout(vae) -> PmVaeLayout:
@@ -100,4 +100,5 @@ def make_batch(graph, plan_tokens, is_drum_u8, et, ed) -> PmBatch:
     b.tokens, b.s_tensor = plan_tokens.data_ptr(), graph.s_tensor.data_ptr()
     b.N, b.E, b.G = graph.bars.shape[0], graph.edge_index.shape[1], graph.s_tensor.shape[0]
     b.n_slots = int(getattr(graph, "n_slots", 15) or 15)
+    b.flags = 1 if getattr(graph, "track_unique", False) else 0   # bit 0: one track relation per node (compact GCL)
     return b

@@ -149,7 +149,7 @@ def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int,
     A = out if out is not None else torch.empty(N, 7 * d, dtype=F32, device=x.device)
     e0 = _prof_begin("segreduce_fwd")
     call("pm_segreduce_fwd", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, float(dropout_p),
-         seed & 0xFFFFFFFF, layer_uid, ptr(A), stream())
+         seed & 0xFFFFFFFF, layer_uid, 0, ptr(A), stream())
     _prof_end("segreduce_fwd", e0, 4.0 * d * N * (1 + C.N_EDGE_TYPES) + 12.0 * plan.E)   # algorithmic HBM bytes
     return A
 
@@ -159,7 +159,7 @@ def segreduce_bwd(x, T, dA, dres, plan: Plan, dropout_p: float, seed: int, layer
     N, d = x.shape
     dx = out if out is not None else torch.empty(N, d, dtype=F32, device=x.device)
     call("pm_segreduce_bwd", ptr(x), ptr(T), ptr(dA), ptr(dres), ptr(plan.buf), N, plan.E, plan.G, d,
-         float(dropout_p), seed & 0xFFFFFFFF, layer_uid, ptr(dx), ptr(dT), stream())
+         float(dropout_p), seed & 0xFFFFFFFF, layer_uid, 0, ptr(dx), ptr(dT), stream())
     return dx
 
 

@@ -143,6 +143,28 @@ int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K,
                         int32_t n_groups, int64_t a_group_stride, int64_t b_group_stride, int64_t c_group_stride,
                         int64_t bias_group_stride, int32_t map_group_stride, int32_t dyn_group_stride,
                         pm_stream_t stream);
+/* Descriptor form of the grouped GEMM, plus "stacked" operands: when b_split_rows > 0 the STORED rows of B below
+ * b_split_rows belong to the group (B + g*b_group_stride) and the rows at and above it are shared by all groups and
+ * read from B + b_shared_off + row*ldb.  c_split_rows / c_shared_off do the same for the rows of C when transA (the
+ * shared rows are then accumulated atomically by all groups).  This binds the whole compact GCL contraction
+ *   h[rows_t] = A'[rows_t, 0:4d] @ [weight[t]; weight[4]; weight[5]; root]        (model.py:112,116)
+ * its input gradient and its weight gradient in one launch each. */
+typedef struct PmGemmDesc {
+  int32_t transA, transB, M, N, K;
+  const float* A; int32_t lda;
+  const float* B; int32_t ldb;
+  float* C; int32_t ldc;
+  const float* bias;
+  int32_t flags, split_k;
+  const int32_t* rowmap; int32_t rows_per_entry;
+  const int32_t* dyn_entries;
+  int32_t n_groups;
+  int64_t a_group_stride, b_group_stride, c_group_stride, bias_group_stride;
+  int32_t map_group_stride, dyn_group_stride;
+  int32_t b_split_rows; int64_t b_shared_off;
+  int32_t c_split_rows; int64_t c_shared_off;
+} PmGemmDesc;
+int pm_gemm_f32_desc(const PmGemmDesc* desc, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ batch normalisation
  * nn.BatchNorm1d / BatchNorm2d / PyG BatchNorm (model.py:203,222,228,282,359-375,338,475,638).

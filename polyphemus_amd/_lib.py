@@ -29,6 +29,7 @@ _SIGS = {
     "pm_segreduce_bwd": "pppppiiiifuuipps",
     "pm_gemm_f32": "iiiiipipipipiipips",
     "pm_gemm_f32_grouped": "iiiiipipipipiipipilllliis",
+    "pm_gemm_f32_desc": "ps",
     "pm_gemm_config": "iiii",
     "pm_gemm_force_config": "i",
     "pm_bn_stats": "piiippppfps",

@@ -27,6 +27,8 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc, rpe, flags, kper, ntm, ntn;
   // grouped launch: blockIdx.y = group; every group has its own operand bases, row-map slice and live count
   int64_t a_boff, b_boff, c_boff, bias_boff; int map_boff, dyn_boff;
+  // stacked operands: stored rows >= split are shared by all groups and live at base + hi (elements)
+  int b_split, c_split; int64_t b_hi, c_hi;
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -56,17 +58,21 @@ struct TileStage {
   __amdgpu_buffer_rsrc_t rsrc;
   const int32_t* map;
   int rpe, ld;
+  int split, lo_b, hi_b;                              // stacked operand: byte offset of stored rows < split / >= split
 
-  __device__ inline void init(const float* P, int ld_, int r0, int rmax, const int32_t* map_, int rpe_) {
+  __device__ inline int stack_off(int row) const { return row < split ? lo_b : hi_b; }
+  __device__ inline void init(const float* P, int ld_, int r0, int rmax, const int32_t* map_, int rpe_, int split_ = 0,
+                              int lo_b_ = 0, int hi_b_ = 0) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, PM_OOB, 0x00020000);
     map = map_; rpe = rpe_; ld = ld_;
+    split = split_; lo_b = lo_b_; hi_b = hi_b_;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       const int f = threadIdx.x + j * THREADS;
       if (KC) {                                        // row fixed per thread: resolve the row map once
         const int r = r0 + (VEC ? f / (BK / 4) : f / BK);
         const int kb = VEC ? (f % (BK / 4)) * 16 : (f % BK) * 4;
-        base[j] = r < rmax ? (int)(map_row(map, rpe, r) * ld * 4) + kb : PM_OOB;
+        base[j] = r < rmax ? (int)(map_row(map, rpe, r) * ld * 4) + kb + stack_off(r) : PM_OOB;
       } else {
         const int r = r0 + (VEC ? (f % (R / 4)) * 4 : f % R);
         base[j] = r < rmax ? r * 4 : PM_OOB;
@@ -86,7 +92,7 @@ struct TileStage {
         // gathered K rows: the row-map entry of THIS tile was fetched while the previous tile was being
         // multiplied (krow), so no index load sits between the MFMAs and the data load
         const int prow = map ? krow[j] : k;
-        off = (k < kmax && base[j] >= 0) ? base[j] + prow * (ld * 4) : PM_OOB;
+        off = (k < kmax && base[j] >= 0) ? base[j] + prow * (ld * 4) + stack_off(k) : PM_OOB;
         if (map) {
           const int kn = k + BK;
           krow[j] = kn < kmax ? (rpe == 1 ? map[kn] : map[kn / rpe] * rpe + kn % rpe) : 0;
@@ -144,28 +150,35 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
 
   if (gridDim.y > 1) {                       // grouped launch (uniform branch): shift everything to this group
     const int64_t bi = blockIdx.y;
-    g.A += bi * g.a_boff; g.B += bi * g.b_boff; g.C += bi * g.c_boff;
+    g.A += bi * g.a_boff;
+    if (g.b_split == 0) g.B += bi * g.b_boff;
+    if (g.c_split == 0) g.C += bi * g.c_boff;
     if (g.bias) g.bias += bi * g.bias_boff;
     if (g.rowmap) g.rowmap += bi * g.map_boff;
     if (g.dyn_entries) g.dyn_entries += bi * g.dyn_boff;
   }
-  int M = g.M, K = g.K;
+  int M = g.M, K = g.K, kper = g.kper;
   if (g.dyn_entries) {                       // data-dependent size of the gathered dimension, read on device
     const int n = *g.dyn_entries * g.rpe;
-    if (TA) K = n < K ? n : K; else M = n < M ? n : M;
+    if (TA) {                                // split-K ranges follow the LIVE length, so every z-slice has work
+      K = n < K ? n : K;
+      kper = (((K + (int)gridDim.z - 1) / (int)gridDim.z + BK - 1) / BK) * BK;
+    } else M = n < M ? n : M;
   }
   // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
   // contiguous run of tiles; tiles of one row panel (n fastest) then share the panel through one L2.
-  const int nwg = g.ntm * g.ntn;
+  // (with a device-side row count only the live row panels take part, so they still spread over all 8 XCDs)
+  const int nwg = (TA ? g.ntm : (M + BM - 1) / BM) * g.ntn;
   int t = blockIdx.x;
+  if (t >= nwg) return;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN;
   if (m0 >= M) return;
-  const int kbeg = blockIdx.z * g.kper;
-  int kend = kbeg + g.kper;
+  const int kbeg = blockIdx.z * kper;
+  int kend = kbeg + kper;
   if (kend > K) kend = K;
   if (kbeg >= kend) return;
 
@@ -189,7 +202,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   sa.init(g.A, g.lda, m0, M, mapA, g.rpe);
-  sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe);
+  sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe, g.b_split, (int)(blockIdx.y * g.b_boff * 4), (int)(g.b_hi * 4));
   sa.prime(kbeg, kend);
   sb.prime(kbeg, kend);
   sa.load(kbeg, kend);
@@ -251,13 +264,19 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
       const int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (row >= M) continue;
       float* crow = g.C + map_row(mapC, g.rpe, row) * g.ldc;
+      bool at = atomic;
+      if (g.c_split > 0) {                   // stacked C (weight gradient): shared rows collect every group's term
+        const bool shared = row >= g.c_split;
+        crow += shared ? g.c_hi : (int64_t)blockIdx.y * g.c_boff;
+        at = atomic || (shared && gridDim.y > 1);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wc * WN + j * 32 + li;
         if (col >= g.N) continue;
         float v = acc[i][j][r];
         if (add_bias) v += g.bias[col];
-        if (atomic) atomicAdd(crow + col, v);
+        if (at) atomicAdd(crow + col, v);
         else {
           if (accum) v += crow[col];
           if (relu) v = fmaxf(v, 0.f);
@@ -316,63 +335,57 @@ static int pick_config(int transA, int M, int N, int K) {
 
 extern "C" int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K) { return pick_config(transA, M, N, K); }
 
-extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
-                                   const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
-                                   int split_k, const int32_t* rowmap, int32_t rows_per_entry,
-                                   const int32_t* dyn_entries, int32_t n_groups, int64_t a_group_stride,
-                                   int64_t b_group_stride, int64_t c_group_stride, int64_t bias_group_stride,
-                                   int32_t map_group_stride, int32_t dyn_group_stride, pm_stream_t stream);
-
-extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
-                           const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
-                           int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
-                           pm_stream_t stream) {
-  return pm_gemm_f32_grouped(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, split_k, rowmap,
-                             rows_per_entry, dyn_entries, 1, 0, 0, 0, 0, 0, 0, stream);
-}
-
-extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
-                                   const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
-                                   int split_k, const int32_t* rowmap, int32_t rows_per_entry,
-                                   const int32_t* dyn_entries, int32_t n_groups, int64_t a_group_stride,
-                                   int64_t b_group_stride, int64_t c_group_stride, int64_t bias_group_stride,
-                                   int32_t map_group_stride, int32_t dyn_group_stride, pm_stream_t stream) {
+extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
+  if (!q) return PM_E_INVALID;
+  const int transA = q->transA, transB = q->transB, M = q->M, N = q->N, K = q->K, n_groups = q->n_groups;
   if (n_groups < 1 || n_groups > 65535) return PM_E_INVALID;
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return PM_E_INVALID;
+  if (!q->A || !q->B || !q->C || M <= 0 || N <= 0 || K <= 0 || q->lda <= 0 || q->ldb <= 0 || q->ldc <= 0) return PM_E_INVALID;
   if (transA && transB) return PM_E_UNSUPPORTED;
-  if ((rowmap || dyn_entries) && rows_per_entry <= 0) return PM_E_INVALID;
+  if ((q->rowmap || q->dyn_entries) && q->rows_per_entry <= 0) return PM_E_INVALID;
+  if (q->b_split_rows < 0 || q->c_split_rows < 0 || (q->c_split_rows > 0 && !transA)) return PM_E_INVALID;
   // operands are addressed with 32-bit byte offsets (buffer loads): each must span < 2 GiB
-  if (!rowmap && ((int64_t)(transA ? K : M) * lda * 4 >= ((int64_t)1 << 31) ||
-                  (int64_t)(transB ? N : K) * ldb * 4 >= ((int64_t)1 << 31))) return PM_E_UNSUPPORTED;
+  if (!q->rowmap && ((int64_t)(transA ? K : M) * q->lda * 4 >= ((int64_t)1 << 31) ||
+                     (int64_t)(transB ? N : K) * q->ldb * 4 >= ((int64_t)1 << 31))) return PM_E_UNSUPPORTED;
+  if (q->b_split_rows > 0 && (q->b_group_stride * (n_groups - 1) * 4 >= ((int64_t)1 << 30) ||
+                              q->b_shared_off * 4 >= ((int64_t)1 << 30) || q->b_shared_off < 0)) return PM_E_UNSUPPORTED;
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias; g.rowmap = rowmap; g.dyn_entries = dyn_entries;
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.rpe = rows_per_entry > 0 ? rows_per_entry : 1; g.flags = flags;
-  g.a_boff = a_group_stride; g.b_boff = b_group_stride; g.c_boff = c_group_stride; g.bias_boff = bias_group_stride;
-  g.map_boff = map_group_stride; g.dyn_boff = dyn_group_stride;
+  g.A = q->A; g.B = q->B; g.C = q->C; g.bias = q->bias; g.rowmap = q->rowmap; g.dyn_entries = q->dyn_entries;
+  g.M = M; g.N = N; g.K = K; g.lda = q->lda; g.ldb = q->ldb; g.ldc = q->ldc;
+  g.rpe = q->rows_per_entry > 0 ? q->rows_per_entry : 1; g.flags = q->flags;
+  g.a_boff = q->a_group_stride; g.b_boff = q->b_group_stride; g.c_boff = q->c_group_stride;
+  g.bias_boff = q->bias_group_stride; g.map_boff = q->map_group_stride; g.dyn_boff = q->dyn_group_stride;
+  g.b_split = q->b_split_rows; g.b_hi = q->b_shared_off; g.c_split = q->c_split_rows; g.c_hi = q->c_shared_off;
   const int cfg = pick_config(transA, M, N, K);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
+  // a gathered dimension with a device-side count per group: the groups PARTITION the rows, so the live work is
+  // about 1/n_groups of the bound the grid is sized for
+  const bool partitioned = q->dyn_entries && n_groups > 1;
+  int split_k = q->split_k;
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
     if (transA && tiles * n_groups < 384) {
       split_k = (int)(512 / (tiles * n_groups));
-      const int maxs = (int)pm_cdiv(K, 8 * BK);
+      const int maxs = (int)pm_cdiv(partitioned ? K / n_groups : K, 8 * BK);
       if (split_k > maxs) split_k = maxs;
       if (split_k < 1) split_k = 1;
     }
   }
+  const int flags = q->flags;
   if (split_k > 1 && ((flags & PM_GEMM_RELU) || !(flags & PM_GEMM_ACCUM))) return PM_E_INVALID;  // needs += semantics
+  if (g.c_split > 0 && n_groups > 1 && !(flags & PM_GEMM_ACCUM)) return PM_E_INVALID;
   const int kper = (int)pm_cdiv(pm_cdiv(K, split_k), BK) * BK;
   g.kper = kper;
-  split_k = (int)pm_cdiv(K, kper);
+  if (!(transA && q->dyn_entries)) split_k = (int)pm_cdiv(K, kper);     // (device-side K: the kernel re-derives kper)
   // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
-  const bool va = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (a_group_stride % 4 == 0);
-  const bool vb = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) && (b_group_stride % 4 == 0);
+  const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
+  const bool vb = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
+                  (q->b_group_stride % 4 == 0) && (q->b_shared_off % 4 == 0);
   dim3 grid((unsigned)tiles, (unsigned)n_groups, (unsigned)split_k);
   hipStream_t st = (hipStream_t)stream;
-  const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), 2.0 * M * N * K);
+  const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
+  const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);
   switch (cfg) {
     case 0: launch_t<64, 64, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
     case 1: launch_t<128, 128, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
@@ -381,6 +394,30 @@ extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N,
   }
   pm_prof_close(st, pe);
   return pm_check_launch();
+}
+
+extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                                   const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
+                                   int split_k, const int32_t* rowmap, int32_t rows_per_entry,
+                                   const int32_t* dyn_entries, int32_t n_groups, int64_t a_group_stride,
+                                   int64_t b_group_stride, int64_t c_group_stride, int64_t bias_group_stride,
+                                   int32_t map_group_stride, int32_t dyn_group_stride, pm_stream_t stream) {
+  PmGemmDesc q;
+  q.transA = transA; q.transB = transB; q.M = M; q.N = N; q.K = K; q.A = A; q.lda = lda; q.B = B; q.ldb = ldb;
+  q.C = C; q.ldc = ldc; q.bias = bias; q.flags = flags; q.split_k = split_k; q.rowmap = rowmap;
+  q.rows_per_entry = rows_per_entry; q.dyn_entries = dyn_entries; q.n_groups = n_groups;
+  q.a_group_stride = a_group_stride; q.b_group_stride = b_group_stride; q.c_group_stride = c_group_stride;
+  q.bias_group_stride = bias_group_stride; q.map_group_stride = map_group_stride; q.dyn_group_stride = dyn_group_stride;
+  q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0;
+  return pm_gemm_f32_desc(&q, stream);
+}
+
+extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                           const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
+                           int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
+                           pm_stream_t stream) {
+  return pm_gemm_f32_grouped(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, split_k, rowmap,
+                             rows_per_entry, dyn_entries, 1, 0, 0, 0, 0, 0, 0, stream);
 }
 
 // ---------------------------------------------------------------- launch-duration profiler (see prof.h)

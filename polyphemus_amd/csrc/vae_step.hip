@@ -87,10 +87,21 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
                   dbias_pre, dx, c.s->bn_scratch, c.st));
 }
 
+// descriptor skeleton of the compact GCL contractions: four track-relation groups, rows of group t listed in
+// plan.trk_list[t*N ..], live count plan.trk_cnt[t]
+PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
+  PmGemmDesc q;
+  memset(&q, 0, sizeof(q));
+  q.split_k = 1; q.rowmap = pv.trk_list; q.rows_per_entry = 1; q.dyn_entries = pv.trk_cnt;
+  q.n_groups = 4; q.map_group_stride = N; q.dyn_group_stride = 1;
+  (void)d;
+  return q;
+}
+
 // GCN.forward (model.py:190-208): L x { A = segreduce(x); h = A @ [W;root] + b; x' = x + relu(BN(h)) }
 // Compact mode (c.compact): A is [N,4d] = [track block | onset | next | x] and the contraction is
-//   h = A[:, d:4d] @ [W_4; W_5; root] + b            one GEMM, K = 3d
-//   h[rows_t] += A[rows_t, 0:d] @ W_t   (t = 0..3)   one grouped launch over the four track relations
+//   h[rows_t] = A[rows_t, 0:4d] @ [W_t; W_4; W_5; root] + b   (t = 0..3)
+// one grouped launch over the four track relations whose B operand is "stacked" (group rows + shared rows),
 // i.e. 8 N d^2 flops instead of 14 N d^2 (the other three track blocks of every row are identically zero).
 float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t seed, uint32_t uid0, float p) {
   Arena& ar = c.s->ar;
@@ -113,10 +124,11 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     if (!c.compact) {
       c.chk(pm_gemm_f32(0, 0, N, d, 7 * d, sv.A[i], 7 * d, W, d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr, 0, nullptr, c.st));
     } else {
-      c.chk(pm_gemm_f32(0, 0, N, d, 3 * d, sv.A[i] + d, 4 * d, W + 4 * dd, d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr, 0,
-                        nullptr, c.st));
-      c.chk(pm_gemm_f32_grouped(0, 0, N, d, d, sv.A[i], 4 * d, W, d, sv.h[i], d, nullptr, PM_GEMM_ACCUM, 1, pv.trk_list, 1,
-                                pv.trk_cnt, 4, 0, dd, 0, 0, N, 1, c.st));
+      PmGemmDesc q = gcl_desc(pv, N, d);                  // h[rows_t] = A'[rows_t] @ [W_t; W_4; W_5; root] + b
+      q.M = N; q.N = d; q.K = 4 * d;
+      q.A = sv.A[i]; q.lda = 4 * d; q.B = W; q.ldb = d; q.C = sv.h[i]; q.ldc = d; q.bias = c.P + g.bias[i];
+      q.b_group_stride = dd; q.b_split_rows = d; q.b_shared_off = 3 * dd;
+      c.chk(pm_gemm_f32_desc(&q, c.st));
     }
     bn_fwd(c, sv.h[i], N, d, 1, g.norm[i], true, sv.x[i], sv.x[i + 1], sv.mean[i], sv.var[i]);
   }
@@ -142,15 +154,16 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
     } else {
-      // dA[:, d:4d] = dh @ [W_4;W_5;root]^T ; dA[rows_t, 0:d] = dh[rows_t] @ W_t^T
-      c.chk(pm_gemm_f32(0, 1, N, 3 * d, d, dh, d, W + 4 * dd, d, dA + d, 4 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
-      c.chk(pm_gemm_f32_grouped(0, 1, N, d, d, dh, d, W, d, dA, 4 * d, nullptr, 0, 1, pv.trk_list, 1, pv.trk_cnt, 4, 0, dd, 0,
-                                0, N, 1, c.st));
-      // d[W_4;W_5;root] += A[:, d:4d]^T dh ; dW_t += A[rows_t, 0:d]^T dh[rows_t]
-      c.chk(pm_gemm_f32(1, 0, 3 * d, d, N, sv.A[i] + d, 4 * d, dh, d, dW + 4 * dd, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0,
-                        nullptr, c.st));
-      c.chk(pm_gemm_f32_grouped(1, 0, d, d, N, sv.A[i], 4 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, pv.trk_list, 1,
-                                pv.trk_cnt, 4, 0, 0, dd, 0, N, 1, c.st));
+      PmGemmDesc q = gcl_desc(pv, N, d);                  // dA'[rows_t] = dh[rows_t] @ [W_t; W_4; W_5; root]^T
+      q.transB = 1; q.M = N; q.N = 4 * d; q.K = d;
+      q.A = dh; q.lda = d; q.B = W; q.ldb = d; q.C = dA; q.ldc = 4 * d;
+      q.b_group_stride = dd; q.b_split_rows = d; q.b_shared_off = 3 * dd;
+      c.chk(pm_gemm_f32_desc(&q, c.st));
+      PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
+      w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM; w.split_k = 0;
+      w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;
+      w.c_group_stride = dd; w.c_split_rows = d; w.c_shared_off = 3 * dd;
+      c.chk(pm_gemm_f32_desc(&w, c.st));
     }
     float* out = (dx == dxa) ? dxb : dxa;
     c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out, dT,

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import ctypes
+
 import torch
 
 from . import constants as C
@@ -176,6 +178,33 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=Non
     call("pm_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
          flags, split_k, ptr(rowmap), rows_per_entry, ptr(dyn_entries), stream())
     _prof_end(cls, e0, 2.0 * M * N * K)                                                  # algorithmic flops
+    return out
+
+
+class _GemmDesc(ctypes.Structure):
+    """ctypes mirror of PmGemmDesc (include/polyphemus_hip.h)."""
+    _fields_ = [("transA", ctypes.c_int32), ("transB", ctypes.c_int32), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("A", ctypes.c_void_p), ("lda", ctypes.c_int32), ("B", ctypes.c_void_p),
+                ("ldb", ctypes.c_int32), ("C", ctypes.c_void_p), ("ldc", ctypes.c_int32), ("bias", ctypes.c_void_p),
+                ("flags", ctypes.c_int32), ("split_k", ctypes.c_int32), ("rowmap", ctypes.c_void_p),
+                ("rows_per_entry", ctypes.c_int32), ("dyn_entries", ctypes.c_void_p), ("n_groups", ctypes.c_int32),
+                ("a_group_stride", ctypes.c_int64), ("b_group_stride", ctypes.c_int64),
+                ("c_group_stride", ctypes.c_int64), ("bias_group_stride", ctypes.c_int64),
+                ("map_group_stride", ctypes.c_int32), ("dyn_group_stride", ctypes.c_int32),
+                ("b_split_rows", ctypes.c_int32), ("b_shared_off", ctypes.c_int64),
+                ("c_split_rows", ctypes.c_int32), ("c_shared_off", ctypes.c_int64)]
+
+
+def gemm_desc(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
+              split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None, n_groups=1, a_group_stride=0,
+              b_group_stride=0, c_group_stride=0, bias_group_stride=0, map_group_stride=0, dyn_group_stride=0,
+              b_split_rows=0, b_shared_off=0, c_split_rows=0, c_shared_off=0):
+    """Grouped / stacked-operand GEMM (`pm_gemm_f32_desc`): see PmGemmDesc in the header."""
+    q = _GemmDesc(int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
+                  (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0), split_k, ptr(rowmap), rows_per_entry,
+                  ptr(dyn_entries), n_groups, a_group_stride, b_group_stride, c_group_stride, bias_group_stride,
+                  map_group_stride, dyn_group_stride, b_split_rows, b_shared_off, c_split_rows, c_shared_off)
+    call("pm_gemm_f32_desc", ctypes.addressof(q), stream())
     return out
 
 

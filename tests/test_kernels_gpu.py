@@ -184,6 +184,50 @@ def test_gemm_strided_views_and_rowmap():
     assert rel_err(dW, want) < 5e-6
 
 
+@pytest.mark.parametrize("Nn,d", [(700, 64), (1000, 32), (333, 128)])
+def test_gemm_grouped_stacked_compact_gcl(Nn, d):
+    """The three contractions of the compact GCL (model.py:112,116 on [track block | onset | next | x]):
+    rows partitioned into four relation groups (row lists + device counts), B / C stacked as
+    [weight[t] (group rows) ; weight[4]; weight[5]; root (shared rows)]."""
+    torch.manual_seed(Nn + d)
+    trel = torch.randint(0, 4, (Nn,), device=DEV)
+    trel[: Nn // 3] = 2                                           # uneven groups
+    lists = torch.full((4, Nn), -7, dtype=torch.int32, device=DEV)   # entries past the live count are never read
+    cnt = torch.zeros(8, dtype=torch.int32, device=DEV)
+    for t in range(4):
+        rows = torch.nonzero(trel == t).flatten().to(torch.int32)
+        lists[t, : rows.numel()] = rows[torch.randperm(rows.numel(), device=DEV)]
+        cnt[t] = rows.numel()
+    A = torch.randn(Nn, 4 * d, device=DEV)
+    W = torch.randn(7 * d, d, device=DEV)                          # [W_0..W_3 | W_4 | W_5 | root]
+    bias = torch.randn(d, device=DEV)
+    dd = d * d
+    Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()  # [4, 4d, d]
+    grp = dict(rowmap=lists, rows_per_entry=1, dyn_entries=cnt, n_groups=4, map_group_stride=Nn, dyn_group_stride=1)
+    # forward
+    h = torch.full((Nn, d), float("nan"), device=DEV)
+    ops.gemm_desc(A, W, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,
+                  b_shared_off=3 * dd, **grp)
+    want = torch.einsum("nk,nkj->nj", A.double(), Wn[trel]) + bias.double()
+    assert rel_err(h, want) < 5e-6
+    # input gradient
+    dh = torch.randn(Nn, d, device=DEV)
+    dA = torch.full((Nn, 4 * d), float("nan"), device=DEV)
+    ops.gemm_desc(dh, W, dA, Nn, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
+                  b_shared_off=3 * dd, **grp)
+    assert rel_err(dA, torch.einsum("nj,nkj->nk", dh.double(), Wn[trel])) < 5e-6
+    # weight gradient (group rows plain / shared rows collected from all groups), accumulating
+    dW = torch.randn(7 * d, d, device=DEV)
+    want = dW.double().clone()
+    for t in range(4):
+        m = trel == t
+        want[t * d:(t + 1) * d] += A[m, :d].double().t() @ dh[m].double()
+    want[4 * d:] += A[:, d:].double().t() @ dh.double()
+    ops.gemm_desc(A, dh, dW, 4 * d, d, Nn, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
+                  c_split_rows=d, c_shared_off=3 * dd, **grp)
+    assert rel_err(dW, want) < 5e-6
+
+
 # ------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize("shape,I", [((1000, 256), 1), ((37, 24), 1), ((500, 1), 1), ((64, 8, 4, 32), 128),
                                      ((20, 16, 4, 8), 32)])

@@ -126,9 +126,12 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] o
  *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
  *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
 enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2 };
-/* tile configuration pm_gemm_f32 picks for a shape: 0 = 64x64x16, 1 = 128x128x16, 2 = 64x64x32, 3 = 128x128x32 (host only) */
+/* tile configuration pm_gemm_f32 picks for a shape (host only).  fp32 MFMA: 0 = 64x64x16, 1 = 128x128x16,
+ * 2 = 64x64x32, 3 = 128x128x32.  Split mode (fp32 operands split exactly into three bf16 terms, six partial products
+ * on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error below an fp32 FMA chain): 4 = 128x128x16, 5 = 128x64x16,
+ * 6 = 64x64x32, 7 = 128x128x32; needs 16-byte aligned operands, otherwise the fp32 rule applies. */
 int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K);
-int pm_gemm_force_config(int32_t cfg); /* -1 = automatic (default); 0..3 pins a configuration (A/B timing) */
+int pm_gemm_force_config(int32_t cfg); /* -1 = automatic (default); 0..7 pins a configuration (A/B timing) */
 int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
                 const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int flags,
                 int split_k, const int32_t* rowmap, int32_t rows_per_entry, const int32_t* dyn_entries,
@@ -285,11 +288,11 @@ uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32
 
 /* ------------------------------------------------------------------ launch-duration profiler (bench.py roofline)
  * HIP events around every GEMM / segment-reduce launch while enabled; pm_prof_end sums the durations per class:
- * classes 0..11 = GEMM tile configuration * 3 + {0 NN, 1 NT, 2 TN}; 12 = segment-reduce forward; 13 = backward.
+ * classes 0..23 = GEMM tile configuration (0..7) * 3 + {0 NN, 1 NT, 2 TN}; 24 = segment-reduce forward; 25 = backward.
  * `work` = algorithmic flops (GEMM) or algorithmic HBM bytes (segment-reduce) of the launches. */
-enum { PM_PROF_NCLASS_PUBLIC = 14 };
+enum { PM_PROF_NCLASS_PUBLIC = 26 };
 int pm_prof_begin(int32_t max_events);
-int pm_prof_end(double* ms /* [14] host */, double* work /* [14] host */, int64_t* count /* [14] host */);
+int pm_prof_end(double* ms /* [26] host */, double* work /* [26] host */, int64_t* count /* [26] host */);
 
 /* ------------------------------------------------------------------ native training step
  * The whole of `PolyphemusTrainer.train`'s inner iteration (training.py:137-166) issued from C++:

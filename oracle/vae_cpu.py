@@ -58,7 +58,7 @@ def gcl_forward(x, edge_index, edge_type, edge_attr, P: Params, key: str, traini
     out = sum_r mean_{e: type r, dst=n} dropout(relu(x[src_e] * edge_nn(onehot dist_e))) @ W_r
           + x @ root + bias, accumulated in relation order 0..5, then root, then bias."""
     N, d_out = x.shape[0], P[key + ".weight"].shape[2]
-    out = torch.zeros(N, d_out)                                            # model.py:79
+    out = torch.zeros(N, d_out, dtype=x.dtype)                             # model.py:79
     eids = torch.arange(edge_index.shape[1])
     for r in range(N_REL):                                                 # model.py:103
         m = edge_type == r                                                 # float column vs int, model.py:104
@@ -72,8 +72,8 @@ def gcl_forward(x, edge_index, edge_type, edge_attr, P: Params, key: str, traini
                 msg = msg * keep_mask(key, eids[m], msg.shape[1]) / (1.0 - msg_dropout)
             else:
                 msg = F.dropout(msg, p=msg_dropout, training=True)
-        h = torch.zeros(N, msg.shape[1]).index_add_(0, ei[1], msg)         # scatter-sum onto dst
-        cnt = torch.zeros(N).index_add_(0, ei[1], torch.ones(ei.shape[1]))
+        h = torch.zeros(N, msg.shape[1], dtype=msg.dtype).index_add_(0, ei[1], msg)   # scatter-sum onto dst
+        cnt = torch.zeros(N, dtype=msg.dtype).index_add_(0, ei[1], torch.ones(ei.shape[1], dtype=msg.dtype))
         h = h / cnt.clamp(min=1).unsqueeze(1)                              # reduce='mean'
         out = out + h @ P[key + ".weight"][r]                              # model.py:112
     out = out + x @ P[key + ".root"]                                       # model.py:116
@@ -136,12 +136,12 @@ def attention_pool(x, seg, P: Params, key: str, cfg, training: bool):
     g = F.dropout(x, cfg["dropout"], training)                             # MLP.forward, model.py:160
     g = _lin(g, P, key + ".gate_nn.0.layers.0")
     g = _bn(g, P, key + ".gate_nn.1", training).view(-1, 1)
-    gmax = torch.full((size, 1), float("-inf")).scatter_reduce(
+    gmax = torch.full((size, 1), float("-inf"), dtype=g.dtype).scatter_reduce(
         0, seg.view(-1, 1), g, reduce="amax", include_self=True)
     e = (g - gmax.index_select(0, seg)).exp()
-    ssum = torch.zeros(size, 1).index_add_(0, seg, e)
+    ssum = torch.zeros(size, 1, dtype=e.dtype).index_add_(0, seg, e)
     gate = e / (ssum.index_select(0, seg) + 1e-16)
-    return torch.zeros(size, x.shape[1]).index_add_(0, seg, gate * x)
+    return torch.zeros(size, x.shape[1], dtype=x.dtype).index_add_(0, seg, gate * x)
 
 
 def content_encoder(graph, P: Params, cfg, training: bool, msg_dropout: float, keep_mask=None):
@@ -283,7 +283,7 @@ def losses(s_tensor, s_logits, c_tensor, c_logits, mu, log_var, beta: float = 0.
         s_in = s_logits.reshape(-1, *s_logits.shape[2:])
     else:
         s_in = s_tensor.reshape(-1, *s_logits.shape[2:])                   # training.py:307
-    s_loss = F.binary_cross_entropy_with_logits(s_in.reshape(-1), s_tensor.reshape(-1).float(),
+    s_loss = F.binary_cross_entropy_with_logits(s_in.reshape(-1), s_tensor.reshape(-1).to(s_in.dtype),
                                                 reduction="none").mean()
     pitch_true = c_tensor[:, :N_PITCH].argmax(dim=1)
     pitch_loss = F.cross_entropy(c_logits[:, :N_PITCH], pitch_true, ignore_index=PITCH_PAD)

@@ -5,11 +5,15 @@
 // bf16 MFMA cannot hold the 1e-4 parity bar through 16 BatchNorm'd layers, so operands stay fp32
 // (157 TFLOP/s peak, MI355X_MICROARCH §Matrix cores).
 //
-// One kernel template, four tile configurations (all 64-lane waves, 32x32 MFMA tiles per wave):
-//   C0  64x64x16   4 waves (2x2)  small problems
-//   C1 128x128x16  4 waves (2x2)  weight gradients (transposed A, split-K)
-//   C2  64x64x32   4 waves (2x2)  long K (>= 1024): half the barriers per flop
-//   C3 128x128x32  4 waves (2x2)  (kept for A/B timing)
+// One kernel template, two arithmetic modes, 4 waves (2x2) of 32x32 MFMA tiles:
+//   fp32 mode (v_mfma_f32_32x32x2_f32):   C0 64x64x16, C1 128x128x16, C2 64x64x32, C3 128x128x32
+//   split mode "x6" (v_mfma_f32_32x32x16_bf16): C4 128x128x16, C5 128x64x16, C6 64x64x32, C7 128x128x32
+// Split mode keeps fp32 operands and fp32 accumulation but forms the products on the 16x faster bf16 pipe:
+// every operand element is split EXACTLY into three bf16 terms (x = x1 + x2 + x3, 8 significand bits each, done
+// once per element while the tile is staged into LDS) and the six partial products of weight >= 2^-16
+//   x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1)
+// are accumulated in the fp32 MFMA accumulators; the three dropped products are <= 2^-24 relative, i.e. below the
+// rounding of an fp32 FMA chain (tests: the same 5e-6 bound against float64 as the fp32 mode, measured ~1e-7).
 // LDS tiles are k-major so an MFMA operand read is 32 consecutive floats per half-wave
 // (conflict-free ds_read_b32); global loads are staged through registers one k-tile ahead
 // (double-buffered LDS, one barrier per k-tile).  Workgroup ids are remapped so that tiles sharing
@@ -36,6 +40,26 @@ __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ static inline unsigned pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// exact three-term bf16 split of a pair: a = a1 + a2 + a3 (each residual is exact in fp32)
+__device__ static inline void split3_pair(float a, float b, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = pk_bf16(a, b);
+  a -= __uint_as_float(h1 << 16); b -= __uint_as_float(h1 & 0xffff0000u);
+  h2 = pk_bf16(a, b);
+  a -= __uint_as_float(h2 << 16); b -= __uint_as_float(h2 & 0xffff0000u);
+  h3 = pk_bf16(a, b);
+}
 #define PM_OOB ((int)0x80000000)     // byte offset >= num_records: the buffer load returns 0, no branch, no fault
 
 // Stage one operand tile (R rows x BK k) through registers into its k-major LDS image S[k][r].
@@ -57,18 +81,18 @@ struct TileStage {
   int krow[NE];                                       // !KC + row map: physical row of the next tile's k (prefetched)
   __amdgpu_buffer_rsrc_t rsrc;
   const int32_t* map;
-  int rpe, ld;
+  int rpe, ld, tid;                                   // tid: index of this thread among the THREADS staging threads
   int split, lo_b, hi_b;                              // stacked operand: byte offset of stored rows < split / >= split
 
   __device__ inline int stack_off(int row) const { return row < split ? lo_b : hi_b; }
   __device__ inline void init(const float* P, int ld_, int r0, int rmax, const int32_t* map_, int rpe_, int split_ = 0,
                               int lo_b_ = 0, int hi_b_ = 0) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, PM_OOB, 0x00020000);
-    map = map_; rpe = rpe_; ld = ld_;
+    map = map_; rpe = rpe_; ld = ld_; tid = threadIdx.x % THREADS;
     split = split_; lo_b = lo_b_; hi_b = hi_b_;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      const int f = threadIdx.x + j * THREADS;
+      const int f = tid + j * THREADS;
       if (KC) {                                        // row fixed per thread: resolve the row map once
         const int r = r0 + (VEC ? f / (BK / 4) : f / BK);
         const int kb = VEC ? (f % (BK / 4)) * 16 : (f % BK) * 4;
@@ -79,10 +103,12 @@ struct TileStage {
       }
     }
   }
-  __device__ inline void load(int k0, int kmax) {
+  __device__ inline void load(int k0, int kmax) { load_to(v, k0, kmax); }
+  template <int NW>
+  __device__ inline void load_to(u32x4 (&w)[NW], int k0, int kmax) {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      const int f = threadIdx.x + j * THREADS;
+      const int f = tid + j * THREADS;
       int off;
       if (KC) {
         const int k = k0 + (VEC ? (f % (BK / 4)) * 4 : f % BK);
@@ -98,7 +124,7 @@ struct TileStage {
           krow[j] = kn < kmax ? (rpe == 1 ? map[kn] : map[kn / rpe] * rpe + kn % rpe) : 0;
         }
       }
-      if (VEC) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      if (VEC) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
       else s[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
     }
   }
@@ -107,16 +133,56 @@ struct TileStage {
     if (KC || !map) return;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      const int f = threadIdx.x + j * THREADS;
+      const int f = tid + j * THREADS;
       const int k = k0 + (VEC ? f / (R / 4) : f / R);
       krow[j] = k < kmax ? (rpe == 1 ? map[k] : map[k / rpe] * rpe + k % rpe) : 0;
     }
   }
+  // ---- split mode: three bf16 planes of the tile.
+  //  KC : image [r][BK], fragments read with ds_read_b128 (8 consecutive k of the lane's row);
+  //  !KC: image [k][R] (as loaded), fragments read with ds_read_b64_tr_b16 (hardware 4x16 transpose).
+  // Row strides are padded so that both the 8-byte stores and the fragment reads are bank-conflict free.
+  static constexpr int XROWB = KC ? 2 * BK + 16 : 2 * R + 64;
+  static constexpr int XPLANE = (KC ? R : BK) * XROWB;
+  static constexpr int XBYTES = 3 * XPLANE;
+  __device__ inline void store_x6(char* __restrict__ S) const { store_x6_from(v, S); }
+  template <int NW>
+  __device__ inline void store_x6_from(const u32x4 (&v)[NW], char* __restrict__ S) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int f = tid + j * THREADS;
+      const int off = KC ? (f / (BK / 4)) * XROWB + (f % (BK / 4)) * 8 : (f / (R / 4)) * XROWB + (f % (R / 4)) * 8;
+      unsigned l1, l2, l3, u1, u2, u3;
+      split3_pair(__uint_as_float(v[j].x), __uint_as_float(v[j].y), l1, l2, l3);
+      split3_pair(__uint_as_float(v[j].z), __uint_as_float(v[j].w), u1, u2, u3);
+      const u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+      *reinterpret_cast<u32x2*>(S + off) = p1;
+      *reinterpret_cast<u32x2*>(S + XPLANE + off) = p2;
+      *reinterpret_cast<u32x2*>(S + 2 * XPLANE + off) = p3;
+    }
+  }
+  // byte offset (inside a plane) of this lane's fragment for 32-row block 0 / k-step 0
+  __device__ static inline int x6_lane_off(int row0, int lane) {
+    if (KC) return (row0 + (lane & 31)) * XROWB + 16 * (lane >> 5);
+    const int g = lane >> 4, i = lane & 15;
+    return (8 * (g >> 1) + (i >> 2)) * XROWB + (row0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+  }
+  static constexpr int XSTEP_I = KC ? 32 * XROWB : 64;          // next 32-row block
+  static constexpr int XSTEP_K = KC ? 32 : 16 * XROWB;          // next 16-wide k-step
+  __device__ static inline bf16x8 x6_frag(const char* p) {
+    if (KC) return *reinterpret_cast<const bf16x8*>(p);
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * XROWB));
+    const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, t);
+  }
+
   __device__ inline void store(float* __restrict__ S) const {
     if (VEC) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const int f = threadIdx.x + j * THREADS;
+        const int f = tid + j * THREADS;
         if (KC) {
           const int r = f / (BK / 4), k = (f % (BK / 4)) * 4;
           S[(k + 0) * LD + r] = __uint_as_float(v[j].x); S[(k + 1) * LD + r] = __uint_as_float(v[j].y);
@@ -129,7 +195,7 @@ struct TileStage {
     } else {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        const int e = threadIdx.x + j * THREADS;
+        const int e = tid + j * THREADS;
         if (KC) S[(e % BK) * LD + e / BK] = __uint_as_float(s[j]);
         else S[(e / R) * LD + e % R] = __uint_as_float(s[j]);
       }
@@ -137,8 +203,12 @@ struct TileStage {
   }
 };
 
-template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB>
-__global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, bool X6>
+__global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs g) {
+  static_assert(!X6 || (VA && VB && BK % 16 == 0), "split mode stages with 16-byte loads");
+  // THREADS = MFMA threads = staging threads.  fp32 mode: the same waves do both.  Split mode: the block has
+  // 2*THREADS threads, waves [0, WVM*WVN) multiply and waves [WVM*WVN, 2*WVM*WVN) load + split + store, so the
+  // conversion arithmetic of tile t+1 runs on the SIMD's vector ALU while its matrix core works on tile t.
   constexpr int THREADS = 64 * WVM * WVN;
   constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
   using StA = TileStage<BM, BK, THREADS, !TA, VA>;
@@ -147,6 +217,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As0 = smem;                              // two A buffers, then two B buffers
   float* const Bs0 = smem + 2 * BK * LDA_S;
+  char* const Ax0 = reinterpret_cast<char*>(smem);      // split mode: two A images (3 planes each), then two B images
+  char* const Bx0 = Ax0 + 2 * StA::XBYTES;
 
   if (gridDim.y > 1) {                       // grouped launch (uniform branch): shift everything to this group
     const int64_t bi = blockIdx.y;
@@ -182,7 +254,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
   if (kend > K) kend = K;
   if (kbeg >= kend) return;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (WVM * WVN);
+  const bool producer = X6 && threadIdx.x >= THREADS;
   const int wr = wave / WVN, wc = wave % WVN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -205,13 +278,66 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
   sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe, g.b_split, (int)(blockIdx.y * g.b_boff * 4), (int)(g.b_hi * 4));
   sa.prime(kbeg, kend);
   sb.prime(kbeg, kend);
-  sa.load(kbeg, kend);
-  sb.load(kbeg, kend);
-  sa.store(As0);
-  sb.store(Bs0);
-  __syncthreads();
+  if (!X6 || producer) {
+    sa.load(kbeg, kend);
+    sb.load(kbeg, kend);
+    if constexpr (X6) { sa.store_x6(Ax0); sb.store_x6(Bx0); }
+    else { sa.store(As0); sb.store(Bs0); }
+  }
 
   int buf = 0;
+  if constexpr (X6) {
+    // Producer waves keep the global loads TWO k-tiles ahead (two register sets): at bf16 rate a k-tile of MFMAs
+    // is ~0.3-0.6 us, about one HBM round trip.  Iteration t: producers issue the loads of tile t+2 and split +
+    // store tile t+1 (loaded during iteration t-1) into LDS buffer (t+1)&1 while the consumers multiply tile t out
+    // of buffer t&1; one barrier per k-tile.
+    constexpr int NVA = StA::NV, NVB = StB::NV;
+    u32x4 ra[2][NVA], rb[2][NVB];
+    const int a_off = StA::x6_lane_off(wr * WM, lane), b_off = StB::x6_lane_off(wc * WN, lane);
+    if (producer) { sa.load_to(ra[1], kbeg + BK, kend); sb.load_to(rb[1], kbeg + BK, kend); }
+    __syncthreads();
+    auto phase = [&](int k0, u32x4 (&la)[NVA], u32x4 (&lb)[NVB], u32x4 (&na)[NVA], u32x4 (&nb)[NVB], int cb) {
+      // la/lb: register set the loads of tile k0+2BK go to; na/nb: set holding tile k0+BK; cb: LDS buffer of tile k0
+      if (producer) {
+        // unconditional (past the end every offset is out of range and the load returns 0 without touching
+        // memory): a conditional issue would make the vmcnt bookkeeping ambiguous and drain the prefetch
+        sa.load_to(la, k0 + 2 * BK, kend); sb.load_to(lb, k0 + 2 * BK, kend);
+        if (k0 + BK < kend) {
+          sa.store_x6_from(na, Ax0 + (cb ^ 1) * StA::XBYTES);
+          sb.store_x6_from(nb, Bx0 + (cb ^ 1) * StB::XBYTES);
+        }
+      } else {
+        const char* as = Ax0 + cb * StA::XBYTES + a_off;
+        const char* bs = Bx0 + cb * StB::XBYTES + b_off;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[p][i] = StA::x6_frag(as + p * StA::XPLANE + i * StA::XSTEP_I + ks * StA::XSTEP_K);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[p][j] = StB::x6_frag(bs + p * StB::XPLANE + j * StB::XSTEP_I + ks * StB::XSTEP_K);
+          }
+          // smallest terms first: (3,1) (2,2) (1,3) | (2,1) (1,2) | (1,1)
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    };
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+      phase(k0, ra[0], rb[0], ra[1], rb[1], 0);
+      if (k0 + BK < kend) phase(k0 + BK, ra[1], rb[1], ra[0], rb[0], 1);
+    }
+  } else {
+  __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
@@ -250,7 +376,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
     __syncthreads();
     buf ^= 1;
   }
+  }
 
+  if (producer) return;
   // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
   const bool atomic = gridDim.z > 1;
   const bool accum = (g.flags & PM_GEMM_ACCUM) != 0;
@@ -287,40 +415,44 @@ __global__ void __launch_bounds__(64 * WVM * WVN) k_gemm(GemmArgs g) {
   }
 }
 
-template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB>
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, bool X6>
 static void launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
   using StA = TileStage<BM, BK, 64 * WVM * WVN, !TA, VA>;
   using StB = TileStage<BN, BK, 64 * WVM * WVN, TB, VB>;
-  const size_t lds = sizeof(float) * 2 * BK * (StA::LD + StB::LD);
-  auto kern = k_gemm<BM, BN, BK, WVM, WVN, TA, TB, VA, VB>;
+  const size_t lds = X6 ? (size_t)2 * (StA::XBYTES + StB::XBYTES) : sizeof(float) * 2 * BK * (StA::LD + StB::LD);
+  auto kern = k_gemm<BM, BN, BK, WVM, WVN, TA, TB, VA, VB, X6>;
   static bool attr_done = false;             // > 64 KiB of dynamic LDS needs the attribute (once per instantiation)
   if (lds > 64 * 1024 && !attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, g);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN * (X6 ? 2 : 1)), lds, st, g);
 }
-template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB>
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool X6>
 static void launch_v(bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
-  if (va && vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true>(grid, st, g);
-  else if (va) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, false>(grid, st, g);
-  else if (vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, true>(grid, st, g);
-  else launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, false>(grid, st, g);
+  if constexpr (X6) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true, true>(grid, st, g);
+  else if (va && vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true, false>(grid, st, g);
+  else if (va) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, false, false>(grid, st, g);
+  else if (vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, true, false>(grid, st, g);
+  else launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, false, false>(grid, st, g);
 }
-template <int BM, int BN, int BK, int WVM, int WVN>
+template <int BM, int BN, int BK, int WVM, int WVN, bool X6>
 static void launch_t(int ta, int tb, bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
-  if (!ta && !tb) launch_v<BM, BN, BK, WVM, WVN, false, false>(va, vb, grid, st, g);
-  else if (!ta && tb) launch_v<BM, BN, BK, WVM, WVN, false, true>(va, vb, grid, st, g);
-  else launch_v<BM, BN, BK, WVM, WVN, true, false>(va, vb, grid, st, g);
+  if (!ta && !tb) launch_v<BM, BN, BK, WVM, WVN, false, false, X6>(va, vb, grid, st, g);
+  else if (!ta && tb) launch_v<BM, BN, BK, WVM, WVN, false, true, X6>(va, vb, grid, st, g);
+  else launch_v<BM, BN, BK, WVM, WVN, true, false, X6>(va, vb, grid, st, g);
 }
 
-static const int CFG_BM[4] = {64, 128, 64, 128}, CFG_BN[4] = {64, 128, 64, 128}, CFG_BK[4] = {16, 16, 32, 32};
+enum { PM_GEMM_NCFG = 8 };                    // 0..3 fp32 MFMA, 4..7 split mode
+static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128};
+static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128};
+static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32};
 
 // Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
 static int g_forced_cfg = -1;
-extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && cfg <= 3) ? cfg : -1; return PM_OK; }
-static int pick_config(int transA, int M, int N, int K) {
-  if (g_forced_cfg >= 0) return g_forced_cfg;
+extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && cfg < PM_GEMM_NCFG) ? cfg : -1; return PM_OK; }
+static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
+  if (g_forced_cfg >= 0 && (g_forced_cfg < 4 || x6_ok)) return g_forced_cfg;
   // Measured on MI355X (tools/bench_gemm.py, shapes of the training step, interleaved A/B in one process):
   //  - NN / NT (the node dimension is M): 64x64 tiles win or tie everywhere: 4 workgroups per CU = 4 waves per
   //    SIMD hide the LDS / barrier latency; the panels they re-read sit in L2 / Infinity Cache.  With a long K
@@ -329,6 +461,16 @@ static int pick_config(int transA, int M, int N, int K) {
   //  - TN (weight gradients, K = node dimension, split-K): 128x128 tiles (98-108 TFLOP/s): both operands are
   //    staged with plain 16-byte LDS rows and 4x fewer atomics leave the workgroup.
   //  8-wave 64x256 / 256x64 shapes (operand streamed exactly once) measured 5-20 % slower at these sizes.
+  //  - Split mode (x6, needs 16-byte aligned operands) wins on every large shape of the step (same harness):
+  //    NN/NT K >= 1024: 128x128x32 126-173 TFLOP/s (fp32 mode 96-118); NN/NT short K: 128x128x16 114-140 (90-108);
+  //    TN: 128x64x16 123-155 (77-107).  Small problems stay on the fp32 tiles (fewer, cheaper workgroups).
+  //    Inside the training step (row-gathered, grouped launches, one 8-wave workgroup per CU) the gain did not
+  //    materialise (10.71 ms against 10.78 ms per step), so split mode is opt-in: PM_GEMM_SPLIT=1 or a forced config.
+  static const bool split_on = getenv("PM_GEMM_SPLIT") && atoi(getenv("PM_GEMM_SPLIT")) > 0;
+  if (split_on && x6_ok && (double)M * N * K >= 1.0e9) {
+    if (transA) return 5;
+    return K >= 1024 ? 7 : 4;
+  }
   if (transA) return ((int64_t)M * N >= 128 * 128 * 2) ? 1 : 0;
   return K >= 1024 ? 2 : 0;
 }
@@ -355,7 +497,11 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   g.a_boff = q->a_group_stride; g.b_boff = q->b_group_stride; g.c_boff = q->c_group_stride;
   g.bias_boff = q->bias_group_stride; g.map_boff = q->map_group_stride; g.dyn_boff = q->dyn_group_stride;
   g.b_split = q->b_split_rows; g.b_hi = q->b_shared_off; g.c_split = q->c_split_rows; g.c_hi = q->c_shared_off;
-  const int cfg = pick_config(transA, M, N, K);
+  // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
+  const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
+  const bool vb = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
+                  (q->b_group_stride % 4 == 0) && (q->b_shared_off % 4 == 0);
+  const int cfg = pick_config(transA, M, N, K, va && vb);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
@@ -378,19 +524,19 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   const int kper = (int)pm_cdiv(pm_cdiv(K, split_k), BK) * BK;
   g.kper = kper;
   if (!(transA && q->dyn_entries)) split_k = (int)pm_cdiv(K, kper);     // (device-side K: the kernel re-derives kper)
-  // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
-  const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
-  const bool vb = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
-                  (q->b_group_stride % 4 == 0) && (q->b_shared_off % 4 == 0);
   dim3 grid((unsigned)tiles, (unsigned)n_groups, (unsigned)split_k);
   hipStream_t st = (hipStream_t)stream;
   const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);
   switch (cfg) {
-    case 0: launch_t<64, 64, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
-    case 1: launch_t<128, 128, 16, 2, 2>(transA, transB, va, vb, grid, st, g); break;
-    case 2: launch_t<64, 64, 32, 2, 2>(transA, transB, va, vb, grid, st, g); break;
-    default: launch_t<128, 128, 32, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 0: launch_t<64, 64, 16, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
+    case 1: launch_t<128, 128, 16, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
+    case 2: launch_t<64, 64, 32, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
+    case 3: launch_t<128, 128, 32, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
+    case 4: launch_t<128, 128, 16, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
+    case 5: launch_t<128, 64, 16, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
+    case 6: launch_t<64, 64, 32, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
+    default: launch_t<128, 128, 32, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
   }
   pm_prof_close(st, pe);
   return pm_check_launch();

@@ -38,7 +38,8 @@ def _prof_end(name: str, e0, work: float):
         PROF[name].append((e0, e1, work))
 
 
-_GEMM_TILES = ("64x64x16", "128x128x16", "64x64x32", "128x128x32")
+_GEMM_TILES = ("64x64x16", "128x128x16", "64x64x32", "128x128x32", "x6:128x128x16", "x6:128x64x16", "x6:64x64x32",
+               "x6:128x128x32")
 
 
 def gemm_class(transA: bool, transB: bool, M: int, N: int, K: int) -> str:

@@ -184,6 +184,30 @@ def test_gemm_strided_views_and_rowmap():
     assert rel_err(dW, want) < 5e-6
 
 
+@pytest.mark.parametrize("cfg", [4, 5, 6, 7])
+@pytest.mark.parametrize("M,N,K,ta,tb", [
+    (1000, 256, 1024, False, False), (333, 1024, 256, False, True), (1024, 256, 3001 * 4, True, False),
+    (130, 132, 36, False, True), (515, 260, 72, False, False), (260, 68, 1028, True, False)])
+def test_gemm_split_mode(cfg, M, N, K, ta, tb):
+    """split mode (three-term bf16 operand split, six products, fp32 accumulate): same bound as the fp32 tiles."""
+    torch.manual_seed(M + N + K + cfg)
+    A = torch.randn((K, M) if ta else (M, K), device=DEV) * 3
+    B = torch.randn((N, K) if tb else (K, N), device=DEV)
+    bias = torch.randn(N, device=DEV)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    try:
+        lib().pm_gemm_force_config(cfg)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(A, B, out, M, N, K, A.stride(0), B.stride(0), N, transA=ta, transB=tb, bias=bias, relu=True)
+        assert rel_err(out, F.relu(ref + bias.double())) < 5e-6
+        acc = torch.randn(M, N, device=DEV)
+        want = acc.double() + ref
+        ops.gemm(A, B, acc, M, N, K, A.stride(0), B.stride(0), N, transA=ta, transB=tb, accum=True, split_k=0)
+        assert rel_err(acc, want) < 5e-6
+    finally:
+        lib().pm_gemm_force_config(-1)
+
+
 @pytest.mark.parametrize("Nn,d", [(700, 64), (1000, 32), (333, 128)])
 def test_gemm_grouped_stacked_compact_gcl(Nn, d):
     """The three contractions of the compact GCL (model.py:112,116 on [track block | onset | next | x]):

@@ -12,11 +12,12 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"k_gemm<(\d+), (\d+), (\d+), \d+, \d+, (\w+), (\w+), (\w+), (\w+)>", name)
+    m = re.match(r"k_gemm<(\d+), (\d+), (\d+), \d+, \d+, (\w+), (\w+), (\w+), (\w+)(?:, (\w+))?>", name)
     if m:
-        bm, bn, bk, ta, tb, va, vb = m.groups()
+        bm, bn, bk, ta, tb, va, vb, x6 = m.groups()
         kind = "TN" if ta == "true" else ("NT" if tb == "true" else "NN")
-        return f"k_gemm<{bm}x{bn}x{bk},{kind}{'' if va == 'true' and vb == 'true' else ',scalar'}>"
+        return (f"k_gemm<{'x6:' if x6 == 'true' else ''}{bm}x{bn}x{bk},{kind}"
+                f"{'' if va == 'true' and vb == 'true' else ',scalar'}>")
     return re.sub(r"\(.*$", "", name)[:70]
 
 

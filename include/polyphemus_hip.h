@@ -125,7 +125,9 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] o
  *   physical row = rowmap[r / rows_per_entry] * rows_per_entry + r % rows_per_entry
  *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
  *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
-enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2 };
+enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2,
+       PM_GEMM_PARTITION = 4 /* grouped + row lists + device counts: the groups' lists partition at most M (K when
+                                transA) rows IN TOTAL; the launch then only enumerates live row panels */ };
 /* tile configuration pm_gemm_f32 picks for a shape (host only).  fp32 MFMA: 0 = 64x64x16, 1 = 128x128x16,
  * 2 = 64x64x32, 3 = 128x128x32.  Split mode (fp32 operands split exactly into three bf16 terms, six partial products
  * on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error below an fp32 FMA chain): 4 = 128x128x16, 5 = 128x64x16,

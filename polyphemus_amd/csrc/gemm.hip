@@ -33,6 +33,9 @@ struct GemmArgs {
   int64_t a_boff, b_boff, c_boff, bias_boff; int map_boff, dyn_boff;
   // stacked operands: stored rows >= split are shared by all groups and live at base + hi (elements)
   int b_split, c_split; int64_t b_hi, c_hi;
+  // ngroups > 1 with packed != 0: the groups partition the gathered rows (device-side counts), and the live row
+  // panels of ALL groups are enumerated along blockIdx.x (gridDim.y == 1) so that no dead workgroup is launched
+  int ngroups, packed;
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -220,8 +223,24 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
   char* const Ax0 = reinterpret_cast<char*>(smem);      // split mode: two A images (3 planes each), then two B images
   char* const Bx0 = Ax0 + 2 * StA::XBYTES;
 
-  if (gridDim.y > 1) {                       // grouped launch (uniform branch): shift everything to this group
-    const int64_t bi = blockIdx.y;
+  int grp = blockIdx.y, t = blockIdx.x, nwg;
+  if (!TA && g.packed) {                     // packed groups: find the group of this tile from the device-side counts
+    int tot = 0;
+    for (int q = 0; q < g.ngroups; ++q) tot += (g.dyn_entries[q * g.dyn_boff] * g.rpe + BM - 1) / BM;
+    nwg = tot * g.ntn;
+    if (t >= nwg) return;
+    {                                        // XCD-aware order over the live tiles of all groups (see below)
+      const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    for (grp = 0; grp < g.ngroups - 1; ++grp) {
+      const int nt = ((g.dyn_entries[grp * g.dyn_boff] * g.rpe + BM - 1) / BM) * g.ntn;
+      if (t < nt) break;
+      t -= nt;
+    }
+  }
+  if (g.ngroups > 1) {                       // grouped launch (uniform branch): shift everything to this group
+    const int64_t bi = grp;
     g.A += bi * g.a_boff;
     if (g.b_split == 0) g.B += bi * g.b_boff;
     if (g.c_split == 0) g.C += bi * g.c_boff;
@@ -240,10 +259,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
   // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
   // contiguous run of tiles; tiles of one row panel (n fastest) then share the panel through one L2.
   // (with a device-side row count only the live row panels take part, so they still spread over all 8 XCDs)
-  const int nwg = (TA ? g.ntm : (M + BM - 1) / BM) * g.ntn;
-  int t = blockIdx.x;
-  if (t >= nwg) return;
-  {
+  if (TA || !g.packed) {
+    nwg = (TA ? g.ntm : (M + BM - 1) / BM) * g.ntn;
+    if (t >= nwg) return;
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -275,7 +293,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   sa.init(g.A, g.lda, m0, M, mapA, g.rpe);
-  sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe, g.b_split, (int)(blockIdx.y * g.b_boff * 4), (int)(g.b_hi * 4));
+  sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe, g.b_split, (int)(grp * g.b_boff * 4), (int)(g.b_hi * 4));
   sa.prime(kbeg, kend);
   sb.prime(kbeg, kend);
   if (!X6 || producer) {
@@ -395,8 +413,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
       bool at = atomic;
       if (g.c_split > 0) {                   // stacked C (weight gradient): shared rows collect every group's term
         const bool shared = row >= g.c_split;
-        crow += shared ? g.c_hi : (int64_t)blockIdx.y * g.c_boff;
-        at = atomic || (shared && gridDim.y > 1);
+        crow += shared ? g.c_hi : (int64_t)grp * g.c_boff;
+        at = atomic || (shared && g.ngroups > 1);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -507,7 +525,9 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
   // a gathered dimension with a device-side count per group: the groups PARTITION the rows, so the live work is
   // about 1/n_groups of the bound the grid is sized for
-  const bool partitioned = q->dyn_entries && n_groups > 1;
+  const bool partitioned = q->dyn_entries && n_groups > 1 && (q->flags & PM_GEMM_PARTITION);
+  g.ngroups = n_groups;
+  g.packed = (partitioned && q->rowmap && !transA && n_groups <= 16) ? 1 : 0;   // row lists that partition <= M rows
   int split_k = q->split_k;
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
@@ -525,6 +545,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   g.kper = kper;
   if (!(transA && q->dyn_entries)) split_k = (int)pm_cdiv(K, kper);     // (device-side K: the kernel re-derives kper)
   dim3 grid((unsigned)tiles, (unsigned)n_groups, (unsigned)split_k);
+  if (g.packed) grid = dim3((unsigned)((g.ntm + n_groups) * g.ntn), 1, (unsigned)split_k);
   hipStream_t st = (hipStream_t)stream;
   const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);

@@ -92,7 +92,7 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
 PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
   PmGemmDesc q;
   memset(&q, 0, sizeof(q));
-  q.split_k = 1; q.rowmap = pv.trk_list; q.rows_per_entry = 1; q.dyn_entries = pv.trk_cnt;
+  q.flags = PM_GEMM_PARTITION; q.split_k = 1; q.rowmap = pv.trk_list; q.rows_per_entry = 1; q.dyn_entries = pv.trk_cnt;
   q.n_groups = 4; q.map_group_stride = N; q.dyn_group_stride = 1;
   (void)d;
   return q;
@@ -160,7 +160,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       q.b_group_stride = dd; q.b_split_rows = d; q.b_shared_off = 3 * dd;
       c.chk(pm_gemm_f32_desc(&q, c.st));
       PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
-      w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM; w.split_k = 0;
+      w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM | PM_GEMM_PARTITION; w.split_k = 0;
       w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;
       w.c_group_stride = dd; w.c_split_rows = d; w.c_shared_off = 3 * dd;
       c.chk(pm_gemm_f32_desc(&w, c.st));

@@ -166,7 +166,7 @@ def segreduce_bwd(x, T, dA, dres, plan: Plan, dropout_p: float, seed: int, layer
     return dx
 
 
-GEMM_RELU, GEMM_ACCUM = 1, 2
+GEMM_RELU, GEMM_ACCUM, GEMM_PARTITION = 1, 2, 4
 
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
@@ -199,10 +199,11 @@ class _GemmDesc(ctypes.Structure):
 def gemm_desc(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
               split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None, n_groups=1, a_group_stride=0,
               b_group_stride=0, c_group_stride=0, bias_group_stride=0, map_group_stride=0, dyn_group_stride=0,
-              b_split_rows=0, b_shared_off=0, c_split_rows=0, c_shared_off=0):
+              b_split_rows=0, b_shared_off=0, c_split_rows=0, c_shared_off=0, partition=False):
     """Grouped / stacked-operand GEMM (`pm_gemm_f32_desc`): see PmGemmDesc in the header."""
     q = _GemmDesc(int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
-                  (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0), split_k, ptr(rowmap), rows_per_entry,
+                  (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_PARTITION if partition else 0),
+                  split_k, ptr(rowmap), rows_per_entry,
                   ptr(dyn_entries), n_groups, a_group_stride, b_group_stride, c_group_stride, bias_group_stride,
                   map_group_stride, dyn_group_stride, b_split_rows, b_shared_off, c_split_rows, c_shared_off)
     call("pm_gemm_f32_desc", ctypes.addressof(q), stream())

@@ -208,8 +208,9 @@ def test_gemm_split_mode(cfg, M, N, K, ta, tb):
         lib().pm_gemm_force_config(-1)
 
 
+@pytest.mark.parametrize("partition", [False, True])
 @pytest.mark.parametrize("Nn,d", [(700, 64), (1000, 32), (333, 128)])
-def test_gemm_grouped_stacked_compact_gcl(Nn, d):
+def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition):
     """The three contractions of the compact GCL (model.py:112,116 on [track block | onset | next | x]):
     rows partitioned into four relation groups (row lists + device counts), B / C stacked as
     [weight[t] (group rows) ; weight[4]; weight[5]; root (shared rows)]."""
@@ -227,7 +228,8 @@ def test_gemm_grouped_stacked_compact_gcl(Nn, d):
     bias = torch.randn(d, device=DEV)
     dd = d * d
     Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()  # [4, 4d, d]
-    grp = dict(rowmap=lists, rows_per_entry=1, dyn_entries=cnt, n_groups=4, map_group_stride=Nn, dyn_group_stride=1)
+    grp = dict(rowmap=lists, rows_per_entry=1, dyn_entries=cnt, n_groups=4, map_group_stride=Nn, dyn_group_stride=1,
+               partition=partition)
     # forward
     h = torch.full((Nn, d), float("nan"), device=DEV)
     ops.gemm_desc(A, W, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,

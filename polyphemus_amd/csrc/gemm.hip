@@ -476,8 +476,9 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
   //    SIMD hide the LDS / barrier latency; the panels they re-read sit in L2 / Infinity Cache.  With a long K
   //    (>= 1024: GCL forward, chord encoder, d(x_L)) BK = 32 halves the barriers per flop: 107-119 TFLOP/s
   //    against 102-112; with K = d = 256 the BK = 16 variant stays ahead (110-114 against 106-108).
-  //  - TN (weight gradients, K = node dimension, split-K): 128x128 tiles (98-108 TFLOP/s): both operands are
-  //    staged with plain 16-byte LDS rows and 4x fewer atomics leave the workgroup.
+  //  - TN (weight gradients, K = node dimension, split-K): in isolation 128x128 and 64x64 tiles tie (98-108
+  //    TFLOP/s), inside the training step 64x64x32 tiles with ~1024 workgroups (4 per CU, split-K sized for it)
+  //    are 18 % faster than 128x128x16 with 512 (65.9 us against 80.3 us average over the 30 TN launches).
   //  8-wave 64x256 / 256x64 shapes (operand streamed exactly once) measured 5-20 % slower at these sizes.
   //  - Split mode (x6, needs 16-byte aligned operands) wins on every large shape of the step (same harness):
   //    NN/NT K >= 1024: 128x128x32 126-173 TFLOP/s (fp32 mode 96-118); NN/NT short K: 128x128x16 114-140 (90-108);
@@ -489,7 +490,6 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
     if (transA) return 5;
     return K >= 1024 ? 7 : 4;
   }
-  if (transA) return ((int64_t)M * N >= 128 * 128 * 2) ? 1 : 0;
   return K >= 1024 ? 2 : 0;
 }
 
@@ -531,8 +531,8 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   int split_k = q->split_k;
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
-    if (transA && tiles * n_groups < 384) {
-      split_k = (int)(512 / (tiles * n_groups));
+    if (transA && tiles * n_groups < 768) {
+      split_k = (int)(1024 / (tiles * n_groups));
       const int maxs = (int)pm_cdiv(partitioned ? K / n_groups : K, 8 * BK);
       if (split_k > maxs) split_k = maxs;
       if (split_k < 1) split_k = 1;

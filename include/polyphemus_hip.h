@@ -168,6 +168,9 @@ typedef struct PmGemmDesc {
   int32_t map_group_stride, dyn_group_stride;
   int32_t b_split_rows; int64_t b_shared_off;
   int32_t c_split_rows; int64_t c_shared_off;
+  double* col_stats; /* optional [PM_BN_REPL][2][N] fp64, += : column sums of the stored C values and of their
+                        squares (the statistics pass of the BatchNorm that follows, fused into the epilogue; the
+                        replica is picked from the row-panel index); !transA, no ACCUM, split_k == 1 */
 } PmGemmDesc;
 int pm_gemm_f32_desc(const PmGemmDesc* desc, pm_stream_t stream);
 
@@ -189,6 +192,19 @@ int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, 
 #define PM_BN_SCRATCH(C) (256 * 3 * (C) + 4 * (C))
 
 /* ------------------------------------------------------------------ element-wise helpers */
+/* Fused forms for row-major [O, C] (I = 1, C % 4 == 0, 16-byte aligned), used by the native step for the GCL norms:
+ * `sums` [PM_BN_REPL][2][C] fp64 = column sums of x and x*x, accumulated by the epilogue of the GEMM that produced x
+ * (PmGemmDesc.col_stats; PM_BN_REPL replicas spread the atomics, consumers add them up); mean / var / running
+ * statistics are written as a side effect (saved for the backward).  pm_bn_bwd_fused accumulates its three column
+ * sums into the caller-ZEROED `acc3` [PM_BN_REPL][3][C] fp64 with atomics and needs no finalize launch. */
+enum { PM_BN_REPL = 8 };
+int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, float eps, const float* gamma,
+                      const float* beta, const float* residual /* or NULL */, int relu, float* y,
+                      float* mean /* [C] out */, float* var /* [C] out */, float* running_mean /* or NULL */,
+                      float* running_var, float momentum, pm_stream_t stream);
+int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
+                    float eps, const float* gamma, const float* beta, int relu, float* dgamma, float* dbeta,
+                    float* dbias_pre /* or NULL */, float* dx, double* acc3, pm_stream_t stream);
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
 int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
 int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);

@@ -35,6 +35,8 @@ _SIGS = {
     "pm_bn_stats": "piiippppfps",
     "pm_bn_apply": "piiippfpppips",
     "pm_bn_bwd": "ppiiippfppippppps",
+    "pm_bn_apply_fused": "piipfpppipppppfs",
+    "pm_bn_bwd_fused": "ppiippfppippppps",
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",
     "pm_colsum_acc": "piiips",

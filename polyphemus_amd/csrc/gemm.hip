@@ -36,6 +36,7 @@ struct GemmArgs {
   // ngroups > 1 with packed != 0: the groups partition the gathered rows (device-side counts), and the live row
   // panels of ALL groups are enumerated along blockIdx.x (gridDim.y == 1) so that no dead workgroup is launched
   int ngroups, packed;
+  double* colstats;                          // optional [2][N]: += column sums of the stored values and of their squares
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -403,6 +404,10 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
   const bool relu = (g.flags & PM_GEMM_RELU) != 0;
   const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
   const int32_t* mapC = TA ? nullptr : g.rowmap;
+  const bool stats = g.colstats != nullptr;
+  double cs[TN], cq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { cs[j] = 0.0; cq[j] = 0.0; }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -427,7 +432,23 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
           if (accum) v += crow[col];
           if (relu) v = fmaxf(v, 0.f);
           crow[col] = v;
+          if (stats) { cs[j] += (double)v; cq[j] += (double)v * (double)v; }
         }
+      }
+    }
+  }
+  // Column statistics of the tile for the BatchNorm that follows (nn.BatchNorm1d over the node rows, model.py:203):
+  // fp64 partial sums per lane, the two half-waves (same columns, different rows) combined by a lane exchange,
+  // one fp64 atomic per column and per wave-row.
+  if (stats && !atomic) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const double s2 = cs[j] + __shfl_xor(cs[j], 32), q2 = cq[j] + __shfl_xor(cq[j], 32);
+      const int col = n0 + wc * WN + j * 32 + li;
+      if (lh == 0 && col < g.N) {              // replica by row panel: <= ~64 serialized atomics per address
+        double* dst = g.colstats + (int64_t)(((m0 / BM) * 2 + wr) % PM_BN_REPL) * 2 * g.N;
+        atomicAdd(dst + col, s2);
+        atomicAdd(dst + g.N + col, q2);
       }
     }
   }
@@ -515,6 +536,8 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   g.a_boff = q->a_group_stride; g.b_boff = q->b_group_stride; g.c_boff = q->c_group_stride;
   g.bias_boff = q->bias_group_stride; g.map_boff = q->map_group_stride; g.dyn_boff = q->dyn_group_stride;
   g.b_split = q->b_split_rows; g.b_hi = q->b_shared_off; g.c_split = q->c_split_rows; g.c_hi = q->c_shared_off;
+  g.colstats = q->col_stats;
+  if (q->col_stats && (transA || (q->flags & PM_GEMM_ACCUM))) return PM_E_INVALID;   // stats of plainly stored tiles only
   // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
   const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
   const bool vb = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
@@ -575,7 +598,7 @@ extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N,
   q.rows_per_entry = rows_per_entry; q.dyn_entries = dyn_entries; q.n_groups = n_groups;
   q.a_group_stride = a_group_stride; q.b_group_stride = b_group_stride; q.c_group_stride = c_group_stride;
   q.bias_group_stride = bias_group_stride; q.map_group_stride = map_group_stride; q.dyn_group_stride = dyn_group_stride;
-  q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0;
+  q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0; q.col_stats = nullptr;
   return pm_gemm_f32_desc(&q, stream);
 }
 

@@ -277,6 +277,178 @@ extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, 
   return pm_check_launch();
 }
 
+// ---------------------------------------------------------------- fused variants for [M, C] rows (I == 1)
+// The column sums come from somewhere else (the epilogue of the producing GEMM, pm_gemm_f32_desc col_stats) or go
+// straight into a caller-zeroed fp64 accumulator with atomics, and mean / variance / the backward means are
+// evaluated by every thread that needs them, so the two single-workgroup "finalize" launches (and, forward, the
+// statistics pass itself) disappear.  Workgroup 0 additionally writes what has to persist: mean, var, the running
+// statistics; dgamma, dbeta and the gradient of a bias in front of the norm.
+// (accumulators are replicated PM_BN_REPL times — the producer picks the replica from its row-panel index — so that
+// no address takes more than ~64 serialized fp64 atomics; consumers add the replicas up once per workgroup into LDS)
+__device__ static inline double repl_sum(const double* __restrict__ acc, int nacc, int C, int a, int c) {
+  double t = 0;
+#pragma unroll
+  for (int r = 0; r < PM_BN_REPL; ++r) t += acc[((int64_t)r * nacc + a) * C + c];
+  return t;
+}
+__global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict__ x, int64_t n4, int C, double count,
+                                                        const double* __restrict__ sums, BnCtx ctx,
+                                                        const float* __restrict__ res, float* __restrict__ y,
+                                                        float* mean, float* var, float* rmean, float* rvar,
+                                                        float momentum) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
+  float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double mu = repl_sum(sums, 2, C, 0, c) / count;
+    double v = repl_sum(sums, 2, C, 1, c) / count - mu * mu;
+    if (v < 0) v = 0;
+    s_m[c] = (float)mu;
+    s_sc[c] = rsqrtf((float)v + ctx.eps) * ctx.gamma[c];
+    s_be[c] = ctx.beta[c];
+    if (blockIdx.x == 0) {
+      mean[c] = (float)mu;
+      var[c] = (float)v;
+      if (rmean) {
+        const double unb = count > 1 ? v * count / (count - 1) : v;
+        rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+      }
+    }
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 m = *reinterpret_cast<const float4*>(s_m + c), sc = *reinterpret_cast<const float4*>(s_sc + c);
+    const float4 be = *reinterpret_cast<const float4*>(s_be + c);
+    float o[4] = {(xv.x - m.x) * sc.x + be.x, (xv.y - m.y) * sc.y + be.y, (xv.z - m.z) * sc.z + be.z,
+                  (xv.w - m.w) * sc.w + be.w};
+    if (ctx.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    if (res) {
+      const float4 rv = reinterpret_cast<const float4*>(res)[i];
+      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+extern "C" int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, float eps,
+                                 const float* gamma, const float* beta, const float* residual, int relu, float* y,
+                                 float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                 pm_stream_t stream) {
+  if (!x || !sums || !gamma || !beta || !y || !mean || !var || O <= 0 || C <= 0 || (C % 4) != 0 || C > 4096)
+    return PM_E_INVALID;
+  if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (residual && ((uintptr_t)residual % 16))) return PM_E_INVALID;
+  BnCtx ctx = {nullptr, nullptr, gamma, beta, eps, relu};
+  const int64_t n = (int64_t)O * C;
+  hipLaunchKernelGGL(k_bn_apply4_sums, dim3(ew_grid(n / 4)), dim3(256), sizeof(float) * 3 * C, (hipStream_t)stream, x,
+                     n / 4, C, (double)O, sums, ctx, residual, y, mean, var, running_mean, running_var, momentum);
+  return pm_check_launch();
+}
+
+// column sums (du, du*xhat, xhat) of the backward straight into acc[PM_BN_REPL][3][C] (fp64 atomics)
+__global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* __restrict__ x,
+                                                                   const float* __restrict__ dy, int O, int C,
+                                                                   BnCtx ctx, int rows_per_chunk,
+                                                                   double* __restrict__ acc3) {
+  __shared__ double sh[4][64][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const bool ok = c < C;
+  double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float m[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = ctx.mean[c + j]; rs[j] = rsqrtf(ctx.var[c + j] + ctx.eps);
+      ga[j] = ctx.gamma[c + j]; be[j] = ctx.beta[c + j];
+    }
+  }
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > O) r1 = O;
+  if (ok) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * C + c);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + (int64_t)r * C + c);
+      bn_acc<1>(xv.x, dv.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4], acc[8]);
+      bn_acc<1>(xv.y, dv.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5], acc[9]);
+      bn_acc<1>(xv.z, dv.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6], acc[10]);
+      bn_acc<1>(xv.w, dv.w, m[3], rs[3], ga[3], be[3], ctx.relu, acc[3], acc[7], acc[11]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) sh[wave][lane][j] = acc[j];
+  __syncthreads();
+  if (wave == 0 && ok) {
+    double* dst = acc3 + (int64_t)(blockIdx.y % PM_BN_REPL) * 3 * C;
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+      atomicAdd(&dst[(int64_t)(j >> 2) * C + c + (j & 3)], sh[0][lane][j] + sh[1][lane][j] + sh[2][lane][j] + sh[3][lane][j]);
+  }
+}
+__global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            int64_t n4, int C, double count, BnCtx ctx,
+                                                            const double* __restrict__ acc3, float* dgamma,
+                                                            float* dbeta, float* dbias_pre, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [6][C]: mean, rstd, gamma, beta, mean(du), mean(du*xhat)
+  float* const s_m = sm; float* const s_rs = sm + C; float* const s_ga = sm + 2 * C; float* const s_be = sm + 3 * C;
+  float* const s_m0 = sm + 4 * C; float* const s_m1 = sm + 5 * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double s0 = repl_sum(acc3, 3, C, 0, c), s1 = repl_sum(acc3, 3, C, 1, c);
+    const double m0 = s0 / count, m1 = s1 / count;
+    s_m[c] = ctx.mean[c]; s_rs[c] = rsqrtf(ctx.var[c] + ctx.eps); s_ga[c] = ctx.gamma[c]; s_be[c] = ctx.beta[c];
+    s_m0[c] = (float)m0; s_m1[c] = (float)m1;
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] += (float)s0;
+      if (dgamma) dgamma[c] += (float)s1;
+      if (dbias_pre) {
+        const double s2 = repl_sum(acc3, 3, C, 2, c);
+        const double rstd = 1.0 / sqrt((double)ctx.var[c] + (double)ctx.eps);
+        dbias_pre[c] += (float)((double)ctx.gamma[c] * rstd * ((s0 - count * m0) - m1 * s2));
+      }
+    }
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i], dv = reinterpret_cast<const float4*>(dy)[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float rstd = s_rs[c + j], ga = s_ga[c + j];
+      const float xh = (xs[j] - s_m[c + j]) * rstd;
+      float du = ds[j];
+      if (ctx.relu && !(xh * ga + s_be[c + j] > 0.f)) du = 0.f;
+      o[j] = ga * rstd * (du - s_m0[c + j] - xh * s_m1[c + j]);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
+                               const float* var, float eps, const float* gamma, const float* beta, int relu,
+                               float* dgamma, float* dbeta, float* dbias_pre, float* dx, double* acc3,
+                               pm_stream_t stream) {
+  if (!x || !dy || !mean || !var || !gamma || !beta || !dx || !acc3 || O <= 0 || C <= 0 || (C % 4) != 0 || C > 4096)
+    return PM_E_INVALID;
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {mean, var, gamma, beta, eps, relu};
+  int nc = (int)pm_cdiv(O, 32);
+  if (nc > BN_MAX_CHUNKS) nc = BN_MAX_CHUNKS;
+  if (nc < 1) nc = 1;
+  const int rpc = (int)pm_cdiv(O, nc);
+  nc = (int)pm_cdiv(O, rpc);
+  hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3);
+  const int64_t n = (int64_t)O * C;
+  hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(ew_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
+                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx);
+  return pm_check_launch();
+}
+
 // ---------------------------------------------------------------- element-wise helpers
 __global__ void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, int64_t n, float* dx) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -29,6 +29,7 @@ struct Arena {
 struct GcnSaved {
   float* T; float* x[PM_MAX_LAYERS + 1]; float* A[PM_MAX_LAYERS]; float* h[PM_MAX_LAYERS];
   float* mean[PM_MAX_LAYERS]; float* var[PM_MAX_LAYERS];
+  double* pool;                          // per layer PM_BN_REPL x ([2][d] forward column sums, [3][d] backward sums), fp64
   uint32_t seed, uid0; float p;
 };
 
@@ -115,22 +116,33 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
   }
   sv.x[0] = x0;
+  sv.pool = ar.dbl((size_t)c.L * 5 * d * PM_BN_REPL);
+  if (ar.base) hipMemsetAsync(sv.pool, 0, sizeof(double) * c.L * 5 * d * PM_BN_REPL, c.st);
   for (int i = 0; i < c.L; ++i) {
     sv.A[i] = ar.f((size_t)N * nb * d); sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
     sv.mean[i] = ar.f(d); sv.var[i] = ar.f(d);
     if (!ar.base) continue;
     const float* W = c.P + g.weight[i];
     c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
+    double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
     if (!c.compact) {
-      c.chk(pm_gemm_f32(0, 0, N, d, 7 * d, sv.A[i], 7 * d, W, d, sv.h[i], d, c.P + g.bias[i], 0, 1, nullptr, 0, nullptr, c.st));
+      PmGemmDesc q;
+      memset(&q, 0, sizeof(q));
+      q.M = N; q.N = d; q.K = 7 * d; q.split_k = 1; q.n_groups = 1;
+      q.A = sv.A[i]; q.lda = 7 * d; q.B = W; q.ldb = d; q.C = sv.h[i]; q.ldc = d; q.bias = c.P + g.bias[i];
+      q.col_stats = sums;
+      c.chk(pm_gemm_f32_desc(&q, c.st));
     } else {
       PmGemmDesc q = gcl_desc(pv, N, d);                  // h[rows_t] = A'[rows_t] @ [W_t; W_4; W_5; root] + b
       q.M = N; q.N = d; q.K = 4 * d;
       q.A = sv.A[i]; q.lda = 4 * d; q.B = W; q.ldb = d; q.C = sv.h[i]; q.ldc = d; q.bias = c.P + g.bias[i];
       q.b_group_stride = dd; q.b_split_rows = d; q.b_shared_off = 3 * dd;
+      q.col_stats = sums;
       c.chk(pm_gemm_f32_desc(&q, c.st));
     }
-    bn_fwd(c, sv.h[i], N, d, 1, g.norm[i], true, sv.x[i], sv.x[i + 1], sv.mean[i], sv.var[i]);
+    const PmBn& bn = g.norm[i];                           // x' = x + relu(BN(h))   (model.py:203-206)
+    c.chk(pm_bn_apply_fused(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
+                            sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.st));
   }
   return sv.x[c.L];
 }
@@ -149,7 +161,9 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   for (int i = c.L - 1; i >= 0; --i) {
     const float* W = c.P + g.weight[i];
     float* dW = c.G + g.weight[i];
-    bn_bwd(c, sv.h[i], dx, N, d, 1, g.norm[i], sv.mean[i], sv.var[i], true, dh, c.G + g.bias[i]);
+    const PmBn& bn = g.norm[i];
+    c.chk(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
+                          c.G + bn.b, c.G + g.bias[i], dh, sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, c.st));
     if (!c.compact) {
       c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));

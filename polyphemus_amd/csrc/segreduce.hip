@@ -12,6 +12,7 @@
 // Algorithmic HBM bytes: forward 4*d*N*(1+R) + 12*E (+4*d*N for the root copy
 // this kernel also writes), backward 4*d*N*(R+1) + 12*E + 4*32*d.
 #include "common.h"
+#include <stdlib.h>
 #include "prof.h"
 
 extern "C" uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel) {
@@ -147,7 +148,7 @@ extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* p
 //   dT[dist] += sum_e  w_e * dA[dst_e, r_e*d:] * keep_e/(1-p) * x[n] * [x[n]*T > 0],   w_e = 1/clamp(count,1)
 // dT is reduced in LDS per workgroup (ds_add_f32) and flushed once with global float atomics.
 template <int NV, bool DROP>
-__global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__ x, const float* __restrict__ T,
+__global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict__ x, const float* __restrict__ T,
                                                        const float* __restrict__ dA, const float* __restrict__ dres,
                                                        const int* __restrict__ colptr, const int* __restrict__ csc_dst,
                                                        const int* __restrict__ csc_reldist,
@@ -155,17 +156,21 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
                                                        const float* __restrict__ csc_invcnt, int N, int d,
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
                                                        int compact, float* __restrict__ dx, float* __restrict__ dT) {
-  extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][d]
+  // LDS image of the table gradient: element (dist, column 4q + j) at dist*d + j*(d/4) + q, so that the four
+  // ds_add_f32 of a lane's float4 hit consecutive addresses across the wave (bank-conflict free)
+  extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][4][d/4]
   for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) sT[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nblk = compact ? 4 : 7;
+  const int dq = d >> 2;
   int c[NV];
   bool ok[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) { c[v] = (lane + v * 64) * 4; ok[v] = c[v] < d; }
-  for (int n0 = blockIdx.x * 4; n0 < N; n0 += gridDim.x * 4) {
+  const int nwv = blockDim.x >> 6;
+  for (int n0 = blockIdx.x * nwv; n0 < N; n0 += gridDim.x * nwv) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
     if (n >= N) continue;
     float4 xv[NV], acc[NV];
@@ -180,30 +185,46 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
       }
     }
     const int beg = colptr[n], end = colptr[n + 1];
-    for (int p = beg; p < end; ++p) {
-      const int dst = csc_dst[p], rd = csc_reldist[p];
-      const int r = rd & 0xff, dist = rd >> 8;
-      const int blk = compact ? (r < 4 ? 0 : r - 3) : r;     // compact: the one track block a node receives
-      const float w = csc_invcnt[p] * scale;
-      uint32_t key = 0;
-      if (DROP) key = pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[p]);
+    for (int p = beg; p < end; p += 2) {                    // two edges per trip: their row gathers overlap
+      int dst[2], dist[2], blk[2];
+      float w[2];
+      uint32_t key[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                          // (edge metadata through the scalar cache: p is uniform)
+        const bool live = p + u < end;
+        const int q = live ? p + u : p;                      // odd tail: edge p again with weight 0
+        dst[u] = csc_dst[q];
+        const int rd = csc_reldist[q];
+        const int r = rd & 0xff;
+        dist[u] = rd >> 8;
+        blk[u] = compact ? (r < 4 ? 0 : r - 3) : r;          // compact: the one track block a node receives
+        w[u] = live ? csc_invcnt[q] * scale : 0.f;
+        key[u] = DROP ? pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[q]) : 0u;
+      }
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if (!ok[v]) continue;
-        const float4 g4 = *reinterpret_cast<const float4*>(dA + ((int64_t)dst * nblk + blk) * d + c[v]);
-        const float4 tv = *reinterpret_cast<const float4*>(T + dist * d + c[v]);
-        float g[4] = {g4.x * w, g4.y * w, g4.z * w, g4.w * w};
+        float4 g4[2], tv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          g4[u] = *reinterpret_cast<const float4*>(dA + ((int64_t)dst[u] * nblk + blk[u]) * d + c[v]);
+          tv[u] = *reinterpret_cast<const float4*>(T + dist[u] * d + c[v]);
+        }
         const float xs[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w};
-        const float ts[4] = {tv.x, tv.y, tv.z, tv.w};
         float* ap = reinterpret_cast<float*>(&acc[v]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bool on = xs[j] * ts[j] > 0.f;
-          if (DROP) on = on && ((pm_elem_hash(key, c[v] + j) >> 8) >= thresh);
-          const float gg = on ? g[j] : 0.f;
-          ap[j] += gg * ts[j];
-          const float gt = gg * xs[j];
-          if (gt != 0.f) atomicAdd(&sT[dist * d + c[v] + j], gt);
+        for (int u = 0; u < 2; ++u) {
+          const float g[4] = {g4[u].x * w[u], g4[u].y * w[u], g4[u].z * w[u], g4[u].w * w[u]};
+          const float ts[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bool on = xs[j] * ts[j] > 0.f;
+            if (DROP) on = on && ((pm_elem_hash(key[u], c[v] + j) >> 8) >= thresh);
+            const float gg = on ? g[j] : 0.f;
+            ap[j] += gg * ts[j];
+            const float gt = gg * xs[j];
+            if (gt != 0.f) atomicAdd(&sT[dist[u] * d + j * dq + (c[v] >> 2)], gt);
+          }
         }
       }
     }
@@ -214,8 +235,9 @@ __global__ void __launch_bounds__(256) k_segreduce_bwd(const float* __restrict__
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {
-    const float v = sT[i];
+  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {       // i runs over dT (coalesced atomics)
+    const int col = i % d;
+    const float v = sT[i - col + (col & 3) * dq + (col >> 2)];
     if (v != 0.f) atomicAdd(&dT[i], v);
   }
 }
@@ -228,9 +250,12 @@ extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA,
     return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
-  int nblk = (int)pm_cdiv(N, 4);
-  if (nblk > 768) nblk = 768;         // waves in flight (latency of colptr -> edge -> row gathers) vs table flushes
-  const dim3 grid(nblk), block(256);
+  // 16-wave workgroups, one per CU: 4096 waves hide the colptr -> edge -> row-gather latency chain while only 256
+  // LDS tables are flushed with global atomics (measured: 48 us; 4-wave workgroups x 768: 59 us; x 1024: 61 us)
+  const int threads = N >= 4096 ? 1024 : 256;
+  int nblk = (int)pm_cdiv(N, threads / 64);
+  if (nblk > 256) nblk = 256;
+  const dim3 grid(nblk), block(threads);
   const size_t lds = sizeof(float) * PM_N_DIST * d;
   const bool drop = dropout_p > 0.f;
   const uint32_t thresh = pm_keep_threshold(dropout_p);

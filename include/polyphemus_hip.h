@@ -110,6 +110,11 @@ int pm_edge_table_bwd(const float* dT /* [32,d] */, int32_t d, float* d_nn_weigh
 int pm_segreduce_fwd(const float* x /* [N,d] */, const float* T /* [32,d] */, const int32_t* plan,
                      int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
                      uint32_t layer_uid, int32_t compact, float* A /* [N,7d] or [N,4d] */, pm_stream_t stream);
+/* Same aggregate written PRE-SPLIT for the planes mode of the GEMM: three bf16 planes (value = p1 + p2 + p3 exactly),
+ * plane k at planes + k*plane_stride, same [N, 7d | 4d] element layout. */
+int pm_segreduce_fwd_planes(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                            int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact,
+                            uint16_t* planes, int64_t plane_stride, pm_stream_t stream);
 int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] or [N,4d] */,
                      const float* dres /* [N,d] or NULL: added to dx (residual path, model.py:206) */,
                      const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p,
@@ -154,6 +159,9 @@ int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N, int32_t K,
  * shared rows are then accumulated atomically by all groups).  This binds the whole compact GCL contraction
  *   h[rows_t] = A'[rows_t, 0:4d] @ [weight[t]; weight[4]; weight[5]; root]        (model.py:112,116)
  * its input gradient and its weight gradient in one launch each. */
+/* fp32 -> three bf16 planes with x = p1 + p2 + p3 EXACTLY (8 significand bits each); n % 4 == 0. */
+int pm_split_planes(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride /* elements, >= n */,
+                    pm_stream_t stream);
 typedef struct PmGemmDesc {
   int32_t transA, transB, M, N, K;
   const float* A; int32_t lda;
@@ -171,6 +179,11 @@ typedef struct PmGemmDesc {
   double* col_stats; /* optional [PM_BN_REPL][2][N] fp64, += : column sums of the stored C values and of their
                         squares (the statistics pass of the BatchNorm that follows, fused into the epilogue; the
                         replica is picked from the row-panel index); !transA, no ACCUM, split_k == 1 */
+  int32_t operand_planes; /* != 0: A and B are given PRE-SPLIT as three bf16 planes each (pm_split_planes and the
+                        plane outputs of pm_segreduce_fwd / pm_bn_bwd_fused): A / B point at plane 0, the planes are
+                        a_plane_stride / b_plane_stride ELEMENTS apart, lda / ldb and the group strides count bf16
+                        elements (multiples of 8); the six-product split GEMM then runs without conversion work */
+  int64_t a_plane_stride, b_plane_stride;
 } PmGemmDesc;
 int pm_gemm_f32_desc(const PmGemmDesc* desc, pm_stream_t stream);
 
@@ -204,7 +217,9 @@ int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, 
                       float* running_var, float momentum, pm_stream_t stream);
 int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
                     float eps, const float* gamma, const float* beta, int relu, float* dgamma, float* dbeta,
-                    float* dbias_pre /* or NULL */, float* dx, double* acc3, pm_stream_t stream);
+                    float* dbias_pre /* or NULL */, float* dx /* fp32 output, or NULL with dx_planes */, double* acc3,
+                    uint16_t* dx_planes /* or NULL: dx as three bf16 planes (PmGemmDesc.operand_planes) */,
+                    int64_t plane_stride /* elements */, pm_stream_t stream);
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
 int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
 int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);
@@ -306,11 +321,11 @@ uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32
 
 /* ------------------------------------------------------------------ launch-duration profiler (bench.py roofline)
  * HIP events around every GEMM / segment-reduce launch while enabled; pm_prof_end sums the durations per class:
- * classes 0..23 = GEMM tile configuration (0..7) * 3 + {0 NN, 1 NT, 2 TN}; 24 = segment-reduce forward; 25 = backward.
+ * classes 0..26 = GEMM tile configuration (0..8) * 3 + {0 NN, 1 NT, 2 TN}; 27 = segment-reduce forward; 28 = backward.
  * `work` = algorithmic flops (GEMM) or algorithmic HBM bytes (segment-reduce) of the launches. */
-enum { PM_PROF_NCLASS_PUBLIC = 26 };
+enum { PM_PROF_NCLASS_PUBLIC = 29 };
 int pm_prof_begin(int32_t max_events);
-int pm_prof_end(double* ms /* [26] host */, double* work /* [26] host */, int64_t* count /* [26] host */);
+int pm_prof_end(double* ms /* [29] host */, double* work /* [29] host */, int64_t* count /* [29] host */);
 
 /* ------------------------------------------------------------------ native training step
  * The whole of `PolyphemusTrainer.train`'s inner iteration (training.py:137-166) issued from C++:

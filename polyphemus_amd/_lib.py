@@ -26,6 +26,7 @@ _SIGS = {
     "pm_edge_table": "ppips",
     "pm_edge_table_bwd": "pipps",
     "pm_segreduce_fwd": "pppiiiifuuips",
+    "pm_segreduce_fwd_planes": "pppiiiifuuipls",
     "pm_segreduce_bwd": "pppppiiiifuuipps",
     "pm_gemm_f32": "iiiiipipipipiipips",
     "pm_gemm_f32_grouped": "iiiiipipipipiipipilllliis",
@@ -36,7 +37,8 @@ _SIGS = {
     "pm_bn_apply": "piiippfpppips",
     "pm_bn_bwd": "ppiiippfppippppps",
     "pm_bn_apply_fused": "piipfpppipppppfs",
-    "pm_bn_bwd_fused": "ppiippfppippppps",
+    "pm_bn_bwd_fused": "ppiippfppippppppls",
+    "pm_split_planes": "plpls",
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",
     "pm_colsum_acc": "piiips",

@@ -68,6 +68,34 @@ __device__ static inline double pm_wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// ---- exact three-term bf16 split of fp32 values (operand planes of the split-product GEMM, gemm.hip)
+typedef __bf16 pm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int pm_u32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ static inline unsigned pm_pk_bf16(float a, float b) {
+  pm_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pm_bf16x2));
+}
+// a = a1 + a2 + a3 exactly (each residual is exact in fp32); h1/h2/h3 hold the pair (a, b)
+__device__ static inline void pm_split3_pair(float a, float b, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = pm_pk_bf16(a, b);
+  a -= __uint_as_float(h1 << 16); b -= __uint_as_float(h1 & 0xffff0000u);
+  h2 = pm_pk_bf16(a, b);
+  a -= __uint_as_float(h2 << 16); b -= __uint_as_float(h2 & 0xffff0000u);
+  h3 = pm_pk_bf16(a, b);
+}
+// four consecutive values -> the three planes (8 bytes each) at element index idx
+__device__ static inline void pm_store_planes4(uint16_t* __restrict__ planes, int64_t plane_stride, int64_t idx, float x0,
+                                               float x1, float x2, float x3) {
+  unsigned l1, l2, l3, u1, u2, u3;
+  pm_split3_pair(x0, x1, l1, l2, l3);
+  pm_split3_pair(x2, x3, u1, u2, u3);
+  const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+  *reinterpret_cast<pm_u32x2*>(planes + idx) = p1;
+  *reinterpret_cast<pm_u32x2*>(planes + plane_stride + idx) = p2;
+  *reinterpret_cast<pm_u32x2*>(planes + 2 * plane_stride + idx) = p3;
+}
 __device__ static inline float pm_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -36,6 +36,7 @@ struct GemmArgs {
   // ngroups > 1 with packed != 0: the groups partition the gathered rows (device-side counts), and the live row
   // panels of ALL groups are enumerated along blockIdx.x (gridDim.y == 1) so that no dead workgroup is launched
   int ngroups, packed;
+  int64_t a_ps, b_ps;                        // planes mode: distance between the bf16 planes of A / B (elements)
   double* colstats;                          // optional [2][N]: += column sums of the stored values and of their squares
 };
 
@@ -51,19 +52,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32, round to nearest even)
-__device__ static inline unsigned pk_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// exact three-term bf16 split of a pair: a = a1 + a2 + a3 (each residual is exact in fp32)
-__device__ static inline void split3_pair(float a, float b, unsigned& h1, unsigned& h2, unsigned& h3) {
-  h1 = pk_bf16(a, b);
-  a -= __uint_as_float(h1 << 16); b -= __uint_as_float(h1 & 0xffff0000u);
-  h2 = pk_bf16(a, b);
-  a -= __uint_as_float(h2 << 16); b -= __uint_as_float(h2 & 0xffff0000u);
-  h3 = pk_bf16(a, b);
-}
 #define PM_OOB ((int)0x80000000)     // byte offset >= num_records: the buffer load returns 0, no branch, no fault
 
 // Stage one operand tile (R rows x BK k) through registers into its k-major LDS image S[k][r].
@@ -157,8 +145,8 @@ struct TileStage {
       const int f = tid + j * THREADS;
       const int off = KC ? (f / (BK / 4)) * XROWB + (f % (BK / 4)) * 8 : (f / (R / 4)) * XROWB + (f % (R / 4)) * 8;
       unsigned l1, l2, l3, u1, u2, u3;
-      split3_pair(__uint_as_float(v[j].x), __uint_as_float(v[j].y), l1, l2, l3);
-      split3_pair(__uint_as_float(v[j].z), __uint_as_float(v[j].w), u1, u2, u3);
+      pm_split3_pair(__uint_as_float(v[j].x), __uint_as_float(v[j].y), l1, l2, l3);
+      pm_split3_pair(__uint_as_float(v[j].z), __uint_as_float(v[j].w), u1, u2, u3);
       const u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
       *reinterpret_cast<u32x2*>(S + off) = p1;
       *reinterpret_cast<u32x2*>(S + XPLANE + off) = p2;
@@ -207,9 +195,85 @@ struct TileStage {
   }
 };
 
-template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, bool X6>
-__global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs g) {
-  static_assert(!X6 || (VA && VB && BK % 16 == 0), "split mode stages with 16-byte loads");
+// Operand given as three bf16 planes (the exact split x = x1 + x2 + x3 done once by the kernel that PRODUCED the
+// tensor): the tile is staged with plain 16-byte loads / ds_write_b128 into the same LDS images as split mode, no
+// conversion arithmetic in the GEMM.  Element = bf16, `ld` in elements, rows addressed like TileStage.
+template <int R, int BK, int THREADS, bool KC>
+struct PlaneStage {
+  using Img = TileStage<R, BK, THREADS, KC, true>;      // image geometry + fragment readers
+  static constexpr int NV = (R * BK / 8) / THREADS;     // 16-byte chunks per plane and thread
+  static_assert((R * BK / 8) % THREADS == 0 && NV >= 1, "tile does not divide over the workgroup");
+  u32x4 v[3][NV];
+  int base[NV], krow[NV];
+  __amdgpu_buffer_rsrc_t rsrc[3];
+  const int32_t* map;
+  int rpe, ld, tid, split, lo_b, hi_b;
+
+  __device__ inline int stack_off(int row) const { return row < split ? lo_b : hi_b; }
+  __device__ inline void init(const char* P, int64_t plane_bytes, int ld_, int r0, int rmax, const int32_t* map_,
+                              int rpe_, int split_ = 0, int lo_b_ = 0, int hi_b_ = 0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      rsrc[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(P + p * plane_bytes), 0, PM_OOB, 0x00020000);
+    map = map_; rpe = rpe_; ld = ld_; tid = threadIdx.x % THREADS;
+    split = split_; lo_b = lo_b_; hi_b = hi_b_;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int f = tid + j * THREADS;
+      if (KC) {
+        const int r = r0 + f / (BK / 8);
+        base[j] = r < rmax ? (int)(map_row(map, rpe, r) * ld * 2) + (f % (BK / 8)) * 16 + stack_off(r) : PM_OOB;
+      } else {
+        const int r = r0 + (f % (R / 8)) * 8;
+        base[j] = r < rmax ? r * 2 : PM_OOB;
+      }
+    }
+  }
+  __device__ inline void prime(int k0, int kmax) {
+    if (KC || !map) return;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + (tid + j * THREADS) / (R / 8);
+      krow[j] = k < kmax ? (rpe == 1 ? map[k] : map[k / rpe] * rpe + k % rpe) : 0;
+    }
+  }
+  __device__ inline void load(int k0, int kmax) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int f = tid + j * THREADS;
+      int off;
+      if (KC) {
+        const int k = k0 + (f % (BK / 8)) * 8;
+        off = (k < kmax && base[j] >= 0) ? base[j] + k0 * 2 : PM_OOB;
+      } else {
+        const int k = k0 + f / (R / 8);
+        const int prow = map ? krow[j] : k;
+        off = (k < kmax && base[j] >= 0) ? base[j] + prow * (ld * 2) + stack_off(k) : PM_OOB;
+        if (map) {
+          const int kn = k + BK;
+          krow[j] = kn < kmax ? (rpe == 1 ? map[kn] : map[kn / rpe] * rpe + kn % rpe) : 0;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) v[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc[p], off, 0, 0);
+    }
+  }
+  __device__ inline void store(char* __restrict__ S) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int f = tid + j * THREADS;
+      const int off = KC ? (f / (BK / 8)) * Img::XROWB + (f % (BK / 8)) * 16 : (f / (R / 8)) * Img::XROWB + (f % (R / 8)) * 16;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(S + p * Img::XPLANE + off) = v[p][j];
+    }
+  }
+};
+
+// MODE 0: fp32 MFMA.  MODE 1 ("x6"): fp32 operands split in the kernel.  MODE 2 ("planes"): operands pre-split.
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
+__global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1)) k_gemm(GemmArgs g) {
+  constexpr bool X6 = MODE == 1, PL = MODE == 2;
+  static_assert(MODE == 0 || (VA && VB && BK % 16 == 0), "split modes stage with 16-byte loads");
   // THREADS = MFMA threads = staging threads.  fp32 mode: the same waves do both.  Split mode: the block has
   // 2*THREADS threads, waves [0, WVM*WVN) multiply and waves [WVM*WVN, 2*WVM*WVN) load + split + store, so the
   // conversion arithmetic of tile t+1 runs on the SIMD's vector ALU while its matrix core works on tile t.
@@ -242,8 +306,13 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
   }
   if (g.ngroups > 1) {                       // grouped launch (uniform branch): shift everything to this group
     const int64_t bi = grp;
-    g.A += bi * g.a_boff;
-    if (g.b_split == 0) g.B += bi * g.b_boff;
+    if (PL) {                                  // bf16 planes: element = 2 bytes
+      g.A = reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.A) + bi * g.a_boff * 2);
+      if (g.b_split == 0) g.B = reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.B) + bi * g.b_boff * 2);
+    } else {
+      g.A += bi * g.a_boff;
+      if (g.b_split == 0) g.B += bi * g.b_boff;
+    }
     if (g.c_split == 0) g.C += bi * g.c_boff;
     if (g.bias) g.bias += bi * g.bias_boff;
     if (g.rowmap) g.rowmap += bi * g.map_boff;
@@ -293,6 +362,56 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  if constexpr (PL) {
+    // Pre-split operands: single LDS image per operand (two barriers per k-tile, 4 workgroups per CU cover them),
+    // the loads of tile t+1 are in flight during the MFMAs of tile t.
+    using PA_ = PlaneStage<BM, BK, THREADS, !TA>;
+    using PB_ = PlaneStage<BN, BK, THREADS, TB>;
+    PA_ pa;
+    PB_ pb;
+    pa.init(reinterpret_cast<const char*>(g.A), g.a_ps * 2, g.lda, m0, M, mapA, g.rpe);
+    pb.init(reinterpret_cast<const char*>(g.B), g.b_ps * 2, g.ldb, n0, g.N, mapB, g.rpe, g.b_split,
+            (int)(grp * g.b_boff * 2), (int)(g.b_hi * 2));
+    pa.prime(kbeg, kend);
+    pb.prime(kbeg, kend);
+    pa.load(kbeg, kend);
+    pb.load(kbeg, kend);
+    char* const Bx1 = Ax0 + StA::XBYTES;
+    pa.store(Ax0);
+    pb.store(Bx1);
+    __syncthreads();
+    const char* as = Ax0 + StA::x6_lane_off(wr * WM, lane);
+    const char* bs = Bx1 + StB::x6_lane_off(wc * WN, lane);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      pa.load(k0 + BK, kend);                  // (past the end: out-of-range offsets, returns 0, no traffic)
+      pb.load(k0 + BK, kend);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[p][i] = StA::x6_frag(as + p * StA::XPLANE + i * StA::XSTEP_I + ks * StA::XSTEP_K);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[p][j] = StB::x6_frag(bs + p * StB::XPLANE + j * StB::XSTEP_I + ks * StB::XSTEP_K);
+        }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (k0 + BK < kend) {
+        pa.store(Ax0);
+        pb.store(Bx1);
+      }
+      __syncthreads();
+    }
+  } else {
   sa.init(g.A, g.lda, m0, M, mapA, g.rpe);
   sb.init(g.B, g.ldb, n0, g.N, mapB, g.rpe, g.b_split, (int)(grp * g.b_boff * 4), (int)(g.b_hi * 4));
   sa.prime(kbeg, kend);
@@ -397,6 +516,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
   }
   }
 
+  }
   if (producer) return;
   // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
   const bool atomic = gridDim.z > 1;
@@ -454,42 +574,44 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (X6 ? 2 : 1)) k_gemm(GemmArgs
   }
 }
 
-template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, bool X6>
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
 static void launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
   using StA = TileStage<BM, BK, 64 * WVM * WVN, !TA, VA>;
   using StB = TileStage<BN, BK, 64 * WVM * WVN, TB, VB>;
-  const size_t lds = X6 ? (size_t)2 * (StA::XBYTES + StB::XBYTES) : sizeof(float) * 2 * BK * (StA::LD + StB::LD);
-  auto kern = k_gemm<BM, BN, BK, WVM, WVN, TA, TB, VA, VB, X6>;
+  const size_t lds = MODE == 1 ? (size_t)2 * (StA::XBYTES + StB::XBYTES)
+                   : MODE == 2 ? (size_t)(StA::XBYTES + StB::XBYTES)
+                               : sizeof(float) * 2 * BK * (StA::LD + StB::LD);
+  auto kern = k_gemm<BM, BN, BK, WVM, WVN, TA, TB, VA, VB, MODE>;
   static bool attr_done = false;             // > 64 KiB of dynamic LDS needs the attribute (once per instantiation)
   if (lds > 64 * 1024 && !attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN * (X6 ? 2 : 1)), lds, st, g);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN * (MODE == 1 ? 2 : 1)), lds, st, g);
 }
-template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool X6>
+template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, int MODE>
 static void launch_v(bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
-  if constexpr (X6) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true, true>(grid, st, g);
-  else if (va && vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true, false>(grid, st, g);
-  else if (va) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, false, false>(grid, st, g);
-  else if (vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, true, false>(grid, st, g);
-  else launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, false, false>(grid, st, g);
+  if constexpr (MODE != 0) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true, MODE>(grid, st, g);
+  else if (va && vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, true, 0>(grid, st, g);
+  else if (va) launch_one<BM, BN, BK, WVM, WVN, TA, TB, true, false, 0>(grid, st, g);
+  else if (vb) launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, true, 0>(grid, st, g);
+  else launch_one<BM, BN, BK, WVM, WVN, TA, TB, false, false, 0>(grid, st, g);
 }
-template <int BM, int BN, int BK, int WVM, int WVN, bool X6>
+template <int BM, int BN, int BK, int WVM, int WVN, int MODE>
 static void launch_t(int ta, int tb, bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
-  if (!ta && !tb) launch_v<BM, BN, BK, WVM, WVN, false, false, X6>(va, vb, grid, st, g);
-  else if (!ta && tb) launch_v<BM, BN, BK, WVM, WVN, false, true, X6>(va, vb, grid, st, g);
-  else launch_v<BM, BN, BK, WVM, WVN, true, false, X6>(va, vb, grid, st, g);
+  if (!ta && !tb) launch_v<BM, BN, BK, WVM, WVN, false, false, MODE>(va, vb, grid, st, g);
+  else if (!ta && tb) launch_v<BM, BN, BK, WVM, WVN, false, true, MODE>(va, vb, grid, st, g);
+  else launch_v<BM, BN, BK, WVM, WVN, true, false, MODE>(va, vb, grid, st, g);
 }
 
-enum { PM_GEMM_NCFG = 8 };                    // 0..3 fp32 MFMA, 4..7 split mode
-static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128};
-static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128};
-static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32};
+enum { PM_GEMM_NCFG = 9 };                    // 0..3 fp32 MFMA, 4..7 split mode, 8 pre-split planes
+static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128, 64};
+static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128, 64};
+static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32, 32};
 
 // Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
 static int g_forced_cfg = -1;
-extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && cfg < PM_GEMM_NCFG) ? cfg : -1; return PM_OK; }
+extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && cfg < 8) ? cfg : -1; return PM_OK; }
 static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
   if (g_forced_cfg >= 0 && (g_forced_cfg < 4 || x6_ok)) return g_forced_cfg;
   // Measured on MI355X (tools/bench_gemm.py, shapes of the training step, interleaved A/B in one process):
@@ -542,7 +664,15 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
   const bool vb = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
                   (q->b_group_stride % 4 == 0) && (q->b_shared_off % 4 == 0);
-  const int cfg = pick_config(transA, M, N, K, va && vb);
+  const bool planes = q->operand_planes != 0;
+  if (planes) {                              // bf16 planes: 16-byte chunks = 8 elements along the contiguous extent
+    if (((uintptr_t)q->A % 16) || ((uintptr_t)q->B % 16) || (q->lda % 8) || (q->ldb % 8) || ((transA ? M : K) % 8) ||
+        ((transB ? K : N) % 8) || (q->a_group_stride % 8) || (q->b_group_stride % 8) || (q->b_shared_off % 8) ||
+        (q->a_plane_stride % 8) || (q->b_plane_stride % 8) || q->a_plane_stride <= 0 || q->b_plane_stride <= 0)
+      return PM_E_INVALID;
+  }
+  g.a_ps = q->a_plane_stride; g.b_ps = q->b_plane_stride;
+  const int cfg = planes ? 8 : pick_config(transA, M, N, K, va && vb);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
@@ -573,14 +703,15 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);
   switch (cfg) {
-    case 0: launch_t<64, 64, 16, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
-    case 1: launch_t<128, 128, 16, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
-    case 2: launch_t<64, 64, 32, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
-    case 3: launch_t<128, 128, 32, 2, 2, false>(transA, transB, va, vb, grid, st, g); break;
-    case 4: launch_t<128, 128, 16, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
-    case 5: launch_t<128, 64, 16, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
-    case 6: launch_t<64, 64, 32, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
-    default: launch_t<128, 128, 32, 2, 2, true>(transA, transB, va, vb, grid, st, g); break;
+    case 0: launch_t<64, 64, 16, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
+    case 1: launch_t<128, 128, 16, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
+    case 2: launch_t<64, 64, 32, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
+    case 3: launch_t<128, 128, 32, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
+    case 4: launch_t<128, 128, 16, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
+    case 5: launch_t<128, 64, 16, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
+    case 6: launch_t<64, 64, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
+    case 7: launch_t<128, 128, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
+    default: launch_t<64, 64, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
   }
   pm_prof_close(st, pe);
   return pm_check_launch();
@@ -599,6 +730,7 @@ extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N,
   q.a_group_stride = a_group_stride; q.b_group_stride = b_group_stride; q.c_group_stride = c_group_stride;
   q.bias_group_stride = bias_group_stride; q.map_group_stride = map_group_stride; q.dyn_group_stride = dyn_group_stride;
   q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0; q.col_stats = nullptr;
+  q.operand_planes = 0; q.a_plane_stride = 0; q.b_plane_stride = 0;
   return pm_gemm_f32_desc(&q, stream);
 }
 
@@ -608,6 +740,25 @@ extern "C" int pm_gemm_f32(int transA, int transB, int32_t M, int32_t N, int32_t
                            pm_stream_t stream) {
   return pm_gemm_f32_grouped(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, split_k, rowmap,
                              rows_per_entry, dyn_entries, 1, 0, 0, 0, 0, 0, 0, stream);
+}
+
+// fp32 -> three bf16 planes (x = x1 + x2 + x3 exactly): the operand format of the planes mode.  Used once per step on
+// the GCL weights; activations are written as planes directly by the kernels that produce them.
+__global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ src, int64_t n4, uint16_t* __restrict__ planes,
+                                                      int64_t plane_stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    pm_store_planes4(planes, plane_stride, i * 4, v.x, v.y, v.z, v.w);
+  }
+}
+extern "C" int pm_split_planes(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride, pm_stream_t stream) {
+  if (!src || !planes || n <= 0 || (n & 3) || plane_stride < n || (plane_stride & 3) || ((uintptr_t)src % 16) ||
+      ((uintptr_t)planes % 8))
+    return PM_E_INVALID;
+  int64_t grid = pm_cdiv(n / 4, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, n / 4, planes, plane_stride);
+  return pm_check_launch();
 }
 
 // ---------------------------------------------------------------- launch-duration profiler (see prof.h)

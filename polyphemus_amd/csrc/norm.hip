@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* 
 __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restrict__ x, const float* __restrict__ dy,
                                                             int64_t n4, int C, double count, BnCtx ctx,
                                                             const double* __restrict__ acc3, float* dgamma,
-                                                            float* dbeta, float* dbias_pre, float* __restrict__ dx) {
+                                                            float* dbeta, float* dbias_pre, float* __restrict__ dx,
+                                                            uint16_t* __restrict__ dx_planes, int64_t plane_stride) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [6][C]: mean, rstd, gamma, beta, mean(du), mean(du*xhat)
   float* const s_m = sm; float* const s_rs = sm + C; float* const s_ga = sm + 2 * C; float* const s_be = sm + 3 * C;
   float* const s_m0 = sm + 4 * C; float* const s_m1 = sm + 5 * C;
@@ -425,16 +426,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
       if (ctx.relu && !(xh * ga + s_be[c + j] > 0.f)) du = 0.f;
       o[j] = ga * rstd * (du - s_m0[c + j] - xh * s_m1[c + j]);
     }
-    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (dx_planes) pm_store_planes4(dx_planes, plane_stride, i * 4, o[0], o[1], o[2], o[3]);   // GEMM operand planes
+    else reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
                                const float* var, float eps, const float* gamma, const float* beta, int relu,
                                float* dgamma, float* dbeta, float* dbias_pre, float* dx, double* acc3,
-                               pm_stream_t stream) {
-  if (!x || !dy || !mean || !var || !gamma || !beta || !dx || !acc3 || O <= 0 || C <= 0 || (C % 4) != 0 || C > 4096)
+                               uint16_t* dx_planes, int64_t plane_stride, pm_stream_t stream) {
+  if (!x || !dy || !mean || !var || !gamma || !beta || (!dx && !dx_planes) || !acc3 || O <= 0 || C <= 0 ||
+      (C % 4) != 0 || C > 4096)
     return PM_E_INVALID;
   if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return PM_E_INVALID;
+  if (dx_planes && (plane_stride < (int64_t)O * C || (plane_stride & 3) || ((uintptr_t)dx_planes % 8))) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   BnCtx ctx = {mean, var, gamma, beta, eps, relu};
   int nc = (int)pm_cdiv(O, 32);
@@ -445,7 +449,7 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
   hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3);
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(ew_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
-                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx);
+                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride);
   return pm_check_launch();
 }
 

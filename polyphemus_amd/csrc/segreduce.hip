@@ -56,10 +56,13 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
                                                        const int* __restrict__ csr_dist, const int* __restrict__ csr_eid,
                                                        int N, int d, uint32_t seed, uint32_t layer_uid,
                                                        uint32_t thresh, float scale, const int* __restrict__ node_trel,
-                                                       float* __restrict__ A) {
+                                                       float* __restrict__ A, uint16_t* __restrict__ planes,
+                                                       int64_t plane_stride) {
   const int lane = threadIdx.x & 63;
   const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (n >= N) return;
+  // planes != NULL: the aggregate is written pre-split (three bf16 planes, x = x1 + x2 + x3 exactly) for the
+  // planes mode of the GEMM instead of as fp32
   // compact layout (node_trel != NULL): A[n] = [track block | onset | next | x], 4 blocks instead of 7 — the
   // three track blocks a node never receives edges of are identically zero and are not stored
   const bool compact = node_trel != nullptr;
@@ -105,22 +108,27 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
       float4 o = make_float4(acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv);
-      *reinterpret_cast<float4*>(A + arow + (int64_t)blk * d + c[v]) = o;
+      if (planes) pm_store_planes4(planes, plane_stride, arow + (int64_t)blk * d + c[v], o.x, o.y, o.z, o.w);
+      else *reinterpret_cast<float4*>(A + arow + (int64_t)blk * d + c[v]) = o;
     }
     beg = end;
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     if (!ok[v]) continue;
-    *reinterpret_cast<float4*>(A + arow + (int64_t)(nblk - 1) * d + c[v]) =
-        *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
+    const float4 xs = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
+    if (planes) pm_store_planes4(planes, plane_stride, arow + (int64_t)(nblk - 1) * d + c[v], xs.x, xs.y, xs.z, xs.w);
+    else *reinterpret_cast<float4*>(A + arow + (int64_t)(nblk - 1) * d + c[v]) = xs;
   }
 }
 
-extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
-                                int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact, float* A,
-                                pm_stream_t stream) {
-  if (!x || !T || !plan || !A || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f || dropout_p >= 1.f)
+static int segreduce_fwd_impl(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                              int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact, float* A,
+                              uint16_t* planes, int64_t plane_stride, pm_stream_t stream) {
+  if (!x || !T || !plan || (!A && !planes) || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f ||
+      dropout_p >= 1.f)
+    return PM_E_INVALID;
+  if (planes && (plane_stride < (int64_t)N * (compact ? 4 : 7) * d || (plane_stride & 3) || ((uintptr_t)planes % 8)))
     return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   const int* trel = compact ? pv.node_trel : nullptr;
@@ -131,15 +139,29 @@ extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* p
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
 #define LAUNCH(NV, DR)                                                                                              \
   hipLaunchKernelGGL((k_segreduce_fwd<NV, DR>), grid, block, 0, st, x, T, pv.rowptr, pv.csr_src, pv.csr_dist,       \
-                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, trel, A)
+                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, trel, A, planes, plane_stride)
   const int nv = (int)pm_cdiv(d, 256);
-  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_FWD, 4.0 * d * (double)N * (1 + (compact ? 3 : PM_N_REL)) + 12.0 * E);
+  const double bytes_out = (planes ? 6.0 : 4.0) * d * (double)N * (compact ? 4 : 7);
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_FWD, 4.0 * d * (double)N + bytes_out + 12.0 * E);
   if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
   else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
   else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();
+}
+extern "C" int pm_segreduce_fwd(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact, float* A,
+                                pm_stream_t stream) {
+  if (!A) return PM_E_INVALID;
+  return segreduce_fwd_impl(x, T, plan, N, E, G, d, dropout_p, seed, layer_uid, compact, A, nullptr, 0, stream);
+}
+extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E,
+                                       int32_t G, int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid,
+                                       int32_t compact, uint16_t* planes, int64_t plane_stride, pm_stream_t stream) {
+  if (!planes) return PM_E_INVALID;
+  return segreduce_fwd_impl(x, T, plan, N, E, G, d, dropout_p, seed, layer_uid, compact, nullptr, planes, plane_stride,
+                            stream);
 }
 
 // ---------------------------------------------------------------- backward

@@ -29,6 +29,8 @@ struct Arena {
 struct GcnSaved {
   float* T; float* x[PM_MAX_LAYERS + 1]; float* A[PM_MAX_LAYERS]; float* h[PM_MAX_LAYERS];
   float* mean[PM_MAX_LAYERS]; float* var[PM_MAX_LAYERS];
+  uint16_t* Ap[PM_MAX_LAYERS];           // planes mode: the aggregates as three bf16 planes (A[] is then unused)
+  uint16_t* Wp; int64_t wp_stride; int64_t wp_base;   // planes of the parameter range [wp_base, wp_base + wp_stride)
   double* pool;                          // per layer PM_BN_REPL x ([2][d] forward column sums, [3][d] backward sums), fp64
   uint32_t seed, uid0; float p;
 };
@@ -57,6 +59,7 @@ struct Ctx {
   StepState* s; hipStream_t st; int rc;
   int N, E, Gn, B, d, nb, L, S;          // S = active token slots (1..15)
   int compact;                           // 1: one track relation per node -> [N,4d] aggregates, K = 4d
+  int planes;                            // 1 (needs compact): GCL GEMM operands as pre-split bf16 planes
   const float* P; float* G; float* Bf;
   void chk(int r) { if (r != PM_OK && rc == PM_OK) rc = r; }
 };
@@ -118,12 +121,26 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
   sv.x[0] = x0;
   sv.pool = ar.dbl((size_t)c.L * 5 * d * PM_BN_REPL);
   if (ar.base) hipMemsetAsync(sv.pool, 0, sizeof(double) * c.L * 5 * d * PM_BN_REPL, c.st);
+  const int64_t aps = (int64_t)N * nb * d;                // plane stride of the aggregates (elements)
+  if (c.planes) {                                         // the GCL weights of this stack, split once per step
+    sv.wp_base = g.weight[0];
+    sv.wp_stride = (g.weight[c.L - 1] + 7 * dd - g.weight[0] + 7) & ~(int64_t)7;
+    for (int i = 0; i < c.L; ++i)
+      if (g.weight[i] < sv.wp_base || ((g.weight[i] - sv.wp_base) & 7)) c.chk(PM_E_INVALID);
+    sv.Wp = (uint16_t*)ar.take((size_t)sv.wp_stride * 6);
+    if (ar.base) c.chk(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
+  }
   for (int i = 0; i < c.L; ++i) {
-    sv.A[i] = ar.f((size_t)N * nb * d); sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
+    if (c.planes) { sv.Ap[i] = (uint16_t*)ar.take((size_t)aps * 6); sv.A[i] = nullptr; }
+    else sv.A[i] = ar.f((size_t)N * nb * d);
+    sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
     sv.mean[i] = ar.f(d); sv.var[i] = ar.f(d);
     if (!ar.base) continue;
     const float* W = c.P + g.weight[i];
-    c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
+    if (c.planes)
+      c.chk(pm_segreduce_fwd_planes(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
+    else
+      c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
     double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
     if (!c.compact) {
       PmGemmDesc q;
@@ -138,6 +155,10 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       q.A = sv.A[i]; q.lda = 4 * d; q.B = W; q.ldb = d; q.C = sv.h[i]; q.ldc = d; q.bias = c.P + g.bias[i];
       q.b_group_stride = dd; q.b_split_rows = d; q.b_shared_off = 3 * dd;
       q.col_stats = sums;
+      if (c.planes) {
+        q.operand_planes = 1; q.A = (const float*)sv.Ap[i]; q.a_plane_stride = aps;
+        q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
+      }
       c.chk(pm_gemm_f32_desc(&q, c.st));
     }
     const PmBn& bn = g.norm[i];                           // x' = x + relu(BN(h))   (model.py:203-206)
@@ -154,6 +175,8 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   float* dT = ar.f((size_t)PM_N_DIST * d);
   float* dh = ar.f((size_t)N * d);
   float* dA = ar.f((size_t)N * nb * d);
+  const int64_t aps = (int64_t)N * nb * d, dps = (int64_t)N * d;
+  uint16_t* dhp = c.planes ? (uint16_t*)ar.take((size_t)dps * 6) : nullptr;   // dh as operand planes
   float* dxa = ar.f((size_t)N * d);
   float* dxb = ar.f((size_t)N * d);
   PmPlanView pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
@@ -163,7 +186,8 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     float* dW = c.G + g.weight[i];
     const PmBn& bn = g.norm[i];
     c.chk(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
-                          c.G + bn.b, c.G + g.bias[i], dh, sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, c.st));
+                          c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
+                          sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, c.st));
     if (!c.compact) {
       c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
@@ -172,11 +196,19 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       q.transB = 1; q.M = N; q.N = 4 * d; q.K = d;
       q.A = dh; q.lda = d; q.B = W; q.ldb = d; q.C = dA; q.ldc = 4 * d;
       q.b_group_stride = dd; q.b_split_rows = d; q.b_shared_off = 3 * dd;
+      if (c.planes) {
+        q.operand_planes = 1; q.A = (const float*)dhp; q.a_plane_stride = dps;
+        q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
+      }
       c.chk(pm_gemm_f32_desc(&q, c.st));
       PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
       w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM | PM_GEMM_PARTITION; w.split_k = 0;
       w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;
       w.c_group_stride = dd; w.c_split_rows = d; w.c_shared_off = 3 * dd;
+      if (c.planes) {
+        w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
+        w.B = (const float*)dhp; w.b_plane_stride = dps;
+      }
       c.chk(pm_gemm_f32_desc(&w, c.st));
     }
     float* out = (dx == dxa) ? dxb : dxa;
@@ -195,6 +227,7 @@ Ctx make_ctx(StepState* s, hipStream_t st) {
   c.d = s->lay.d; c.nb = s->lay.n_bars; c.L = s->lay.n_layers;
   c.S = s->bt.n_slots;
   c.compact = (s->bt.flags & 1) ? 1 : 0;
+  c.planes = (c.compact && (s->bt.flags & 2) && (s->lay.d % 8) == 0) ? 1 : 0;
   c.P = s->P; c.G = s->G; c.Bf = s->Bf;
   return c;
 }
@@ -429,11 +462,12 @@ void measure_backward(Ctx& c) {
   // mirrors the ar.f() calls of backward_decoder / backward_encoder / gcn_backward (x2)
   Arena& ar = c.s->ar;
   const size_t N = c.N, Gn = c.Gn, B = c.B, d = c.d, dh = d / 2, R = N * c.S;
-  size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d) + Gn * d +   // (7d: upper bound)
+  size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d + 2 * N * d) + Gn * d +   // (7d: upper bound)
                   (Gn * 8 * 128 * 2 + Gn * 512 + 2 * Gn * d) + B * 2 * d + B * d +
                   2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + R * d + 2 * d + 4 * PM_N_PITCH * dh +
                   (2 * Gn * d + 2 * Gn * 512 + Gn * 8 * 32 + 2 * Gn * 8 * 128);
   ar.take(floats * sizeof(float) + 256 * 256);    // + alignment slack of the ~60 carve-outs
+  ar.take((size_t)2 * c.L * (7 * d * d + 64 * d) * 6);   // planes mode: bf16 planes of the two GCN weight ranges
 }
 
 }  // namespace

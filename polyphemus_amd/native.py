@@ -4,12 +4,16 @@ after the reference's modules) and the batch descriptor."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from ._lib import lib
 
 PM_MAX_LAYERS = 16
+
+
+_PLANES = os.environ.get("PM_GCL_PLANES", "1") != "0"
 
 
 class PmLin(C.Structure):
@@ -100,5 +104,6 @@ def make_batch(graph, plan_tokens, is_drum_u8, et, ed) -> PmBatch:
     b.tokens, b.s_tensor = plan_tokens.data_ptr(), graph.s_tensor.data_ptr()
     b.N, b.E, b.G = graph.bars.shape[0], graph.edge_index.shape[1], graph.s_tensor.shape[0]
     b.n_slots = int(getattr(graph, "n_slots", 15) or 15)
-    b.flags = 1 if getattr(graph, "track_unique", False) else 0   # bit 0: one track relation per node (compact GCL)
+    # bit 0: one track relation per node (compact GCL); bit 1: GCL GEMM operands as pre-split bf16 planes
+    b.flags = (1 if getattr(graph, "track_unique", False) else 0) | (2 if _PLANES else 0)
     return b

@@ -208,9 +208,18 @@ def test_gemm_split_mode(cfg, M, N, K, ta, tb):
         lib().pm_gemm_force_config(-1)
 
 
+def test_split_planes_is_exact():
+    torch.manual_seed(1)
+    x = torch.randn(4096, device=DEV) * torch.logspace(-20, 20, 4096, device=DEV)
+    p = ops.split_planes(x)
+    f = lambda t: (t.to(torch.int32) << 16).view(torch.float32).double()     # bf16 bits -> value
+    assert torch.equal((f(p[0]) + f(p[1]) + f(p[2])).float(), x)
+
+
+@pytest.mark.parametrize("planes", [False, True])
 @pytest.mark.parametrize("partition", [False, True])
 @pytest.mark.parametrize("Nn,d", [(700, 64), (1000, 32), (333, 128)])
-def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition):
+def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition, planes):
     """The three contractions of the compact GCL (model.py:112,116 on [track block | onset | next | x]):
     rows partitioned into four relation groups (row lists + device counts), B / C stacked as
     [weight[t] (group rows) ; weight[4]; weight[5]; root (shared rows)]."""
@@ -230,17 +239,29 @@ def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition):
     Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()  # [4, 4d, d]
     grp = dict(rowmap=lists, rows_per_entry=1, dyn_entries=cnt, n_groups=4, map_group_stride=Nn, dyn_group_stride=1,
                partition=partition)
+    if planes:                                                    # operands pre-split into three bf16 planes
+        Ap, Wp = ops.split_planes(A), ops.split_planes(W)
+        pa, pw = dict(planes=True, a_plane_stride=A.numel(), b_plane_stride=W.numel()), None
     # forward
     h = torch.full((Nn, d), float("nan"), device=DEV)
-    ops.gemm_desc(A, W, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,
-                  b_shared_off=3 * dd, **grp)
+    if planes:
+        ops.gemm_desc(Ap, Wp, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,
+                      b_shared_off=3 * dd, **pa, **grp)
+    else:
+        ops.gemm_desc(A, W, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,
+                      b_shared_off=3 * dd, **grp)
     want = torch.einsum("nk,nkj->nj", A.double(), Wn[trel]) + bias.double()
     assert rel_err(h, want) < 5e-6
     # input gradient
     dh = torch.randn(Nn, d, device=DEV)
     dA = torch.full((Nn, 4 * d), float("nan"), device=DEV)
-    ops.gemm_desc(dh, W, dA, Nn, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
-                  b_shared_off=3 * dd, **grp)
+    if planes:
+        dhp = ops.split_planes(dh)
+        ops.gemm_desc(dhp, Wp, dA, Nn, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
+                      b_shared_off=3 * dd, planes=True, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), **grp)
+    else:
+        ops.gemm_desc(dh, W, dA, Nn, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
+                      b_shared_off=3 * dd, **grp)
     assert rel_err(dA, torch.einsum("nj,nkj->nk", dh.double(), Wn[trel])) < 5e-6
     # weight gradient (group rows plain / shared rows collected from all groups), accumulating
     dW = torch.randn(7 * d, d, device=DEV)
@@ -249,8 +270,13 @@ def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition):
         m = trel == t
         want[t * d:(t + 1) * d] += A[m, :d].double().t() @ dh[m].double()
     want[4 * d:] += A[:, d:].double().t() @ dh.double()
-    ops.gemm_desc(A, dh, dW, 4 * d, d, Nn, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
-                  c_split_rows=d, c_shared_off=3 * dd, **grp)
+    if planes:
+        ops.gemm_desc(Ap, dhp, dW, 4 * d, d, Nn, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
+                      c_split_rows=d, c_shared_off=3 * dd, planes=True, a_plane_stride=A.numel(),
+                      b_plane_stride=dh.numel(), **grp)
+    else:
+        ops.gemm_desc(A, dh, dW, 4 * d, d, Nn, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
+                      c_split_rows=d, c_shared_off=3 * dd, **grp)
     assert rel_err(dW, want) < 5e-6
 
 

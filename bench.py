@@ -154,13 +154,13 @@ def main():
         out = trainer.train_step(batch)
     sync()
     elapsed = time.perf_counter() - t0
-    NCLS = 29
+    NCLS = 35
     ms_a, work_a, cnt_a = (ctypes.c_double * NCLS)(), (ctypes.c_double * NCLS)(), (ctypes.c_int64 * NCLS)()
     L.pm_prof_end(ctypes.cast(ms_a, ctypes.c_void_p), ctypes.cast(work_a, ctypes.c_void_p), ctypes.cast(cnt_a, ctypes.c_void_p))
     tiles = ("64x64x16", "128x128x16", "64x64x32", "128x128x32", "x6:128x128x16", "x6:128x64x16", "x6:64x64x32",
-             "x6:128x128x32", "planes:64x64x32")
+             "x6:128x128x32", "planes:64x64x32", "planes:128x64x32", "planes:128x128x32")
     lay = ("NN", "NT", "TN")
-    names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(27)] + ["segreduce_fwd", "segreduce_bwd"]
+    names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(33)] + ["segreduce_fwd", "segreduce_bwd"]
     gst = {names[c]: dict(launches=int(cnt_a[c]), total_ms=ms_a[c], avg_us=1e3 * ms_a[c] / cnt_a[c], work=work_a[c])
            for c in range(NCLS) if cnt_a[c] > 0}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

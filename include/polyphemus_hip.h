@@ -321,11 +321,11 @@ uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32
 
 /* ------------------------------------------------------------------ launch-duration profiler (bench.py roofline)
  * HIP events around every GEMM / segment-reduce launch while enabled; pm_prof_end sums the durations per class:
- * classes 0..26 = GEMM tile configuration (0..8) * 3 + {0 NN, 1 NT, 2 TN}; 27 = segment-reduce forward; 28 = backward.
+ * classes 0..32 = GEMM tile configuration (0..10) * 3 + {0 NN, 1 NT, 2 TN}; 33 = segment-reduce forward; 34 = backward.
  * `work` = algorithmic flops (GEMM) or algorithmic HBM bytes (segment-reduce) of the launches. */
-enum { PM_PROF_NCLASS_PUBLIC = 29 };
+enum { PM_PROF_NCLASS_PUBLIC = 35 };
 int pm_prof_begin(int32_t max_events);
-int pm_prof_end(double* ms /* [29] host */, double* work /* [29] host */, int64_t* count /* [29] host */);
+int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_t* count /* [35] host */);
 
 /* ------------------------------------------------------------------ native training step
  * The whole of `PolyphemusTrainer.train`'s inner iteration (training.py:137-166) issued from C++:

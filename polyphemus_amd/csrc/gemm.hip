@@ -134,7 +134,7 @@ struct TileStage {
   //  KC : image [r][BK], fragments read with ds_read_b128 (8 consecutive k of the lane's row);
   //  !KC: image [k][R] (as loaded), fragments read with ds_read_b64_tr_b16 (hardware 4x16 transpose).
   // Row strides are padded so that both the 8-byte stores and the fragment reads are bank-conflict free.
-  static constexpr int XROWB = KC ? 2 * BK + 16 : 2 * R + 64;
+  static constexpr int XROWB = KC ? 2 * BK + 16 : 2 * R + 32;
   static constexpr int XPLANE = (KC ? R : BK) * XROWB;
   static constexpr int XBYTES = 3 * XPLANE;
   __device__ inline void store_x6(char* __restrict__ S) const { store_x6_from(v, S); }
@@ -237,7 +237,8 @@ struct PlaneStage {
       krow[j] = k < kmax ? (rpe == 1 ? map[k] : map[k / rpe] * rpe + k % rpe) : 0;
     }
   }
-  __device__ inline void load(int k0, int kmax) {
+  __device__ inline void load(int k0, int kmax) { load_to(v, k0, kmax); }
+  __device__ inline void load_to(u32x4 (&v)[3][NV], int k0, int kmax) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int f = tid + j * THREADS;
@@ -258,7 +259,8 @@ struct PlaneStage {
       for (int p = 0; p < 3; ++p) v[p][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc[p], off, 0, 0);
     }
   }
-  __device__ inline void store(char* __restrict__ S) const {
+  __device__ inline void store(char* __restrict__ S) const { store_from(v, S); }
+  __device__ inline void store_from(const u32x4 (&v)[3][NV], char* __restrict__ S) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int f = tid + j * THREADS;
@@ -270,8 +272,12 @@ struct PlaneStage {
 };
 
 // MODE 0: fp32 MFMA.  MODE 1 ("x6"): fp32 operands split in the kernel.  MODE 2 ("planes"): operands pre-split.
+// (planes mode, 64x64 tile: capped at 100 VGPRs so that FIVE workgroups fit a CU — the 1036 tiles of a GCL
+//  contraction then run as one resident wave of workgroups instead of 1024 + a 12-tile tail)
 template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
-__global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1)) k_gemm(GemmArgs g) {
+__global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
+    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? 5 : 1, (MODE == 2 && BM * BN <= 64 * 64) ? 5 : 8)))
+    k_gemm(GemmArgs g) {
   constexpr bool X6 = MODE == 1, PL = MODE == 2;
   static_assert(MODE == 0 || (VA && VB && BK % 16 == 0), "split modes stage with 16-byte loads");
   // THREADS = MFMA threads = staging threads.  fp32 mode: the same waves do both.  Split mode: the block has
@@ -288,7 +294,19 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1)) k_gemm(G
   char* const Ax0 = reinterpret_cast<char*>(smem);      // split mode: two A images (3 planes each), then two B images
   char* const Bx0 = Ax0 + 2 * StA::XBYTES;
 
-  int grp = blockIdx.y, t = blockIdx.x, nwg;
+  int grp = blockIdx.y, t = blockIdx.x, zs = blockIdx.z, nwg;
+  if (TA) {
+    // weight gradients: XCD-aware order over the WHOLE grid (tiles x groups x K-slices).  Workgroup L runs on XCD
+    // L % 8; each XCD gets a contiguous run of (group, K-slice) slabs, so a K range of the two operands is
+    // fetched into ONE L2 instead of all eight (measured: 312 MB -> memory-side reads per launch before).
+    const int nx = g.ntm * g.ntn, ny = gridDim.y, total = nx * ny * (int)gridDim.z;
+    const int L = t + nx * (grp + ny * zs);
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    const int V = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    t = V % nx;
+    grp = (V / nx) % ny;
+    zs = (V / nx) / ny;
+  }
   if (!TA && g.packed) {                     // packed groups: find the group of this tile from the device-side counts
     int tot = 0;
     for (int q = 0; q < g.ngroups; ++q) tot += (g.dyn_entries[q * g.dyn_boff] * g.rpe + BM - 1) / BM;
@@ -329,15 +347,15 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1)) k_gemm(G
   // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
   // contiguous run of tiles; tiles of one row panel (n fastest) then share the panel through one L2.
   // (with a device-side row count only the live row panels take part, so they still spread over all 8 XCDs)
-  if (TA || !g.packed) {
-    nwg = (TA ? g.ntm : (M + BM - 1) / BM) * g.ntn;
+  if (!TA && !g.packed) {
+    nwg = ((M + BM - 1) / BM) * g.ntn;
     if (t >= nwg) return;
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN;
   if (m0 >= M) return;
-  const int kbeg = blockIdx.z * kper;
+  const int kbeg = zs * kper;
   int kend = kbeg + kper;
   if (kend > K) kend = K;
   if (kbeg >= kend) return;
@@ -522,7 +540,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1)) k_gemm(G
   const bool atomic = gridDim.z > 1;
   const bool accum = (g.flags & PM_GEMM_ACCUM) != 0;
   const bool relu = (g.flags & PM_GEMM_RELU) != 0;
-  const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
+  const bool add_bias = g.bias != nullptr && zs == 0;
   const int32_t* mapC = TA ? nullptr : g.rowmap;
   const bool stats = g.colstats != nullptr;
   double cs[TN], cq[TN];
@@ -604,10 +622,10 @@ static void launch_t(int ta, int tb, bool va, bool vb, dim3 grid, hipStream_t st
   else launch_v<BM, BN, BK, WVM, WVN, true, false, MODE>(va, vb, grid, st, g);
 }
 
-enum { PM_GEMM_NCFG = 9 };                    // 0..3 fp32 MFMA, 4..7 split mode, 8 pre-split planes
-static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128, 64};
-static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128, 64};
-static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32, 32};
+enum { PM_GEMM_NCFG = 11 };                   // 0..3 fp32 MFMA, 4..7 split mode, 8..10 pre-split planes
+static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128, 64, 128, 128};
+static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128, 64, 64, 128};
+static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32, 32, 32, 32};
 
 // Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
 static int g_forced_cfg = -1;
@@ -672,6 +690,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
       return PM_E_INVALID;
   }
   g.a_ps = q->a_plane_stride; g.b_ps = q->b_plane_stride;
+  // planes mode: 64x64x32 tiles (measured in the step: 128x64x32 85 us, 128x128x32 97-130 us against 70-80 us)
   const int cfg = planes ? 8 : pick_config(transA, M, N, K, va && vb);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
@@ -711,7 +730,9 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
     case 5: launch_t<128, 64, 16, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
     case 6: launch_t<64, 64, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
     case 7: launch_t<128, 128, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
-    default: launch_t<64, 64, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 8: launch_t<64, 64, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 9: launch_t<128, 64, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    default: launch_t<128, 128, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
   }
   pm_prof_close(st, pe);
   return pm_check_launch();

@@ -6,10 +6,10 @@
 #include <stdint.h>
 
 enum {
-  PM_PROF_GEMM0 = 0,            // 27 GEMM classes: tile config (0..8) * 3 + {NN, NT, TN}
-  PM_PROF_SEGREDUCE_FWD = 27,
-  PM_PROF_SEGREDUCE_BWD = 28,
-  PM_PROF_NCLASS = 29
+  PM_PROF_GEMM0 = 0,            // 33 GEMM classes: tile config (0..10) * 3 + {NN, NT, TN}
+  PM_PROF_SEGREDUCE_FWD = 33,
+  PM_PROF_SEGREDUCE_BWD = 34,
+  PM_PROF_NCLASS = 35
 };
 struct PmProfEvent { hipEvent_t a, b; int cls; double work; };
 struct PmProfState { bool on; int n, cap; PmProfEvent* ev; };

@@ -39,7 +39,7 @@ def _prof_end(name: str, e0, work: float):
 
 
 _GEMM_TILES = ("64x64x16", "128x128x16", "64x64x32", "128x128x32", "x6:128x128x16", "x6:128x64x16", "x6:64x64x32",
-               "x6:128x128x32", "planes:64x64x32")
+               "x6:128x128x32", "planes:64x64x32", "planes:128x64x32", "planes:128x128x32")
 
 
 def gemm_class(transA: bool, transB: bool, M: int, N: int, K: int) -> str:

@@ -27,6 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak; a split-mode fp32 product costs SIX bf16 MFMA products
+# Memory-side bytes per launch of the dominant kernels at the DEFAULT workload, from separate `rocprofv3 --pmc FETCH_SIZE`
+# / `--pmc WRITE_SIZE` passes over this same command (profiles/r01_v4_kernel_stats.md; reads doubled per the gfx950
+# FETCH_SIZE rule of MI355X_MICROARCH.md).  bench.py cannot read PMC counters itself; other workloads report null.
+PMC_TRAFFIC_DEFAULT = {"gemm_NT_planes:64x64x32": 109.6e6, "gemm_NN_planes:64x64x32": 136.2e6,
+                       "gemm_TN_planes:64x64x32": 142.9e6, "segreduce_fwd": 163.8e6}
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; ~6.3 TB/s achievable
 
 
@@ -178,9 +184,15 @@ def main():
         tf = ds["work"] / (ds["total_ms"] * 1e-3) / 1e12
         gemm_ms = sum(gst[k]["total_ms"] for k in gemm_keys)
         gemm_tf = sum(gst[k]["work"] for k in gemm_keys) / (gemm_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[8:]},{dom[5:7]}> (v_mfma_f32_32x32x2_f32)",
-                "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        split = dom[8:].startswith(("planes", "x6"))          # fp32 product = 6 bf16 MFMA products (fp32 accumulate)
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
+        insn = "v_mfma_f32_32x32x16_bf16, 6 products per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
+        default_wl = (args.batch, args.d, args.n_bars, args.layers, args.dense) == (256, 256, 2, 8, False)
+        roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[8:]},{dom[5:7]}> ({insn})",
+                "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "traffic": PMC_TRAFFIC_DEFAULT.get(dom) if default_wl else None,
+                "peak_note": ("dense bf16 MFMA peak / 6 (fp32-equivalent flops)" if split else "dense fp32 MFMA peak")
+                             + f"; {round(tf / PEAK_FP32_MFMA_TFLOPS, 3)} of the 157.3 TFLOP/s fp32 MFMA peak",
                 "launches_per_step": ds["launches"] / args.steps, "avg_launch_us": round(ds["avg_us"], 2),
                 "algorithmic_gflop_per_launch": round(ds["work"] / ds["launches"] / 1e9, 3),
                 "all_gemm": {"TFLOP/s": round(gemm_tf, 2), "ms_per_step": round(gemm_ms / args.steps, 3)},
@@ -191,7 +203,8 @@ def main():
         ss = gst["segreduce_fwd"]
         gbs = ss["work"] / (ss["total_ms"] * 1e-3) / 1e9
         roof_seg = {"bound": "hbm", "kernel": "k_segreduce_fwd", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "traffic": PMC_TRAFFIC_DEFAULT.get("segreduce_fwd") if default_wl else None,
                     "launches_per_step": ss["launches"] / args.steps, "avg_launch_us": round(ss["avg_us"], 2),
                     "algorithmic_bytes_per_launch": ss["work"] / ss["launches"]}
         sb = gst.get("segreduce_bwd")

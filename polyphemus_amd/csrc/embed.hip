@@ -24,10 +24,11 @@ __device__ static inline void table_src(int t, int& wsel, int& vocab) {
   wsel = t < 2 ? t : 2; vocab = t < 2 ? PM_N_PITCH : PM_N_DUR;
 }
 
-// one thread per (kind, channel); kind 2 (duration) handles tables 2 and 3 in order.
-__global__ void k_embed_tables(EmbParams P, const int* __restrict__ hist, int dh, int training, float eps,
-                               float momentum, float* __restrict__ tables, float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per (kind, channel), lanes over the vocabulary; kind 2 (duration) handles tables 2 and 3 in order.
+__global__ void __launch_bounds__(256) k_embed_tables(EmbParams P, const int* __restrict__ hist, int dh, int training,
+                                                      float eps, float momentum, float* __restrict__ tables,
+                                                      float* __restrict__ stats) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (i >= 3 * dh) return;
   const int kind = i / dh, c = i % dh;
   const int t0 = kind < 2 ? kind : 2, t1 = kind < 2 ? kind + 1 : 4;
@@ -38,25 +39,33 @@ __global__ void k_embed_tables(EmbParams P, const int* __restrict__ hist, int dh
     const float bias = P.b[wsel][c];
     const int* h = hist + t * EMB_V;
     double cnt = 0, s0 = 0, s1 = 0;
-    for (int v = 0; v < V; ++v) {
+    for (int v = lane; v < V; v += 64) {
       const double tv = (double)(w[v] + bias), hv = (double)h[v];
       cnt += hv; s0 += hv * tv; s1 += hv * tv * tv;
     }
+    cnt = pm_wave_sum_d(cnt); s0 = pm_wave_sum_d(s0); s1 = pm_wave_sum_d(s1);
     float mean, var;
     if (training) {
-      if (cnt < 1) { stats[(t * 2) * dh + c] = 0.f; stats[(t * 2 + 1) * dh + c] = 1.f; continue; }  // empty group
+      if (cnt < 1) {                                                     // empty group
+        if (lane == 0) { stats[(t * 2) * dh + c] = 0.f; stats[(t * 2 + 1) * dh + c] = 1.f; }
+        continue;
+      }
       const double mu = s0 / cnt;
       double vv = s1 / cnt - mu * mu;
       if (vv < 0) vv = 0;
       mean = (float)mu; var = (float)vv;
-      const double unb = cnt > 1 ? vv * cnt / (cnt - 1) : vv;
-      P.rm[wsel][c] = (float)((1.0 - momentum) * P.rm[wsel][c] + momentum * mu);
-      P.rv[wsel][c] = (float)((1.0 - momentum) * P.rv[wsel][c] + momentum * unb);
+      if (lane == 0) {
+        const double unb = cnt > 1 ? vv * cnt / (cnt - 1) : vv;
+        P.rm[wsel][c] = (float)((1.0 - momentum) * P.rm[wsel][c] + momentum * mu);
+        P.rv[wsel][c] = (float)((1.0 - momentum) * P.rv[wsel][c] + momentum * unb);
+      }
     } else { mean = P.rm[wsel][c]; var = P.rv[wsel][c]; }
-    stats[(t * 2) * dh + c] = mean;
-    stats[(t * 2 + 1) * dh + c] = var;
+    if (lane == 0) {
+      stats[(t * 2) * dh + c] = mean;
+      stats[(t * 2 + 1) * dh + c] = var;
+    }
     const float rstd = rsqrtf(var + eps), ga = P.g[wsel][c], be = P.be[wsel][c];
-    for (int v = 0; v < V; ++v) tables[((int64_t)t * EMB_V + v) * dh + c] = ((w[v] + bias) - mean) * rstd * ga + be;
+    for (int v = lane; v < V; v += 64) tables[((int64_t)t * EMB_V + v) * dh + c] = ((w[v] + bias) - mean) * rstd * ga + be;
   }
 }
 
@@ -72,7 +81,7 @@ extern "C" int pm_embed_tables(const float* w_pd, const float* b_pd, const float
   P.g[0] = g_d; P.g[1] = g_n; P.g[2] = g_u; P.be[0] = be_d; P.be[1] = be_n; P.be[2] = be_u;
   P.rm[0] = rm_d; P.rm[1] = rm_n; P.rm[2] = rm_u; P.rv[0] = rv_d; P.rv[1] = rv_n; P.rv[2] = rv_u;
   const int dh = d / 2;
-  hipLaunchKernelGGL(k_embed_tables, dim3(pm_cdiv(3 * dh, 64)), dim3(64), 0, (hipStream_t)stream, P, tok_hist, dh,
+  hipLaunchKernelGGL(k_embed_tables, dim3(pm_cdiv(3 * dh, 4)), dim3(256), 0, (hipStream_t)stream, P, tok_hist, dh,
                      training, eps, momentum, tables, stats);
   return pm_check_launch();
 }
@@ -109,7 +118,7 @@ extern "C" int pm_embed_gather(const float* tables, const int32_t* tokens, const
 // grid = (blocks, 4 tables); the table of a block lives in LDS ([V][d/2] floats, ds_add_f32) and is
 // flushed once with global float atomics.  PAD rows dominate (>= 10 of 15 slots), so almost all
 // adds collide on one LDS row and never reach L2.
-__global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restrict__ dX, const int* __restrict__ tok,
+__global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restrict__ dX, const int* __restrict__ tok,
                                                            const int* __restrict__ group_list,
                                                            const int* __restrict__ group_cnt, int N, int d,
                                                            int NS, float* __restrict__ S) {
@@ -127,19 +136,33 @@ __global__ void __launch_bounds__(256) k_embed_bwd_scatter(const float* __restri
   // hit the LDS row once, instead of serialising thousands of ds_add_f32 on one address.
   const int pad = kind == 0 ? 130 : 98;
   float2 pacc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // channels lane*2 + 128*j  (d/2 <= 512)
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int n = list[row / NS], s = (int)(row % NS) + 1;
-    const int v = tok[((int64_t)n * 16 + s) * 2 + kind];
-    const float* src = dX + ((int64_t)n * NS + (s - 1)) * d + kind * dh;
+  const int nwv = blockDim.x >> 6;        // 16 waves per workgroup: the row -> token -> gradient-row chain is latency bound
+  constexpr int U = 4;                    // slots in flight per wave (independent token / row loads)
+  (void)rows;
+  for (int i = blockIdx.x * nwv + wave; i < cnt; i += gridDim.x * nwv) {          // one node of the group per trip
+    const int n = list[i];
+    const int* tk = tok + (int64_t)n * 32 + 2 + kind;                            // slot 1.. of node n
+    const float* base = dX + (int64_t)n * NS * d + kind * dh;
+    for (int s0 = 0; s0 < NS; s0 += U) {
+      int v[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = lane * 2 + 128 * j;
-      if (c >= dh) break;
-      const float2 g = *reinterpret_cast<const float2*>(src + c);
-      if (v == pad) { pacc[j].x += g.x; pacc[j].y += g.y; }
-      else {
-        if (g.x != 0.f) atomicAdd(&sS[v * dh + c], g.x);
-        if (g.y != 0.f) atomicAdd(&sS[v * dh + c + 1], g.y);
+      for (int u = 0; u < U; ++u) v[u] = s0 + u < NS ? tk[(s0 + u) * 2] : -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = lane * 2 + 128 * j;
+        if (c >= dh) break;
+        float2 g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) g[u] = *reinterpret_cast<const float2*>(base + (int64_t)(s0 + u < NS ? s0 + u : s0) * d + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (v[u] < 0) continue;
+          if (v[u] == pad) { pacc[j].x += g[u].x; pacc[j].y += g[u].y; }
+          else {
+            if (g[u].x != 0.f) atomicAdd(&sS[v[u] * dh + c], g[u].x);
+            if (g[u].y != 0.f) atomicAdd(&sS[v[u] * dh + c + 1], g[u].y);
+          }
+        }
       }
     }
   }
@@ -170,9 +193,9 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
   if (lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
-  int nb = (int)pm_cdiv((int64_t)N * n_slots, 4 * 64);
+  int nb = (int)pm_cdiv((int64_t)N * n_slots, 16 * 64);
   if (nb > 96) nb = 96;
-  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(256), lds, st, dX, tokens, pv.group_list, pv.group_cnt, N, d,
+  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(1024), lds, st, dX, tokens, pv.group_list, pv.group_cnt, N, d,
                      n_slots, S);
   return pm_check_launch();
 }
@@ -181,9 +204,10 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
 //   dbeta = sum_v S[v];  dgamma = sum_v S[v]*xhat[v];
 //   dT[v] = gamma*rstd*(S[v] - h[v]*dbeta/M - h[v]*xhat[v]*dgamma/M);  dW[:, v] += dT[v];  db += sum_v dT[v]
 struct EmbGrads { float* dw[3]; float* db[3]; float* dg[3]; float* dbe[3]; };
-__global__ void k_embed_tables_bwd(const float* __restrict__ S, EmbParams P, EmbGrads Gd, const float* __restrict__ stats,
-                                   const int* __restrict__ hist, int dh, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_embed_tables_bwd(const float* __restrict__ S, EmbParams P, EmbGrads Gd,
+                                                          const float* __restrict__ stats,
+                                                          const int* __restrict__ hist, int dh, float eps) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;   // one wave per (kind, channel)
   if (i >= 3 * dh) return;
   const int kind = i / dh, c = i % dh;
   const int t0 = kind < 2 ? kind : 2, t1 = kind < 2 ? kind + 1 : 4;
@@ -197,22 +221,26 @@ __global__ void k_embed_tables_bwd(const float* __restrict__ S, EmbParams P, Emb
     const float mean = stats[(t * 2) * dh + c], rstd = rsqrtf(stats[(t * 2 + 1) * dh + c] + eps);
     const float ga = P.g[wsel][c];
     double cnt = 0, db = 0, dg = 0;
-    for (int v = 0; v < V; ++v) {
+    for (int v = lane; v < V; v += 64) {
       const double sv = s[(int64_t)v * dh];
       cnt += h[v]; db += sv; dg += sv * (double)(((w[v] + bias) - mean) * rstd);
     }
+    cnt = pm_wave_sum_d(cnt); db = pm_wave_sum_d(db); dg = pm_wave_sum_d(dg);
     if (cnt < 1) continue;
-    Gd.dbe[wsel][c] += (float)db;
-    Gd.dg[wsel][c] += (float)dg;
+    if (lane == 0) {
+      Gd.dbe[wsel][c] += (float)db;
+      Gd.dg[wsel][c] += (float)dg;
+    }
     double dbias = 0;
     float* dw = Gd.dw[wsel] + (int64_t)c * V;
-    for (int v = 0; v < V; ++v) {
+    for (int v = lane; v < V; v += 64) {
       const double xh = (double)(((w[v] + bias) - mean) * rstd);
       const double dt = (double)ga * rstd * ((double)s[(int64_t)v * dh] - h[v] * db / cnt - h[v] * xh * dg / cnt);
       dw[v] += (float)dt;
       dbias += dt;
     }
-    Gd.db[wsel][c] += (float)dbias;
+    dbias = pm_wave_sum_d(dbias);
+    if (lane == 0) Gd.db[wsel][c] += (float)dbias;
   }
 }
 extern "C" int pm_embed_tables_bwd(const float* S, const float* w_pd, const float* b_pd, const float* w_pn,
@@ -230,7 +258,7 @@ extern "C" int pm_embed_tables_bwd(const float* S, const float* w_pd, const floa
   Gd.dw[0] = dw_pd; Gd.dw[1] = dw_pn; Gd.dw[2] = dw_du; Gd.db[0] = db_pd; Gd.db[1] = db_pn; Gd.db[2] = db_du;
   Gd.dg[0] = dg_d; Gd.dg[1] = dg_n; Gd.dg[2] = dg_u; Gd.dbe[0] = dbe_d; Gd.dbe[1] = dbe_n; Gd.dbe[2] = dbe_u;
   const int dh = d / 2;
-  hipLaunchKernelGGL(k_embed_tables_bwd, dim3(pm_cdiv(3 * dh, 64)), dim3(64), 0, (hipStream_t)stream, S, P, Gd, stats,
+  hipLaunchKernelGGL(k_embed_tables_bwd, dim3(pm_cdiv(3 * dh, 4)), dim3(256), 0, (hipStream_t)stream, S, P, Gd, stats,
                      tok_hist, dh, eps);
   return pm_check_launch();
 }

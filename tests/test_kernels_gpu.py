@@ -308,6 +308,72 @@ def test_bn_train_fwd_bwd(shape, I):
     assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, ber.grad) < 1e-5
 
 
+def _planes_value(p):
+    """int16 [3, n] bf16 planes -> float64 value p1 + p2 + p3"""
+    f = lambda t: (t.to(torch.int32) << 16).view(torch.float32).double()
+    return f(p[0]) + f(p[1]) + f(p[2])
+
+
+@pytest.mark.parametrize("M,K,C", [(1000, 64, 256), (333, 40, 32), (5000, 128, 128)])
+def test_gcl_norm_fused_with_gemm_epilogue(M, K, C):
+    """The GCL norm of the native step: column statistics accumulated by the GEMM epilogue (col_stats, replicated
+    fp64 accumulators), pm_bn_apply_fused (mean / var / running stats as a side effect, + ReLU + residual) and
+    pm_bn_bwd_fused (atomics instead of a finalize launch; dx as fp32 and as three bf16 planes)."""
+    torch.manual_seed(M + C)
+    R = 8                                                              # PM_BN_REPL
+    A = torch.randn(M, K, device=DEV)
+    W = torch.randn(K, C, device=DEV) * 0.3
+    bias = torch.randn(C, device=DEV)
+    h = torch.empty(M, C, device=DEV)
+    sums = torch.zeros(R, 2, C, dtype=torch.float64, device=DEV)
+    ops.gemm_desc(A, W, h, M, C, K, K, C, C, bias=bias, col_stats=sums)
+    href = A.double() @ W.double() + bias.double()
+    assert rel_err(h, href) < 5e-6
+    assert rel_err(sums.sum(0)[0], h.double().sum(0)) < 1e-12 and rel_err(sums.sum(0)[1], (h.double() ** 2).sum(0)) < 1e-12
+    g, be = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    res = torch.randn(M, C, device=DEV)
+    y, mean, var = torch.empty_like(h), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("pm_bn_apply_fused", ptr(h), M, C, ptr(sums), 1e-5, ptr(g), ptr(be), ptr(res), 1, ptr(y), ptr(mean), ptr(var),
+         ptr(rm), ptr(rv), 0.1, stream())
+    xr = h.double().requires_grad_(True)
+    gr, ber = g.double().requires_grad_(True), be.double().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device=DEV, dtype=torch.float64), torch.ones(C, device=DEV, dtype=torch.float64)
+    yr = F.relu(F.batch_norm(xr, rm2, rv2, gr, ber, True, 0.1, 1e-5)) + res.double()
+    assert rel_err(y, yr.detach()) < 1e-5
+    assert rel_err(mean, h.double().mean(0)) < 1e-6 and rel_err(var, h.double().var(0, unbiased=False)) < 1e-5
+    assert rel_err(rm, rm2) < 1e-5 and rel_err(rv, rv2) < 1e-5
+    dy = torch.randn(M, C, device=DEV)
+    yr.backward(dy.double())
+    for planes in (False, True):
+        dg, db, dbp = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        acc3 = torch.zeros(R, 3, C, dtype=torch.float64, device=DEV)
+        dx = torch.full((M, C), float("nan"), device=DEV)
+        dxp = torch.zeros(3, M * C, dtype=torch.int16, device=DEV)
+        call("pm_bn_bwd_fused", ptr(h), ptr(dy), M, C, ptr(mean), ptr(var), 1e-5, ptr(g), ptr(be), 1, ptr(dg), ptr(db),
+             ptr(dbp), None if planes else ptr(dx), ptr(acc3), ptr(dxp) if planes else None, M * C, stream())
+        got = _planes_value(dxp).view(M, C) if planes else dx
+        assert rel_err(got, xr.grad) < 1e-5
+        assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, ber.grad) < 1e-5
+        assert float(dbp.abs().max()) < 1e-3 * float(dy.abs().sum(0).max())   # bias in front of a batch-stat norm: zero
+
+
+def test_segreduce_planes_output_equals_fp32_output(small):
+    b, plan = small
+    torch.manual_seed(11)
+    N, d = plan.N, 64
+    x = torch.randn(N, d, device=DEV)
+    T = ops.edge_table(torch.randn(d, 32, device=DEV) * 0.5, torch.randn(d, device=DEV) * 0.1)
+    for compact in (0, 1):
+        nb = 4 if compact else 7
+        A = torch.empty(N, nb * d, device=DEV)
+        P = torch.zeros(3, N * nb * d, dtype=torch.int16, device=DEV)
+        call("pm_segreduce_fwd", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, 0.1, 5, 2, compact, ptr(A), stream())
+        call("pm_segreduce_fwd_planes", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, 0.1, 5, 2, compact, ptr(P),
+             N * nb * d, stream())
+        assert torch.equal(_planes_value(P).float().view(N, nb * d), A)        # the split is exact
+
+
 def test_bn_eval_uses_running_stats():
     x = torch.randn(300, 64, device=DEV)
     rm, rv = torch.randn(64, device=DEV), torch.rand(64, device=DEV) + 0.5

@@ -115,6 +115,19 @@ int pm_segreduce_fwd(const float* x /* [N,d] */, const float* T /* [32,d] */, co
 int pm_segreduce_fwd_planes(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                             int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact,
                             uint16_t* planes, int64_t plane_stride, pm_stream_t stream);
+/* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
+ * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
+ * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */
+typedef struct PmNormSums {
+  const float* h;                  /* [N,d] input of that norm (pre-norm GCL output of the layer below) */
+  const float* mean; const float* var; const float* gamma; const float* beta;   /* [d] */
+  float eps; int32_t relu;
+  double* acc3;
+} PmNormSums;
+int pm_segreduce_bwd_norm(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
+                          int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
+                          uint32_t layer_uid, int32_t compact, float* dx, float* dT, const PmNormSums* next_norm,
+                          pm_stream_t stream);
 int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] or [N,4d] */,
                      const float* dres /* [N,d] or NULL: added to dx (residual path, model.py:206) */,
                      const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p,
@@ -219,7 +232,9 @@ int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const
                     float eps, const float* gamma, const float* beta, int relu, float* dgamma, float* dbeta,
                     float* dbias_pre /* or NULL */, float* dx /* fp32 output, or NULL with dx_planes */, double* acc3,
                     uint16_t* dx_planes /* or NULL: dx as three bf16 planes (PmGemmDesc.operand_planes) */,
-                    int64_t plane_stride /* elements */, pm_stream_t stream);
+                    int64_t plane_stride /* elements */,
+                    int32_t sums_ready /* != 0: acc3 already holds the sums (pm_segreduce_bwd_norm) */,
+                    pm_stream_t stream);
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
 int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
 int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);

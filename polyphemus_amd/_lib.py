@@ -28,6 +28,7 @@ _SIGS = {
     "pm_segreduce_fwd": "pppiiiifuuips",
     "pm_segreduce_fwd_planes": "pppiiiifuuipls",
     "pm_segreduce_bwd": "pppppiiiifuuipps",
+    "pm_segreduce_bwd_norm": "pppppiiiifuuippps",
     "pm_gemm_f32": "iiiiipipipipiipips",
     "pm_gemm_f32_grouped": "iiiiipipipipiipipilllliis",
     "pm_gemm_f32_desc": "ps",
@@ -37,7 +38,7 @@ _SIGS = {
     "pm_bn_apply": "piiippfpppips",
     "pm_bn_bwd": "ppiiippfppippppps",
     "pm_bn_apply_fused": "piipfpppipppppfs",
-    "pm_bn_bwd_fused": "ppiippfppippppppls",
+    "pm_bn_bwd_fused": "ppiippfppipppppplis",
     "pm_split_planes": "plpls",
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",

@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
 extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
                                const float* var, float eps, const float* gamma, const float* beta, int relu,
                                float* dgamma, float* dbeta, float* dbias_pre, float* dx, double* acc3,
-                               uint16_t* dx_planes, int64_t plane_stride, pm_stream_t stream) {
+                               uint16_t* dx_planes, int64_t plane_stride, int32_t sums_ready, pm_stream_t stream) {
   if (!x || !dy || !mean || !var || !gamma || !beta || (!dx && !dx_planes) || !acc3 || O <= 0 || C <= 0 ||
       (C % 4) != 0 || C > 4096)
     return PM_E_INVALID;
@@ -446,7 +446,8 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
   if (nc < 1) nc = 1;
   const int rpc = (int)pm_cdiv(O, nc);
   nc = (int)pm_cdiv(O, rpc);
-  hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3);
+  if (!sums_ready)
+    hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3);
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(ew_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
                      (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride);

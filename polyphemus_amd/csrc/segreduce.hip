@@ -12,6 +12,7 @@
 // Algorithmic HBM bytes: forward 4*d*N*(1+R) + 12*E (+4*d*N for the root copy
 // this kernel also writes), backward 4*d*N*(R+1) + 12*E + 4*32*d.
 #include "common.h"
+#include <string.h>
 #include <stdlib.h>
 #include "prof.h"
 
@@ -169,7 +170,10 @@ extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int
 //   dx[n]     = dA[n, 6d:7d] (+ dres[n]) + sum_e  w_e * dA[dst_e, r_e*d:] * keep_e/(1-p) * T[dist_e] * [x[n]*T > 0]
 //   dT[dist] += sum_e  w_e * dA[dst_e, r_e*d:] * keep_e/(1-p) * x[n] * [x[n]*T > 0],   w_e = 1/clamp(count,1)
 // dT is reduced in LDS per workgroup (ds_add_f32) and flushed once with global float atomics.
-template <int NV, bool DROP>
+// FUSE: dx is the output gradient of the BatchNorm of the layer below (x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206);
+// the three column sums its backward needs (sum du, sum du*xhat, sum xhat; du = dx * [BN(h) > 0]) are accumulated here,
+// while the dx row is still in registers, instead of by a separate pass over dx and h (pm_bn_bwd_fused, sums_ready).
+template <int NV, bool DROP, bool FUSE>
 __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict__ x, const float* __restrict__ T,
                                                        const float* __restrict__ dA, const float* __restrict__ dres,
                                                        const int* __restrict__ colptr, const int* __restrict__ csc_dst,
@@ -177,7 +181,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
                                                        const int* __restrict__ csc_eid,
                                                        const float* __restrict__ csc_invcnt, int N, int d,
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
-                                                       int compact, float* __restrict__ dx, float* __restrict__ dT) {
+                                                       int compact, float* __restrict__ dx, float* __restrict__ dT,
+                                                       PmNormSums nn) {
   // LDS image of the table gradient: element (dist, column 4q + j) at dist*d + j*(d/4) + q, so that the four
   // ds_add_f32 of a lane's float4 hit consecutive addresses across the wave (bank-conflict free)
   extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][4][d/4]
@@ -192,6 +197,18 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
 #pragma unroll
   for (int v = 0; v < NV; ++v) { c[v] = (lane + v * 64) * 4; ok[v] = c[v] < d; }
   const int nwv = blockDim.x >> 6;
+  float nm[NV][4], nrs[NV][4], nga[NV][4], nbe[NV][4];
+  double ns0[NV][4], ns1[NV][4], ns2[NV][4];
+  if (FUSE) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = ok[v] ? c[v] + j : 0;
+        nm[v][j] = nn.mean[col]; nrs[v][j] = rsqrtf(nn.var[col] + nn.eps); nga[v][j] = nn.gamma[col]; nbe[v][j] = nn.beta[col];
+        ns0[v][j] = 0; ns1[v][j] = 0; ns2[v][j] = 0;
+      }
+  }
   for (int n0 = blockIdx.x * nwv; n0 < N; n0 += gridDim.x * nwv) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
     if (n >= N) continue;
@@ -254,6 +271,18 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
       *reinterpret_cast<float4*>(dx + (int64_t)n * d + c[v]) = acc[v];
+      if (FUSE) {
+        const float4 hv = *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
+        const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
+        const float ds[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (hs[j] - nm[v][j]) * nrs[v][j];
+          float du = ds[j];
+          if (nn.relu && !(xh * nga[v][j] + nbe[v][j] > 0.f)) du = 0.f;
+          ns0[v][j] += (double)du; ns1[v][j] += (double)du * (double)xh; ns2[v][j] += (double)xh;
+        }
+      }
     }
   }
   __syncthreads();
@@ -262,14 +291,45 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     const float v = sT[i - col + (col & 3) * dq + (col >> 2)];
     if (v != 0.f) atomicAdd(&dT[i], v);
   }
+  if (FUSE) {
+    // the waves' fp64 partial sums: four LDS slots of [3][d] doubles (the table image is free now), four waves per
+    // round, then one fp64 atomic per column and sum into this workgroup's replica of the accumulator
+    __syncthreads();
+    double* sd = reinterpret_cast<double*>(sT);                          // 32*d floats = 16*d doubles >= 4*3*d
+    for (int r = 0; r * 4 < nwv; ++r) {
+      if ((wave >> 2) == r) {
+        double* slot = sd + (int64_t)(wave & 3) * 3 * d;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          if (!ok[v]) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = c[v] + j;
+            if (r == 0) { slot[col] = ns0[v][j]; slot[d + col] = ns1[v][j]; slot[2 * d + col] = ns2[v][j]; }
+            else { slot[col] += ns0[v][j]; slot[d + col] += ns1[v][j]; slot[2 * d + col] += ns2[v][j]; }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int nslot = nwv < 4 ? nwv : 4;
+    double* dst = nn.acc3 + (int64_t)(blockIdx.x % PM_BN_REPL) * 3 * d;
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) {
+      double t = 0;
+      for (int q = 0; q < nslot; ++q) t += sd[(int64_t)q * 3 * d + i];
+      atomicAdd(&dst[i], t);
+    }
+  }
 }
 
-extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
-                                int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
-                                uint32_t layer_uid, int32_t compact, float* dx, float* dT, pm_stream_t stream) {
+static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
+                              int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
+                              uint32_t layer_uid, int32_t compact, float* dx, float* dT, const PmNormSums* nn,
+                              pm_stream_t stream) {
   if (!x || !T || !dA || !plan || !dx || !dT || N <= 0 || d <= 0 || (d & 3) || d > 1024 || dropout_p < 0.f ||
       dropout_p >= 1.f)
     return PM_E_INVALID;
+  if (nn && (!nn->h || !nn->mean || !nn->var || !nn->gamma || !nn->beta || !nn->acc3)) return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
   // 16-wave workgroups, one per CU: 4096 waves hide the colptr -> edge -> row-gather latency chain while only 256
@@ -282,15 +342,32 @@ extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA,
   const bool drop = dropout_p > 0.f;
   const uint32_t thresh = pm_keep_threshold(dropout_p);
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
-#define LAUNCH(NV, DR)                                                                                               \
-  hipLaunchKernelGGL((k_segreduce_bwd<NV, DR>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,          \
-                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT)
+  PmNormSums none;
+  memset(&none, 0, sizeof(none));
+  const PmNormSums nv_ = nn ? *nn : none;
+#define LAUNCH(NV, DR, FU)                                                                                           \
+  hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,      \
+                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_)
+#define LAUNCH2(NV, DR) do { if (nn) LAUNCH(NV, DR, true); else LAUNCH(NV, DR, false); } while (0)
   const int nv = (int)pm_cdiv(d, 256);
-  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 3 : PM_N_REL) + 1) + 12.0 * E + 128.0 * d);
-  if (nv == 1) { if (drop) LAUNCH(1, true); else LAUNCH(1, false); }
-  else if (nv == 2) { if (drop) LAUNCH(2, true); else LAUNCH(2, false); }
-  else { if (drop) LAUNCH(4, true); else LAUNCH(4, false); }
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 3 : PM_N_REL) + 1 + (nn ? 1 : 0)) + 12.0 * E + 128.0 * d);
+  if (nv == 1) { if (drop) LAUNCH2(1, true); else LAUNCH2(1, false); }
+  else if (nv == 2) { if (drop) LAUNCH2(2, true); else LAUNCH2(2, false); }
+  else { if (drop) LAUNCH2(4, true); else LAUNCH2(4, false); }
+#undef LAUNCH2
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();
+}
+extern "C" int pm_segreduce_bwd(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
+                                int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
+                                uint32_t layer_uid, int32_t compact, float* dx, float* dT, pm_stream_t stream) {
+  return segreduce_bwd_impl(x, T, dA, dres, plan, N, E, G, d, dropout_p, seed, layer_uid, compact, dx, dT, nullptr, stream);
+}
+extern "C" int pm_segreduce_bwd_norm(const float* x, const float* T, const float* dA, const float* dres,
+                                     const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p,
+                                     uint32_t seed, uint32_t layer_uid, int32_t compact, float* dx, float* dT,
+                                     const PmNormSums* next_norm, pm_stream_t stream) {
+  if (!next_norm) return PM_E_INVALID;
+  return segreduce_bwd_impl(x, T, dA, dres, plan, N, E, G, d, dropout_p, seed, layer_uid, compact, dx, dT, next_norm, stream);
 }

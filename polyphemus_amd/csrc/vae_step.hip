@@ -187,7 +187,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const PmBn& bn = g.norm[i];
     c.chk(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
                           c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
-                          sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, c.st));
+                          sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1) ? 1 : 0, c.st));
     if (!c.compact) {
       c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
@@ -212,8 +212,17 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       c.chk(pm_gemm_f32_desc(&w, c.st));
     }
     float* out = (dx == dxa) ? dxb : dxa;
-    c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out, dT,
-                           c.st));
+    if (i > 0) {                                          // + the column sums of the norm backward of layer i-1
+      const PmBn& pb = g.norm[i - 1];
+      PmNormSums nn;
+      nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
+      nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
+      c.chk(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact,
+                                  out, dT, &nn, c.st));
+    } else {
+      c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out,
+                             dT, c.st));
+    }
     dx = out;
   }
   c.chk(pm_edge_table_bwd(dT, d, c.G + g.nn_w, c.G + g.nn_b, c.st));

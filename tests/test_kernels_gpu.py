@@ -351,7 +351,7 @@ def test_gcl_norm_fused_with_gemm_epilogue(M, K, C):
         dx = torch.full((M, C), float("nan"), device=DEV)
         dxp = torch.zeros(3, M * C, dtype=torch.int16, device=DEV)
         call("pm_bn_bwd_fused", ptr(h), ptr(dy), M, C, ptr(mean), ptr(var), 1e-5, ptr(g), ptr(be), 1, ptr(dg), ptr(db),
-             ptr(dbp), None if planes else ptr(dx), ptr(acc3), ptr(dxp) if planes else None, M * C, stream())
+             ptr(dbp), None if planes else ptr(dx), ptr(acc3), ptr(dxp) if planes else None, M * C, 0, stream())
         got = _planes_value(dxp).view(M, C) if planes else dx
         assert rel_err(got, xr.grad) < 1e-5
         assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, ber.grad) < 1e-5

@@ -364,6 +364,14 @@ class VAE(nn.Module):
             for n, b in bufs:
                 bflat[boffs[n]:boffs[n] + b.numel()].copy_(b.data.reshape(-1))
                 b.data = bflat[boffs[n]:boffs[n] + b.numel()].view(b.shape)
+            # integer buffers (BatchNorm.num_batches_tracked): one int64 vector, so a step bumps them with one launch
+            ibufs = [(n, b) for n, b in self.named_buffers() if not b.dtype.is_floating_point and b.numel() == 1]
+            cflat = torch.zeros(max(len(ibufs), 1), dtype=torch.int64, device=dev)
+            for i, (n, b) in enumerate(ibufs):
+                cflat[i] = b.data.reshape(()).to(torch.int64)
+                b.data = cflat[i]
+        self.__dict__["flat_counters"] = cflat
+        self.__dict__["_counter_index"] = {n: i for i, (n, _) in enumerate(ibufs)}
         self.__dict__["flat_params"], self.__dict__["flat_buffers"] = flat, bflat
         self.__dict__["_offsets"], self.__dict__["_param_names"] = offs, [n for n, _ in named]
         self.__dict__["_buf_offsets"] = boffs

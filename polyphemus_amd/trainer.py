@@ -87,11 +87,17 @@ class HipTrainer:
         self._state = ctypes.create_string_buffer(int(lib().pm_vae_step_state_bytes()))
         self._ws: Optional[torch.Tensor] = None
         self._plan_buf: Optional[torch.Tensor] = None
-        sd = dict(vae.named_buffers())
-        emb = {"encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur"}
-        self._nbt = [b for n, b in sd.items() if n.endswith("num_batches_tracked") and n.rsplit(".", 1)[0] not in emb]
-        self._nbt_emb = [sd[k + ".num_batches_tracked"] for k in
-                         ("encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur")]
+        # num_batches_tracked of every BatchNorm: views of vae.flat_counters; +1 per step, except the three embedding
+        # norms, which follow their group counts (weights [has_drum, has_non_drum] -> bn_drums, bn_non_drums, bn_dur)
+        ci = vae._counter_index
+        emb = ["encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur"]
+        inc = torch.ones(vae.flat_counters.numel(), dtype=torch.int64, device=flat.device)
+        sel = torch.zeros(2, vae.flat_counters.numel(), dtype=torch.int64, device=flat.device)
+        for k, row in zip(emb, ((1, 0), (0, 1), (1, 1))):
+            i = ci[k + ".num_batches_tracked"]
+            inc[i] = 0
+            sel[0, i], sel[1, i] = row
+        self._nbt_inc, self._nbt_sel = inc, sel
 
     # ------------------------------------------------------------------------------------------
     def _prep_inputs(self, graph):
@@ -144,12 +150,9 @@ class HipTrainer:
         self.buckets.launch(0)                               # encoder gradients
         # num_batches_tracked (int64 bookkeeping of nn.BatchNorm): +1 per forward; the embedding norms only
         # when their group is non-empty, bn_dur once per non-empty group (model.py:362,375)
-        torch._foreach_add_(self._nbt, 1)
         i = PLAN_FIELDS.index("group_cnt")
         has = (self._plan_buf[off[i]:off[i] + 2] > 0).to(torch.int64)
-        self._nbt_emb[0] += has[0]
-        self._nbt_emb[1] += has[1]
-        self._nbt_emb[2] += has[0] + has[1]
+        vae.flat_counters.add_(self._nbt_inc).add_((has.view(2, 1) * self._nbt_sel).sum(0))
         return self.loss_buf
 
     def _python_forward_backward(self, graph, eps):

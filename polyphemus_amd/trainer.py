@@ -204,6 +204,48 @@ class HipTrainer:
             self.lr = self.sched.step()
         return out
 
+    # ---- checkpoint interop (training.py:503-519 saves `optimizer.state_dict()` of torch.optim.Adam) ----------
+    def optimizer_state_dict(self) -> dict:
+        """The fused Adam's state in `torch.optim.Adam.state_dict()` layout: parameter ids follow
+        `named_parameters()` order, `exp_avg` / `exp_avg_sq` are per-parameter copies of the flat
+        moment buffers; loadable by `torch.optim.Adam(vae.parameters(), ...).load_state_dict`."""
+        vae = self.vae
+        P = dict(vae.named_parameters())
+        state = {}
+        for i, n in enumerate(vae._param_names):
+            o, k = vae._offsets[n], P[n].numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + k].view(P[n].shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view(P[n].shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(vae._param_names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Inverse of `optimizer_state_dict`; also accepts a checkpoint written by the reference's
+        `torch.optim.Adam` (parameters that never received a gradient have no entry there: their moments stay 0)."""
+        vae = self.vae
+        P = dict(vae.named_parameters())
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(vae._param_names):
+            raise ValueError("optimizer state does not match the model's parameter list")
+        self.lr, self.betas, self.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, n in enumerate(vae._param_names):
+            st = sd["state"].get(group["params"][i])
+            if st is None:
+                continue
+            o, k = vae._offsets[n], P[n].numel()
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused Adam keeps one step count")
+        self.step_count = steps.pop() if steps else 0
+
     def losses_dict(self, out: torch.Tensor) -> dict:
         """Host copy of the loss vector in the reference's dict layout (this DOES sync)."""
         p, d, s, k = out.tolist()

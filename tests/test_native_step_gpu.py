@@ -67,3 +67,44 @@ def test_python_orchestrated_trainer_matches_reference_losses(case):
         got = tr.losses_dict(tr.train_step(g, eps))
         for k, v in json.loads(str(z[f"train{step}/losses"])).items():
             assert abs(got[k] - v) <= REL_TOL * max(1.0, abs(v)), (step, k)
+
+
+def test_optimizer_state_interop_with_torch_adam():
+    """`optimizer_state_dict()` is loadable by torch.optim.Adam (the reference's checkpoint format, training.py:518),
+    and a trainer restored from it continues exactly like the original."""
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    batch = synthetic_batch(6, 2, p=0.25, seed=9).to(DEV)
+    eps = torch.randn(6, 32, device=DEV)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.train()
+    vae.msg_dropout = 0.0
+    tr = HipTrainer(vae, lr=1e-4)
+    for _ in range(2):
+        tr.train_step(batch, eps)
+    sd = tr.optimizer_state_dict()
+    ref = torch.optim.Adam(vae.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    ref.load_state_dict(sd)                                        # the layout torch expects
+    names = [n for n, _ in vae.named_parameters()]
+    p0 = dict(vae.named_parameters())[names[0]]
+    assert torch.equal(ref.state[p0]["exp_avg"], sd["state"][0]["exp_avg"])
+    model_sd = {k: v.clone() for k, v in vae.state_dict().items()}
+    model_flat = vae.flat_params.clone()
+    tr.train_step(batch, eps)
+    want = vae.flat_params.clone()
+    torch.manual_seed(0)
+    vae2 = VAE(**cfg, device=DEV).to(DEV)
+    vae2.load_state_dict(model_sd)
+    vae2.train()
+    vae2.msg_dropout = 0.0
+    vae2.seed, vae2._step = vae.seed, 4                            # (dropout is off: the seeds do not matter)
+    tr2 = HipTrainer(vae2, lr=1e-4)
+    tr2.load_optimizer_state_dict(sd)
+    assert tr2.step_count == 2
+    tr2.train_step(batch, eps)
+    # same moments + same step count -> same update; elements whose gradient is atomics-order rounding noise may
+    # move by up to +-lr with either sign (see test_model_gpu.params_close), everything else agrees closely
+    diff = (vae2.flat_params - want).abs()
+    assert float(diff.max()) <= 2.5e-4 and float(diff.mean()) < 2e-6
+    step = (want - model_flat).abs()
+    assert float(((vae2.flat_params - model_flat) * (want - model_flat)).sum() / (step.norm() ** 2)) > 0.98

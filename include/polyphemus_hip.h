@@ -326,6 +326,17 @@ int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float be
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,
                   double* out, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ evaluation metrics
+ * `_accuracies` (training.py:349-497) as integer counts on the device (the reference takes 9 `.item()` syncs per batch):
+ * counts[0..7] = {pitch correct, pitch not-PAD, pitch correct on drum nodes, pitch not-PAD on drum nodes,
+ *                 duration correct, duration not-PAD, note (pitch and duration) correct, 0}; slots 1..15 of every node. */
+int pm_content_accuracy(const float* c_logits /* [N,15,230] */, const int32_t* tokens /* [N,16,2] */,
+                        const uint8_t* is_drum /* [N] */, int32_t N, int64_t* counts /* [8] */, pm_stream_t stream);
+/* counts[0..3] = {prediction == target, true positives, predicted positives, target positives},
+ * prediction = sigmoid(logit) >= 0.5 (training.py:470-497). */
+int pm_structure_metrics(const float* s_logits, const float* s_target, int64_t n, int64_t* counts /* [4] */,
+                         pm_stream_t stream);
+
 /* ------------------------------------------------------------------ optimiser (train.py:181, training.py:160-166)
  * torch.optim.Adam (no weight decay, no amsgrad) over one flat fp32 buffer. */
 int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -46,7 +46,7 @@ os.chdir(_cwd)
 from polyphemus_amd import constants as C          # noqa: E402
 from polyphemus_amd.synthetic import disk_sample   # noqa: E402
 
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("PM_GOLDEN_OUT", os.path.join(REPO, "tests", "golden"))
 torch.set_num_threads(1)
 
 
@@ -185,7 +185,18 @@ def capture_case(name, cfg, batch_size, p, seed, corner=False):
         sched.step()                                                     # training.py:170
         for k, v in vae.state_dict().items():
             out[f"{pre}/sd_after/{k}"] = v.numpy().copy()
+    # ---- evaluation metrics of the reference (training.py:349-497 `_accuracies`, `_losses` in eval mode) on the
+    #      eval-mode outputs; kept in a separate small file
+    vae.load_state_dict(sd0)
+    vae.eval()
+    with torch.no_grad():
+        s_logits, c_logits, mu, lv = fwd(vae, graph)
+        _, ev_losses = trainer._losses(graph.s_tensor, s_logits, graph.c_tensor, c_logits, mu, lv)
+        accs = trainer._accuracies(graph.s_tensor, s_logits, graph.c_tensor, c_logits, graph.is_drum)
+    np.savez_compressed(os.path.join(OUT, f"{name}_metrics.npz"), accs=np.array(json.dumps(accs)),
+                        losses=np.array(json.dumps(ev_losses)))
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}_metrics.npz: {accs}")
     print(f"{name}.npz: N={int(graph.num_nodes)} E={graph.edge_index.shape[1]} "
           f"params={sum(q.numel() for q in vae.parameters())} losses={losses}")
 

@@ -296,6 +296,28 @@ def losses(s_tensor, s_logits, c_tensor, c_logits, mu, log_var, beta: float = 0.
                  "reconstruction": rec, "kld": kld, "beta*kld": beta * kld}
 
 
+def accuracies(s_tensor, s_logits, c_tensor, c_logits, is_drum, structure_on_logits: bool = False):
+    """`PolyphemusTrainer._accuracies` (training.py:349-497): note / pitch / pitch_drums / pitch_non_drums / dur
+    accuracies over the non-PAD tokens of slots 1..15 and the structure accuracy / precision / recall / f1 —
+    with the same quirk as `_losses` (training.py:356): the structure "logits" are the target itself."""
+    c_true = c_tensor[..., 1:, :]
+    p_rec, p_true = c_logits[..., :N_PITCH].softmax(-1).argmax(-1), c_true[..., :N_PITCH].argmax(-1)
+    d_rec, d_true = c_logits[..., N_PITCH:].softmax(-1).argmax(-1), c_true[..., N_PITCH:].argmax(-1)
+    np_, nd_ = p_true != PITCH_PAD, d_true != DUR_PAD
+    cp, cd = (p_rec == p_true) & np_, (d_rec == d_true) & nd_
+    drum = is_drum.bool()
+    s_in = (s_logits if structure_on_logits else s_tensor).reshape(-1).float()
+    pred = (torch.sigmoid(s_in) >= 0.5).float()                                # training.py:472-474
+    tgt = s_tensor.reshape(-1).float()
+    tp = tgt[pred == 1].sum()
+    prec, rec = tp / pred.sum(), tp / tgt.sum()
+    return {"note": ((cp & cd).sum() / np_.sum()).item(), "pitch": (cp.sum() / np_.sum()).item(),
+            "pitch_drums": (cp[drum].sum() / np_[drum].sum()).item(),
+            "pitch_non_drums": (cp[~drum].sum() / np_[~drum].sum()).item(),
+            "dur": (cd.sum() / nd_.sum()).item(), "s_acc": ((pred == tgt).sum() / tgt.numel()).item(),
+            "s_precision": prec.item(), "s_recall": rec.item(), "s_f1": (2 * rec * prec / (rec + prec)).item()}
+
+
 def exp_decay_lr(update_steps: int, peak_lr, warmup_steps, final_lr_scale, decay_steps):
     """`ExpDecayLRScheduler.step` value after `update_steps` calls (training.py:43-75)."""
     if update_steps <= warmup_steps:

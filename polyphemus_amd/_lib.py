@@ -65,6 +65,8 @@ _SIGS = {
     "pm_content_ce": "ppppiifppppps",
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
+    "pm_content_accuracy": "pppips",
+    "pm_structure_metrics": "pplps",
     "pm_adam_step": "pppplffffifs",
     "pm_prof_begin": "i",
     "pm_prof_end": "ppp",

@@ -154,3 +154,89 @@ extern "C" int pm_bce_logits(const float* logits, const float* target, int64_t n
   hipLaunchKernelGGL(k_bce, dim3(nb), dim3(256), 0, st, logits, target, n, grad_scale, dlogits, out);
   return pm_check_launch();
 }
+
+// ---------------------------------------------------------------- evaluation metrics (training.py:349-497)
+// `_accuracies` without its 9 `.item()` syncs: integer counts on the device, ratios taken by the caller.
+//   counts[0..7] = {pitch correct, pitch not-PAD, pitch correct on drum nodes, pitch not-PAD on drum nodes,
+//                   duration correct, duration not-PAD, note (pitch AND duration) correct, 0}
+// One wave per (node, slot) row: arg-max of the 131 pitch logits and of the 99 duration logits (softmax is monotone,
+// so `argmax(softmax(x)) == argmax(x)`; first index on ties, as torch.argmax), compared with the target token ids.
+__global__ void __launch_bounds__(256) k_content_accuracy(const float* __restrict__ logits, const int* __restrict__ tok,
+                                                          const uint8_t* __restrict__ is_drum, int64_t rows,
+                                                          unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int sh[8];
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int c[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int64_t n = row / PM_N_SLOTS;
+    const int s = (int)(row % PM_N_SLOTS) + 1;                          // slot 0 is SOS (training.py:352)
+    const float* x = logits + row * PM_N_TOK;
+    float bp = -INFINITY, bd = -INFINITY;
+    int ip = 0x7fffffff, id = 0x7fffffff;
+    for (int i = lane; i < PM_N_TOK; i += 64) {
+      const float v = x[i];
+      if (i < PM_N_PITCH) { if (v > bp) { bp = v; ip = i; } }
+      else if (v > bd) { bd = v; id = i - PM_N_PITCH; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float op = __shfl_xor(bp, o, 64), od = __shfl_xor(bd, o, 64);
+      const int jp = __shfl_xor(ip, o, 64), jd = __shfl_xor(id, o, 64);
+      if (op > bp || (op == bp && jp < ip)) { bp = op; ip = jp; }
+      if (od > bd || (od == bd && jd < id)) { bd = od; id = jd; }
+    }
+    if (lane == 0) {
+      const int tp = tok[(n * 16 + s) * 2], td = tok[(n * 16 + s) * 2 + 1];
+      const bool np_ = tp != PM_N_PITCH - 1, nd_ = td != PM_N_DUR - 1;     // PAD is the last token of both vocabularies
+      const bool cp = np_ && ip == tp, cd = nd_ && id == td;
+      const bool drum = is_drum[n] != 0;
+      c[0] += cp; c[1] += np_; c[2] += cp && drum; c[3] += np_ && drum; c[4] += cd; c[5] += nd_; c[6] += cp && cd;
+    }
+  }
+  if (lane == 0)
+    for (int k = 0; k < 7; ++k) if (c[k]) atomicAdd(&sh[k], c[k]);
+  __syncthreads();
+  if (threadIdx.x < 7 && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+extern "C" int pm_content_accuracy(const float* c_logits, const int32_t* tokens, const uint8_t* is_drum, int32_t N,
+                                   int64_t* counts, pm_stream_t stream) {
+  if (!c_logits || !tokens || !is_drum || !counts || N <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(counts, 0, 8 * sizeof(int64_t), st);
+  const int64_t rows = (int64_t)N * PM_N_SLOTS;
+  int nb = (int)pm_cdiv(rows, 4);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_content_accuracy, dim3(nb), dim3(256), 0, st, c_logits, tokens, is_drum, rows,
+                     reinterpret_cast<unsigned long long*>(counts));
+  return pm_check_launch();
+}
+// structure metrics (`_structure_accuracy / _precision / _recall`, training.py:470-497): prediction = sigmoid(x) >= 0.5
+//   counts[0..3] = {prediction == target, target where prediction == 1 (true positives), predictions == 1, targets == 1}
+__global__ void __launch_bounds__(256) k_structure_metrics(const float* __restrict__ logits, const float* __restrict__ target,
+                                                           int64_t n, unsigned long long* __restrict__ counts) {
+  unsigned int c[4] = {0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float p = 1.0f / (1.0f + expf(-logits[i]));
+    const bool pred = p >= 0.5f, t = target[i] != 0.f;
+    c[0] += pred == t; c[1] += pred && t; c[2] += pred; c[3] += t;
+  }
+  for (int k = 0; k < 4; ++k) {
+    unsigned int v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counts[k], (unsigned long long)v);
+  }
+}
+extern "C" int pm_structure_metrics(const float* s_logits, const float* s_target, int64_t n, int64_t* counts,
+                                    pm_stream_t stream) {
+  if (!s_logits || !s_target || !counts || n <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(counts, 0, 4 * sizeof(int64_t), st);
+  int nb = (int)pm_cdiv(n, 256 * 4);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(k_structure_metrics, dim3(nb), dim3(256), 0, st, s_logits, s_target, n,
+                     reinterpret_cast<unsigned long long*>(counts));
+  return pm_check_launch();
+}

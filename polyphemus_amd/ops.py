@@ -384,6 +384,24 @@ def bce_logits(logits, target, out, grad_scale=1.0, want_grad=False):
     return out, dl
 
 
+def content_accuracy(c_logits, tokens, is_drum):
+    """Counts of `_accuracies` (training.py:349-468) on the device: int64 [8] =
+    {pitch correct, pitch not-PAD, pitch correct (drums), pitch not-PAD (drums), dur correct, dur not-PAD, note correct, 0}."""
+    _chk(c_logits, F32, "c_logits"); _chk(tokens, I32, "tokens")
+    drum = is_drum.view(U8) if is_drum.dtype == torch.bool else is_drum
+    out = torch.empty(8, dtype=I64, device=c_logits.device)
+    call("pm_content_accuracy", ptr(c_logits), ptr(tokens), ptr(drum.contiguous()), c_logits.shape[0], ptr(out), stream())
+    return out
+
+
+def structure_metrics(s_logits, s_target):
+    """int64 [4] = {prediction == target, true positives, predicted positives, target positives} (training.py:470-497)."""
+    _chk(s_logits, F32, "s_logits"); _chk(s_target, F32, "s_target")
+    out = torch.empty(4, dtype=I64, device=s_logits.device)
+    call("pm_structure_metrics", ptr(s_logits), ptr(s_target), s_logits.numel(), ptr(out), stream())
+    return out
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
     for t, n in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, F32, n)

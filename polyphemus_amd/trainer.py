@@ -204,6 +204,45 @@ class HipTrainer:
             self.lr = self.sched.step()
         return out
 
+    # ---- evaluation (training.py:250-296 `evaluate`, :298-347 `_losses`, :349-497 `_accuracies`) --------------
+    def evaluate_batch(self, graph, eps: Optional[torch.Tensor] = None):
+        """One batch of `PolyphemusTrainer.evaluate`: eval-mode forward, the 7 losses and the 9 accuracies of the
+        reference (same keys), computed by the loss / metric kernels with ONE host sync at the end (the reference
+        takes 16).  Quirk kept (SURVEY B-1): the structure terms are evaluated on the target itself unless the
+        trainer was built with `structure_loss_on_logits=True`."""
+        vae = self.vae
+        was_training = vae.training
+        vae.eval()
+        try:
+            with torch.no_grad():
+                mu, lv = vae.encoder(graph)
+                e = eps if eps is not None else torch.randn_like(mu)
+                z = ops.reparam_fwd(mu.contiguous(), lv.contiguous(), e)
+                s_logits, c_logits = vae.decoder(z, graph)
+                plan = prepare_graph(graph, vae.cfg["n_bars"])
+                s_t = graph.s_tensor.float().contiguous()
+                out = torch.zeros(4, dtype=torch.float64, device=mu.device)
+                ops.content_ce(c_logits.contiguous(), plan, want_grad=False, out=out)
+                ops.kld(mu.contiguous(), lv.contiguous(), out, beta=self.beta)
+                s_in = s_logits.reshape(-1).contiguous() if self.fix_structure_loss else s_t.reshape(-1)
+                ops.bce_logits(s_in, s_t.reshape(-1), out, 1.0, want_grad=False)
+                cc = ops.content_accuracy(c_logits.contiguous(), plan.tokens, plan.is_drum)
+                sc = ops.structure_metrics(s_in, s_t.reshape(-1))
+                host = torch.cat([out, cc.double(), sc.double()]).tolist()          # the one sync
+        finally:
+            vae.train(was_training)
+        p, d, s, k = host[:4]
+        c, m = host[4:12], host[12:16]
+        div = lambda a, b: a / b if b else float("nan")
+        prec, rec = div(m[1], m[2]), div(m[1], m[3])
+        losses = {"tot": p + d + s + self.beta * k, "pitch": p, "dur": d, "structure": s, "reconstruction": p + d + s,
+                  "kld": k, "beta*kld": self.beta * k}
+        accs = {"note": div(c[6], c[1]), "pitch": div(c[0], c[1]), "pitch_drums": div(c[2], c[3]),
+                "pitch_non_drums": div(c[0] - c[2], c[1] - c[3]), "dur": div(c[4], c[5]),
+                "s_acc": m[0] / max(s_t.numel(), 1), "s_precision": prec, "s_recall": rec,
+                "s_f1": div(2 * rec * prec, rec + prec)}
+        return losses, accs
+
     # ---- checkpoint interop (training.py:503-519 saves `optimizer.state_dict()` of torch.optim.Adam) ----------
     def optimizer_state_dict(self) -> dict:
         """The fused Adam's state in `torch.optim.Adam.state_dict()` layout: parameter ids follow

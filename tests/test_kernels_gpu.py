@@ -587,3 +587,33 @@ def test_adam_matches_torch(n):
         ops.adam_step(p, g, m, v, lr, 0.9, 0.98, 1e-9, step)
         assert rel_err(p, pref.detach()) < 1e-6
     assert float((p - pref.detach()).abs().max()) < 2.5e-7
+
+
+# ------------------------------------------------------------------ evaluation metrics
+def test_accuracy_and_structure_metric_kernels():
+    """integer counts of `_accuracies` (training.py:349-497) against a torch restatement, bit-exact."""
+    torch.manual_seed(5)
+    N = 700
+    tok = torch.stack([torch.randint(0, 131, (N, 16)), torch.randint(0, 99, (N, 16))], -1).to(torch.int32)
+    tok[:, 6:, 0], tok[:, 6:, 1] = 130, 98                                   # PAD tail
+    tok[::7, 3:, 0], tok[::7, 3:, 1] = 130, 98
+    logits = torch.randn(N, 15, 230)
+    hit_p, hit_d = torch.rand(N, 15) < 0.6, torch.rand(N, 15) < 0.5        # plant correct predictions
+    tp, td = tok[:, 1:, 0].long(), tok[:, 1:, 1].long()
+    logits.scatter_add_(2, tp.unsqueeze(-1), 9.0 * hit_p.unsqueeze(-1).float())
+    logits.scatter_add_(2, (131 + td).unsqueeze(-1), 9.0 * hit_d.unsqueeze(-1).float())
+    logits[5, 2, 17] = logits[5, 2, 40] = 50.0                               # a tie: first index wins (torch.argmax)
+    drum = torch.rand(N) < 0.3
+    got = ops.content_accuracy(logits.to(DEV), tok.to(DEV), drum.to(DEV)).cpu()
+    pr, dr = logits[..., :131].argmax(-1), logits[..., 131:].argmax(-1)
+    np_, nd_ = tp != 130, td != 98
+    cp, cd = (pr == tp) & np_, (dr == td) & nd_
+    want = [cp.sum(), np_.sum(), cp[drum].sum(), np_[drum].sum(), cd.sum(), nd_.sum(), (cp & cd).sum(), 0]
+    assert got.tolist() == [int(v) for v in want]
+    s_log = torch.randn(64, 4, 32)
+    s_log.view(-1)[:5] = torch.tensor([0.0, -0.0, 1e-3, -1e-3, 30.0])
+    s_tgt = (torch.rand(64, 4, 32) < 0.2).float()
+    m = ops.structure_metrics(s_log.to(DEV).contiguous(), s_tgt.to(DEV).contiguous()).cpu().tolist()
+    pred = torch.sigmoid(s_log) >= 0.5
+    t = s_tgt.bool()
+    assert m == [int((pred == t).sum()), int((pred & t).sum()), int(pred.sum()), int(t.sum())]

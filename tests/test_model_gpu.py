@@ -249,3 +249,26 @@ def test_fused_trainer_matches_reference_golden(case):
                 gk = f"train1/grad/{k}"
                 assert params_close(sd[k], v, sd0[k], lr_sum, ZERO_GRAD.search(k) is not None,
                                     z[gk] if gk in z.files else None), (step, k)
+
+
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+def test_evaluate_batch_matches_reference_metrics(case):
+    """`HipTrainer.evaluate_batch` = one batch of `PolyphemusTrainer.evaluate` (training.py:250-296): the reference's
+    eval-mode losses and its 9 accuracies, captured from the reference in tests/golden/<case>_metrics.npz."""
+    import os
+    import numpy as np
+    from polyphemus_amd.trainer import HipTrainer
+    z, cfg = load_case(case)
+    m = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{case}_metrics.npz"), allow_pickle=True)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.load_state_dict(state_dict_from_golden(z))
+    g = batch_from_golden(z, cfg).to(DEV)
+    tr = HipTrainer(vae)
+    losses, accs = tr.evaluate_batch(g, torch.from_numpy(z["in/eps"]).to(DEV))
+    assert vae.training                                            # mode restored
+    for k, v in json.loads(str(m["losses"])).items():
+        assert abs(losses[k] - v) <= REL_TOL * max(1.0, abs(v)), (k, losses[k], v)
+    want = json.loads(str(m["accs"]))
+    assert set(accs) == set(want)
+    for k, v in want.items():
+        assert abs(accs[k] - v) < 1e-6, (k, accs[k], v)

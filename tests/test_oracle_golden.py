@@ -102,3 +102,20 @@ def test_binary_from_logits_forces_empty_bars():
     assert b[0, 0].sum() == 1 and b[0, 0, 1, 5]
     for i, j in ((0, 1), (1, 0), (1, 1)):
         assert b[i, j].sum() == 1 and b[i, j, 0, 0]
+
+
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+def test_oracle_accuracies_match_reference(case):
+    """oracle.accuracies == the reference's `_accuracies` (training.py:349-497) on the captured eval-mode outputs."""
+    import json
+    import os
+    import numpy as np
+    z, cfg = load_case(case)
+    m = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{case}_metrics.npz"), allow_pickle=True)
+    want = json.loads(str(m["accs"]))
+    g = batch_from_golden(z, cfg)
+    got = vae_cpu.accuracies(g.s_tensor, torch.from_numpy(z["eval/s_logits"]), g.c_tensor,
+                             torch.from_numpy(z["eval/c_logits"]), g.is_drum)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert abs(got[k] - v) < 1e-7, (k, got[k], v)

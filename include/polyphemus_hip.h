@@ -92,6 +92,23 @@ int pm_edge_attrs_to_ids(const float* edge_attrs /* [E,33] */, int32_t E, int32_
 int pm_tokens_from_onehot(const float* c_tensor /* [N,16,230] */, int32_t N, int32_t* tokens /* [N,16,2] */,
                           pm_stream_t stream);
 
+/* ------------------------------------------------------------------ device-side graph construction
+ * `graph_from_tensor` + the PyG collate of the reference (data.py:24-204) for a whole batch of bars on
+ * the device: same node numbering (active cells in (track, timestep) order), same edge order (per bar: track edges per
+ * track forward-then-inverse, onset edges per timestep forward-then-inverse, next edges forward only; self loop for an
+ * edgeless bar), cell [0,0] of an empty bar switched on in place.  Two calls, the caller sizes the outputs in between
+ * (totals[0] = N, totals[1] = E; the only host read):
+ *   pm_graph_count: per-bar node / edge counts and their exclusive scans node_ptr / edge_ptr [G+1];
+ *   pm_graph_emit : edge_index [2,E] (int64, batch-global node ids), edge_type / edge_dist [E], bars / batch [N]
+ *                   (bar index inside the sample, sample index), is_drum [N], node_cell [N] = (g*4 + track)*32 + timestep
+ *                   (gathers per-cell payloads such as the token grid). */
+int pm_graph_count(float* s_tensor /* [G,4,32] 0/1, empty bars fixed in place */, int32_t G, int32_t* bar_nodes /* [G] */,
+                   int32_t* bar_edges /* [G] */, int32_t* node_ptr /* [G+1] */, int32_t* edge_ptr /* [G+1] */,
+                   int32_t* totals /* [2] */, pm_stream_t stream);
+int pm_graph_emit(float* s_tensor, int32_t G, int32_t n_bars, const int32_t* node_ptr, const int32_t* edge_ptr, int64_t N,
+                  int64_t E, int64_t* edge_index, int32_t* edge_type, int32_t* edge_dist, int64_t* bars, int64_t* batch,
+                  uint8_t* is_drum, int32_t* node_cell, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ message aggregation
  * `GCL.message` + PyG `propagate` + torch_scatter mean (model.py:110,123-135):
  *   A[n, r*d:(r+1)*d] = mean_{e: dst=n, type=r} keep_e * relu(x[src_e] * T[dist_e]) / (1-p)

@@ -25,6 +25,8 @@ _SIGS = {
     "pm_tokens_from_onehot": "pips",
     "pm_edge_table": "ppips",
     "pm_edge_table_bwd": "pipps",
+    "pm_graph_count": "pippppps",
+    "pm_graph_emit": "piippllppppppps",
     "pm_segreduce_fwd": "pppiiiifuuips",
     "pm_segreduce_fwd_planes": "pppiiiifuuipls",
     "pm_segreduce_bwd": "pppppiiiifuuipps",

@@ -191,3 +191,19 @@ def collate_samples(samples: Sequence[dict], n_bars: int) -> BarGraphBatch:
         bars=torch.from_numpy(cat("bars")),
         batch=torch.from_numpy(np.concatenate(batch)),
         num_nodes=off, n_bars=n_bars)
+
+
+def device_batch_from_structure(s_tensor: torch.Tensor, n_bars: int, token_grid: Optional[torch.Tensor] = None) -> BarGraphBatch:
+    """The batch of `collate_samples(graph_from_structure(...))`, built ON THE DEVICE from the activation grids
+    (`ops.graph_build`, csrc/graph.hip): `s_tensor` [B*n_bars,4,32] (0/1, any dtype, cuda).
+    `token_grid` (optional) is the dense per-cell payload [B*n_bars,4,32,16,2] of token ids; the nodes' rows are
+    gathered from it.  Bit-identical to the host construction (tests/test_graphs_gpu.py)."""
+    from . import ops
+    s = s_tensor.to(torch.float32).contiguous().clone()
+    g = ops.graph_build(s, n_bars)
+    kw = dict(n_slots=15, track_unique=True, edge_index=g["edge_index"], edge_type=g["edge_type"],
+              edge_dist=g["edge_dist"], s_tensor=s, is_drum=g["is_drum"], bars=g["bars"], batch=g["batch"],
+              num_nodes=g["num_nodes"], n_bars=n_bars, node_cell=g["node_cell"])
+    if token_grid is not None:
+        kw["tokens"] = token_grid.reshape(-1, C.MAX_SIMU_TOKENS, 2).to(torch.int32)[g["node_cell"].long()].contiguous()
+    return BarGraphBatch(**kw)

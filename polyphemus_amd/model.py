@@ -27,7 +27,7 @@ from . import constants as C
 from . import ops
 from ._lib import HipExtensionError
 from .engine import Engine
-from .graphs import BarGraphBatch, collate_samples, graph_from_structure
+from .graphs import device_batch_from_structure, BarGraphBatch, collate_samples, graph_from_structure
 
 
 # --------------------------------------------------------------------------- parameter containers
@@ -288,8 +288,15 @@ class Decoder(nn.Module):
         self.c_decoder = ContentDecoder(**kw)
         self.sigmoid_thresh = 0.5
 
-    # host-side helpers of the generation path (reference model.py:596-632)
+    # helpers of the generation path (reference model.py:596-632).  A cuda structure is turned into its batch of bar
+    # graphs ON THE DEVICE (csrc/graph.hip: the reference's node numbering and edge order, one host read of (N, E));
+    # a CPU structure takes the numpy restatement of `graph_from_tensor`.
     def _structure_from_binary(self, s_tensor):
+        if s_tensor.is_cuda:
+            b = device_batch_from_structure(s_tensor.reshape(-1, 4, 32), self.n_bars)
+            s_tensor.copy_(b.s_tensor.view_as(s_tensor).to(s_tensor.dtype))      # empty bars get [0,0] (data.py:152-153)
+            b.tokens = torch.zeros(b.num_nodes, 16, 2, dtype=torch.int32, device=s_tensor.device)
+            return b
         s_np = s_tensor.detach().cpu().numpy().astype(bool)
         samples = []
         for i in range(s_np.shape[0]):

@@ -146,6 +146,28 @@ def edge_table_bwd(dT, d_nn_weight, d_nn_bias):
     call("pm_edge_table_bwd", ptr(dT), dT.shape[1], ptr(d_nn_weight), ptr(d_nn_bias), stream())
 
 
+def graph_build(s_tensor: torch.Tensor, n_bars: int):
+    """Bar graphs of a batch on the device (`pm_graph_count` + `pm_graph_emit`): `s_tensor` float32 [G,4,32] 0/1
+    (empty bars get cell [0,0] switched on in place, data.py:152-153).  Returns a dict of device tensors with the
+    reference's node numbering and edge order; ONE host read (N, E) sizes the outputs."""
+    _chk(s_tensor, F32, "s_tensor")
+    G = s_tensor.shape[0]
+    dev = s_tensor.device
+    bn, be = torch.empty(G, dtype=I32, device=dev), torch.empty(G, dtype=I32, device=dev)
+    npt, ept = torch.empty(G + 1, dtype=I32, device=dev), torch.empty(G + 1, dtype=I32, device=dev)
+    tot = torch.empty(2, dtype=I32, device=dev)
+    call("pm_graph_count", ptr(s_tensor), G, ptr(bn), ptr(be), ptr(npt), ptr(ept), ptr(tot), stream())
+    N, E = (int(v) for v in tot.tolist())
+    out = dict(edge_index=torch.empty(2, E, dtype=I64, device=dev), edge_type=torch.empty(E, dtype=I32, device=dev),
+               edge_dist=torch.empty(E, dtype=I32, device=dev), bars=torch.empty(N, dtype=I64, device=dev),
+               batch=torch.empty(N, dtype=I64, device=dev), is_drum=torch.empty(N, dtype=U8, device=dev),
+               node_cell=torch.empty(N, dtype=I32, device=dev), node_ptr=npt, edge_ptr=ept, num_nodes=N)
+    call("pm_graph_emit", ptr(s_tensor), G, n_bars, ptr(npt), ptr(ept), N, E, ptr(out["edge_index"]), ptr(out["edge_type"]),
+         ptr(out["edge_dist"]), ptr(out["bars"]), ptr(out["batch"]), ptr(out["is_drum"]), ptr(out["node_cell"]), stream())
+    out["is_drum"] = out["is_drum"].view(torch.bool)
+    return out
+
+
 def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int, out=None):
     _chk(x, F32, "x"); _chk(T, F32, "T")
     N, d = x.shape

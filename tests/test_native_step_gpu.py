@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("B,nb,d,L,fix", [(8, 2, 64, 2, False), (6, 3, 32, 3, True), (16, 2, 256, 2, False)])
+@pytest.mark.parametrize("B,nb,d,L,fix", [(8, 2, 64, 2, False), (6, 3, 32, 3, True), (16, 2, 256, 2, False),
+                                          (1, 1, 8, 1, False), (3, 2, 24, 2, True), (2, 4, 40, 1, False)])
 def test_native_step_equals_python_step(B, nb, d, L, fix):
     cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=L, d=d, n_bars=nb, resolution=8)
     batch = synthetic_batch(B, nb, p=0.25, seed=3 + B).to(DEV)
@@ -36,7 +37,8 @@ def test_native_step_equals_python_step(B, nb, d, L, fix):
     (la, sa, ga), (lb, sb, gb) = results
     for k in la[0]:                                            # first step: identical inputs and weights
         assert abs(la[0][k] - lb[0][k]) <= 1e-6 * max(1.0, abs(lb[0][k])), k   # (native: active slots + closed-form PAD tail)
-    assert rel_err(ga, gb) < 1e-5
+    # (tiny batches: BatchNorm over a handful of rows amplifies the rounding difference between the two GEMM modes)
+    assert rel_err(ga, gb) < (1e-5 if B >= 6 else 1e-4)
     for x, y in zip(la[1:], lb[1:]):                           # later steps: Adam has amplified atomics-order noise
         for k in x:
             assert abs(x[k] - y[k]) <= 1e-4 * max(1.0, abs(y[k])), k
@@ -47,7 +49,7 @@ def test_native_step_equals_python_step(B, nb, d, L, fix):
             assert torch.equal(sa[k], sb[k]), k
     # tight check on tensors whose gradient is far above rounding noise
     for k in ("encoder.c_encoder.graph_encoder.layers.0.weight", "decoder.c_decoder.chord_decoder.weight",
-              "encoder.c_encoder.chord_encoder.weight", "decoder.c_decoder.graph_decoder.layers.1.nn.weight"):
+              "encoder.c_encoder.chord_encoder.weight", f"decoder.c_decoder.graph_decoder.layers.{L - 1}.nn.weight"):
         a, b = sa[k].double(), sb[k].double()
         assert float((a - b).abs().mean()) < 1e-6, k
 

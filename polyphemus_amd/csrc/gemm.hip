@@ -656,6 +656,8 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
 
 extern "C" int pm_gemm_config(int32_t transA, int32_t M, int32_t N, int32_t K) { return pick_config(transA, M, N, K); }
 
+static inline bool ldc_contig(const PmGemmDesc* q, int N) { return q->ldc == N; }
+
 extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   if (!q) return PM_E_INVALID;
   const int transA = q->transA, transB = q->transB, M = q->M, N = q->N, K = q->K, n_groups = q->n_groups;
@@ -710,7 +712,20 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
       if (split_k < 1) split_k = 1;
     }
   }
-  const int flags = q->flags;
+  int flags = q->flags;
+  hipStream_t st = (hipStream_t)stream;
+  // Latency-bound small products (the heads: a few dozen tiles, K of 512 or more): the K loop is the critical path, so
+  // split it over the otherwise idle CUs.  C is cleared first and accumulated with atomics (bias by slice 0);
+  // only for a plainly stored contiguous C (no ReLU / statistics / row map / accumulate).
+  if (!transA && q->split_k == 1 && n_groups == 1 && tiles <= 64 && K >= 512 && ldc_contig(q, N) &&
+      !(flags & (PM_GEMM_RELU | PM_GEMM_ACCUM)) && !q->col_stats && !q->rowmap && !planes) {
+    split_k = K / 128 < 8 ? K / 128 : 8;
+    if (split_k > 1) {
+      hipMemsetAsync(q->C, 0, sizeof(float) * (size_t)M * N, st);
+      flags |= PM_GEMM_ACCUM;
+      g.flags = flags;
+    } else split_k = 1;
+  }
   if (split_k > 1 && ((flags & PM_GEMM_RELU) || !(flags & PM_GEMM_ACCUM))) return PM_E_INVALID;  // needs += semantics
   if (g.c_split > 0 && n_groups > 1 && !(flags & PM_GEMM_ACCUM)) return PM_E_INVALID;
   const int kper = (int)pm_cdiv(pm_cdiv(K, split_k), BK) * BK;
@@ -718,7 +733,6 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   if (!(transA && q->dyn_entries)) split_k = (int)pm_cdiv(K, kper);     // (device-side K: the kernel re-derives kper)
   dim3 grid((unsigned)tiles, (unsigned)n_groups, (unsigned)split_k);
   if (g.packed) grid = dim3((unsigned)((g.ntm + n_groups) * g.ntn), 1, (unsigned)split_k);
-  hipStream_t st = (hipStream_t)stream;
   const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);
   switch (cfg) {

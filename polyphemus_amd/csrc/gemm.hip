@@ -630,7 +630,7 @@ static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32, 32, 32,
 // Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
 static int g_forced_cfg = -1;
 extern "C" int pm_gemm_force_config(int32_t cfg) { g_forced_cfg = (cfg >= 0 && cfg < 8) ? cfg : -1; return PM_OK; }
-static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
+static int pick_config(int transA, int M, int N, int K, bool x6_ok = false, bool ungrouped = false) {
   if (g_forced_cfg >= 0 && (g_forced_cfg < 4 || x6_ok)) return g_forced_cfg;
   // Measured on MI355X (tools/bench_gemm.py, shapes of the training step, interleaved A/B in one process):
   //  - NN / NT (the node dimension is M): 64x64 tiles win or tie everywhere: 4 workgroups per CU = 4 waves per
@@ -647,7 +647,10 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false) {
   //    Inside the training step (row-gathered, grouped launches, one 8-wave workgroup per CU) the gain did not
   //    materialise (10.71 ms against 10.78 ms per step), so split mode is opt-in: PM_GEMM_SPLIT=1 or a forced config.
   static const bool split_on = getenv("PM_GEMM_SPLIT") && atoi(getenv("PM_GEMM_SPLIT")) > 0;
-  if (split_on && x6_ok && (double)M * N * K >= 1.0e9) {
+  // default: the large UNGROUPED NN / NT products (chord encoder / decoder and their input gradients) run in split
+  // mode (78-90 us against 99-112 us in the step); weight gradients stay on the fp32 tiles (split mode: 132 against 106 us)
+  static const bool split_ungrouped = !(getenv("PM_GEMM_SPLIT_UNGROUPED") && atoi(getenv("PM_GEMM_SPLIT_UNGROUPED")) == 0);
+  if ((split_on || (split_ungrouped && ungrouped && !transA)) && x6_ok && (double)M * N * K >= 1.0e9) {
     if (transA) return 5;
     return K >= 1024 ? 7 : 4;
   }
@@ -693,7 +696,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   }
   g.a_ps = q->a_plane_stride; g.b_ps = q->b_plane_stride;
   // planes mode: 64x64x32 tiles (measured in the step: 128x64x32 85 us, 128x128x32 97-130 us against 70-80 us)
-  const int cfg = planes ? 8 : pick_config(transA, M, N, K, va && vb);
+  const int cfg = planes ? 8 : pick_config(transA, M, N, K, va && vb, n_groups == 1 && !q->rowmap);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;

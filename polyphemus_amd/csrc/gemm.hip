@@ -1,24 +1,26 @@
-// gemm.hip — fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 = fmaf chain).
+// gemm.hip — fp32-accurate GEMM on the CDNA4 matrix cores.
 //
-// Replaces every `addmm` / `mm` on the path: nn.Linear layers, and the 6 relation GEMMs + root
-// GEMM of GCL.forward (model.py:112,116) which become ONE call on A = [h_0|...|h_5|x] (K = 7d).
-// bf16 MFMA cannot hold the 1e-4 parity bar through 16 BatchNorm'd layers, so operands stay fp32
-// (157 TFLOP/s peak, MI355X_MICROARCH §Matrix cores).
-//
-// One kernel template, two arithmetic modes, 4 waves (2x2) of 32x32 MFMA tiles:
-//   fp32 mode (v_mfma_f32_32x32x2_f32):   C0 64x64x16, C1 128x128x16, C2 64x64x32, C3 128x128x32
-//   split mode "x6" (v_mfma_f32_32x32x16_bf16): C4 128x128x16, C5 128x64x16, C6 64x64x32, C7 128x128x32
-// Split mode keeps fp32 operands and fp32 accumulation but forms the products on the 16x faster bf16 pipe:
-// every operand element is split EXACTLY into three bf16 terms (x = x1 + x2 + x3, 8 significand bits each, done
-// once per element while the tile is staged into LDS) and the six partial products of weight >= 2^-16
+// Replaces every `addmm` / `mm` on the path: nn.Linear layers, and the 6 relation GEMMs + root GEMM of GCL.forward
+// (model.py:112,116), which become ONE grouped launch on the compact aggregate [track block | onset | next | x]
+// (K = 4d, row lists per track relation, stacked weights) — or one plain call on [h_0|...|h_5|x] (K = 7d).
+// Plain bf16 MFMA cannot hold the 1e-4 parity bar through 16 BatchNorm'd layers; three arithmetic modes keep fp32
+// accuracy (one kernel template, 4 waves (2x2) of 32x32 MFMA tiles per workgroup unless noted):
+//   MODE 0  fp32 MFMA   v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak)      C0 64x64x16, C1 128x128x16, C2 64x64x32, C3 128x128x32
+//   MODE 1  split "x6"  v_mfma_f32_32x32x16_bf16, fp32 operands split in the kernel by 4 extra producer waves
+//                                                                      C4 128x128x16, C5 128x64x16, C6 64x64x32, C7 128x128x32
+//   MODE 2  planes      v_mfma_f32_32x32x16_bf16, operands PRE-SPLIT by the kernels that produced them
+//                                                                      C8 64x64x32 (C9 128x64x32, C10 128x128x32 measured slower)
+// Split arithmetic: every fp32 value is EXACTLY the sum of three bf16 terms (x = x1 + x2 + x3, 8 significand bits each,
+// same exponent range) and the six partial products of weight >= 2^-16
 //   x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1)
 // are accumulated in the fp32 MFMA accumulators; the three dropped products are <= 2^-24 relative, i.e. below the
 // rounding of an fp32 FMA chain (tests: the same 5e-6 bound against float64 as the fp32 mode, measured ~1e-7).
-// LDS tiles are k-major so an MFMA operand read is 32 consecutive floats per half-wave
-// (conflict-free ds_read_b32); global loads are staged through registers one k-tile ahead
-// (double-buffered LDS, one barrier per k-tile).  Workgroup ids are remapped so that tiles sharing
-// a row panel run on the same XCD (shared L2).  The gathered dimension may be indirect (row map +
-// device-side count) for the drum / non-drum routing of the content decoder (model.py:552-576).
+// fp32 mode: k-major LDS tiles (an MFMA operand read is 32 consecutive floats per half-wave, conflict-free
+// ds_read_b32), global loads staged through registers one k-tile ahead, double-buffered LDS, one barrier per k-tile.
+// Split modes: three bf16 plane images per operand, fragments by ds_read_b128 (k-contiguous operands) or
+// ds_read_b64_tr_b16 (row-contiguous operands, hardware transpose).  Workgroup ids are remapped so that tiles sharing
+// an operand panel run on the same XCD (shared L2).  The gathered dimension may be indirect (row map + device-side
+// count): drum / non-drum routing of the content decoder (model.py:552-576), per-relation row lists of the GCL.
 #include "common.h"
 #include "prof.h"
 #include <stdlib.h>

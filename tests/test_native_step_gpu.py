@@ -110,3 +110,31 @@ def test_optimizer_state_interop_with_torch_adam():
     assert float(diff.max()) <= 2.5e-4 and float(diff.mean()) < 2e-6
     step = (want - model_flat).abs()
     assert float(((vae2.flat_params - model_flat) * (want - model_flat)).sum() / (step.norm() ** 2)) > 0.98
+
+
+def test_native_step_on_foreign_graphs_takes_the_seven_block_path():
+    """A graph that does NOT follow the reference's construction rules (a node receiving track edges of two relations)
+    breaks the premise of the compact GCL (`track_unique` False): the native step must then use the 7-block aggregate
+    and agree with the python orchestration (which always does)."""
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    batch = synthetic_batch(6, 2, p=0.3, seed=4)
+    et = batch.edge_type.clone()
+    trk = torch.nonzero(et < 4).flatten()
+    et[trk[::3]] = (et[trk[::3]] + 1) % 4                          # re-label a third of the track edges
+    batch.edge_type = et
+    batch.track_unique = False
+    batch.__dict__.pop("_edge_attrs", None)
+    batch = batch.to(DEV)
+    eps = torch.randn(6, 32, device=DEV)
+    res = []
+    for native in (True, False):
+        torch.manual_seed(0)
+        vae = VAE(**cfg, device=DEV).to(DEV)
+        vae.train()
+        tr = HipTrainer(vae, lr=5e-6, native=native)
+        out = tr.losses_dict(tr.train_step(batch, eps))
+        res.append((out, tr.grads.clone()))
+    (la, ga), (lb, gb) = res
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(lb[k])), k
+    assert rel_err(ga, gb) < 1e-4

@@ -375,10 +375,12 @@ int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_
  * ~330 kernel launches per step with no interpreter between them.  The model is described by
  * offsets (in floats) into the caller's flat parameter / buffer / gradient arrays, named after the
  * reference's modules; activations live in a caller-provided workspace arena.
- * Three calls so that the data-parallel gradient buckets can be exchanged as soon as they are final:
+ * Four calls so that the data-parallel gradient buckets can be exchanged as soon as they are final:
  *   pm_vae_step_forward  : plan -> encoder -> reparam -> decoder -> losses (+ d loss / d logits)
  *   pm_vae_step_backward_decoder : decoder gradients are final afterwards
- *   pm_vae_step_backward_encoder : encoder gradients are final afterwards
+ *   pm_vae_step_backward_encoder : encoder head, attention pooling, graph encoder: the gradients of every encoder
+ *                                  parameter from `c_encoder.graph_encoder` to the end of the encoder are final
+ *   pm_vae_step_backward_encoder_tail : chord encoder, embeddings, structure encoder: all gradients final
  * `state` is a caller-owned HOST blob of pm_vae_step_state_bytes() that carries the saved-activation
  * pointers between the calls.  Training mode only (batch statistics, running stats updated). */
 #define PM_MAX_LAYERS 16
@@ -420,6 +422,7 @@ int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buff
                         pm_stream_t stream);
 int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder(void* state, pm_stream_t stream);
+int pm_vae_step_backward_encoder_tail(void* state, pm_stream_t stream);
 
 #ifdef __cplusplus
 }

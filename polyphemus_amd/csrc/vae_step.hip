@@ -51,6 +51,7 @@ struct StepState {
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
+  float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
   int rc;
 };
 constexpr uint64_t kMagic = 0x504d5354455031ULL;
@@ -429,6 +430,17 @@ void backward_encoder(Ctx& c) {
                         c.G + Y.enc_gate_bn.b, pscr, c.st));
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
   c.chk(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
+  s.bk_dx0 = dx0; s.bk_dzcat = dzcat;
+}
+// Second half of the encoder backward: chord encoder, embeddings, structure branch.  Split off so that the gradients
+// of the graph encoder / attention / merge layers (final after the first half, ~15 MB) can be exchanged meanwhile.
+void backward_encoder_tail(Ctx& c) {
+  StepState& s = *c.s;
+  Arena& ar = s.ar;
+  const PmVaeLayout& Y = s.lay;
+  const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
+  float* dx0 = s.bk_dx0;
+  float* dzcat = s.bk_dzcat;
   const int S = c.S;
   float* dX = ar.f((size_t)N * S * d);
   float* Stab = ar.f((size_t)4 * PM_N_PITCH * dh);
@@ -536,7 +548,18 @@ extern "C" int pm_vae_step_backward_encoder(void* state, pm_stream_t stream) {
   StepState* s = (StepState*)state;
   if (!s || s->magic != kMagic || s->rc != PM_OK) return PM_E_INVALID;
   Ctx c = make_ctx(s, (hipStream_t)stream);
+  s->bk_dx0 = nullptr;
   backward_encoder(c);
+  if (s->ar.overflow) return PM_E_INVALID;
+  s->rc = c.rc;
+  return c.rc;
+}
+extern "C" int pm_vae_step_backward_encoder_tail(void* state, pm_stream_t stream) {
+  StepState* s = (StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK || !s->bk_dx0) return PM_E_INVALID;
+  Ctx c = make_ctx(s, (hipStream_t)stream);
+  backward_encoder_tail(c);
+  s->bk_dx0 = nullptr;
   if (s->ar.overflow) return PM_E_INVALID;
   s->rc = c.rc;
   return c.rc;

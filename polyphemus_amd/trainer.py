@@ -6,12 +6,12 @@ but without autograd bookkeeping and without the reference's 7 `.item()` host sy
 
     plan build -> encoder -> reparametrisation -> decoder -> fused CE/KLD/BCE loss (+ dlogits)
     -> decoder backward -> reparam backward -> encoder backward
-    -> [data parallel: RCCL all-reduce of the flat gradient, two buckets overlapped with the
-        encoder backward] -> fused Adam on the flat parameter buffer
+    -> [data parallel: RCCL all-reduce of the flat gradient in three buckets, two of them overlapped
+        with the encoder backward] -> fused Adam on the flat parameter buffer
 
 Two orchestrations of the SAME kernels:
-  * native (default): three C calls (`pm_vae_step_forward`, `..._backward_decoder`,
-    `..._backward_encoder`, csrc/vae_step.hip) issue the ~330 launches of a step from C++;
+  * native (default): four C calls (`pm_vae_step_forward`, `..._backward_decoder`,
+    `..._backward_encoder`, `..._backward_encoder_tail`, csrc/vae_step.hip) issue the ~330 launches of a step from C++;
   * python (`native=False`): the same sequence through `engine.Engine` (the executable
     specification the autograd drop-in path uses); kept for cross-checking.
 
@@ -77,8 +77,15 @@ class HipTrainer:
                 head, tail = k.split(".layers.0.nn.")
                 for i in range(1, vae.cfg["gnn_n_layers"]):
                     self._G[f"{head}.layers.{i}.nn.{tail}"] = self._G[k]
-        dec_lo = vae._offsets[vae._names("decoder.")[0]]              # [0, dec_lo) = encoder grads
-        self.buckets = GradBuckets(self.grads, [dec_lo], process_group)  # bucket 0 encoder, bucket 1 decoder
+        # gradient buckets in flat order: 0 = structure encoder + embeddings + chord encoder (final last),
+        # 1 = graph encoder .. end of the encoder (final after the first half of the encoder backward), 2 = decoder
+        dec_lo = vae._offsets[vae._names("decoder.")[0]]
+        mid_lo = vae._offsets[vae._names("encoder.c_encoder.graph_encoder.")[0]]
+        for n in vae._names("encoder."):                              # the layout the native split relies on
+            late = n.startswith(("encoder.s_encoder.", "encoder.c_encoder.non_drums", "encoder.c_encoder.drums",
+                                 "encoder.c_encoder.dur_emb", "encoder.c_encoder.bn_", "encoder.c_encoder.chord_encoder"))
+            assert (vae._offsets[n] < mid_lo) == late, f"unexpected parameter order at {n}"
+        self.buckets = GradBuckets(self.grads, [mid_lo, dec_lo], process_group)
         self.world = self.buckets.world
         broadcast_([vae.flat_params, vae.flat_buffers], 0, process_group)
         # native step plumbing
@@ -145,9 +152,11 @@ class HipTrainer:
              self._ws.numel(), ctypes.addressof(self._state), ptr(self.loss_buf), st)
         state = ctypes.addressof(self._state)
         call("pm_vae_step_backward_decoder", state, st)
-        self.buckets.launch(1)                               # decoder gradients: overlapped with the encoder backward
+        self.buckets.launch(2)                               # decoder gradients: overlapped with the encoder backward
         call("pm_vae_step_backward_encoder", state, st)
-        self.buckets.launch(0)                               # encoder gradients
+        self.buckets.launch(1)                               # graph encoder .. encoder head: overlapped with the tail
+        call("pm_vae_step_backward_encoder_tail", state, st)
+        self.buckets.launch(0)                               # chord encoder, embeddings, structure encoder
         # num_batches_tracked (int64 bookkeeping of nn.BatchNorm): +1 per forward; the embedding norms only
         # when their group is non-empty, bn_dur once per non-empty group (model.py:362,375)
         i = PLAN_FIELDS.index("group_cnt")
@@ -177,9 +186,10 @@ class HipTrainer:
             ops.bce_logits(s_tensor.reshape(-1), s_tensor.reshape(-1), out, 1.0, want_grad=False)
             ds = None
         dz = eng.decoder_backward(dsv, ds, dc, G)
-        self.buckets.launch(1)
+        self.buckets.launch(2)
         ops.reparam_bwd(dz, lv, eps, dmu, dlv)
         eng.encoder_backward(esv, dmu, dlv, G)
+        self.buckets.launch(1)
         self.buckets.launch(0)
         return out
 

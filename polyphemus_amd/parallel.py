@@ -4,8 +4,9 @@ xGMI on ROCm; "gloo" in the CPU tests).
 The reference is single-device (train.py:120-122).  Bar-graphs of different samples never share
 an edge, so the batch shards by sample with no data-path collective; the only exchange is ONE
 sum-all-reduce of the flat fp32 gradient buffer per optimizer step (43 MB at d=256, 169 MB at
-d=512), issued as two buckets — decoder gradients as soon as the decoder backward has finished,
-encoder gradients at the end — so the first (larger) bucket overlaps the encoder backward.
+d=512), issued as three buckets — decoder gradients as soon as the decoder backward has finished, the graph
+encoder .. encoder head after the first half of the encoder backward, the rest at the end — so the two large
+buckets overlap the encoder backward.
 BatchNorm uses per-replica statistics (standard DDP semantics; >= 16 k nodes per replica).
 """
 from __future__ import annotations

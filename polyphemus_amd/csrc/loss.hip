@@ -9,13 +9,13 @@
 // one wave per (node, slot) row.  out[0] += pitch CE / n_valid_pitch, out[1] += dur CE / n_valid_dur.
 // Optionally also the gradients of the three un-embedding biases (column sums of d_logits over the drum rows,
 // the non-drum rows and all rows: model.py:561-567), accumulated in registers while the rows stream by.
-__global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ logits, const int* __restrict__ tok,
+__global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ logits, const int* __restrict__ tok,
                                                     const int* __restrict__ hist, const uint8_t* __restrict__ is_drum,
                                                     int64_t rows, int S, float grad_scale, float* __restrict__ dlogits,
                                                     float* db_pitch_d, float* db_pitch_nd, float* db_dur,
                                                     double* __restrict__ out) {
-  __shared__ double sh[2][4];
-  __shared__ float sb[4][2][256];
+  __shared__ double sh[2][16];
+  __shared__ float sb[16][2][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // valid rows = all (node, slot 1..15) rows - PAD rows (token histogram of the plan: tables 0/1 pitch, 2/3 dur);
   // only the first S slots are present in `logits` (the others are PAD in every node and contribute nothing)
@@ -26,8 +26,9 @@ __global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ lo
   const bool want_b = db_pitch_d != nullptr && dlogits != nullptr;
   double lp = 0, ld = 0;
   float bacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // [drum?][column lane + 64 j]
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int n = (int)(row / S), s = (int)(row % S) + 1;
+  const int nwv = blockDim.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * nwv + wave; row < rows; row += (int64_t)gridDim.x * nwv) {
+    const int n = (int)((unsigned)row / (unsigned)S), s = (int)((unsigned)row % (unsigned)S) + 1;   // rows < 2^31 (checked by the host)
     const int tp = tok[((int64_t)n * 16 + s) * 2], td = tok[((int64_t)n * 16 + s) * 2 + 1];
     const float* r = logits + row * PM_N_TOK;
     float v[4];                                               // lanes cover 230 = 3 full passes + 38
@@ -74,13 +75,15 @@ __global__ void __launch_bounds__(256) k_content_ce(const float* __restrict__ lo
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&out[0], (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / np);
-    atomicAdd(&out[1], (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / nd);
+    double a = 0, b = 0;
+    for (int w = 0; w < nwv; ++w) { a += sh[0][w]; b += sh[1][w]; }
+    atomicAdd(&out[0], a / np);
+    atomicAdd(&out[1], b / nd);
   }
   if (want_b && threadIdx.x < PM_N_TOK) {
     const int c = threadIdx.x;
-    const float nd_sum = sb[0][0][c] + sb[1][0][c] + sb[2][0][c] + sb[3][0][c];
-    const float d_sum = sb[0][1][c] + sb[1][1][c] + sb[2][1][c] + sb[3][1][c];
+    float nd_sum = 0.f, d_sum = 0.f;
+    for (int w = 0; w < nwv; ++w) { nd_sum += sb[w][0][c]; d_sum += sb[w][1][c]; }
     if (c < PM_N_PITCH) {
       if (d_sum != 0.f) atomicAdd(&db_pitch_d[c], d_sum);
       if (nd_sum != 0.f) atomicAdd(&db_pitch_nd[c], nd_sum);
@@ -95,9 +98,13 @@ extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(out, 0, 2 * sizeof(double), st);
   const int64_t rows = (int64_t)N * n_slots;
-  int nb = (int)pm_cdiv(rows, 4 * 8);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(256), 0, st, c_logits, tokens, tok_hist, is_drum, rows, n_slots, grad_scale,
+  if (rows >= ((int64_t)1 << 31)) return PM_E_UNSUPPORTED;
+  // 16-wave workgroups: the token -> logit-row chain is latency bound (many waves), while every workgroup ends with
+  // 460 bias-gradient atomics on the same addresses (few workgroups)
+  const int threads = rows >= 4096 ? 1024 : 256;
+  int nb = (int)pm_cdiv(rows, (threads / 64) * 8);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(threads), 0, st, c_logits, tokens, tok_hist, is_drum, rows, n_slots, grad_scale,
                      d_logits, db_pitch_drum, db_pitch_nd, db_dur, out);
   return pm_check_launch();
 }

@@ -11,6 +11,7 @@
 //            2 = drum duration, 3 = non-drum duration (both bn_dur: applied to the drum rows first,
 //            then to the non-drum rows, so its running stats are updated twice — model.py:362,375).
 #include "common.h"
+#include <stdlib.h>
 
 #define EMB_V PM_N_PITCH   /* rows allocated per table (duration tables use the first 99) */
 
@@ -134,8 +135,9 @@ __global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // PAD is the token of >= 10 of the 15 slots of every node: its rows are summed in registers per wave and
   // hit the LDS row once, instead of serialising thousands of ds_add_f32 on one address.
-  const int pad = kind == 0 ? 130 : 98;
+  const int pad = kind == 0 ? 130 : 98, eos = pad - 1;      // EOS closes every chord: as frequent as a node
   float2 pacc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // channels lane*2 + 128*j  (d/2 <= 512)
+  float2 eacc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   const int nwv = blockDim.x >> 6;        // 16 waves per workgroup: the row -> token -> gradient-row chain is latency bound
   constexpr int U = 4;                    // slots in flight per wave (independent token / row loads)
   (void)rows;
@@ -158,6 +160,7 @@ __global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restr
         for (int u = 0; u < U; ++u) {
           if (v[u] < 0) continue;
           if (v[u] == pad) { pacc[j].x += g[u].x; pacc[j].y += g[u].y; }
+          else if (v[u] == eos) { eacc[j].x += g[u].x; eacc[j].y += g[u].y; }
           else {
             if (g[u].x != 0.f) atomicAdd(&sS[v[u] * dh + c], g[u].x);
             if (g[u].y != 0.f) atomicAdd(&sS[v[u] * dh + c + 1], g[u].y);
@@ -172,6 +175,8 @@ __global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restr
     if (c >= dh) break;
     if (pacc[j].x != 0.f) atomicAdd(&sS[pad * dh + c], pacc[j].x);
     if (pacc[j].y != 0.f) atomicAdd(&sS[pad * dh + c + 1], pacc[j].y);
+    if (eacc[j].x != 0.f) atomicAdd(&sS[eos * dh + c], eacc[j].x);
+    if (eacc[j].y != 0.f) atomicAdd(&sS[eos * dh + c + 1], eacc[j].y);
   }
   __syncthreads();
   float* out = S + (int64_t)t * EMB_V * dh;

@@ -209,6 +209,13 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         ns0[v][j] = 0; ns1[v][j] = 0; ns2[v][j] = 0;
       }
   }
+  // distance 0 (every onset edge) would be the most contended row of the LDS table (same-address ds_add_f32 from all
+  // waves serialise): its contributions are summed in registers and added once per wave
+  float z0[NV][4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z0[v][j] = 0.f;
   for (int n0 = blockIdx.x * nwv; n0 < N; n0 += gridDim.x * nwv) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
     if (n >= N) continue;
@@ -262,7 +269,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
             const float gg = on ? g[j] : 0.f;
             ap[j] += gg * ts[j];
             const float gt = gg * xs[j];
-            if (gt != 0.f) atomicAdd(&sT[dist[u] * d + j * dq + (c[v] >> 2)], gt);
+            if (dist[u] == 0) z0[v][j] += gt;               // onset edges (a third of all): row 0 stays in registers
+            else if (gt != 0.f) atomicAdd(&sT[dist[u] * d + j * dq + (c[v] >> 2)], gt);
           }
         }
       }
@@ -284,6 +292,13 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         }
       }
     }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    if (!ok[v]) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (z0[v][j] != 0.f) atomicAdd(&sT[j * dq + (c[v] >> 2)], z0[v][j]);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {       // i runs over dT (coalesced atomics)

@@ -372,7 +372,7 @@ int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_
 
 /* ------------------------------------------------------------------ native training step
  * The whole of `PolyphemusTrainer.train`'s inner iteration (training.py:137-166) issued from C++:
- * ~330 kernel launches per step with no interpreter between them.  The model is described by
+ * ~340 kernel launches per step with no interpreter between them.  The model is described by
  * offsets (in floats) into the caller's flat parameter / buffer / gradient arrays, named after the
  * reference's modules; activations live in a caller-provided workspace arena.
  * Four calls so that the data-parallel gradient buckets can be exchanged as soon as they are final:

@@ -11,7 +11,7 @@ but without autograd bookkeeping and without the reference's 7 `.item()` host sy
 
 Two orchestrations of the SAME kernels:
   * native (default): four C calls (`pm_vae_step_forward`, `..._backward_decoder`,
-    `..._backward_encoder`, `..._backward_encoder_tail`, csrc/vae_step.hip) issue the ~330 launches of a step from C++;
+    `..._backward_encoder`, `..._backward_encoder_tail`, csrc/vae_step.hip) issue the ~340 launches of a step from C++;
   * python (`native=False`): the same sequence through `engine.Engine` (the executable
     specification the autograd drop-in path uses); kept for cross-checking.
 

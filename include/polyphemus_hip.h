@@ -71,8 +71,11 @@ enum {
   PM_PLAN_ROW_LIST,     /* [2*15N] (node, slot) rows = node*15 + slot of the drum nodes in [0, 15 n_drum),
                            of the non-drum nodes from 15N on: row maps of the un-embedding GEMMs */
   PM_PLAN_NODE_TREL,    /* [N] the track relation (0..3) that has in-edges at the node (see pm_segreduce_fwd) */
-  PM_PLAN_TRK_LIST,     /* [4N] nodes grouped by that relation: group t at offset t*N                   */
-  PM_PLAN_TRK_CNT,      /* [8] {4 group sizes, #nodes with in-edges of more than one track relation, 0,0,0} */
+  PM_PLAN_TRK_LIST,     /* [4N] nodes grouped by that relation (group t at offset t*N), inside a group sorted by
+                           class (receives onset edges, receives next edges) in the order (0,0) (1,0) (1,1) (0,1) */
+  PM_PLAN_TRK_CNT,      /* [32] {4 group sizes, #nodes with in-edges of more than one track relation, 0,0,0,
+                           then 5 class boundaries b0..b4 per group at [8 + 5t + k]: rows [b1,b3) of the list
+                           receive onset edges, rows [b2,b4) receive next edges} */
   PM_PLAN_SCRATCH,      /* cursors + scan partials                                */
   PM_PLAN_NFIELDS
 };

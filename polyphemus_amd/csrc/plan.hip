@@ -14,7 +14,7 @@ void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   sz[PM_PLAN_CSC_DST] = E; sz[PM_PLAN_CSC_RELDIST] = E; sz[PM_PLAN_CSC_EID] = E; sz[PM_PLAN_CSC_INVCNT] = E;
   sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = 2 * (int64_t)N;
   sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH; sz[PM_PLAN_ROW_LIST] = 2 * (int64_t)N * PM_N_SLOTS;
-  sz[PM_PLAN_NODE_TREL] = N; sz[PM_PLAN_TRK_LIST] = 4 * (int64_t)N; sz[PM_PLAN_TRK_CNT] = 8;
+  sz[PM_PLAN_NODE_TREL] = N; sz[PM_PLAN_TRK_LIST] = 4 * (int64_t)N; sz[PM_PLAN_TRK_CNT] = 32;
   // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums | track flags/positions 4 x [N+1]
   sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64 +
                         4 * ((int64_t)N + 1);
@@ -189,23 +189,77 @@ __global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restr
 // A node only receives track edges of its own track (data.py:36-49; the fake self-loop of a single-node bar is
 // type 0 and is then the node's only edge, data.py:173-176), so the four track blocks of the GCL aggregate are
 // block-sparse: one non-zero block per node.  cnt[4] counts nodes that violate this (foreign graphs).
-__global__ void k_node_trel(const int* __restrict__ rowptr, int N, int* trel, int* flags4, int* cnt) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+//
+// The nodes of a track relation are listed (PM_PLAN_TRK_LIST) sorted by CLASS = (receives onset edges, receives next
+// edges) in the Gray order (0,0) (1,0) (1,1) (0,1): the rows whose onset block of the aggregate is non-zero are then the
+// contiguous range [b1, b3) of the list and those with a non-zero next block the range [b2, b4), so the GCL
+// contractions can skip the all-zero blocks (42 % / 19 % of the nodes at the default density) tile by tile.
+// Stable counting sort over 16 classes (track * 4 + Gray code): per-workgroup histograms, one scan, ranked scatter;
+// within a class the nodes stay in ascending order (deterministic).
+#define CLS_T 256
+__device__ static inline int node_class(const int* __restrict__ rowptr, int n, int* nrel_out) {
   int t = -1, nrel = 0;
+  const int* rp = rowptr + (int64_t)n * PM_N_REL;
   for (int r = 0; r < 4; ++r)
-    if (rowptr[n * PM_N_REL + r + 1] > rowptr[n * PM_N_REL + r]) { if (t < 0) t = r; ++nrel; }
+    if (rp[r + 1] > rp[r]) { if (t < 0) t = r; ++nrel; }
   if (t < 0) t = 0;
-  if (nrel > 1) atomicAdd(&cnt[4], 1);
-  trel[n] = t;
-  for (int r = 0; r < 4; ++r) flags4[(int64_t)r * (N + 1) + n] = (r == t) ? 1 : 0;
+  const int on = rp[5] > rp[4], nx = rp[6] > rp[5];
+  *nrel_out = nrel;
+  return t * 4 + (on ? (nx ? 2 : 1) : (nx ? 3 : 0));
 }
-__global__ void k_trk_list(const int* __restrict__ trel, const int* __restrict__ pos4, int N, int* list, int* cnt) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < 4) cnt[n] = pos4[(int64_t)n * (N + 1) + N];
-  if (n >= N) return;
-  const int t = trel[n];
-  list[(int64_t)t * N + pos4[(int64_t)t * (N + 1) + n]] = n;
+__global__ void __launch_bounds__(CLS_T) k_node_class(const int* __restrict__ rowptr, int N, int* __restrict__ trel,
+                                                     int* __restrict__ cls, int* __restrict__ bh, int* __restrict__ cnt) {
+  __shared__ int h[16];
+  if (threadIdx.x < 16) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = blockIdx.x * CLS_T + threadIdx.x;
+  if (n < N) {
+    int nrel;
+    const int c = node_class(rowptr, n, &nrel);
+    if (nrel > 1) atomicAdd(&cnt[4], 1);
+    trel[n] = c >> 2;
+    cls[n] = c;
+    atomicAdd(&h[c], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) bh[blockIdx.x * 16 + threadIdx.x] = h[threadIdx.x];
+}
+// bh[b][c] -> first list position of class c in workgroup b; cnt[0..3] = track sizes; cnt[8 + 5t + k] = boundaries b_k
+__global__ void __launch_bounds__(64) k_class_scan(int* __restrict__ bh, int nblk, int N, int* __restrict__ cnt) {
+  __shared__ int tot[16];
+  const int c = threadIdx.x;
+  if (c < 16) {
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) { const int v = bh[b * 16 + c]; bh[b * 16 + c] = run; run += v; }
+    tot[c] = run;
+  }
+  __syncthreads();
+  if (c < 16) {
+    const int t = c >> 2;
+    int off = 0;
+    for (int k = t * 4; k < c; ++k) off += tot[k];
+    const int base = t * N + off;
+    for (int b = 0; b < nblk; ++b) bh[b * 16 + c] += base;
+    cnt[8 + t * 5 + (c & 3)] = off;
+    if ((c & 3) == 3) { cnt[8 + t * 5 + 4] = off + tot[c]; cnt[t] = off + tot[c]; }
+  }
+}
+__global__ void __launch_bounds__(CLS_T) k_class_scatter(const int* __restrict__ cls, const int* __restrict__ bh, int N,
+                                                        int* __restrict__ list) {
+  __shared__ int wcnt[CLS_T / 64][16];
+  const int n = blockIdx.x * CLS_T + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = n < N ? cls[n] : -1;
+  int rank = 0;
+  for (int k = 0; k < 16; ++k) {                                   // stable rank inside the wave, class by class
+    const unsigned long long m = __ballot(c == k);
+    if (c == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[w][k] = __popcll(m);
+  }
+  __syncthreads();
+  if (c >= 0) {
+    for (int q = 0; q < w; ++q) rank += wcnt[q][c];
+    list[bh[blockIdx.x * 16 + c] + rank] = n;
+  }
 }
 
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
@@ -252,14 +306,14 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
                      colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
                      reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
   {
-    int* flags4 = sums + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;
+    int* cls = sums + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;     // [N] node class, then [nblk][16] histograms
+    const int nblk = (int)pm_cdiv(N, CLS_T);
+    int* bh = cls + N;
     int* tcnt = plan + o[PM_PLAN_TRK_CNT];
-    hipMemsetAsync(tcnt, 0, sizeof(int) * 8, st);
-    hipMemsetAsync(flags4, 0, sizeof(int) * 4 * ((int64_t)N + 1), st);
-    hipLaunchKernelGGL(k_node_trel, dim3(pm_cdiv(N, T)), dim3(T), 0, st, rowptr, N, plan + o[PM_PLAN_NODE_TREL], flags4, tcnt);
-    for (int t = 0; t < 4; ++t) exclusive_scan(flags4 + (int64_t)t * (N + 1), (int64_t)N + 1, sums, st);
-    hipLaunchKernelGGL(k_trk_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, plan + o[PM_PLAN_NODE_TREL], flags4, N,
-                       plan + o[PM_PLAN_TRK_LIST], tcnt);
+    hipMemsetAsync(tcnt, 0, sizeof(int) * 32, st);
+    hipLaunchKernelGGL(k_node_class, dim3(nblk), dim3(CLS_T), 0, st, rowptr, N, plan + o[PM_PLAN_NODE_TREL], cls, bh, tcnt);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, st, bh, nblk, N, tcnt);
+    hipLaunchKernelGGL(k_class_scatter, dim3(nblk), dim3(CLS_T), 0, st, cls, bh, N, plan + o[PM_PLAN_TRK_LIST]);
   }
   hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N, n_slots,
                      plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_ROW_LIST], plan + o[PM_PLAN_GROUP_CNT]);

@@ -217,6 +217,12 @@ typedef struct PmGemmDesc {
                         a_plane_stride / b_plane_stride ELEMENTS apart, lda / ldb and the group strides count bf16
                         elements (multiples of 8); the six-product split GEMM then runs without conversion work */
   int64_t a_plane_stride, b_plane_stride;
+  const int32_t* class_ptr; /* optional, with row lists: per group 5 boundaries b0..b4 of the list (PM_PLAN_TRK_CNT + 8):
+                        rows [b1,b3) have a non-zero second block, rows [b2,b4) a non-zero third block of the
+                        [4 x class_block] blocked dimension (K when !transA && !transB, N when transB, M when transA);
+                        the all-zero blocks are skipped tile by tile (C tiles that only hold such blocks are left
+                        untouched when transB).  Results are unchanged where they are defined. */
+  int32_t class_block;
 } PmGemmDesc;
 int pm_gemm_f32_desc(const PmGemmDesc* desc, pm_stream_t stream);
 

@@ -39,6 +39,8 @@ struct GemmArgs {
   // panels of ALL groups are enumerated along blockIdx.x (gridDim.y == 1) so that no dead workgroup is launched
   int ngroups, packed;
   int64_t a_ps, b_ps;                        // planes mode: distance between the bf16 planes of A / B (elements)
+  // row classes of the compact GCL (see PmGemmDesc.class_ptr): boundaries [ngroups][5], block size, masked dimension
+  const int32_t* cls_ptr; int cls_blk, cls_dim;
   double* colstats;                          // optional [2][N]: += column sums of the stored values and of their squares
 };
 
@@ -357,6 +359,30 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
   }
   const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN;
   if (m0 >= M) return;
+  // Row classes (compact GCL): rows [b1,b3) of the group's list receive onset edges, rows [b2,b4) next edges; for all
+  // other rows that block of the aggregate is identically zero.  Forward (cls_dim 1): skip those K blocks for a row
+  // tile without such rows; input gradient (2): skip the output tiles nobody reads; weight gradient (3): contract
+  // only over the rows whose block is non-zero.
+  bool use_on = true, use_nx = true;
+  if (g.cls_dim) {
+    const int* cb = g.cls_ptr + grp * 5;
+    const int on_lo = cb[1], on_hi = cb[3], nx_lo = cb[2], nx_hi = cb[4];
+    if (TA) {
+      const int mb = m0 / g.cls_blk;
+      const int lo = mb == 1 ? on_lo : (mb == 2 ? nx_lo : 0), hi = mb == 1 ? on_hi : (mb == 2 ? nx_hi : K);
+      g.rowmap += lo;
+      K = hi - lo;
+      if (K <= 0) return;
+      kper = (((K + (int)gridDim.z - 1) / (int)gridDim.z + BK - 1) / BK) * BK;
+    } else {
+      use_on = m0 < on_hi && m0 + BM > on_lo;
+      use_nx = m0 < nx_hi && m0 + BM > nx_lo;
+      if (g.cls_dim == 2) {
+        const int nb_ = n0 / g.cls_blk;
+        if ((nb_ == 1 && !use_on) || (nb_ == 2 && !use_nx)) return;
+      }
+    }
+  }
   const int kbeg = zs * kper;
   int kend = kbeg + kper;
   if (kend > K) kend = K;
@@ -392,19 +418,33 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     pa.init(reinterpret_cast<const char*>(g.A), g.a_ps * 2, g.lda, m0, M, mapA, g.rpe);
     pb.init(reinterpret_cast<const char*>(g.B), g.b_ps * 2, g.ldb, n0, g.N, mapB, g.rpe, g.b_split,
             (int)(grp * g.b_boff * 2), (int)(g.b_hi * 2));
+    // k sequence: all of [kbeg, kend), or (forward with row classes) only the K blocks this row tile needs
+    int kblk = kend - kbeg, kv_end = kend - kbeg, s1 = 1, s2 = 2;          // (scalars: no indexed private array)
+    if (!TA && g.cls_dim == 1) {
+      kblk = g.cls_blk;
+      s1 = use_on ? 1 : (use_nx ? 2 : 3);
+      s2 = use_on ? (use_nx ? 2 : 3) : 3;
+      kv_end = (2 + (use_on ? 1 : 0) + (use_nx ? 1 : 0)) * kblk;
+    }
+    auto kmap = [&](int v) {                     // virtual k (multiple of BK) -> k; past the end -> kend (loads return 0)
+      if (v >= kv_end) return kend;
+      if (kblk == kend - kbeg) return kbeg + v;
+      const int q = v / kblk;
+      return (q == 0 ? 0 : q == 1 ? s1 : q == 2 ? s2 : 3) * kblk + (v - q * kblk);
+    };
     pa.prime(kbeg, kend);
     pb.prime(kbeg, kend);
-    pa.load(kbeg, kend);
-    pb.load(kbeg, kend);
+    pa.load(kmap(0), kend);
+    pb.load(kmap(0), kend);
     char* const Bx1 = Ax0 + StA::XBYTES;
     pa.store(Ax0);
     pb.store(Bx1);
     __syncthreads();
     const char* as = Ax0 + StA::x6_lane_off(wr * WM, lane);
     const char* bs = Bx1 + StB::x6_lane_off(wc * WN, lane);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      pa.load(k0 + BK, kend);                  // (past the end: out-of-range offsets, returns 0, no traffic)
-      pb.load(k0 + BK, kend);
+    for (int v0 = 0; v0 < kv_end; v0 += BK) {
+      pa.load(kmap(v0 + BK), kend);            // (past the end: out-of-range offsets, returns 0, no traffic)
+      pb.load(kmap(v0 + BK), kend);
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 a[3][TM], b[3][TN];
@@ -425,7 +465,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
-      if (k0 + BK < kend) {
+      if (v0 + BK < kv_end) {
         pa.store(Ax0);
         pb.store(Bx1);
       }
@@ -697,9 +737,16 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
       return PM_E_INVALID;
   }
   g.a_ps = q->a_plane_stride; g.b_ps = q->b_plane_stride;
+  g.cls_ptr = q->class_ptr; g.cls_blk = q->class_block; g.cls_dim = 0;
   // planes mode: 64x64x32 tiles (measured in the step: 128x64x32 85 us, 128x128x32 97-130 us against 70-80 us)
   const int cfg = planes ? 8 : pick_config(transA, M, N, K, va && vb, n_groups == 1 && !q->rowmap);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
+  if (q->class_ptr && q->class_block > 0 && q->rowmap && q->dyn_entries && q->rows_per_entry == 1) {
+    const int blk = q->class_block;           // which dimension carries the [track | onset | next | x] blocks
+    if (transA) { if (M == 4 * blk && blk % BM == 0) g.cls_dim = 3; }
+    else if (transB) { if (N == 4 * blk && blk % BN == 0) g.cls_dim = 2; }
+    else if (planes && K == 4 * blk && blk % BK == 0 && q->split_k == 1) g.cls_dim = 1;
+  }
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
   // a gathered dimension with a device-side count per group: the groups PARTITION the rows, so the live work is
@@ -771,6 +818,7 @@ extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N,
   q.bias_group_stride = bias_group_stride; q.map_group_stride = map_group_stride; q.dyn_group_stride = dyn_group_stride;
   q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0; q.col_stats = nullptr;
   q.operand_planes = 0; q.a_plane_stride = 0; q.b_plane_stride = 0;
+  q.class_ptr = nullptr; q.class_block = 0;
   return pm_gemm_f32_desc(&q, stream);
 }
 

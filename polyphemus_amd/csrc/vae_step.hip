@@ -98,8 +98,8 @@ PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
   PmGemmDesc q;
   memset(&q, 0, sizeof(q));
   q.flags = PM_GEMM_PARTITION; q.split_k = 1; q.rowmap = pv.trk_list; q.rows_per_entry = 1; q.dyn_entries = pv.trk_cnt;
+  if (!getenv("PM_GCL_NO_CLASSES")) { q.class_ptr = pv.trk_cnt + 8; q.class_block = d; }   // skip all-zero onset / next blocks
   q.n_groups = 4; q.map_group_stride = N; q.dyn_group_stride = 1;
-  (void)d;
   return q;
 }
 

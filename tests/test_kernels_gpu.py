@@ -617,3 +617,63 @@ def test_accuracy_and_structure_metric_kernels():
     pred = torch.sigmoid(s_log) >= 0.5
     t = s_tgt.bool()
     assert m == [int((pred == t).sum()), int((pred & t).sum()), int(pred.sum()), int(t.sum())]
+
+
+def test_plan_track_lists_are_class_sorted_and_gemm_skips_zero_blocks():
+    """PM_PLAN_TRK_LIST / TRK_CNT: per track relation the nodes sorted by (receives onset edges, receives next edges) in
+    the order (0,0) (1,0) (1,1) (0,1) with boundaries b0..b4, ascending inside a class; and the three GCL contractions
+    with `class_ptr` (all-zero onset / next blocks skipped tile by tile) equal the unmasked ones wherever defined."""
+    cpu = synthetic_batch(24, 2, p=0.2, seed=13)
+    b, plan = make_plan(cpu)
+    N = cpu.num_nodes
+    dst, et = cpu.edge_index[1].numpy(), cpu.edge_type.numpy()
+    on, nx = np.zeros(N, bool), np.zeros(N, bool)
+    on[dst[et == 4]] = True
+    nx[dst[et == 5]] = True
+    trel = np.zeros(N, np.int64)
+    for r in range(4):
+        trel[dst[et == r]] = r
+    cnt = plan.field("trk_cnt").cpu().numpy()
+    lists = plan.field("trk_list").cpu().numpy()[:4 * N].reshape(4, N)
+    gray = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}
+    cls = np.array([gray[(bool(a), bool(c))] for a, c in zip(on, nx)])
+    for t in range(4):
+        bnd = cnt[8 + 5 * t: 8 + 5 * t + 5]
+        assert bnd[0] == 0 and bnd[4] == cnt[t] == int((trel == t).sum())
+        for k in range(4):
+            want = np.nonzero((trel == t) & (cls == k))[0]
+            np.testing.assert_array_equal(lists[t, bnd[k]:bnd[k + 1]], want)
+    # masked contractions == unmasked ones (d = 64: one 64-wide tile per block column)
+    d = 64
+    dd = d * d
+    torch.manual_seed(0)
+    A = torch.randn(N, 4 * d, device=DEV)
+    nodes = torch.arange(N)
+    A[torch.from_numpy(~on), d:2 * d] = 0                           # the aggregate's zero blocks
+    A[torch.from_numpy(~nx), 2 * d:3 * d] = 0
+    W = torch.randn(7 * d, d, device=DEV)
+    dh = torch.randn(N, d, device=DEV)
+    Ap, Wp, dhp = ops.split_planes(A), ops.split_planes(W), ops.split_planes(dh)
+    tl = plan.field("trk_list")
+    tc = plan.field("trk_cnt")
+    grp = dict(rowmap=tl, rows_per_entry=1, dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1,
+               partition=True, planes=True)
+    res = []
+    for masked in (False, True):
+        ck = dict(class_ptr=tc[8:], class_block=d) if masked else {}
+        h = torch.zeros(N, d, device=DEV)
+        ops.gemm_desc(Ap, Wp, h, N, d, 4 * d, 4 * d, d, d, b_group_stride=dd, b_split_rows=d, b_shared_off=3 * dd,
+                      a_plane_stride=A.numel(), b_plane_stride=W.numel(), **grp, **ck)
+        dA = torch.zeros(N, 4 * d, device=DEV)
+        ops.gemm_desc(dhp, Wp, dA, N, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
+                      b_shared_off=3 * dd, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), **grp, **ck)
+        dW = torch.zeros(7 * d, d, device=DEV)
+        ops.gemm_desc(Ap, dhp, dW, 4 * d, d, N, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
+                      c_split_rows=d, c_shared_off=3 * dd, a_plane_stride=A.numel(), b_plane_stride=dh.numel(), **grp, **ck)
+        res.append((h, dA, dW))
+    (h0, dA0, dW0), (h1, dA1, dW1) = res
+    assert rel_err(h1, h0) < 1e-6 and rel_err(dW1, dW0) < 1e-6
+    keep = torch.ones(N, 4 * d, dtype=torch.bool, device=DEV)      # dA: only the blocks a node's edges can read are defined
+    keep[torch.from_numpy(~on), d:2 * d] = False
+    keep[torch.from_numpy(~nx), 2 * d:3 * d] = False
+    assert rel_err(dA1[keep], dA0[keep]) < 1e-6

@@ -31,8 +31,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak; a split-mode fp32 p
 # Memory-side bytes per launch of the dominant kernels at the DEFAULT workload, from separate `rocprofv3 --pmc FETCH_SIZE`
 # / `--pmc WRITE_SIZE` passes over this same command (profiles/r01_v5_kernel_stats.md; reads doubled per the gfx950
 # FETCH_SIZE rule of MI355X_MICROARCH.md).  bench.py cannot read PMC counters itself; other workloads report null.
-PMC_TRAFFIC_DEFAULT = {"gemm_NT_planes:64x64x32": 109.4e6, "gemm_NN_planes:64x64x32": 136.5e6,
-                       "gemm_TN_planes:64x64x32": 142.9e6, "segreduce_fwd": 163.6e6}
+PMC_TRAFFIC_DEFAULT = {"gemm_NT_planes:64x64x32": 99.7e6, "gemm_NN_planes:64x64x32": 119.6e6,
+                       "gemm_TN_planes:64x64x32": 152.5e6, "segreduce_fwd": 163.9e6}
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; ~6.3 TB/s achievable
 
 

@@ -141,3 +141,27 @@ def test_native_step_on_foreign_graphs_takes_the_seven_block_path():
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(lb[k])), k
     assert rel_err(ga, gb) < 1e-4
+
+
+def test_native_step_with_all_fifteen_slots_active():
+    """`n_slots` = 15 (no PAD-only tail: the chord encoder / decoder take their plain full-width path) must give the
+    same step as the batch's own (smaller) active-slot count and as the python orchestration."""
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    base = synthetic_batch(6, 2, p=0.3, seed=21)
+    assert base.n_slots < 15
+    eps = torch.randn(6, 32, device=DEV)
+    res = []
+    for native, slots in ((True, 15), (True, base.n_slots), (False, base.n_slots)):
+        batch = synthetic_batch(6, 2, p=0.3, seed=21)
+        batch.n_slots = slots
+        torch.manual_seed(0)
+        vae = VAE(**cfg, device=DEV).to(DEV)
+        vae.train()
+        vae.msg_dropout = 0.0
+        tr = HipTrainer(vae, lr=5e-6, native=native)
+        out = tr.losses_dict(tr.train_step(batch.to(DEV), eps))
+        res.append((out, tr.grads.clone()))
+    for (la, ga) in res[:2]:
+        for k in la:
+            assert abs(la[k] - res[2][0][k]) <= 1e-6 * max(1.0, abs(res[2][0][k])), k
+        assert rel_err(ga, res[2][1]) < 2e-3

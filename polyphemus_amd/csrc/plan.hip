@@ -224,22 +224,34 @@ __global__ void __launch_bounds__(CLS_T) k_node_class(const int* __restrict__ ro
   __syncthreads();
   if (threadIdx.x < 16) bh[blockIdx.x * 16 + threadIdx.x] = h[threadIdx.x];
 }
-// bh[b][c] -> first list position of class c in workgroup b; cnt[0..3] = track sizes; cnt[8 + 5t + k] = boundaries b_k
-__global__ void __launch_bounds__(64) k_class_scan(int* __restrict__ bh, int nblk, int N, int* __restrict__ cnt) {
+// bh[b][c] -> first list position of class c in workgroup b; cnt[0..3] = track sizes; cnt[8 + 5t + k] = boundaries b_k.
+// One wave per class (16 waves): column sums, then an exclusive scan down the column 64 workgroups at a time.
+__global__ void __launch_bounds__(1024) k_class_scan(int* __restrict__ bh, int nblk, int N, int* __restrict__ cnt) {
   __shared__ int tot[16];
-  const int c = threadIdx.x;
-  if (c < 16) {
-    int run = 0;
-    for (int b = 0; b < nblk; ++b) { const int v = bh[b * 16 + c]; bh[b * 16 + c] = run; run += v; }
-    tot[c] = run;
-  }
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int sum = 0;
+  for (int b = lane; b < nblk; b += 64) sum += bh[b * 16 + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) tot[c] = sum;
   __syncthreads();
-  if (c < 16) {
-    const int t = c >> 2;
-    int off = 0;
-    for (int k = t * 4; k < c; ++k) off += tot[k];
-    const int base = t * N + off;
-    for (int b = 0; b < nblk; ++b) bh[b * 16 + c] += base;
+  const int t = c >> 2;
+  int off = 0;
+  for (int k = t * 4; k < c; ++k) off += tot[k];
+  int run = t * N + off;
+  for (int base = 0; base < nblk; base += 64) {
+    const int b = base + lane;
+    const int v = b < nblk ? bh[b * 16 + c] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (b < nblk) bh[b * 16 + c] = run + x - v;
+    run += __shfl(x, 63, 64);
+  }
+  if (lane == 0) {
     cnt[8 + t * 5 + (c & 3)] = off;
     if ((c & 3) == 3) { cnt[8 + t * 5 + 4] = off + tot[c]; cnt[t] = off + tot[c]; }
   }
@@ -312,7 +324,7 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
     int* tcnt = plan + o[PM_PLAN_TRK_CNT];
     hipMemsetAsync(tcnt, 0, sizeof(int) * 32, st);
     hipLaunchKernelGGL(k_node_class, dim3(nblk), dim3(CLS_T), 0, st, rowptr, N, plan + o[PM_PLAN_NODE_TREL], cls, bh, tcnt);
-    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, st, bh, nblk, N, tcnt);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(1024), 0, st, bh, nblk, N, tcnt);
     hipLaunchKernelGGL(k_class_scatter, dim3(nblk), dim3(CLS_T), 0, st, cls, bh, N, plan + o[PM_PLAN_TRK_LIST]);
   }
   hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N, n_slots,

@@ -204,7 +204,35 @@ struct TileStage {
 // conversion arithmetic in the GEMM.  Element = bf16, `ld` in elements, rows addressed like TileStage.
 template <int R, int BK, int THREADS, bool KC>
 struct PlaneStage {
-  using Img = TileStage<R, BK, THREADS, KC, true>;      // image geometry + fragment readers
+  using Img = TileStage<R, BK, THREADS, KC, true>;      // padded image geometry (shared with the in-kernel split mode)
+  // XOR-swizzled images where the row is exactly 64 bytes (KC, BK = 32) or 128 bytes (!KC, R = 64): no pad, and
+  // both the 16-byte stores and the fragment reads are bank-conflict free —
+  //   KC : 16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 group reads hit 16
+  //        different 16-byte slots of the 256-byte bank window, a row stays one contiguous 64-byte line for the stores;
+  //   !KC: the two 64-byte halves of k-row k are swapped when (k >> 1) & 1: the four k-rows of a ds_read_b64_tr_b16
+  //        block land in four different 64-byte slots.
+  static constexpr bool SWZ = KC ? (BK == 32) : (R == 64);
+  static constexpr int PROWB = SWZ ? (KC ? 64 : 128) : Img::XROWB;
+  static constexpr int PPLANE = (KC ? R : BK) * PROWB;
+  static constexpr int PBYTES = 3 * PPLANE;
+  // fragment of the 32-row block starting at tile row `row0` for k-step ks (16 wide), plane base S
+  __device__ static inline bf16x8 frag(const char* S, int row0, int ks, int lane) {
+    if (KC) {
+      const int rr = row0 + (lane & 31), c = ks * 2 + (lane >> 5);
+      const int cc = SWZ ? (c ^ ((rr >> 2) & 3)) : c;
+      return *reinterpret_cast<const bf16x8*>(S + rr * PROWB + cc * 16);
+    }
+    const int g = lane >> 4, i = lane & 15, q = i >> 2;
+    const int k = ks * 16 + 8 * (g >> 1) + q;
+    int colb = (row0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+    if (SWZ) colb ^= ((k >> 1) & 1) << 6;                 // (same for k + 4)
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const char* p0 = S + k * PROWB + colb;
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * PROWB));
+    const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, t);
+  }
   static constexpr int NV = (R * BK / 8) / THREADS;     // 16-byte chunks per plane and thread
   static_assert((R * BK / 8) % THREADS == 0 && NV >= 1, "tile does not divide over the workgroup");
   u32x4 v[3][NV];
@@ -268,9 +296,16 @@ struct PlaneStage {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int f = tid + j * THREADS;
-      const int off = KC ? (f / (BK / 8)) * Img::XROWB + (f % (BK / 8)) * 16 : (f / (R / 8)) * Img::XROWB + (f % (R / 8)) * 16;
+      int off;
+      if (KC) {
+        const int r = f / (BK / 8), kc = f % (BK / 8);
+        off = r * PROWB + (SWZ ? (kc ^ ((r >> 2) & 3)) : kc) * 16;
+      } else {
+        const int k = f / (R / 8), rc = f % (R / 8);
+        off = k * PROWB + (SWZ ? ((rc * 16) ^ (((k >> 1) & 1) << 6)) : rc * 16);
+      }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(S + p * Img::XPLANE + off) = v[p][j];
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(S + p * PPLANE + off) = v[p][j];
     }
   }
 };
@@ -436,12 +471,10 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     pb.prime(kbeg, kend);
     pa.load(kmap(0), kend);
     pb.load(kmap(0), kend);
-    char* const Bx1 = Ax0 + StA::XBYTES;
+    char* const Bx1 = Ax0 + PA_::PBYTES;
     pa.store(Ax0);
     pb.store(Bx1);
     __syncthreads();
-    const char* as = Ax0 + StA::x6_lane_off(wr * WM, lane);
-    const char* bs = Bx1 + StB::x6_lane_off(wc * WN, lane);
     for (int v0 = 0; v0 < kv_end; v0 += BK) {
       pa.load(kmap(v0 + BK), kend);            // (past the end: out-of-range offsets, returns 0, no traffic)
       pb.load(kmap(v0 + BK), kend);
@@ -451,9 +484,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[p][i] = StA::x6_frag(as + p * StA::XPLANE + i * StA::XSTEP_I + ks * StA::XSTEP_K);
+          for (int i = 0; i < TM; ++i) a[p][i] = PA_::frag(Ax0 + p * PA_::PPLANE, wr * WM + i * 32, ks, lane);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[p][j] = StB::x6_frag(bs + p * StB::XPLANE + j * StB::XSTEP_I + ks * StB::XSTEP_K);
+          for (int j = 0; j < TN; ++j) b[p][j] = PB_::frag(Bx1 + p * PB_::PPLANE, wc * WN + j * 32, ks, lane);
         }
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
@@ -638,9 +671,11 @@ template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, b
 static void launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
   using StA = TileStage<BM, BK, 64 * WVM * WVN, !TA, VA>;
   using StB = TileStage<BN, BK, 64 * WVM * WVN, TB, VB>;
-  const size_t lds = MODE == 1 ? (size_t)2 * (StA::XBYTES + StB::XBYTES)
-                   : MODE == 2 ? (size_t)(StA::XBYTES + StB::XBYTES)
-                               : sizeof(float) * 2 * BK * (StA::LD + StB::LD);
+  size_t lds;
+  if constexpr (MODE == 2)
+    lds = (size_t)(PlaneStage<BM, BK, 64 * WVM * WVN, !TA>::PBYTES + PlaneStage<BN, BK, 64 * WVM * WVN, TB>::PBYTES);
+  else
+    lds = MODE == 1 ? (size_t)2 * (StA::XBYTES + StB::XBYTES) : sizeof(float) * 2 * BK * (StA::LD + StB::LD);
   auto kern = k_gemm<BM, BN, BK, WVM, WVN, TA, TB, VA, VB, MODE>;
   static bool attr_done = false;             // > 64 KiB of dynamic LDS needs the attribute (once per instantiation)
   if (lds > 64 * 1024 && !attr_done) {

@@ -112,6 +112,20 @@ int pm_graph_emit(float* s_tensor, int32_t G, int32_t n_bars, const int32_t* nod
                   int64_t E, int64_t* edge_index, int32_t* edge_type, int32_t* edge_dist, int64_t* bars, int64_t* batch,
                   uint8_t* is_drum, int32_t* node_cell, pm_stream_t stream);
 
+/* Generation helpers, no host synchronisation:
+ *   pm_binary_from_logits: `Decoder._binary_from_logits` (model.py:609-623): sigmoid(s_logits) >= thresh, an empty bar
+ *                          gets cell [0,0]; written as float 0/1 and / or bytes (either output may be NULL, not both).
+ *   pm_mtp_from_logits   : `mtp_from_logits` (utils.py:59-79): mtp [G,4,32,15,230] = the node's logits on active cells
+ *                          (nodes numbered in cell order), the hard silence elsewhere (row 0 one-hot pitch EOS = 129,
+ *                          rows 1..14 one-hot pitch PAD = 130).  bar_nodes [G] and node_ptr [G+1] are workspaces;
+ *                          node_ptr[G] returns the number of active cells, which the caller compares with N (the
+ *                          reference raises on a mismatch; the kernel itself writes silence for nodes >= N). */
+int pm_binary_from_logits(const float* s_logits /* [G,4,32] */, int32_t G, float thresh, float* s_f32 /* [G,4,32] */,
+                          uint8_t* s_u8 /* [G,4,32] */, pm_stream_t stream);
+int pm_mtp_from_logits(const float* c_logits /* [N,15,230] */, const float* s_tensor /* [G,4,32] 0/1 */, int32_t G,
+                       int64_t N, int32_t* bar_nodes /* [G] */, int32_t* node_ptr /* [G+1] */,
+                       float* mtp /* [G,4,32,15,230] */, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ message aggregation
  * `GCL.message` + PyG `propagate` + torch_scatter mean (model.py:110,123-135):
  *   A[n, r*d:(r+1)*d] = mean_{e: dst=n, type=r} keep_e * relu(x[src_e] * T[dist_e]) / (1-p)

@@ -19,7 +19,9 @@ What is captured:
                   parameter; buffers + parameters after 1 and 2 Adam steps
                   (train.py:181, training.py:152-172, lr from ExpDecayLRScheduler).
 
-Usage:  python oracle/make_golden.py      (from the repo root)
+  <case>_generate.npz   the generation helpers (`_binary_from_logits`, `decoder(z, None)`, `mtp_from_logits`)
+
+Usage:  python oracle/make_golden.py [generate]     (from the repo root; `generate` rewrites only <case>_generate.npz)
 """
 import json
 import os
@@ -201,10 +203,65 @@ def capture_case(name, cfg, batch_size, p, seed, corner=False):
           f"params={sum(q.numel() for q in vae.parameters())} losses={losses}")
 
 
+def capture_generation(name):
+    """Generation helpers of the reference on the committed case `name` (its state_dict and inputs are read back
+    from tests/golden/<name>.npz, so the big case files need not be regenerated):
+      cond/*  `mtp_from_logits(eval c_logits, batch s_tensor)` (utils.py:59-79; generate.py:26-35 with s_tensor_cond)
+      gen/*   `vae.decoder(z, None)` in eval mode (model.py:634-655: threshold -> host graph build -> content decoder),
+              `_binary_from_logits` (model.py:609-623) and the resulting mtp.
+    The [.,4,32,15,230] pianorolls are stored as a sha256 of their bytes plus per-cell sums; c_logits of the gen path as
+    per-node sums, arg-max tokens and the first nodes' rows."""
+    import hashlib
+    os.chdir(REF)
+    import utils as ref_utils
+    os.chdir(_cwd)
+    z0 = np.load(os.path.join(REPO, "tests", "golden", f"{name}.npz"))
+    cfg = json.loads(str(z0["cfg"]))
+    vae = ref_model.VAE(**cfg, device=torch.device("cpu"))
+    vae.load_state_dict({k[3:]: torch.from_numpy(z0[k]) for k in z0.files if k.startswith("sd/")})
+    vae.eval()
+    out = {}
+    B, nb = z0["in/eps"].shape[0], cfg["n_bars"]
+    s_cond = torch.from_numpy(z0["in/s_tensor"]).view(B, nb, 4, 32).float()
+    mtp = ref_utils.mtp_from_logits(torch.from_numpy(z0["eval/c_logits"]), s_cond)
+    out["cond/mtp_sha256"] = np.array(hashlib.sha256(mtp.numpy().tobytes()).hexdigest())
+    out["cond/mtp_cellsum"] = mtp.double().sum(dim=(-1, -2)).numpy()
+    zs = torch.from_numpy(z0["in/eps"]) * 3.0                       # a wider latent sample: more varied structures
+    with torch.no_grad():
+        s_logits, c_logits = vae.decoder(zs, None)
+        s_bin = vae.decoder._binary_from_logits(s_logits)
+        mtp = ref_utils.mtp_from_logits(c_logits, s_bin)
+    out["gen/z"], out["gen/s_logits"] = zs.numpy(), s_logits.numpy()
+    out["gen/s_binary"] = s_bin.numpy().astype(np.uint8)
+    out["gen/num_nodes"] = np.int32(c_logits.shape[0])
+    out["gen/c_logits_head"] = c_logits[:4].numpy()
+    out["gen/c_logits_nodesum"] = c_logits.double().sum(dim=(-1, -2)).numpy()
+    out["gen/c_argmax"] = np.stack([c_logits[..., :C.N_PITCH_TOKENS].argmax(-1).numpy(),
+                                    c_logits[..., C.N_PITCH_TOKENS:].argmax(-1).numpy()], -1).astype(np.int16)
+    out["gen/mtp_cellsum"] = mtp.double().sum(dim=(-1, -2)).numpy()
+    # threshold corner cases: logits around 0 (sigmoid rounds to exactly 0.5 for tiny negative logits), +-inf, an empty bar
+    corner = torch.zeros(1, 4, 4, 32)
+    corner[0, 0] = torch.linspace(-2e-7, 2e-7, 128).view(4, 32)
+    corner[0, 1] = -5.0                                              # empty bar -> [0,0] switched on
+    corner[0, 2] = torch.randn(4, 32, generator=torch.Generator().manual_seed(5)) * 1e-3
+    corner[0, 3, 0, :4] = torch.tensor([float("inf"), float("-inf"), 88.0, -104.0])
+    out["corner/s_logits"] = corner.numpy()
+    out["corner/s_binary"] = vae.decoder._binary_from_logits(corner).numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}_generate.npz"), **out)
+    print(f"{name}_generate.npz: gen nodes={int(c_logits.shape[0])} active={int(s_bin.sum())} "
+          f"corner on={int(out['corner/s_binary'].sum())}")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["generate"]:
+        capture_generation("lmd2_tiny")
+        capture_generation("nb3_tiny")
+        sys.exit(0)
     make_graphs()
     capture_case("lmd2_tiny", dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8),
                  batch_size=8, p=0.06, seed=11, corner=True)
     capture_case("nb3_tiny", dict(dropout=0, batch_norm=True, gnn_n_layers=1, d=16, n_bars=3, resolution=8),
                  batch_size=6, p=0.05, seed=12)
+    capture_generation("lmd2_tiny")
+    capture_generation("nb3_tiny")

@@ -262,12 +262,27 @@ def vae_forward(graph, P: Params, cfg, training: bool, eps: Optional[torch.Tenso
 
 
 def binary_from_logits(s_logits, thresh: float = 0.5):
-    """`Decoder._binary_from_logits` (model.py:609-623)."""
-    s = torch.sigmoid(s_logits) >= thresh
+    """`Decoder._binary_from_logits` (model.py:609-623): >= thresh -> 1, < thresh -> 0, `.bool()` (a NaN stays NaN and
+    becomes True); empty bars get cell [0,0]."""
+    s = ~(torch.sigmoid(s_logits) < thresh)
     empty = ~s.any(dim=-1).any(dim=-1)
     idx = torch.nonzero(empty, as_tuple=True)
     s[idx + (0, 0)] = True
     return s
+
+
+def mtp_from_logits(c_logits, s_tensor):
+    """`mtp_from_logits` (utils.py:59-79): [B,nb,4,32,15,230]; active cells (row-major, the node order) take the nodes'
+    logits, the others the hard silence: row 0 one-hot pitch EOS (129), rows 1.. one-hot pitch PAD (130)."""
+    n_slots, d_tok = c_logits.shape[-2], c_logits.shape[-1]
+    on = s_tensor.bool().reshape(-1)
+    mtp = torch.zeros(on.numel(), n_slots, d_tok, dtype=c_logits.dtype)
+    silence = torch.zeros(n_slots, d_tok, dtype=c_logits.dtype)
+    silence[0, 129] = 1.0                                                    # constants.py:24
+    silence[1:, 130] = 1.0                                                   # constants.py:25
+    mtp[on] = c_logits                                                       # raises when the counts differ (utils.py:74)
+    mtp[~on] = silence
+    return mtp.reshape(*s_tensor.shape, n_slots, d_tok)
 
 
 # --------------------------------------------------------------------------- loss / optimiser

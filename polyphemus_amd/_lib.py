@@ -27,6 +27,8 @@ _SIGS = {
     "pm_edge_table_bwd": "pipps",
     "pm_graph_count": "pippppps",
     "pm_graph_emit": "piippllppppppps",
+    "pm_binary_from_logits": "pifpps",
+    "pm_mtp_from_logits": "ppilppps",
     "pm_segreduce_fwd": "pppiiiifuuips",
     "pm_segreduce_fwd_planes": "pppiiiifuuipls",
     "pm_segreduce_bwd": "pppppiiiifuuipps",

@@ -308,7 +308,11 @@ class Decoder(nn.Module):
         return collate_samples(samples, self.n_bars).to(next(self.parameters()).device)
 
     def _binary_from_logits(self, s_logits):
-        s = torch.sigmoid(s_logits) >= self.sigmoid_thresh
+        # model.py:609-623.  A cuda tensor takes one kernel (csrc/generate.hip, no `nonzero` host sync); a host tensor
+        # (generate.py prepares its structures on the CPU) the reference's own few torch lines.
+        if s_logits.is_cuda:
+            return ops.binary_from_logits(s_logits.detach().contiguous().float(), self.sigmoid_thresh)
+        s = ~(torch.sigmoid(s_logits) < self.sigmoid_thresh)
         empty = ~s.any(dim=-1).any(dim=-1)
         idx = torch.nonzero(empty, as_tuple=True)
         s[idx + (0, 0)] = True

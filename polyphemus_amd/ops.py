@@ -168,6 +168,37 @@ def graph_build(s_tensor: torch.Tensor, n_bars: int):
     return out
 
 
+def binary_from_logits(s_logits: torch.Tensor, thresh: float = 0.5) -> torch.Tensor:
+    """`Decoder._binary_from_logits` (model.py:609-623) without the `nonzero` sync: bool tensor of s_logits' shape."""
+    _chk(s_logits, F32, "s_logits")
+    if s_logits.shape[-2:] != (4, 32):
+        raise ValueError("s_logits must be [..., 4, 32]")
+    out = torch.empty(s_logits.shape, dtype=U8, device=s_logits.device)
+    call("pm_binary_from_logits", ptr(s_logits), s_logits.numel() // 128, float(thresh), None, ptr(out), stream())
+    return out.view(torch.bool)
+
+
+def mtp_from_logits(c_logits: torch.Tensor, s_tensor: torch.Tensor, check: bool = True) -> torch.Tensor:
+    """`mtp_from_logits` (utils.py:59-79): [B,nb,4,32,15,230] with the nodes' logits on the active cells of `s_tensor`
+    ([B,nb,4,32], any dtype) and hard silences elsewhere.  `check` reads the active-cell count back (one host sync) and
+    raises like the reference's masked assignment when it differs from c_logits' node count."""
+    _chk(c_logits, F32, "c_logits")
+    if c_logits.dim() != 3 or c_logits.shape[1:] != (C.MAX_SIMU_TOKENS - 1, C.D_TOKEN_PAIR):
+        raise ValueError("c_logits must be [N,15,230]")
+    if s_tensor.dim() != 4 or s_tensor.shape[-2:] != (4, 32):
+        raise ValueError("s_tensor must be [B,n_bars,4,32]")
+    s = s_tensor.to(F32).contiguous()
+    G, N, dev = s.numel() // 128, c_logits.shape[0], c_logits.device
+    bn, npt = torch.empty(G, dtype=I32, device=dev), torch.empty(G + 1, dtype=I32, device=dev)
+    mtp = torch.empty(*s_tensor.shape, C.MAX_SIMU_TOKENS - 1, C.D_TOKEN_PAIR, dtype=F32, device=dev)
+    call("pm_mtp_from_logits", ptr(c_logits), ptr(s), G, N, ptr(bn), ptr(npt), ptr(mtp), stream())
+    if check:
+        active = int(npt[G])
+        if active != N:
+            raise ValueError(f"shape mismatch: s_tensor has {active} active cells, c_logits has {N} nodes")
+    return mtp
+
+
 def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int, out=None):
     _chk(x, F32, "x"); _chk(T, F32, "T")
     N, d = x.shape

@@ -119,3 +119,49 @@ def test_oracle_accuracies_match_reference(case):
     assert set(got) == set(want)
     for k, v in want.items():
         assert abs(got[k] - v) < 1e-7, (k, got[k], v)
+
+
+def _generate_golden(case):
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", f"{case}_generate.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_generation_helpers_match_reference(case):
+    """oracle.binary_from_logits / mtp_from_logits / decoder_forward on a thresholded structure == the reference's
+    `_binary_from_logits` (model.py:609-623), `mtp_from_logits` (utils.py:59-79) and `decoder(z, None)`
+    (model.py:634-655), captured by `oracle/make_golden.py generate`."""
+    import hashlib
+    from polyphemus_amd.graphs import collate_samples, graph_from_structure
+    z, cfg = load_case(case)
+    gg = _generate_golden(case)
+    # thresholding, including logits around 0, +-inf and an empty bar
+    for k in ("gen", "corner"):
+        got = vae_cpu.binary_from_logits(torch.from_numpy(gg[f"{k}/s_logits"]))
+        assert np.array_equal(got.numpy().astype(np.uint8), gg[f"{k}/s_binary"]), k
+    # the pianoroll laid out on the batch's own structure (generate.py:26-35 with s_tensor_cond): exact bytes
+    B, nb = z["in/eps"].shape[0], cfg["n_bars"]
+    s_cond = torch.from_numpy(z["in/s_tensor"]).view(B, nb, 4, 32)
+    mtp = vae_cpu.mtp_from_logits(torch.from_numpy(z["eval/c_logits"]), s_cond)
+    assert hashlib.sha256(mtp.numpy().tobytes()).hexdigest() == str(gg["cond/mtp_sha256"])
+    assert np.array_equal(mtp.double().sum(dim=(-1, -2)).numpy(), gg["cond/mtp_cellsum"])
+    with pytest.raises((RuntimeError, IndexError, ValueError)):
+        vae_cpu.mtp_from_logits(torch.from_numpy(z["eval/c_logits"][:-1]), s_cond)
+    # decoder(z, None): structure from the thresholded logits, then the content decoder on the graphs built from it
+    s_bin = gg["gen/s_binary"].astype(bool)
+    samples = []
+    for i in range(B):
+        g = graph_from_structure(s_bin[i])
+        g["tokens"] = np.zeros((g["num_nodes"], 16, 2), np.int32)
+        g["s_tensor"] = s_bin[i].astype(np.float32)
+        samples.append(g)
+    graph = collate_samples(samples, nb)
+    assert graph.num_nodes == int(gg["gen/num_nodes"])
+    P, _ = vae_cpu.split_state(state_dict_from_golden(z), [str(n) for n in z["param_names"]])
+    with torch.no_grad():
+        s_logits, c_logits = vae_cpu.decoder_forward(torch.from_numpy(gg["gen/z"]), graph, P, cfg, False)
+    assert rel_err(s_logits, gg["gen/s_logits"]) < 1e-6
+    assert rel_err(c_logits[:4], gg["gen/c_logits_head"]) < 1e-5
+    assert rel_err(c_logits.double().sum(dim=(-1, -2)), gg["gen/c_logits_nodesum"]) < 1e-5
+    mtp = vae_cpu.mtp_from_logits(c_logits, torch.from_numpy(s_bin))
+    assert rel_err(mtp.double().sum(dim=(-1, -2)), gg["gen/mtp_cellsum"]) < 1e-5

@@ -382,6 +382,10 @@ int pm_structure_metrics(const float* s_logits, const float* s_target, int64_t n
 int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                  float beta1, float beta2, float eps, int32_t step, float grad_scale, pm_stream_t stream);
 
+/* Gradient accumulation over `iters_to_accumulate` micro-batches (training.py:149,158: backward of tot_loss / k, optimizer
+ * step every k-th batch): accum = (first ? 0 : accum) + scale * grads, scale = 1 / k. */
+int pm_grad_accumulate(const float* grads, float* accum, int64_t n, float scale, int32_t first, pm_stream_t stream);
+
 /* Counter-based dropout mask shared by device code and the oracle (host-callable). */
 uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel);
 

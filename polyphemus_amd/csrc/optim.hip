@@ -37,6 +37,22 @@ __global__ void __launch_bounds__(256) k_adam1(float* __restrict__ p, const floa
     p[i] -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
   }
 }
+// acc = (first ? 0 : acc) + scale * g   (gradient accumulation over micro-batches, training.py:149,158)
+__global__ void __launch_bounds__(256) k_grad_accumulate(const float* __restrict__ g, float* __restrict__ acc, int64_t n,
+                                                         float scale, int first) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = g[i] * scale;
+    acc[i] = first ? v : acc[i] + v;
+  }
+}
+extern "C" int pm_grad_accumulate(const float* grads, float* accum, int64_t n, float scale, int32_t first,
+                                  pm_stream_t stream) {
+  if (!grads || !accum || n <= 0) return PM_E_INVALID;
+  int64_t nb = pm_cdiv(n, 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_grad_accumulate, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, grads, accum, n, scale,
+                     first);
+  return pm_check_launch();
+}
 extern "C" int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                             float beta1, float beta2, float eps, int32_t step, float grad_scale, pm_stream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return PM_E_INVALID;

@@ -325,6 +325,15 @@ def add(a, b, out=None):
     return o
 
 
+def grad_accumulate(grads, accum, scale: float, first: bool):
+    """accum = (0 if first else accum) + scale * grads (training.py:149,158)."""
+    _chk(grads, F32, "grads"); _chk(accum, F32, "accum")
+    if grads.numel() != accum.numel():
+        raise ValueError("grads / accum size mismatch")
+    call("pm_grad_accumulate", ptr(grads), ptr(accum), grads.numel(), float(scale), int(bool(first)), stream())
+    return accum
+
+
 def colsum_acc(x, M, C_, ld, out):
     call("pm_colsum_acc", ptr(x), M, C_, ld, ptr(out), stream())
 

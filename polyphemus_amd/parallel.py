@@ -53,9 +53,10 @@ class GradBuckets:
         self.views: List[torch.Tensor] = [flat_grads[a:b] for a, b in zip(edges[:-1], edges[1:])]
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._work = []
+        self.hold = False        # True: launches are skipped (micro-batches of a gradient accumulation)
 
     def launch(self, i: int) -> None:
-        if self.world > 1:
+        if self.world > 1 and not self.hold:
             self._work.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> float:

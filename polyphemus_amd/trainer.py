@@ -51,7 +51,8 @@ class ExpDecayLR:
 
 class HipTrainer:
     def __init__(self, vae: VAE, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler: Optional[dict] = None,
-                 structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None, native: bool = True):
+                 structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None, native: bool = True,
+                 iters_to_accumulate: int = 1):
         self.vae = vae
         self.lr, self.betas, self.eps = lr, betas, eps
         self.sched = ExpDecayLR(**lr_scheduler) if lr_scheduler else None
@@ -59,6 +60,10 @@ class HipTrainer:
         self.beta = beta
         self.pg = process_group
         self.native = native
+        if iters_to_accumulate < 1:
+            raise ValueError("iters_to_accumulate must be >= 1")
+        self.iters_to_accumulate = int(iters_to_accumulate)            # training.py:83,149,158
+        self.micro_batches = 0                                         # `tot_batches` of the reference
         flat = vae.flat_params
         if not flat.is_cuda:
             raise RuntimeError("HipTrainer needs the model on the GPU (vae.to('cuda')) before it is built")
@@ -87,6 +92,9 @@ class HipTrainer:
             assert (vae._offsets[n] < mid_lo) == late, f"unexpected parameter order at {n}"
         self.buckets = GradBuckets(self.grads, [mid_lo, dec_lo], process_group)
         self.world = self.buckets.world
+        # gradient accumulation: running sum of grads / k; all-reduced (one bucket) and consumed by Adam every k-th batch
+        self.grad_accum = torch.zeros_like(flat) if self.iters_to_accumulate > 1 else None
+        self._accum_bucket = GradBuckets(self.grad_accum, [], process_group) if self.grad_accum is not None else None
         broadcast_([vae.flat_params, vae.flat_buffers], 0, process_group)
         # native step plumbing
         self._layout = build_layout(vae)
@@ -194,8 +202,9 @@ class HipTrainer:
         return out
 
     def train_step(self, graph, eps: Optional[torch.Tensor] = None):
-        """One optimizer step on `graph` (device batch).  Returns the device tensor
-        [pitch, dur, structure, kld] of loss values (float64, no host sync)."""
+        """One batch of the training loop (training.py:137-172) on `graph` (device batch): forward, losses, backward
+        and — every `iters_to_accumulate`-th call — the Adam update and the LR-schedule step.  Returns the device
+        tensor [pitch, dur, structure, kld] of this batch's loss values (float64, no host sync)."""
         vae = self.vae
         if not vae.training:
             raise RuntimeError("train_step needs vae.train()")
@@ -204,11 +213,24 @@ class HipTrainer:
         if not vae.cfg["batch_norm"] or vae.cfg["dropout"] != 0:
             raise NotImplementedError("HIP path: needs batch_norm=True and cfg dropout == 0 (training.json)")
         self.grads.zero_()
+        k = self.iters_to_accumulate
+        self.buckets.hold = k > 1                      # micro-batches of an accumulation are not all-reduced one by one
         out = (self._native_forward_backward if self.native else self._python_forward_backward)(graph, eps)
-        mean_scale = self.buckets.wait()
+        self.micro_batches += 1
+        grads = self.grads
+        if k > 1:
+            # training.py:149: backward of tot_loss / k, summed into .grad; the update waits for the k-th batch (:158)
+            ops.grad_accumulate(self.grads, self.grad_accum, 1.0 / k, self.micro_batches % k == 1)
+            if self.micro_batches % k != 0:
+                return out
+            self._accum_bucket.launch(0)
+            mean_scale = self._accum_bucket.wait()
+            grads = self.grad_accum
+        else:
+            mean_scale = self.buckets.wait()
         # ---- optimizer (training.py:160-172)
         self.step_count += 1
-        ops.adam_step(vae.flat_params, self.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+        ops.adam_step(vae.flat_params, grads, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.step_count, grad_scale=mean_scale)
         if self.sched is not None:
             self.lr = self.sched.step()

@@ -165,3 +165,60 @@ def test_native_step_with_all_fifteen_slots_active():
         for k in la:
             assert abs(la[k] - res[2][0][k]) <= 1e-6 * max(1.0, abs(res[2][0][k])), k
         assert rel_err(ga, res[2][1]) < 2e-3
+
+
+def test_gradient_accumulation_matches_reference_loop():
+    """`iters_to_accumulate` = 2 (training.py:149,158): backward of tot_loss / 2 on two different batches, ONE Adam update
+    and ONE LR-schedule step per pair — against the drop-in module driven by the reference's own loop with
+    torch.optim.Adam (the path pinned to the goldens in test_model_gpu)."""
+    from oracle import vae_cpu
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    batches = [synthetic_batch(5 + i, 2, p=0.25, seed=40 + i).to(DEV) for i in range(4)]
+    epss = [torch.randn(5 + i, 32, generator=torch.Generator().manual_seed(60 + i)).to(DEV) for i in range(4)]
+    sched = dict(peak_lr=1e-4, warmup_steps=1, final_lr_scale=0.5, decay_steps=2)
+    torch.manual_seed(0)
+    ref = VAE(**cfg, device=DEV).to(DEV)
+    ref.train()
+    ref.msg_dropout = 0.0
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    flat0 = ref.flat_params.clone()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    acc_grads = []
+    for i, (g, e) in enumerate(zip(batches, epss)):
+        mu, lv = ref.encoder(g)
+        z = torch.exp(0.5 * lv) * e + mu
+        s_logits, c_logits = ref.decoder(z, g)
+        tot, _ = vae_cpu.losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, lv)
+        (tot / 2).backward()
+        if (i + 1) % 2 == 0:
+            acc_grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten()
+                                        for p in ref.parameters()]))
+            opt.step()
+            opt.zero_grad()
+            for pg in opt.param_groups:
+                pg["lr"] = vae_cpu.exp_decay_lr((i + 1) // 2, **sched)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.load_state_dict(sd0)
+    vae.train()
+    vae.msg_dropout = 0.0
+    tr = HipTrainer(vae, lr=1e-4, lr_scheduler=sched, iters_to_accumulate=2)
+    order = torch.cat([torch.arange(vae._offsets[n], vae._offsets[n] + p.numel()) for n, p in vae.named_parameters()])
+    for i, (g, e) in enumerate(zip(batches, epss)):
+        before = vae.flat_params.clone()
+        tr.train_step(g, e)
+        if (i + 1) % 2:
+            assert torch.equal(vae.flat_params, before) and tr.step_count == i // 2      # no update on the odd batch
+        else:
+            assert tr.step_count == (i + 1) // 2
+            if i == 1:                                                  # same weights on both sides for the first pair
+                assert rel_err(tr.grad_accum[order.to(DEV)], acc_grads[0]) < 2e-3
+    assert tr.micro_batches == 4 and abs(tr.lr - opt.param_groups[0]["lr"]) < 1e-12
+    nbt = [v for k, v in vae.state_dict().items() if k.endswith("graph_encoder.norm_layers.0.module.num_batches_tracked")]
+    assert int(nbt[0]) == 4                                             # BatchNorm sees every micro-batch
+    diff = (vae.flat_params - ref.flat_params).abs()
+    step = (ref.flat_params - flat0)
+    assert float(diff.max()) <= 4.5e-4 and float(diff.mean()) < 4e-6   # +-lr per update on rounding-noise gradients
+    assert float(((vae.flat_params - flat0) * step).sum() / (step.norm() ** 2)) > 0.98
+    with pytest.raises(ValueError):
+        HipTrainer(vae, iters_to_accumulate=0)

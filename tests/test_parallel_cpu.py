@@ -44,6 +44,18 @@ def _worker(rank, world, port, q):
         p = torch.full((16,), float(rank))
         broadcast_([p], 0)
         ok = ok and bool((p == 0).all())
+        # gradient accumulation (trainer.iters_to_accumulate > 1): micro-batch launches are held back, the running sum
+        # travels as ONE bucket on the k-th batch
+        held = mine.clone()
+        gh = GradBuckets(held, [384])
+        gh.hold = True
+        gh.launch(1); gh.launch(0)
+        ok = ok and gh.wait() == 1.0 / world and torch.equal(held, mine)
+        acc = mine.clone()
+        one = GradBuckets(acc, [])
+        one.launch(0)
+        one.wait()
+        ok = ok and len(one.views) == 1 and torch.allclose(acc, sum(allg))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -78,3 +78,28 @@ def test_dense_stress_graph():
     b = synthetic_batch(2, 2, dense=True)
     assert b.num_nodes == 2 * 2 * 128 and b.edge_index.shape[1] == 4 * 128 * 127
     assert int(b.edge_dist.max()) == 31
+
+
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+def test_dataset_relayout_matches_reference_getitem(case, tmp_path):
+    """`PolyphemusDataset.__getitem__` (token ids bar by bar, data.py:226-233): the active cells' rows, in cell order,
+    are the reference batch's token rows; no GPU involved."""
+    import os
+    from polyphemus_amd.data import PolyphemusDataset
+    z, cfg = load_case(case)
+    nb = cfg["n_bars"]
+    n = len([k for k in z.files if k.startswith("disk/") and k.endswith("/s_tensor")])
+    for i in range(n):
+        np.savez(os.path.join(tmp_path, f"{i:04d}.npz"), c_tensor=z[f"disk/{i}/c_tensor"], s_tensor=z[f"disk/{i}/s_tensor"])
+    ds = PolyphemusDataset(str(tmp_path), nb)
+    assert len(ds) == n
+    rows = []
+    for i in range(n):
+        tok, s = ds[i]
+        assert tok.shape == (nb, 4, 32, 16, 2) and tok.dtype == np.int16 and s.shape == (nb, 4, 32) and s.dtype == np.uint8
+        s = s.astype(bool)
+        for b in range(nb):                                   # data.py:152-153: an empty bar gets cell [0,0]
+            if not s[b].any():
+                s[b, 0, 0] = True
+        rows.append(tok.reshape(-1, 16, 2)[s.reshape(-1)])
+    assert np.array_equal(np.concatenate(rows), z["in/tokens"])

@@ -26,3 +26,23 @@ for pin in (False, True):
     dt = (time.perf_counter() - t0) / 20
     print(f"batch of 256 samples: {nbytes / 1e6:.2f} MB in {len([1 for v in b.__dict__.values() if torch.is_tensor(v)])} tensors, "
           f"{'pinned' if pin else 'pageable'} host memory: {dt * 1e3:.3f} ms per batch ({nbytes / dt / 1e9:.1f} GB/s)")
+
+# ---- the device-collate path (polyphemus_amd/data.py): token grids + structures in, batch of bar graphs built on the GPU
+import numpy as np                                                    # noqa: E402
+from polyphemus_amd.data import _staging, collate_on_device, relayout_sample   # noqa: E402
+from polyphemus_amd.synthetic import disk_sample                      # noqa: E402
+
+rng = np.random.default_rng(0)
+samples = [relayout_sample(*disk_sample(rng, 2, 0.25), 2) for _ in range(256)]
+stage = _staging(256, 2, pin=True)
+for _ in range(3):
+    collate_on_device(samples, 2, "cuda", stage)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    collate_on_device(samples, 2, "cuda", stage)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+nb = stage[0].numel() * 2 + stage[1].numel()
+print(f"device collate of 256 samples: {nb / 1e6:.2f} MB staged, {dt * 1e3:.3f} ms per batch "
+      f"(host stacking + H2D + graph kernels + token gather)")

@@ -275,6 +275,21 @@ class HipTrainer:
                 "s_f1": div(2 * rec * prec, rec + prec)}
         return losses, accs
 
+    def evaluate(self, loader):
+        """`PolyphemusTrainer.evaluate(loader)` (training.py:250-296): per-batch losses / accuracies averaged over the
+        batches of `loader` (plain means of the per-batch values, like the reference's `mean(l)`); restores the
+        training mode it found."""
+        losses: Dict[str, list] = {}
+        accs: Dict[str, list] = {}
+        for graph in loader:
+            lb, ab = self.evaluate_batch(graph)
+            for k, v in lb.items():
+                losses.setdefault(k, []).append(v)
+            for k, v in ab.items():
+                accs.setdefault(k, []).append(v)
+        mean = lambda l: sum(l) / len(l)
+        return {k: mean(l) for k, l in losses.items()}, {k: mean(l) for k, l in accs.items()}
+
     # ---- checkpoint interop (training.py:503-519 saves `optimizer.state_dict()` of torch.optim.Adam) ----------
     def optimizer_state_dict(self) -> dict:
         """The fused Adam's state in `torch.optim.Adam.state_dict()` layout: parameter ids follow
@@ -316,6 +331,28 @@ class HipTrainer:
         if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused Adam keeps one step count")
         self.step_count = steps.pop() if steps else 0
+
+    def save_checkpoint(self, path: str, **extra) -> None:
+        """The reference's checkpoint file (`_save_model`, training.py:498-519): a `torch.save`d dict with
+        'model_state_dict' (the 255 reference keys), 'optimizer_state_dict' (torch.optim.Adam layout) and
+        'tot_batches'; `extra` carries the bookkeeping entries of the reference's loop (epoch, lrs, ...).
+        `generate.load_model` of the reference reads 'model_state_dict' from it."""
+        ckpt = dict(extra)
+        ckpt.update(tot_batches=self.micro_batches,
+                    model_state_dict={k: v.detach().cpu().clone() for k, v in self.vae.state_dict().items()},
+                    optimizer_state_dict=self.optimizer_state_dict())
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path: str) -> dict:
+        """Restore model, Adam moments, step count and LR-schedule position from `save_checkpoint` / a reference
+        checkpoint; returns the remaining entries."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        self.vae.load_state_dict(ckpt.pop("model_state_dict"))
+        self.load_optimizer_state_dict(ckpt.pop("optimizer_state_dict"))
+        self.micro_batches = int(ckpt.get("tot_batches", self.step_count * self.iters_to_accumulate))
+        if self.sched is not None:
+            self.sched.update_steps = self.step_count
+        return ckpt
 
     def losses_dict(self, out: torch.Tensor) -> dict:
         """Host copy of the loss vector in the reference's dict layout (this DOES sync)."""

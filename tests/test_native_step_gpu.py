@@ -222,3 +222,57 @@ def test_gradient_accumulation_matches_reference_loop():
     assert float(((vae.flat_params - flat0) * step).sum() / (step.norm() ** 2)) > 0.98
     with pytest.raises(ValueError):
         HipTrainer(vae, iters_to_accumulate=0)
+
+
+def test_evaluate_loop_and_checkpoint_round_trip(tmp_path):
+    """`evaluate(loader)` = means of the per-batch values (training.py:250-296); `save_checkpoint` writes the
+    reference's checkpoint layout (training.py:498-519) and `load_checkpoint` resumes from it."""
+    import os
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    batches = [synthetic_batch(4 + i, 2, p=0.25, seed=70 + i).to(DEV) for i in range(3)]
+    sched = dict(peak_lr=1e-4, warmup_steps=1, final_lr_scale=0.5, decay_steps=4)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.train()
+    vae.msg_dropout = 0.0
+    tr = HipTrainer(vae, lr=1e-4, lr_scheduler=sched)
+    epss = [torch.randn(4 + i, 32, generator=torch.Generator().manual_seed(i)).to(DEV) for i in range(3)]
+    for b, e in zip(batches[:2], epss):
+        tr.train_step(b, e)
+    # ---- evaluate
+    torch.manual_seed(1)
+    per = [tr.evaluate_batch(b) for b in batches]
+    torch.manual_seed(1)
+
+    class Loader:                                       # evaluate() draws eps itself: same generator state, same values
+        def __iter__(self):
+            return iter(batches)
+    losses, accs = tr.evaluate(Loader())
+    assert vae.training
+    assert set(losses) == {"tot", "pitch", "dur", "structure", "reconstruction", "kld", "beta*kld"} and len(accs) == 9
+    for k in losses:
+        assert abs(losses[k] - sum(p[0][k] for p in per) / 3) < 1e-9, k
+    for k in accs:
+        want = sum(p[1][k] for p in per) / 3
+        assert (accs[k] != accs[k] and want != want) or abs(accs[k] - want) < 1e-12, k
+    # ---- checkpoint
+    path = os.path.join(tmp_path, "checkpoint")
+    tr.save_checkpoint(path, epoch=3, lrs=[1e-4, tr.lr])
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert list(ck["model_state_dict"]) == list(vae.state_dict()) and ck["tot_batches"] == 2 and ck["epoch"] == 3
+    torch.optim.Adam(vae.parameters()).load_state_dict(ck["optimizer_state_dict"])     # the reference's resume path
+    tr.train_step(batches[2], epss[2])
+    want, want_lr = vae.flat_params.clone(), tr.lr
+    torch.manual_seed(5)
+    vae2 = VAE(**cfg, device=DEV).to(DEV)                       # different init: everything must come from the file
+    vae2.train()
+    vae2.msg_dropout = 0.0
+    tr2 = HipTrainer(vae2, lr=3e-3, lr_scheduler=sched)
+    rest = tr2.load_checkpoint(path)
+    assert rest["epoch"] == 3 and tr2.step_count == 2 and tr2.micro_batches == 2
+    for k, v in vae2.state_dict().items():
+        assert torch.equal(v.cpu(), ck["model_state_dict"][k]), k
+    tr2.train_step(batches[2], epss[2])
+    assert abs(tr2.lr - want_lr) < 1e-15
+    diff = (vae2.flat_params - want).abs()
+    assert float(diff.max()) <= 2.5e-4 and float(diff.mean()) < 2e-6

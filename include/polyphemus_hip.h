@@ -390,10 +390,13 @@ int pm_grad_accumulate(const float* grads, float* accum, int64_t n, float scale,
 uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel);
 
 /* ------------------------------------------------------------------ launch-duration profiler (bench.py roofline)
- * HIP events around every GEMM / segment-reduce launch while enabled; pm_prof_end sums the durations per class:
+ * HIP events around GEMM / segment-reduce launches while enabled; pm_prof_end sums the durations per class.  Every event
+ * costs ~4 us of GPU idle time, so pm_prof_configure selects WHICH launches are bracketed: the classes of `class_mask`
+ * (bit c = class c), every `stride`-th launch of each (default: all classes, every launch).
  * classes 0..32 = GEMM tile configuration (0..10) * 3 + {0 NN, 1 NT, 2 TN}; 33 = segment-reduce forward; 34 = backward.
  * `work` = algorithmic flops (GEMM) or algorithmic HBM bytes (segment-reduce) of the launches. */
 enum { PM_PROF_NCLASS_PUBLIC = 35 };
+int pm_prof_configure(int64_t class_mask, int32_t stride);
 int pm_prof_begin(int32_t max_events);
 int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_t* count /* [35] host */);
 

@@ -73,6 +73,7 @@ _SIGS = {
     "pm_content_accuracy": "pppips",
     "pm_structure_metrics": "pplps",
     "pm_adam_step": "pppplffffifs",
+    "pm_prof_configure": "li",
     "pm_prof_begin": "i",
     "pm_prof_end": "ppp",
     "pm_vae_step_workspace_bytes": "piiiii",

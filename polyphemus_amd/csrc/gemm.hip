@@ -885,7 +885,16 @@ extern "C" int pm_split_planes(const float* src, int64_t n, uint16_t* planes, in
 }
 
 // ---------------------------------------------------------------- launch-duration profiler (see prof.h)
-PmProfState g_pm_prof = {false, 0, 0, nullptr};
+PmProfState g_pm_prof = {false, 0, 0, nullptr, ~0ull, 1, {0}};
+
+// Which launches pm_prof_begin .. pm_prof_end bracket: classes of `class_mask`, every `stride`-th launch of each.
+extern "C" int pm_prof_configure(int64_t class_mask, int32_t stride) {
+  if (stride < 1) return PM_E_INVALID;
+  g_pm_prof.mask = (uint64_t)class_mask;
+  g_pm_prof.stride = stride;
+  return PM_OK;
+}
+
 
 extern "C" int pm_prof_begin(int32_t max_events) {
   PmProfState& p = g_pm_prof;
@@ -900,6 +909,7 @@ extern "C" int pm_prof_begin(int32_t max_events) {
     p.cap = max_events;
   }
   p.n = 0;
+  for (int c = 0; c < PM_PROF_NCLASS; ++c) p.seen[c] = 0;
   p.on = true;
   return PM_OK;
 }

@@ -12,12 +12,18 @@ enum {
   PM_PROF_NCLASS = 35
 };
 struct PmProfEvent { hipEvent_t a, b; int cls; double work; };
-struct PmProfState { bool on; int n, cap; PmProfEvent* ev; };
+struct PmProfState {
+  bool on; int n, cap; PmProfEvent* ev;
+  uint64_t mask;                 // classes that are bracketed (bit c = class c)
+  int stride;                    // every stride-th launch of a selected class is bracketed (events cost ~4 us of GPU idle each)
+  int seen[PM_PROF_NCLASS];
+};
 extern PmProfState g_pm_prof;
 
 static inline int pm_prof_open(hipStream_t st, int cls, double work) {
   PmProfState& p = g_pm_prof;
-  if (!p.on || p.n >= p.cap) return -1;
+  if (!p.on || p.n >= p.cap || !((p.mask >> cls) & 1ull)) return -1;
+  if (p.stride > 1 && (p.seen[cls]++ % p.stride) != 0) return -1;
   const int i = p.n++;
   p.ev[i].cls = cls; p.ev[i].work = work;
   hipEventRecord(p.ev[i].a, st);

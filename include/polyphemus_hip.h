@@ -275,6 +275,11 @@ int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const
                     int64_t plane_stride /* elements */,
                     int32_t sums_ready /* != 0: acc3 already holds the sums (pm_segreduce_bwd_norm) */,
                     pm_stream_t stream);
+/* `num_batches_tracked` of all BatchNorm modules after a training forward: counters[i] += inc[i] + [group_cnt[0] > 0] *
+ * sel[0][i] + [group_cnt[1] > 0] * sel[1][i] (the embedding norms only count when their node group — drums / non-drums,
+ * plan field GROUP_CNT — is non-empty, model.py:362,375). */
+int pm_bn_counters_update(int64_t* counters /* [n] */, const int64_t* inc /* [n] */, const int64_t* sel /* [2,n] */,
+                          const int32_t* group_cnt /* [2] */, int32_t n, pm_stream_t stream);
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
 int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
 int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);

@@ -46,6 +46,7 @@ _SIGS = {
     "pm_split_planes": "plpls",
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",
+    "pm_bn_counters_update": "ppppis",
     "pm_grad_accumulate": "pplfis",
     "pm_colsum_acc": "piiips",
     "pm_colsum_rows_acc": "piipipips",

@@ -468,6 +468,20 @@ extern "C" int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx
   hipLaunchKernelGGL(k_relu_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);
   return pm_check_launch();
 }
+// num_batches_tracked of every BatchNorm in one launch: counters[i] += inc[i] + [g0 > 0] * sel[0][i] + [g1 > 0] * sel[1][i]
+// (the embedding norms only count when their node group is non-empty, model.py:362,375)
+__global__ void k_bn_counters(int64_t* __restrict__ counters, const int64_t* __restrict__ inc,
+                              const int64_t* __restrict__ sel, const int* __restrict__ group_cnt, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  counters[i] += inc[i] + (group_cnt[0] > 0 ? sel[i] : 0) + (group_cnt[1] > 0 ? sel[n + i] : 0);
+}
+extern "C" int pm_bn_counters_update(int64_t* counters, const int64_t* inc, const int64_t* sel, const int32_t* group_cnt,
+                                     int32_t n, pm_stream_t stream) {
+  if (!counters || !inc || !sel || !group_cnt || n <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_bn_counters, dim3(pm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, counters, inc, sel, group_cnt, n);
+  return pm_check_launch();
+}
 extern "C" int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream) {
   if (!a || !b || !out || n <= 0) return PM_E_INVALID;
   hipLaunchKernelGGL(k_add, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);

@@ -274,6 +274,14 @@ __global__ void __launch_bounds__(CLS_T) k_class_scatter(const int* __restrict__
   }
 }
 
+struct ZeroRegions { int* p[6]; int64_t n[6]; };
+__global__ void __launch_bounds__(256) k_zero_regions(ZeroRegions z) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+    for (int64_t i = tid; i < z.n[r]; i += step) z.p[r][i] = 0;
+}
+
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
                              const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
                              const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
@@ -291,11 +299,20 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   int* cur_out = cur_in + (int64_t)N * PM_N_REL;
   int* drumpos = cur_out + N;
   int* sums = drumpos + N + 1;
-  hipMemsetAsync(rowptr, 0, sizeof(int) * ((int64_t)N * PM_N_REL + 1), st);
-  hipMemsetAsync(colptr, 0, sizeof(int) * ((int64_t)N + 1), st);
-  hipMemsetAsync(barptr, 0, sizeof(int) * ((int64_t)G + 1), st);
-  hipMemsetAsync(plan + o[PM_PLAN_GROUP_CNT], 0, sizeof(int) * (o[PM_PLAN_ROW_LIST] - o[PM_PLAN_GROUP_CNT]), st);
-  hipMemsetAsync(cur_in, 0, sizeof(int) * ((int64_t)N * PM_N_REL + N + N + 1), st);
+  {                                          // every counter array of the plan in ONE launch (six memsets before)
+    ZeroRegions z;
+    z.p[0] = rowptr; z.n[0] = (int64_t)N * PM_N_REL + 1;
+    z.p[1] = colptr; z.n[1] = (int64_t)N + 1;
+    z.p[2] = barptr; z.n[2] = (int64_t)G + 1;
+    z.p[3] = plan + o[PM_PLAN_GROUP_CNT]; z.n[3] = o[PM_PLAN_ROW_LIST] - o[PM_PLAN_GROUP_CNT];
+    z.p[4] = cur_in; z.n[4] = (int64_t)N * PM_N_REL + N + N + 1;
+    z.p[5] = plan + o[PM_PLAN_TRK_CNT]; z.n[5] = 32;
+    int64_t tot = 0;
+    for (int r = 0; r < 6; ++r) tot += z.n[r];
+    int nb = (int)pm_cdiv(tot, 1024);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_zero_regions, dim3(nb), dim3(256), 0, st, z);
+  }
   const int T = 256;
   hipLaunchKernelGGL(k_count_edges, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr);
   hipLaunchKernelGGL(k_count_nodes, dim3(pm_cdiv(N, T)), dim3(T), 0, st, bars, batch, is_drum, n_bars, N,
@@ -322,7 +339,6 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
     const int nblk = (int)pm_cdiv(N, CLS_T);
     int* bh = cls + N;
     int* tcnt = plan + o[PM_PLAN_TRK_CNT];
-    hipMemsetAsync(tcnt, 0, sizeof(int) * 32, st);
     hipLaunchKernelGGL(k_node_class, dim3(nblk), dim3(CLS_T), 0, st, rowptr, N, plan + o[PM_PLAN_NODE_TREL], cls, bh, tcnt);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(1024), 0, st, bh, nblk, N, tcnt);
     hipLaunchKernelGGL(k_class_scatter, dim3(nblk), dim3(CLS_T), 0, st, cls, bh, N, plan + o[PM_PLAN_TRK_LIST]);

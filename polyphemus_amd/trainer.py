@@ -168,8 +168,8 @@ class HipTrainer:
         # num_batches_tracked (int64 bookkeeping of nn.BatchNorm): +1 per forward; the embedding norms only
         # when their group is non-empty, bn_dur once per non-empty group (model.py:362,375)
         i = PLAN_FIELDS.index("group_cnt")
-        has = (self._plan_buf[off[i]:off[i] + 2] > 0).to(torch.int64)
-        vae.flat_counters.add_(self._nbt_inc).add_((has.view(2, 1) * self._nbt_sel).sum(0))
+        call("pm_bn_counters_update", ptr(vae.flat_counters), ptr(self._nbt_inc), ptr(self._nbt_sel),
+             ptr(self._plan_buf[off[i]:off[i] + 2]), vae.flat_counters.numel(), st)
         return self.loss_buf
 
     def _python_forward_backward(self, graph, eps):

@@ -793,7 +793,8 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
     if (transA && tiles * n_groups < 768) {
-      split_k = (int)(1024 / (tiles * n_groups));
+      static const int tn_target = getenv("PM_GEMM_TN_TARGET") ? atoi(getenv("PM_GEMM_TN_TARGET")) : 1024;
+      split_k = (int)(tn_target / (tiles * n_groups));
       const int maxs = (int)pm_cdiv(partitioned ? K / n_groups : K, 8 * BK);
       if (split_k > maxs) split_k = maxs;
       if (split_k < 1) split_k = 1;

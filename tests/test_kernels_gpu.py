@@ -677,3 +677,34 @@ def test_plan_track_lists_are_class_sorted_and_gemm_skips_zero_blocks():
     keep[torch.from_numpy(~on), d:2 * d] = False
     keep[torch.from_numpy(~nx), 2 * d:3 * d] = False
     assert rel_err(dA1[keep], dA0[keep]) < 1e-6
+
+
+def test_launch_profiler_class_mask_and_stride():
+    """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
+    launch of each; durations and algorithmic work come back per class."""
+    import ctypes
+    L = lib()
+    A = torch.randn(256, 128, device=DEV)
+    B = torch.randn(128, 64, device=DEV)
+    out = torch.empty(256, 64, device=DEV)
+
+    def run(mask, stride, launches):
+        L.pm_prof_configure(mask, stride)
+        L.pm_prof_begin(64)
+        for _ in range(launches):
+            ops.gemm(A, B, out, 256, 64, 128, 128, 64, 64)            # NN, 64x64x16 tiles: class 0
+        torch.cuda.synchronize()
+        ms, work, cnt = (ctypes.c_double * 35)(), (ctypes.c_double * 35)(), (ctypes.c_int64 * 35)()
+        assert L.pm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p),
+                             ctypes.cast(cnt, ctypes.c_void_p)) == 0
+        return list(ms), list(work), list(cnt)
+    try:
+        ms, work, cnt = run(-1, 1, 6)
+        assert cnt[0] == 6 and sum(cnt) == 6 and ms[0] > 0 and work[0] == 6 * 2.0 * 256 * 64 * 128
+        ms, work, cnt = run(-1, 4, 9)                                 # launches 0, 4, 8
+        assert cnt[0] == 3
+        ms, work, cnt = run(1 << 33, 1, 5)                            # segment-reduce forward only: no GEMM is timed
+        assert sum(cnt) == 0
+        assert L.pm_prof_configure(-1, 0) != 0
+    finally:
+        L.pm_prof_configure(-1, 1)

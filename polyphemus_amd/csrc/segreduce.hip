@@ -58,9 +58,14 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
                                                        int N, int d, uint32_t seed, uint32_t layer_uid,
                                                        uint32_t thresh, float scale, const int* __restrict__ node_trel,
                                                        float* __restrict__ A, uint16_t* __restrict__ planes,
-                                                       int64_t plane_stride) {
+                                                       int64_t plane_stride, int xcd_chunk) {
   const int lane = threadIdx.x & 63;
-  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  // XCD-aware node order: workgroup b runs on XCD b % 8, which has its own L2.  The neighbours of a node are the nodes
+  // of its own bar, so each XCD takes one CONTIGUOUS eighth of the nodes (whole bars) and the x[src] rows of a bar are
+  // filled into one L2 instead of all eight.
+  int wg = blockIdx.x;
+  if (xcd_chunk > 0) wg = (wg & 7) * xcd_chunk + (wg >> 3);
+  const int n = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
   if (n >= N) return;
   // planes != NULL: the aggregate is written pre-split (three bf16 planes, x = x1 + x2 + x3 exactly) for the
   // planes mode of the GEMM instead of as fp32
@@ -123,6 +128,12 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
   }
 }
 
+// A/B switch: PM_SEG_XCD=0 restores the plain node order of both segment-reduce kernels
+static bool seg_xcd_aware() {
+  static const bool on = !(getenv("PM_SEG_XCD") && atoi(getenv("PM_SEG_XCD")) == 0);
+  return on;
+}
+
 static int segreduce_fwd_impl(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                               int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact, float* A,
                               uint16_t* planes, int64_t plane_stride, pm_stream_t stream) {
@@ -134,13 +145,15 @@ static int segreduce_fwd_impl(const float* x, const float* T, const int32_t* pla
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   const int* trel = compact ? pv.node_trel : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(pm_cdiv(N, 4)), block(256);
+  int nwg = (int)pm_cdiv(N, 4), xcd_chunk = 0;
+  if (seg_xcd_aware() && nwg >= 64) { xcd_chunk = (int)pm_cdiv(nwg, 8); nwg = xcd_chunk * 8; }
+  const dim3 grid(nwg), block(256);
   const bool drop = dropout_p > 0.f;
   const uint32_t thresh = pm_keep_threshold(dropout_p);
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
 #define LAUNCH(NV, DR)                                                                                              \
   hipLaunchKernelGGL((k_segreduce_fwd<NV, DR>), grid, block, 0, st, x, T, pv.rowptr, pv.csr_src, pv.csr_dist,       \
-                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, trel, A, planes, plane_stride)
+                     pv.csr_eid, N, d, seed, layer_uid, thresh, scale, trel, A, planes, plane_stride, xcd_chunk)
   const int nv = (int)pm_cdiv(d, 256);
   const double bytes_out = (planes ? 6.0 : 4.0) * d * (double)N * (compact ? 4 : 7);
   const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_FWD, 4.0 * d * (double)N + bytes_out + 12.0 * E);
@@ -182,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
                                                        const float* __restrict__ csc_invcnt, int N, int d,
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
                                                        int compact, float* __restrict__ dx, float* __restrict__ dT,
-                                                       PmNormSums nn) {
+                                                       PmNormSums nn, int xcd_nodes) {
   // LDS image of the table gradient: element (dist, column 4q + j) at dist*d + j*(d/4) + q, so that the four
   // ds_add_f32 of a lane's float4 hit consecutive addresses across the wave (bank-conflict free)
   extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][4][d/4]
@@ -197,6 +210,9 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
 #pragma unroll
   for (int v = 0; v < NV; ++v) { c[v] = (lane + v * 64) * 4; ok[v] = c[v] < d; }
   const int nwv = blockDim.x >> 6;
+  // the norm's per-column constants stay in registers only at d <= 256 (NV = 1); wider rows re-read them per node
+  // (L1-resident), which keeps the 16-wave workgroup inside its 128-VGPR budget (17 spilled registers before)
+  constexpr bool KEEP = NV == 1;
   float nm[NV][4], nrs[NV][4], nga[NV][4], nbe[NV][4];
   double ns0[NV][4], ns1[NV][4], ns2[NV][4];
   if (FUSE) {
@@ -205,7 +221,9 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = ok[v] ? c[v] + j : 0;
-        nm[v][j] = nn.mean[col]; nrs[v][j] = rsqrtf(nn.var[col] + nn.eps); nga[v][j] = nn.gamma[col]; nbe[v][j] = nn.beta[col];
+        if (KEEP) {
+          nm[v][j] = nn.mean[col]; nrs[v][j] = rsqrtf(nn.var[col] + nn.eps); nga[v][j] = nn.gamma[col]; nbe[v][j] = nn.beta[col];
+        }
         ns0[v][j] = 0; ns1[v][j] = 0; ns2[v][j] = 0;
       }
   }
@@ -216,9 +234,17 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   for (int v = 0; v < NV; ++v)
 #pragma unroll
     for (int j = 0; j < 4; ++j) z0[v][j] = 0.f;
-  for (int n0 = blockIdx.x * nwv; n0 < N; n0 += gridDim.x * nwv) {
+  // XCD-aware node order (see k_segreduce_fwd): XCD b % 8 walks its own contiguous eighth of the nodes, so the dA rows
+  // of a bar are gathered through ONE L2
+  int n_lo = blockIdx.x * nwv, n_hi = N, n_step = gridDim.x * nwv;
+  if (xcd_nodes > 0) {
+    n_lo = (blockIdx.x & 7) * xcd_nodes + (blockIdx.x >> 3) * nwv;
+    n_hi = min(N, ((int)(blockIdx.x & 7) + 1) * xcd_nodes);
+    n_step = (gridDim.x >> 3) * nwv;
+  }
+  for (int n0 = n_lo; n0 < n_hi; n0 += n_step) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
-    if (n >= N) continue;
+    if (n >= n_hi) continue;
     float4 xv[NV], acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -283,11 +309,23 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         const float4 hv = *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
         const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
         const float ds[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
+        float m4[4], r4[4], g4n[4], b4[4];
+        if (KEEP) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { m4[j] = nm[v][j]; r4[j] = nrs[v][j]; g4n[j] = nga[v][j]; b4[j] = nbe[v][j]; }
+        } else {
+          const float4 mv = *reinterpret_cast<const float4*>(nn.mean + c[v]), vv = *reinterpret_cast<const float4*>(nn.var + c[v]);
+          const float4 gv = *reinterpret_cast<const float4*>(nn.gamma + c[v]), bv = *reinterpret_cast<const float4*>(nn.beta + c[v]);
+          m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w;
+          r4[0] = rsqrtf(vv.x + nn.eps); r4[1] = rsqrtf(vv.y + nn.eps); r4[2] = rsqrtf(vv.z + nn.eps); r4[3] = rsqrtf(vv.w + nn.eps);
+          g4n[0] = gv.x; g4n[1] = gv.y; g4n[2] = gv.z; g4n[3] = gv.w;
+          b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float xh = (hs[j] - nm[v][j]) * nrs[v][j];
+          const float xh = (hs[j] - m4[j]) * r4[j];
           float du = ds[j];
-          if (nn.relu && !(xh * nga[v][j] + nbe[v][j] > 0.f)) du = 0.f;
+          if (nn.relu && !(xh * g4n[j] + b4[j] > 0.f)) du = 0.f;
           ns0[v][j] += (double)du; ns1[v][j] += (double)du * (double)xh; ns2[v][j] += (double)xh;
         }
       }
@@ -353,6 +391,8 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   int nblk = (int)pm_cdiv(N, threads / 64);
   if (nblk > 256) nblk = 256;
   const dim3 grid(nblk), block(threads);
+  int xcd_nodes = 0;                                    // nodes per XCD, a multiple of the waves per workgroup
+  if (seg_xcd_aware() && nblk >= 16 && (nblk & 7) == 0) xcd_nodes = (int)pm_cdiv(pm_cdiv(N, 8), threads / 64) * (threads / 64);
   const size_t lds = sizeof(float) * PM_N_DIST * d;
   const bool drop = dropout_p > 0.f;
   const uint32_t thresh = pm_keep_threshold(dropout_p);
@@ -362,7 +402,7 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   const PmNormSums nv_ = nn ? *nn : none;
 #define LAUNCH(NV, DR, FU)                                                                                           \
   hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,      \
-                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_)
+                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes)
 #define LAUNCH2(NV, DR) do { if (nn) LAUNCH(NV, DR, true); else LAUNCH(NV, DR, false); } while (0)
   const int nv = (int)pm_cdiv(d, 256);
   const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 3 : PM_N_REL) + 1 + (nn ? 1 : 0)) + 12.0 * E + 128.0 * d);

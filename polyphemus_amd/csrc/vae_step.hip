@@ -182,13 +182,16 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   float* dxb = ar.f((size_t)N * d);
   PmPlanView pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
   hipMemsetAsync(dT, 0, sizeof(float) * PM_N_DIST * d, c.st);
+  // the segment-reduce backward of layer i also accumulates the column sums of the norm backward of layer i-1; beyond
+  // d = 512 that variant spills (16-wave workgroups: 128 VGPRs), so wider models take the separate column-sum pass
+  const bool fuse_sums = d <= 512;
   for (int i = c.L - 1; i >= 0; --i) {
     const float* W = c.P + g.weight[i];
     float* dW = c.G + g.weight[i];
     const PmBn& bn = g.norm[i];
     c.chk(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
                           c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
-                          sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1) ? 1 : 0, c.st));
+                          sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1 && fuse_sums) ? 1 : 0, c.st));
     if (!c.compact) {
       c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
@@ -213,7 +216,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       c.chk(pm_gemm_f32_desc(&w, c.st));
     }
     float* out = (dx == dxa) ? dxb : dxa;
-    if (i > 0) {                                          // + the column sums of the norm backward of layer i-1
+    if (i > 0 && fuse_sums) {                             // + the column sums of the norm backward of layer i-1
       const PmBn& pb = g.norm[i - 1];
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;

@@ -288,15 +288,23 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         for (int u = 0; u < 2; ++u) {
           const float g[4] = {g4[u].x * w[u], g4[u].y * w[u], g4[u].z * w[u], g4[u].w * w[u]};
           const float ts[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
+          float gt[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             bool on = xs[j] * ts[j] > 0.f;
             if (DROP) on = on && ((pm_elem_hash(key[u], c[v] + j) >> 8) >= thresh);
             const float gg = on ? g[j] : 0.f;
             ap[j] += gg * ts[j];
-            const float gt = gg * xs[j];
-            if (dist[u] == 0) z0[v][j] += gt;               // onset edges (a third of all): row 0 stays in registers
-            else if (gt != 0.f) atomicAdd(&sT[dist[u] * d + j * dq + (c[v] >> 2)], gt);
+            gt[j] = gg * xs[j];
+          }
+          if (dist[u] == 0) {                                // onset edges (a third of all): row 0 stays in registers
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z0[v][j] += gt[j];
+          } else {                                           // one uniform branch per edge, not per element
+            float* row = sT + dist[u] * d + (c[v] >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gt[j] != 0.f) atomicAdd(row + j * dq, gt[j]);
           }
         }
       }

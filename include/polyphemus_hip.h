@@ -237,7 +237,17 @@ typedef struct PmGemmDesc {
                         the all-zero blocks are skipped tile by tile (C tiles that only hold such blocks are left
                         untouched when transB).  Results are unchanged where they are defined. */
   int32_t class_block;
+  const void* b_frag;       /* optional, planes mode, !transA: B (a weight matrix, possibly stacked via b_split_rows)
+                               additionally as FRAGMENT-MAJOR planes (pm_split_planes_frag: kind 0 when transB, kind 1
+                               otherwise, over the whole stored matrix with `ldb` columns).  The kernel then takes its B
+                               operands straight from memory into registers (no LDS image of B); used when the shape
+                               is aligned with the fragment grid (N % 128 == 0, K % 32 == 0), ignored otherwise. */
 } PmGemmDesc;
+/* Fragment-major bf16 planes of weight matrices W [rows, cols] (fp32; rows, cols multiples of 32) for PmGemmDesc.b_frag:
+ * per (32-wide n tile, 16-wide k-step) three contiguous 1 KiB blocks (planes) in MFMA operand order.  kind 0: n = row,
+ * k = column (the product uses W transposed: transB); kind 1: k = row, n = column.  out: rows*cols*3 bf16 per matrix. */
+int pm_split_planes_frag(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats, int64_t src_stride,
+                         int64_t dst_stride, uint16_t* out, pm_stream_t stream);
 int pm_gemm_f32_desc(const PmGemmDesc* desc, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ batch normalisation

@@ -44,6 +44,7 @@ _SIGS = {
     "pm_bn_apply_fused": "piipfpppipppppfs",
     "pm_bn_bwd_fused": "ppiippfppipppppplis",
     "pm_split_planes": "plpls",
+    "pm_split_planes_frag": "piiiillps",
     "pm_relu_bwd": "pplps",
     "pm_add": "pplps",
     "pm_bn_counters_update": "ppppis",

@@ -42,6 +42,8 @@ struct GemmArgs {
   // row classes of the compact GCL (see PmGemmDesc.class_ptr): boundaries [ngroups][5], block size, masked dimension
   const int32_t* cls_ptr; int cls_blk, cls_dim;
   double* colstats;                          // optional [2][N]: += column sums of the stored values and of their squares
+  // MODE 3: B (a weight matrix) as fragment-major planes (pm_split_planes_frag); bf_n = K/16 (transB) or N/32 tiles
+  const char* bfrag; int bf_n;
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -315,9 +317,10 @@ struct PlaneStage {
 //  contraction then run as one resident wave of workgroups instead of 1024 + a 12-tile tail)
 template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
 __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
-    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? 5 : 1, (MODE == 2 && BM * BN <= 64 * 64) ? 5 : 8)))
+    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? 4 : 1),
+                                       (MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? 4 : 8))))
     k_gemm(GemmArgs g) {
-  constexpr bool X6 = MODE == 1, PL = MODE == 2;
+  constexpr bool X6 = MODE == 1, PL = MODE >= 2, BD = MODE == 3;
   static_assert(MODE == 0 || (VA && VB && BK % 16 == 0), "split modes stage with 16-byte loads");
   // THREADS = MFMA threads = staging threads.  fp32 mode: the same waves do both.  Split mode: the block has
   // 2*THREADS threads, waves [0, WVM*WVN) multiply and waves [WVM*WVN, 2*WVM*WVN) load + split + store, so the
@@ -451,8 +454,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     PA_ pa;
     PB_ pb;
     pa.init(reinterpret_cast<const char*>(g.A), g.a_ps * 2, g.lda, m0, M, mapA, g.rpe);
-    pb.init(reinterpret_cast<const char*>(g.B), g.b_ps * 2, g.ldb, n0, g.N, mapB, g.rpe, g.b_split,
-            (int)(grp * g.b_boff * 2), (int)(g.b_hi * 2));
+    if constexpr (!BD)
+      pb.init(reinterpret_cast<const char*>(g.B), g.b_ps * 2, g.ldb, n0, g.N, mapB, g.rpe, g.b_split,
+              (int)(grp * g.b_boff * 2), (int)(g.b_hi * 2));
     // k sequence: all of [kbeg, kend), or (forward with row classes) only the K blocks this row tile needs
     int kblk = kend - kbeg, kv_end = kend - kbeg, s1 = 1, s2 = 2;          // (scalars: no indexed private array)
     if (!TA && g.cls_dim == 1) {
@@ -467,6 +471,71 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
       const int q = v / kblk;
       return (q == 0 ? 0 : q == 1 ? s1 : q == 2 ? s2 : 3) * kblk + (v - q * kblk);
     };
+    if constexpr (BD) {
+      // B direct (MODE 3): B is a weight matrix kept as FRAGMENT-MAJOR planes (pm_split_planes_frag): the 1 KiB that a
+      // wave needs for one (32-row tile, 16-wide k-step, plane) MFMA operand is contiguous, so every wave takes its B
+      // fragments straight from L2 into registers with one coalesced 16-byte load per lane — B never touches LDS
+      // (half the LDS bytes of the LDS-staged tile), and only the A image (12 KB) is staged.  The fragment registers
+      // of k-step t are refilled with those of k-step t+1 as soon as their MFMAs have issued.
+      static_assert(!TA, "B direct: the weight operand of the forward / input-gradient products");
+      const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.bfrag), 0, PM_OOB, 0x00020000);
+      const int shift_lo = g.b_split > 0 ? (int)(grp * g.b_boff / g.ldb) : 0, shift_hi = g.b_split > 0 ? (int)(g.b_hi / g.ldb) : 0;
+      int bbase[TN];                                    // TB: byte offset of the row tile; !TB: index of the column tile
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nrow = n0 + wc * WN + j * 32;
+        if (nrow >= g.N) bbase[j] = -1;
+        else if (TB) bbase[j] = ((nrow + (nrow < g.b_split ? shift_lo : shift_hi)) >> 5) * g.bf_n * 3072 + lane * 16;
+        else bbase[j] = (nrow >> 5) * 3072 + lane * 16;
+      }
+      auto bload = [&](bf16x8 (&dst)[3][TN], int k) {   // fragments of the 16-wide k-step starting at real k
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int off = PM_OOB;
+          if (k < kend && bbase[j] >= 0) {
+            if (TB) off = bbase[j] + (k >> 4) * 3072;
+            else off = bbase[j] + ((k + (k < g.b_split ? shift_lo : shift_hi)) >> 4) * g.bf_n * 3072;
+          }
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, off + p * 1024, 0, 0));
+        }
+      };
+      bf16x8 bq[BK / 16][3][TN];
+      pa.prime(kbeg, kend);
+      pa.load(kmap(0), kend);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int k = kmap(0);
+        bload(bq[ks], k < kend ? k + ks * 16 : kend);
+      }
+      pa.store(Ax0);
+      __syncthreads();
+      for (int v0 = 0; v0 < kv_end; v0 += BK) {
+        const int kn = kmap(v0 + BK);
+        pa.load(kn, kend);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          bf16x8 a[3][TM];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[p][i] = PA_::frag(Ax0 + p * PA_::PPLANE, wr * WM + i * 32, ks, lane);
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+          for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks][PB[t6]][j], acc[i][j], 0, 0, 0);
+          bload(bq[ks], kn < kend ? kn + ks * 16 : kend);
+        }
+        __syncthreads();
+        if (v0 + BK < kv_end) pa.store(Ax0);
+        __syncthreads();
+      }
+    } else {
     pa.prime(kbeg, kend);
     pb.prime(kbeg, kend);
     pa.load(kmap(0), kend);
@@ -503,6 +572,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
         pb.store(Bx1);
       }
       __syncthreads();
+    }
     }
   } else {
   sa.init(g.A, g.lda, m0, M, mapA, g.rpe);
@@ -672,7 +742,9 @@ static void launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
   using StA = TileStage<BM, BK, 64 * WVM * WVN, !TA, VA>;
   using StB = TileStage<BN, BK, 64 * WVM * WVN, TB, VB>;
   size_t lds;
-  if constexpr (MODE == 2)
+  if constexpr (MODE == 3)
+    lds = (size_t)PlaneStage<BM, BK, 64 * WVM * WVN, !TA>::PBYTES;
+  else if constexpr (MODE == 2)
     lds = (size_t)(PlaneStage<BM, BK, 64 * WVM * WVN, !TA>::PBYTES + PlaneStage<BN, BK, 64 * WVM * WVN, TB>::PBYTES);
   else
     lds = MODE == 1 ? (size_t)2 * (StA::XBYTES + StB::XBYTES) : sizeof(float) * 2 * BK * (StA::LD + StB::LD);
@@ -696,12 +768,12 @@ template <int BM, int BN, int BK, int WVM, int WVN, int MODE>
 static void launch_t(int ta, int tb, bool va, bool vb, dim3 grid, hipStream_t st, const GemmArgs& g) {
   if (!ta && !tb) launch_v<BM, BN, BK, WVM, WVN, false, false, MODE>(va, vb, grid, st, g);
   else if (!ta && tb) launch_v<BM, BN, BK, WVM, WVN, false, true, MODE>(va, vb, grid, st, g);
-  else launch_v<BM, BN, BK, WVM, WVN, true, false, MODE>(va, vb, grid, st, g);
+  else if constexpr (MODE != 3) launch_v<BM, BN, BK, WVM, WVN, true, false, MODE>(va, vb, grid, st, g);
 }
 
-enum { PM_GEMM_NCFG = 11 };                   // 0..3 fp32 MFMA, 4..7 split mode, 8..10 pre-split planes
-static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128, 64, 128, 128};
-static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128, 64, 64, 128};
+enum { PM_GEMM_NCFG = 11 };                   // 0..3 fp32 MFMA, 4..7 split mode, 8 / 10 pre-split planes, 9 planes with B direct
+static const int CFG_BM[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 128, 64, 128, 64, 64, 128};
+static const int CFG_BN[PM_GEMM_NCFG] = {64, 128, 64, 128, 128, 64, 64, 128, 64, 128, 128};
 static const int CFG_BK[PM_GEMM_NCFG] = {16, 16, 32, 32, 16, 16, 32, 32, 32, 32, 32};
 
 // Tile configuration: an explicit override (pm_gemm_force_config, for A/B timing in one process) or the shape rule.
@@ -772,9 +844,17 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
       return PM_E_INVALID;
   }
   g.a_ps = q->a_plane_stride; g.b_ps = q->b_plane_stride;
+  g.bfrag = reinterpret_cast<const char*>(q->b_frag); g.bf_n = transB ? q->ldb / 16 : q->ldb / 32;
   g.cls_ptr = q->class_ptr; g.cls_blk = q->class_block; g.cls_dim = 0;
   // planes mode: 64x64x32 tiles (measured in the step: 128x64x32 85 us, 128x128x32 97-130 us against 70-80 us)
-  const int cfg = planes ? 8 : pick_config(transA, M, N, K, va && vb, n_groups == 1 && !q->rowmap);
+  // B direct (config 9): B given additionally as fragment-major planes; forward / input-gradient products whose tiles
+  // are aligned with the fragment grid (and, with row classes, with the 128-wide column tile)
+  static const bool bdirect_on = !(getenv("PM_GEMM_BDIRECT") && atoi(getenv("PM_GEMM_BDIRECT")) == 0);
+  const bool bdirect = planes && q->b_frag && bdirect_on && !transA && N % 128 == 0 && K % 32 == 0 && q->ldb % 32 == 0 &&
+                       (n_groups == 1 || q->b_split_rows > 0) && q->b_split_rows % 32 == 0 &&
+                       (q->b_split_rows == 0 || (q->b_group_stride % q->ldb == 0 && q->b_shared_off % q->ldb == 0)) &&
+                       ((uintptr_t)q->b_frag % 16 == 0) && (!q->class_ptr || q->class_block % 128 == 0);
+  const int cfg = planes ? (bdirect ? 9 : 8) : pick_config(transA, M, N, K, va && vb, n_groups == 1 && !q->rowmap);
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg], BK = CFG_BK[cfg];
   if (q->class_ptr && q->class_block > 0 && q->rowmap && q->dyn_entries && q->rows_per_entry == 1) {
     const int blk = q->class_block;           // which dimension carries the [track | onset | next | x] blocks
@@ -833,7 +913,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
     case 6: launch_t<64, 64, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
     case 7: launch_t<128, 128, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
     case 8: launch_t<64, 64, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
-    case 9: launch_t<128, 64, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
+    case 9: launch_t<64, 128, 32, 1, 4, 3>(transA, transB, va, vb, grid, st, g); break;
     default: launch_t<128, 128, 32, 2, 2, 2>(transA, transB, va, vb, grid, st, g); break;
   }
   pm_prof_close(st, pe);
@@ -854,7 +934,7 @@ extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N,
   q.bias_group_stride = bias_group_stride; q.map_group_stride = map_group_stride; q.dyn_group_stride = dyn_group_stride;
   q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0; q.col_stats = nullptr;
   q.operand_planes = 0; q.a_plane_stride = 0; q.b_plane_stride = 0;
-  q.class_ptr = nullptr; q.class_block = 0;
+  q.class_ptr = nullptr; q.class_block = 0; q.b_frag = nullptr;
   return pm_gemm_f32_desc(&q, stream);
 }
 
@@ -882,6 +962,57 @@ extern "C" int pm_split_planes(const float* src, int64_t n, uint16_t* planes, in
   int64_t grid = pm_cdiv(n / 4, 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_split_planes, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, n / 4, planes, plane_stride);
+  return pm_check_launch();
+}
+
+// Fragment-major planes of a weight matrix W [rows, cols] (fp32) for the B-direct GEMM mode: per (32-wide tile of the
+// n dimension, 16-wide k-step, plane) one contiguous 1 KiB block holding, for lane l, the 8 bf16 of
+// (n = tile*32 + l % 32, k = step*16 + 8 * (l / 32) .. + 8) — exactly the B operand of v_mfma_f32_32x32x16_bf16.
+//   kind 0 (the product uses W as B[n][k], transB): n = W row, k = W column; blocks ordered [row tile][k-step][plane]
+//   kind 1 (the product uses W as B[k][n])        : k = W row, n = W column; blocks ordered [k-step][column tile][plane]
+// rows % 32 == 0 and cols % 32 == 0; `n_mats` matrices `src_stride` floats apart go to blocks `dst_stride` bf16 apart.
+__global__ void __launch_bounds__(256) k_split_planes_frag(const float* __restrict__ W, int rows, int cols, int kind,
+                                                           int64_t src_stride, int64_t dst_stride,
+                                                           uint16_t* __restrict__ out) {
+  const float* src = W + (int64_t)blockIdx.y * src_stride;
+  uint16_t* dst = out + (int64_t)blockIdx.y * dst_stride;
+  const int64_t chunks = (int64_t)rows * cols / 8;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (int64_t)gridDim.x * blockDim.x) {
+    float x[8];
+    int64_t blk;
+    int lane;
+    if (kind == 0) {                                       // chunk = 8 consecutive columns of one row
+      const int n = (int)(c / (cols / 8)), k0 = (int)(c % (cols / 8)) * 8;
+      const float4 u = *reinterpret_cast<const float4*>(src + (int64_t)n * cols + k0);
+      const float4 w = *reinterpret_cast<const float4*>(src + (int64_t)n * cols + k0 + 4);
+      x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+      blk = (int64_t)(n >> 5) * (cols / 16) + (k0 >> 4);
+      lane = ((k0 >> 3) & 1) * 32 + (n & 31);
+    } else {                                               // chunk = 8 consecutive rows of one column (n fastest: coalesced)
+      const int n = (int)(c % cols), k0 = (int)(c / cols) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = src[(int64_t)(k0 + e) * cols + n];
+      blk = (int64_t)(k0 >> 4) * (cols / 32) + (n >> 5);
+      lane = ((k0 >> 3) & 1) * 32 + (n & 31);
+    }
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
+    uint16_t* o = dst + blk * 1536 + lane * 8;             // 3 planes x 512 bf16 per block
+    *reinterpret_cast<u32x4*>(o) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(o + 512) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    *reinterpret_cast<u32x4*>(o + 1024) = u32x4{p3[0], p3[1], p3[2], p3[3]};
+  }
+}
+extern "C" int pm_split_planes_frag(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,
+                                    int64_t src_stride, int64_t dst_stride, uint16_t* out, pm_stream_t stream) {
+  if (!W || !out || rows <= 0 || cols <= 0 || (rows % 32) || (cols % 32) || (kind != 0 && kind != 1) || n_mats <= 0 ||
+      ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (src_stride % 4) || (dst_stride % 8))
+    return PM_E_INVALID;
+  int64_t grid = pm_cdiv((int64_t)rows * cols / 8, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_split_planes_frag, dim3((unsigned)grid, (unsigned)n_mats), dim3(256), 0, (hipStream_t)stream, W,
+                     rows, cols, kind, src_stride, dst_stride, out);
   return pm_check_launch();
 }
 

@@ -9,6 +9,7 @@
 // Activations are carved from a caller-provided arena (pure function of the shapes, so the same
 // arena is reused every step and the sequence is hipGraph-capturable).
 #include "common.h"
+#include <stdio.h>
 #include <string.h>
 
 namespace {
@@ -31,6 +32,9 @@ struct GcnSaved {
   float* mean[PM_MAX_LAYERS]; float* var[PM_MAX_LAYERS];
   uint16_t* Ap[PM_MAX_LAYERS];           // planes mode: the aggregates as three bf16 planes (A[] is then unused)
   uint16_t* Wp; int64_t wp_stride; int64_t wp_base;   // planes of the parameter range [wp_base, wp_base + wp_stride)
+  // the [weight; root] matrices [7d, d] of the layers as FRAGMENT-MAJOR planes (B-direct GEMM mode): kind 1 for the
+  // forward product, kind 0 for the input gradient; wf_stride bf16 per layer (null: not available)
+  uint16_t* Wfn; uint16_t* Wft; int64_t wf_stride;
   double* pool;                          // per layer PM_BN_REPL x ([2][d] forward column sums, [3][d] backward sums), fp64
   uint32_t seed, uid0; float p;
 };
@@ -62,7 +66,12 @@ struct Ctx {
   int compact;                           // 1: one track relation per node -> [N,4d] aggregates, K = 4d
   int planes;                            // 1 (needs compact): GCL GEMM operands as pre-split bf16 planes
   const float* P; float* G; float* Bf;
-  void chk(int r) { if (r != PM_OK && rc == PM_OK) rc = r; }
+  void chk(int r, int line = __builtin_LINE()) {       // first failure wins; PM_DEBUG=1 names the call site
+    if (r != PM_OK && rc == PM_OK) {
+      rc = r;
+      if (getenv("PM_DEBUG")) fprintf(stderr, "[polyphemus_hip] vae_step.hip:%d returned %d\n", line, r);
+    }
+  }
 };
 
 // y[M, Nout] = x @ W^T + b      (x: leading dim lda, y: leading dim ldc)
@@ -130,6 +139,26 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       if (g.weight[i] < sv.wp_base || ((g.weight[i] - sv.wp_base) & 7)) c.chk(PM_E_INVALID);
     sv.Wp = (uint16_t*)ar.take((size_t)sv.wp_stride * 6);
     if (ar.base) c.chk(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
+    // fragment-major copies for the B-direct mode (d a multiple of 32, the layers' matrices equally spaced)
+    sv.Wfn = sv.Wft = nullptr; sv.wf_stride = 7 * dd * 3;
+    // (layer 0 is followed by the shared edge_nn parameters, so it is converted on its own; layers 1.. are equally
+    //  spaced and go in one batched launch per kind)
+    const int64_t lstride = c.L > 2 ? g.weight[2] - g.weight[1] : 7 * dd;
+    bool even = (d % 32) == 0 && c.compact && (lstride % 4) == 0 && !getenv("PM_GCL_NO_BFRAG");
+    for (int i = 2; i < c.L; ++i) even = even && (g.weight[i] - g.weight[i - 1] == lstride);
+    if (even) {
+      sv.Wfn = (uint16_t*)ar.take((size_t)sv.wf_stride * 2 * c.L);
+      sv.Wft = (uint16_t*)ar.take((size_t)sv.wf_stride * 2 * c.L);
+      if (ar.base) {
+        for (int kind = 0; kind < 2; ++kind) {
+          uint16_t* dst = kind ? sv.Wfn : sv.Wft;
+          c.chk(pm_split_planes_frag(c.P + g.weight[0], 7 * d, d, kind, 1, 7 * dd, sv.wf_stride, dst, c.st));
+          if (c.L > 1)
+            c.chk(pm_split_planes_frag(c.P + g.weight[1], 7 * d, d, kind, c.L - 1, lstride, sv.wf_stride,
+                                       dst + sv.wf_stride, c.st));
+        }
+      }
+    }
   }
   for (int i = 0; i < c.L; ++i) {
     if (c.planes) { sv.Ap[i] = (uint16_t*)ar.take((size_t)aps * 6); sv.A[i] = nullptr; }
@@ -159,6 +188,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       if (c.planes) {
         q.operand_planes = 1; q.A = (const float*)sv.Ap[i]; q.a_plane_stride = aps;
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
+        if (sv.Wfn) q.b_frag = sv.Wfn + (int64_t)i * sv.wf_stride;
       }
       c.chk(pm_gemm_f32_desc(&q, c.st));
     }
@@ -203,6 +233,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       if (c.planes) {
         q.operand_planes = 1; q.A = (const float*)dhp; q.a_plane_stride = dps;
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
+        if (sv.Wft) q.b_frag = sv.Wft + (int64_t)i * sv.wf_stride;
       }
       c.chk(pm_gemm_f32_desc(&q, c.st));
       PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
@@ -511,7 +542,11 @@ extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N
   Ctx c = make_ctx(&s, nullptr);
   forward(c, 0.f, 0, 0);
   measure_backward(c);
-  return (int64_t)s.ar.used + 4096;
+  // the measuring pass runs the fp32 7-block layout; the planes layout additionally keeps the GCL weights of both
+  // stacks as bf16 planes (row-major + two fragment-major copies): 3 x 6 bytes per stored weight element
+  const int64_t d = lay->d, per_layer = 7 * d * d + 64 * d + 256;
+  const int64_t weight_planes = 2 * (int64_t)lay->n_layers * per_layer * 6 * 3 + (1 << 16);
+  return (int64_t)s.ar.used + weight_planes + 4096;
 }
 
 extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,

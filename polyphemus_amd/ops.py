@@ -39,7 +39,7 @@ def _prof_end(name: str, e0, work: float):
 
 
 _GEMM_TILES = ("64x64x16", "128x128x16", "64x64x32", "128x128x32", "x6:128x128x16", "x6:128x64x16", "x6:64x64x32",
-               "x6:128x128x32", "planes:64x64x32", "planes:128x64x32", "planes:128x128x32")
+               "x6:128x128x32", "planes:64x64x32", "planesB:64x128x32", "planes:128x128x32")
 
 
 def gemm_class(transA: bool, transB: bool, M: int, N: int, K: int) -> str:
@@ -248,20 +248,22 @@ class _GemmDesc(ctypes.Structure):
                 ("b_split_rows", ctypes.c_int32), ("b_shared_off", ctypes.c_int64),
                 ("c_split_rows", ctypes.c_int32), ("c_shared_off", ctypes.c_int64), ("col_stats", ctypes.c_void_p),
                 ("operand_planes", ctypes.c_int32), ("a_plane_stride", ctypes.c_int64),
-                ("b_plane_stride", ctypes.c_int64), ("class_ptr", ctypes.c_void_p), ("class_block", ctypes.c_int32)]
+                ("b_plane_stride", ctypes.c_int64), ("class_ptr", ctypes.c_void_p), ("class_block", ctypes.c_int32),
+                ("b_frag", ctypes.c_void_p)]
 
 
 def gemm_desc(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
               split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None, n_groups=1, a_group_stride=0,
               b_group_stride=0, c_group_stride=0, bias_group_stride=0, map_group_stride=0, dyn_group_stride=0,
               b_split_rows=0, b_shared_off=0, c_split_rows=0, c_shared_off=0, partition=False, col_stats=None, planes=False, a_plane_stride=0,
-              b_plane_stride=0, class_ptr=None, class_block=0):
+              b_plane_stride=0, class_ptr=None, class_block=0, b_frag=None):
     """Grouped / stacked-operand GEMM (`pm_gemm_f32_desc`): see PmGemmDesc in the header."""
     q = _GemmDesc(int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
                   (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_PARTITION if partition else 0),
                   split_k, ptr(rowmap), rows_per_entry,
                   ptr(dyn_entries), n_groups, a_group_stride, b_group_stride, c_group_stride, bias_group_stride,
-                  map_group_stride, dyn_group_stride, b_split_rows, b_shared_off, c_split_rows, c_shared_off, ptr(col_stats), int(planes), a_plane_stride, b_plane_stride, ptr(class_ptr), class_block)
+                  map_group_stride, dyn_group_stride, b_split_rows, b_shared_off, c_split_rows, c_shared_off, ptr(col_stats), int(planes), a_plane_stride, b_plane_stride, ptr(class_ptr), class_block,
+                  ptr(b_frag))
     call("pm_gemm_f32_desc", ctypes.addressof(q), stream())
     return out
 
@@ -273,6 +275,17 @@ def split_planes(x: torch.Tensor) -> torch.Tensor:
     n = x.numel()
     out = torch.empty(3, n, dtype=torch.int16, device=x.device)
     call("pm_split_planes", ptr(x), n, ptr(out), n, stream())
+    return out
+
+
+def split_planes_frag(W: torch.Tensor, kind: int) -> torch.Tensor:
+    """Fragment-major bf16 planes of weight matrices W [n_mats, rows, cols] or [rows, cols] (`pm_split_planes_frag`;
+    the `b_frag` operand of `gemm_desc`): kind 0 for a product that uses W transposed (transB), 1 otherwise."""
+    _chk(W, F32, "W")
+    mats = W.shape[0] if W.dim() == 3 else 1
+    rows, cols = W.shape[-2:]
+    out = torch.empty(mats, rows * cols * 3, dtype=torch.int16, device=W.device)
+    call("pm_split_planes_frag", ptr(W), rows, cols, kind, mats, rows * cols, rows * cols * 3, ptr(out), stream())
     return out
 
 

@@ -216,9 +216,9 @@ def test_split_planes_is_exact():
     assert torch.equal((f(p[0]) + f(p[1]) + f(p[2])).float(), x)
 
 
-@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("planes", [False, True, "bfrag"])
 @pytest.mark.parametrize("partition", [False, True])
-@pytest.mark.parametrize("Nn,d", [(700, 64), (1000, 32), (333, 128)])
+@pytest.mark.parametrize("Nn,d", [(700, 64), (1000, 32), (333, 128), (2100, 256)])
 def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition, planes):
     """The three contractions of the compact GCL (model.py:112,116 on [track block | onset | next | x]):
     rows partitioned into four relation groups (row lists + device counts), B / C stacked as
@@ -242,11 +242,14 @@ def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition, planes):
     if planes:                                                    # operands pre-split into three bf16 planes
         Ap, Wp = ops.split_planes(A), ops.split_planes(W)
         pa, pw = dict(planes=True, a_plane_stride=A.numel(), b_plane_stride=W.numel()), None
+    # "bfrag": the weights additionally as fragment-major planes (B taken straight into registers where the shape allows)
+    fn = dict(b_frag=ops.split_planes_frag(W, 1)) if planes == "bfrag" else {}
+    ft = dict(b_frag=ops.split_planes_frag(W, 0)) if planes == "bfrag" else {}
     # forward
     h = torch.full((Nn, d), float("nan"), device=DEV)
     if planes:
         ops.gemm_desc(Ap, Wp, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,
-                      b_shared_off=3 * dd, **pa, **grp)
+                      b_shared_off=3 * dd, **pa, **grp, **fn)
     else:
         ops.gemm_desc(A, W, h, Nn, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d,
                       b_shared_off=3 * dd, **grp)
@@ -258,7 +261,7 @@ def test_gemm_grouped_stacked_compact_gcl(Nn, d, partition, planes):
     if planes:
         dhp = ops.split_planes(dh)
         ops.gemm_desc(dhp, Wp, dA, Nn, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
-                      b_shared_off=3 * dd, planes=True, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), **grp)
+                      b_shared_off=3 * dd, planes=True, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), **grp, **ft)
     else:
         ops.gemm_desc(dh, W, dA, Nn, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
                       b_shared_off=3 * dd, **grp)
@@ -306,6 +309,47 @@ def test_bn_train_fwd_bwd(shape, I):
     dx = ops.bn_bwd(x, dy, O, Cn, I, mean, var, g, be, dg, db, relu=True)
     assert rel_err(dx, xr.grad) < 1e-5
     assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, ber.grad) < 1e-5
+
+
+def test_split_planes_frag_layout():
+    """`pm_split_planes_frag`: per (32-wide n tile, 16-wide k-step, plane) a 1 KiB block in MFMA operand order; the three
+    planes still sum to the fp32 value exactly."""
+    torch.manual_seed(2)
+    W = torch.randn(2, 96, 64, device=DEV) * torch.logspace(-3, 3, 64, device=DEV)
+    f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
+    for kind in (0, 1):
+        out = ops.split_planes_frag(W, kind)                          # [2, 96*64*3]
+        for m in range(2):
+            Wm = W[m] if kind == 0 else W[m].t()                     # [n, k]
+            n_tot, k_tot = Wm.shape
+            blocks = out[m].view(-1, 3, 64, 8)                       # [block, plane, lane, 8]
+            val = (f(blocks[:, 0]) + f(blocks[:, 1]) + f(blocks[:, 2]))   # [block, lane, 8]
+            if kind == 0:
+                val = val.view(n_tot // 32, k_tot // 16, 2, 32, 8)   # [ntile, kstep, half, n, e]
+                got = val.permute(0, 3, 1, 2, 4).reshape(n_tot, k_tot)
+            else:
+                val = val.view(k_tot // 16, n_tot // 32, 2, 32, 8)   # [kstep, ntile, half, n, e]
+                got = val.permute(1, 3, 0, 2, 4).reshape(n_tot, k_tot)
+            assert torch.equal(got, Wm)
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(1000, 256, 1024, False), (777, 1024, 256, True), (64, 128, 32, True),
+                                       (130, 384, 96, False)])
+def test_gemm_planes_b_direct(M, N, K, tb):
+    """planes-mode GEMM with the weight operand as fragment-major planes (config 9) against fp64, with bias / ReLU /
+    column statistics in the epilogue like the GCL forward."""
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device=DEV)
+    W = torch.randn((N, K) if tb else (K, N), device=DEV)
+    bias = torch.randn(N, device=DEV)
+    ref = A.double() @ (W.double().t() if tb else W.double()) + bias.double()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    sums = torch.zeros(8, 2, N, dtype=torch.float64, device=DEV)
+    ops.gemm_desc(ops.split_planes(A), ops.split_planes(W), out, M, N, K, K, K if tb else N, N, transB=tb, bias=bias,
+                  planes=True, a_plane_stride=A.numel(), b_plane_stride=W.numel(), col_stats=sums,
+                  b_frag=ops.split_planes_frag(W, 0 if tb else 1))
+    assert rel_err(out, ref) < 5e-6
+    assert rel_err(sums.sum(0)[0], out.double().sum(0)) < 1e-9
 
 
 def _planes_value(p):

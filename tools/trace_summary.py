@@ -16,7 +16,7 @@ def short(name: str) -> str:
     if m:
         bm, bn, bk, ta, tb, va, vb, x6 = m.groups()
         kind = "TN" if ta == "true" else ("NT" if tb == "true" else "NN")
-        mode = {"1": "x6:", "true": "x6:", "2": "planes:"}.get(x6, "")
+        mode = {"1": "x6:", "true": "x6:", "2": "planes:", "3": "planesB:"}.get(x6, "")
         return (f"k_gemm<{mode}{bm}x{bn}x{bk},{kind}"
                 f"{'' if va == 'true' and vb == 'true' else ',scalar'}>")
     return re.sub(r"\(.*$", "", name)[:70]

@@ -27,6 +27,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef PM_BD_WAVES
+#define PM_BD_WAVES 5
+#endif
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias;
   const int32_t* rowmap; const int32_t* dyn_entries;
@@ -317,8 +320,8 @@ struct PlaneStage {
 //  contraction then run as one resident wave of workgroups instead of 1024 + a 12-tile tail)
 template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
 __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
-    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? 4 : 1),
-                                       (MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? 4 : 8))))
+    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? PM_BD_WAVES : 1),
+                                       (MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? PM_BD_WAVES : 8))))
     k_gemm(GemmArgs g) {
   constexpr bool X6 = MODE == 1, PL = MODE >= 2, BD = MODE == 3;
   static_assert(MODE == 0 || (VA && VB && BK % 16 == 0), "split modes stage with 16-byte loads");

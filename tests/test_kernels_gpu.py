@@ -687,8 +687,13 @@ def test_plan_track_lists_are_class_sorted_and_gemm_skips_zero_blocks():
         for k in range(4):
             want = np.nonzero((trel == t) & (cls == k))[0]
             np.testing.assert_array_equal(lists[t, bnd[k]:bnd[k + 1]], want)
-    # masked contractions == unmasked ones (d = 64: one 64-wide tile per block column)
-    d = 64
+    # masked contractions == unmasked ones (d = 64: one 64-wide tile per block column; d = 128 also with the weights
+    # as fragment-major planes: the B-direct tiles are 128 wide)
+    for d, bfrag in ((64, False), (128, False), (128, True)):
+        _masked_contractions(plan, N, on, nx, d, bfrag)
+
+
+def _masked_contractions(plan, N, on, nx, d, bfrag):
     dd = d * d
     torch.manual_seed(0)
     A = torch.randn(N, 4 * d, device=DEV)
@@ -698,6 +703,8 @@ def test_plan_track_lists_are_class_sorted_and_gemm_skips_zero_blocks():
     W = torch.randn(7 * d, d, device=DEV)
     dh = torch.randn(N, d, device=DEV)
     Ap, Wp, dhp = ops.split_planes(A), ops.split_planes(W), ops.split_planes(dh)
+    fn = dict(b_frag=ops.split_planes_frag(W, 1)) if bfrag else {}
+    ft = dict(b_frag=ops.split_planes_frag(W, 0)) if bfrag else {}
     tl = plan.field("trk_list")
     tc = plan.field("trk_cnt")
     grp = dict(rowmap=tl, rows_per_entry=1, dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1,
@@ -707,16 +714,19 @@ def test_plan_track_lists_are_class_sorted_and_gemm_skips_zero_blocks():
         ck = dict(class_ptr=tc[8:], class_block=d) if masked else {}
         h = torch.zeros(N, d, device=DEV)
         ops.gemm_desc(Ap, Wp, h, N, d, 4 * d, 4 * d, d, d, b_group_stride=dd, b_split_rows=d, b_shared_off=3 * dd,
-                      a_plane_stride=A.numel(), b_plane_stride=W.numel(), **grp, **ck)
+                      a_plane_stride=A.numel(), b_plane_stride=W.numel(), **grp, **ck, **fn)
         dA = torch.zeros(N, 4 * d, device=DEV)
         ops.gemm_desc(dhp, Wp, dA, N, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
-                      b_shared_off=3 * dd, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), **grp, **ck)
+                      b_shared_off=3 * dd, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), **grp, **ck, **ft)
         dW = torch.zeros(7 * d, d, device=DEV)
         ops.gemm_desc(Ap, dhp, dW, 4 * d, d, N, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
                       c_split_rows=d, c_shared_off=3 * dd, a_plane_stride=A.numel(), b_plane_stride=dh.numel(), **grp, **ck)
         res.append((h, dA, dW))
     (h0, dA0, dW0), (h1, dA1, dW1) = res
     assert rel_err(h1, h0) < 1e-6 and rel_err(dW1, dW0) < 1e-6
+    trel_t = plan.field("node_trel").long()[:N]
+    Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()
+    assert rel_err(h1, torch.einsum("nk,nkj->nj", A.double(), Wn[trel_t])) < 5e-6
     keep = torch.ones(N, 4 * d, dtype=torch.bool, device=DEV)      # dA: only the blocks a node's edges can read are defined
     keep[torch.from_numpy(~on), d:2 * d] = False
     keep[torch.from_numpy(~nx), 2 * d:3 * d] = False

@@ -7,6 +7,7 @@
 // stats = one read of x; apply = read x (+ residual), write y.  Column sums are accumulated in
 // fp64 so that var = E[x^2] - E[x]^2 keeps fp32 parity.
 #include "common.h"
+#include <stdlib.h>
 
 #define BN_MAX_CHUNKS 256
 #define BN_NACC 3          /* accumulators per column: stats use 2, backward uses 3 */
@@ -230,6 +231,10 @@ __global__ void __launch_bounds__(256) k_bn_apply1(const float* __restrict__ x, 
     y[i] = v;
   }
 }
+static inline int fused_grid(int64_t n) {      // fewer, longer workgroups: each one first reduces the replicated sums
+  static const int cap = getenv("PM_BN_GRID") ? atoi(getenv("PM_BN_GRID")) : 1024;
+  int64_t g = pm_cdiv(n, 256); return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
 static inline int ew_grid(int64_t n) { int64_t g = pm_cdiv(n, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 extern "C" int pm_bn_apply(const float* x, int32_t O, int32_t C, int32_t I, const float* mean, const float* var,
@@ -343,7 +348,7 @@ extern "C" int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const dou
   if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (residual && ((uintptr_t)residual % 16))) return PM_E_INVALID;
   BnCtx ctx = {nullptr, nullptr, gamma, beta, eps, relu};
   const int64_t n = (int64_t)O * C;
-  hipLaunchKernelGGL(k_bn_apply4_sums, dim3(ew_grid(n / 4)), dim3(256), sizeof(float) * 3 * C, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(k_bn_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 3 * C, (hipStream_t)stream, x,
                      n / 4, C, (double)O, sums, ctx, residual, y, mean, var, running_mean, running_var, momentum);
   return pm_check_launch();
 }
@@ -449,7 +454,7 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
   if (!sums_ready)
     hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3);
   const int64_t n = (int64_t)O * C;
-  hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(ew_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
+  hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
                      (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride);
   return pm_check_launch();
 }

@@ -195,14 +195,19 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
                                                        const float* __restrict__ csc_invcnt, int N, int d,
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
                                                        int compact, float* __restrict__ dx, float* __restrict__ dT,
-                                                       PmNormSums nn, int xcd_nodes) {
+                                                       PmNormSums nn, int xcd_nodes, int pr) {
   // LDS image of the table gradient: element (dist, column 4q + j) at dist*d + j*(d/4) + q, so that the four
   // ds_add_f32 of a lane's float4 hit consecutive addresses across the wave (bank-conflict free)
-  extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][4][d/4]
-  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) sT[i] = 0.f;
+  extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][4][d/4], then per wave `pr` private rows [d]
+  // LDS float atomics run at about one lane per clock, so the most frequent distances 1..pr (time gaps are geometric:
+  // 25 %, 19 %, 14 %, ...) go to rows PRIVATE to the wave — plain 16-byte read-add-write, no atomics, masked elements
+  // simply add 0 — and only the rare long distances take the shared table; distance 0 stays in registers (z0 below)
+  const int nwv0 = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < (PM_N_DIST + nwv0 * pr) * d; i += blockDim.x) sT[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  float* const sP = sT + PM_N_DIST * d + wave * pr * d;          // this wave's rows for distances 1..pr, lane-major
   const int nblk = compact ? 4 : 7;
   const int dq = d >> 2;
   int c[NV];
@@ -300,6 +305,11 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
           if (dist[u] == 0) {                                // onset edges (a third of all): row 0 stays in registers
 #pragma unroll
             for (int j = 0; j < 4; ++j) z0[v][j] += gt[j];
+          } else if (dist[u] <= pr) {                        // private row: no atomics
+            float4* pp = reinterpret_cast<float4*>(sP + (dist[u] - 1) * d + c[v]);
+            float4 t = *pp;
+            t.x += gt[0]; t.y += gt[1]; t.z += gt[2]; t.w += gt[3];
+            *pp = t;
           } else {                                           // one uniform branch per edge, not per element
             float* row = sT + dist[u] * d + (c[v] >> 2);
 #pragma unroll
@@ -347,6 +357,13 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       if (z0[v][j] != 0.f) atomicAdd(&sT[j * dq + (c[v] >> 2)], z0[v][j]);
   }
   __syncthreads();
+  for (int i = threadIdx.x; i < pr * d; i += blockDim.x) {               // private rows of all waves -> shared image
+    const int r = i / d, col = i - r * d;
+    float t = 0.f;
+    for (int w = 0; w < nwv0; ++w) t += sT[PM_N_DIST * d + (w * pr + r) * d + col];
+    sT[(r + 1) * d + (col & 3) * dq + (col >> 2)] += t;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {       // i runs over dT (coalesced atomics)
     const int col = i % d;
     const float v = sT[i - col + (col & 3) * dq + (col >> 2)];
@@ -383,6 +400,11 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   }
 }
 
+// > 64 KiB of dynamic LDS needs the attribute (cheap; the runtime caches it per function)
+static void seg_bwd_lds_attr(const void* fn, size_t lds) {
+  if (lds > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
                               int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
                               uint32_t layer_uid, int32_t compact, float* dx, float* dT, const PmNormSums* nn,
@@ -401,7 +423,12 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   const dim3 grid(nblk), block(threads);
   int xcd_nodes = 0;                                    // nodes per XCD, a multiple of the waves per workgroup
   if (seg_xcd_aware() && nblk >= 16 && (nblk & 7) == 0) xcd_nodes = (int)pm_cdiv(pm_cdiv(N, 8), threads / 64) * (threads / 64);
-  const size_t lds = sizeof(float) * PM_N_DIST * d;
+  // private distance rows per wave: as many as fit 144 KB of LDS next to the shared table (default cap 4: measured 42.1 us against 42.5 at 7 and 48.7 without, d = 256)
+  static const int pr_cap = getenv("PM_SEG_PRIV") ? atoi(getenv("PM_SEG_PRIV")) : 4;
+  int pr = (int)((144 * 1024 / sizeof(float) / d - PM_N_DIST) / (threads / 64));
+  if (pr > pr_cap) pr = pr_cap;
+  if (pr < 0) pr = 0;
+  const size_t lds = sizeof(float) * (PM_N_DIST + (size_t)(threads / 64) * pr) * d;
   const bool drop = dropout_p > 0.f;
   const uint32_t thresh = pm_keep_threshold(dropout_p);
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
@@ -409,8 +436,9 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   memset(&none, 0, sizeof(none));
   const PmNormSums nv_ = nn ? *nn : none;
 #define LAUNCH(NV, DR, FU)                                                                                           \
+  do { seg_bwd_lds_attr(reinterpret_cast<const void*>(&k_segreduce_bwd<NV, DR, FU>), lds);                           \
   hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,      \
-                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes)
+                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes, pr); } while (0)
 #define LAUNCH2(NV, DR) do { if (nn) LAUNCH(NV, DR, true); else LAUNCH(NV, DR, false); } while (0)
   const int nv = (int)pm_cdiv(d, 256);
   const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 3 : PM_N_REL) + 1 + (nn ? 1 : 0)) + 12.0 * E + 128.0 * d);

@@ -137,22 +137,38 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
   const float mean = gm[0], rstd = rsqrtf(gv[0] + eps), ga = bg[0];
   const float m0 = (float)(sums[0] / N), m1 = (float)(sums[1] / N);
   if (blockIdx.x == 0 && threadIdx.x == 0) { dbn_b[0] += (float)sums[0]; dbn_g[0] += (float)sums[1]; }
+  // the gate-weight gradient of the wave's nodes is summed in registers (LDS float atomics run at about one lane per
+  // clock: one per node and element cost most of this kernel); d <= 1024: four float4 per lane
+  float4 wacc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wacc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bacc = 0.f;
   for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
     const float gh = (g[n] - mean) * rstd;
     const float dg = ga * rstd * (dgn[n] - m0 - gh * m1);
     const float a = alpha[n];
     const int b = node_bar[n];
-    for (int c = lane * 4; c < d; c += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + k * 256;
+      if (c >= d) continue;
       const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c);
       const float4 dv = *reinterpret_cast<const float4*>(dout + (int64_t)b * d + c);
       const float4 wv = *reinterpret_cast<const float4*>(w + c);
       *reinterpret_cast<float4*>(dx + (int64_t)n * d + c) =
           make_float4(a * dv.x + dg * wv.x, a * dv.y + dg * wv.y, a * dv.z + dg * wv.z, a * dv.w + dg * wv.w);
-      atomicAdd(&sW[c + 0], dg * xv.x); atomicAdd(&sW[c + 1], dg * xv.y);
-      atomicAdd(&sW[c + 2], dg * xv.z); atomicAdd(&sW[c + 3], dg * xv.w);
+      wacc[k].x += dg * xv.x; wacc[k].y += dg * xv.y; wacc[k].z += dg * xv.z; wacc[k].w += dg * xv.w;
     }
-    if (lane == 0) atomicAdd(&sW[d], dg);
+    bacc += dg;
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane * 4 + k * 256;
+    if (c >= d) continue;
+    atomicAdd(&sW[c + 0], wacc[k].x); atomicAdd(&sW[c + 1], wacc[k].y);
+    atomicAdd(&sW[c + 2], wacc[k].z); atomicAdd(&sW[c + 3], wacc[k].w);
+  }
+  if (lane == 0) atomicAdd(&sW[d], bacc);
   __syncthreads();
   for (int i = threadIdx.x; i < d; i += blockDim.x) atomicAdd(&dW[i], sW[i]);
   if (threadIdx.x == 0) atomicAdd(&db[0], sW[d]);
@@ -163,7 +179,7 @@ extern "C" int pm_attnpool_bwd(const float* x, const float* g, const float* g_me
                                float* d_gate_w, float* d_gate_b, float* d_bn_g, float* d_bn_b, float* scratch,
                                pm_stream_t stream) {
   if (!x || !g || !g_mean || !g_var || !bn_g || !alpha || !dout || !gate_w || !plan || !dx || !d_gate_w || !d_gate_b ||
-      !d_bn_g || !d_bn_b || !scratch || N <= 0 || G <= 0 || d <= 0 || (d & 3) || ((uintptr_t)scratch & 7))
+      !d_bn_g || !d_bn_b || !scratch || N <= 0 || G <= 0 || d <= 0 || (d & 3) || d > 1024 || ((uintptr_t)scratch & 7))
     return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   PmPlanView pv = pm_plan_view(plan, N, E, G);

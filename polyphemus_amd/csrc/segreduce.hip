@@ -400,9 +400,15 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   }
 }
 
-// > 64 KiB of dynamic LDS needs the attribute (cheap; the runtime caches it per function)
-static void seg_bwd_lds_attr(const void* fn, size_t lds) {
-  if (lds > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// > 64 KiB of dynamic LDS needs the attribute: set once per instantiation and size
+template <int NV, bool DR, bool FU>
+static void seg_bwd_lds_attr(size_t lds) {
+  static size_t granted = 64 * 1024;
+  if (lds > granted) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segreduce_bwd<NV, DR, FU>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = lds;
+  }
 }
 
 static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
@@ -436,7 +442,7 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   memset(&none, 0, sizeof(none));
   const PmNormSums nv_ = nn ? *nn : none;
 #define LAUNCH(NV, DR, FU)                                                                                           \
-  do { seg_bwd_lds_attr(reinterpret_cast<const void*>(&k_segreduce_bwd<NV, DR, FU>), lds);                           \
+  do { seg_bwd_lds_attr<NV, DR, FU>(lds);                                                                         \
   hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,      \
                      pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes, pr); } while (0)
 #define LAUNCH2(NV, DR) do { if (nn) LAUNCH(NV, DR, true); else LAUNCH(NV, DR, false); } while (0)

@@ -29,10 +29,11 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak; a split-mode fp32 product costs SIX bf16 MFMA products
 # Memory-side bytes per launch of the dominant kernels at the DEFAULT workload, from separate `rocprofv3 --pmc FETCH_SIZE`
-# / `--pmc WRITE_SIZE` passes over this same command (profiles/r01_v5_kernel_stats.md; reads doubled per the gfx950
+# / `--pmc WRITE_SIZE` passes over this same command (profiles/r01_v7_kernel_stats.md, v5 for the LDS-staged tiles; reads doubled per the gfx950
 # FETCH_SIZE rule of MI355X_MICROARCH.md).  bench.py cannot read PMC counters itself; other workloads report null.
 PMC_TRAFFIC_DEFAULT = {"gemm_NT_planes:64x64x32": 99.7e6, "gemm_NN_planes:64x64x32": 119.6e6,
-                       "gemm_TN_planes:64x64x32": 152.5e6, "segreduce_fwd": 163.9e6}
+                       "gemm_TN_planes:64x64x32": 152.7e6, "gemm_NT_planesB:64x128x32": 104.9e6,
+                       "gemm_NN_planesB:64x128x32": 117.9e6, "segreduce_fwd": 121.4e6}
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; ~6.3 TB/s achievable
 
 

@@ -465,6 +465,15 @@ int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buff
                         uint32_t seed_enc, uint32_t seed_dec, float beta, int structure_loss_on_logits,
                         void* workspace, int64_t workspace_bytes, void* state, double* losses /* [4] dev */,
                         pm_stream_t stream);
+/* Introspection of the last forward (host only): info = {compact GCL, bf16-planes GEMM operands, active slots S,
+ * fragment-major weight planes built (B-direct GEMM mode), N, E, G, B}.  The parity tests use it to assert that the
+ * golden-pinned step IS the measured variant. */
+int pm_vae_step_info(const void* state, int32_t* info /* [8] host */);
+/* The model outputs of `VAE.forward` (model.py:665-678) as the last forward computed them, copied out of the arena
+ * (async on `stream`; any pointer may be NULL): s_logits [G,4,32], c_logits [N,S,230] (active slots only), mu and
+ * log_var [B,d].  Valid until the next pm_vae_step_forward on this state. */
+int pm_vae_step_outputs(const void* state, float* s_logits, float* c_logits, float* mu, float* log_var,
+                        pm_stream_t stream);
 int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder_tail(void* state, pm_stream_t stream);

@@ -80,6 +80,8 @@ _SIGS = {
     "pm_prof_end": "ppp",
     "pm_vae_step_workspace_bytes": "piiiii",
     "pm_vae_step_forward": "pppppppfuufiplpps",
+    "pm_vae_step_info": "pp",
+    "pm_vae_step_outputs": "ppppps".replace(" ", ""),
     "pm_vae_step_backward_decoder": "ps",
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",

@@ -573,6 +573,35 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
   s->rc = c.rc;
   return c.rc;
 }
+// Which variant of the step the last pm_vae_step_forward selected (host only): the parity tests assert that the path
+// they pin to the reference goldens is the path bench.py measures.
+extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
+  const StepState* s = (const StepState*)state;
+  if (!s || !info || s->magic != kMagic) return PM_E_INVALID;
+  StepState tmp = *s;
+  Ctx c = make_ctx(&tmp, nullptr);
+  info[0] = c.compact; info[1] = c.planes; info[2] = c.S;
+  info[3] = (s->eg.Wfn && s->dg.Wfn) ? 1 : 0;          // fragment-major weight planes built (B-direct GEMM mode available)
+  info[4] = c.N; info[5] = c.E; info[6] = c.Gn; info[7] = c.B;
+  return PM_OK;
+}
+// Model outputs of the last forward (the arena keeps them until the next pm_vae_step_forward): asynchronous
+// device-to-device copies on `stream`.  c_logits covers the ACTIVE slots only, [N, S, 230] (slots >= S hold PAD in every
+// node: no loss, never computed).  Any destination may be NULL.
+extern "C" int pm_vae_step_outputs(const void* state, float* s_logits, float* c_logits, float* mu, float* log_var,
+                                   pm_stream_t stream) {
+  const StepState* s = (const StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK || !s->s_logits) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t N = s->bt.N, S = s->bt.n_slots, G = s->bt.G, B = s->bt.B, d = s->lay.d;
+  hipError_t e = hipSuccess;
+  if (s_logits && e == hipSuccess) e = hipMemcpyAsync(s_logits, s->s_logits, sizeof(float) * G * 128, hipMemcpyDeviceToDevice, st);
+  if (c_logits && e == hipSuccess) e = hipMemcpyAsync(c_logits, s->c_logits, sizeof(float) * N * S * PM_N_TOK, hipMemcpyDeviceToDevice, st);
+  if (mu && e == hipSuccess) e = hipMemcpyAsync(mu, s->mu, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
+  if (log_var && e == hipSuccess) e = hipMemcpyAsync(log_var, s->lv, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
+  return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
+}
+
 extern "C" int pm_vae_step_backward_decoder(void* state, pm_stream_t stream) {
   StepState* s = (StepState*)state;
   if (!s || s->magic != kMagic || s->rc != PM_OK) return PM_E_INVALID;

@@ -131,6 +131,30 @@ class BarGraphBatch:
         return int(self.s_tensor.shape[0])
 
 
+def batch_flags(tokens: torch.Tensor, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int):
+    """(n_slots, track_unique) of a batch that does not carry them (a foreign PyG batch, a golden fixture): the two
+    host-known facts that select the measured path of the native step — active token slots (`PmBatch.n_slots`) and
+    "every node receives track edges of at most one relation" (`PmBatch.flags` bit 0, compact GCL).  Same definitions as
+    `collate_samples`; on device tensors this costs ONE host read per batch object (callers cache the result)."""
+    tok = tokens.long()
+    live = (tok[:, 1:, 0] != C.PITCH_PAD) | (tok[:, 1:, 1] != C.DUR_PAD)
+    slot_live = live.any(dim=0)
+    et = edge_type.long()
+    trk = et < C.N_TRACKS
+    seen = torch.zeros(max(int(num_nodes), 1), C.N_TRACKS, dtype=torch.bool, device=et.device)
+    seen[edge_index[1].long()[trk], et[trk]] = True
+    multi = (seen.sum(dim=1) > 1).any()
+    last = (slot_live.long() * torch.arange(1, slot_live.numel() + 1, device=slot_live.device)).max()
+    # ids index LDS / global tables inside the kernels: range-check them here (same host read)
+    ei = edge_index.long()
+    bad = ((tok[..., 0] < 0) | (tok[..., 0] >= C.N_PITCH_TOKENS) | (tok[..., 1] < 0) | (tok[..., 1] >= C.N_DUR_TOKENS)).any() | \
+          ((et < 0) | (et >= C.N_EDGE_TYPES)).any() | ((ei < 0) | (ei >= int(num_nodes))).any()
+    n_slots, multi, bad = torch.stack([last, multi.long(), bad.long()]).tolist()          # the one sync
+    if bad:
+        raise ValueError("batch holds token ids, edge types or node ids outside their ranges")
+    return max(int(n_slots), 1), not bool(multi)
+
+
 def graph_from_structure(s_tensor: np.ndarray, dense: bool = False):
     """One sample: `s_tensor` [nb,4,32] 0/1 -> dict of numpy arrays.
 

@@ -97,13 +97,21 @@ def build_layout(vae) -> PmVaeLayout:
     return lay
 
 
-def make_batch(graph, plan_tokens, is_drum_u8, et, ed) -> PmBatch:
+def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_slots: int, track_unique: bool) -> PmBatch:
+    """Batch descriptor of the native step; every tensor is a checked device tensor of the dtype the C side reads
+    (int64 edge_index / bars / batch, int32 ids, uint8 is_drum, fp32 s_tensor: `HipTrainer._prep_inputs`)."""
+    for t, dt in ((edge_index, torch.int64), (bars, torch.int64), (batch, torch.int64), (s_tensor, torch.float32),
+                  (tokens, torch.int32), (is_drum_u8, torch.uint8), (et, torch.int32), (ed, torch.int32)):
+        if t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"native step: expected a contiguous cuda {dt} tensor, got {t.dtype} on {t.device}")
     b = PmBatch()
-    b.edge_index, b.edge_type, b.edge_dist = graph.edge_index.data_ptr(), et.data_ptr(), ed.data_ptr()
-    b.bars, b.batch, b.is_drum = graph.bars.data_ptr(), graph.batch.data_ptr(), is_drum_u8.data_ptr()
-    b.tokens, b.s_tensor = plan_tokens.data_ptr(), graph.s_tensor.data_ptr()
-    b.N, b.E, b.G = graph.bars.shape[0], graph.edge_index.shape[1], graph.s_tensor.shape[0]
-    b.n_slots = int(getattr(graph, "n_slots", 15) or 15)
+    b.edge_index, b.edge_type, b.edge_dist = edge_index.data_ptr(), et.data_ptr(), ed.data_ptr()
+    b.bars, b.batch, b.is_drum = bars.data_ptr(), batch.data_ptr(), is_drum_u8.data_ptr()
+    b.tokens, b.s_tensor = tokens.data_ptr(), s_tensor.data_ptr()
+    b.N, b.E, b.G = bars.shape[0], edge_index.shape[1], s_tensor.shape[0]
+    if not 1 <= int(n_slots) <= 15:
+        raise ValueError(f"n_slots must be in 1..15, got {n_slots}")
+    b.n_slots = int(n_slots)
     # bit 0: one track relation per node (compact GCL); bit 1: GCL GEMM operands as pre-split bf16 planes
-    b.flags = (1 if getattr(graph, "track_unique", False) else 0) | (2 if _PLANES else 0)
+    b.flags = (1 if track_unique else 0) | (2 if _PLANES else 0)
     return b

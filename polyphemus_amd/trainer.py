@@ -128,7 +128,17 @@ class HipTrainer:
                 graph.c_tensor.float().contiguous())
             drum = graph.is_drum.contiguous()
             drum = drum.view(torch.uint8) if drum.dtype == torch.bool else drum
-            c = (et, ed, tok, drum)
+            ei, bars, bat = (t.to(torch.int64).contiguous() for t in (graph.edge_index, graph.bars, graph.batch))
+            for t in (et, ed, tok, drum, ei, bars, bat):
+                if not t.is_cuda:
+                    raise RuntimeError("HipTrainer needs the batch on the GPU (graph.to('cuda')); there is no CPU path")
+            # the two host-known facts that pick the native path (active slots, compact GCL): carried by batches of
+            # `collate_samples` / `DeviceLoader`, derived once (one host read) for any other batch object
+            n_slots, unique = getattr(graph, "n_slots", None), getattr(graph, "track_unique", None)
+            if n_slots is None or unique is None:
+                from .graphs import batch_flags
+                n_slots, unique = batch_flags(tok, ei, et, tok.shape[0])
+            c = (et, ed, tok, drum, ei, bars, bat, int(n_slots), bool(unique))
             try:
                 graph.__dict__["_pm_inputs"] = c
             except Exception:
@@ -138,12 +148,11 @@ class HipTrainer:
     def _native_forward_backward(self, graph, eps):
         vae = self.vae
         L = lib()
-        et, ed, tok, drum = self._prep_inputs(graph)
+        et, ed, tok, drum, ei, bars, bat, n_slots, unique = self._prep_inputs(graph)
         s_tensor = graph.s_tensor
         if s_tensor.dtype != torch.float32 or not s_tensor.is_contiguous():
             s_tensor = s_tensor.float().contiguous()
-        bt = make_batch(graph, tok, drum, et, ed)
-        bt.s_tensor = s_tensor.data_ptr()
+        bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, n_slots, unique)
         bt.B = bt.G // vae.cfg["n_bars"]
         need = int(L.pm_vae_step_workspace_bytes(ctypes.byref(self._layout), bt.N, bt.E, bt.G, bt.B, bt.n_slots))
         if self._ws is None or self._ws.numel() < need:

@@ -1,15 +1,13 @@
 """Data-parallel host logic on CPU (gloo, world_size 2): sharding, bucketed gradient
 all-reduce, parameter broadcast, and DP-equivalence of the averaged gradient (oracle)."""
-import os
-import socket
-import sys
+import datetime
 
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from polyphemus_amd.parallel import GradBuckets, broadcast_, shard_range
+from util import run_ranks
 
 
 def test_shard_range_covers_batch_without_overlap():
@@ -20,15 +18,8 @@ def test_shard_range_covers_batch_without_overlap():
         assert seen == list(range(n))
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world):
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
         torch.manual_seed(100 + rank)
         flat = torch.randn(1000)
@@ -56,22 +47,13 @@ def _worker(rank, world, port, q):
         one.launch(0)
         one.wait()
         ok = ok and len(one.views) == 1 and torch.allclose(acc, sum(allg))
-        q.put((rank, ok))
+        return ok
     finally:
         dist.destroy_process_group()
 
 
 def test_bucketed_allreduce_and_broadcast_gloo_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert run_ranks(_worker, 2, timeout=90.0) == [True, True]
 
 
 def test_single_process_is_a_noop():
@@ -79,3 +61,30 @@ def test_single_process_is_a_noop():
     gb = GradBuckets(flat, [4])
     gb.launch(0); gb.launch(1)
     assert gb.wait() == 1.0 and torch.equal(flat, torch.arange(10.0))
+
+
+def _raiser(rank, world):
+    if rank == 1:
+        raise ValueError("boom on rank 1")
+    import time
+    time.sleep(30)                       # rank 0 would wait in a collective for ever
+
+
+def _sleeper(rank, world):
+    import time
+    time.sleep(60)
+
+
+def test_harness_reports_a_failing_rank_and_kills_the_others():
+    """The round-1 GPU suite hung on a rank that never answered: the harness must turn both cases into a prompt
+    exception and leave no child alive."""
+    import multiprocessing
+    import time
+    from util import RanksHung
+    t0 = time.time()
+    with pytest.raises(AssertionError, match="boom on rank 1"):
+        run_ranks(_raiser, 2, timeout=40.0)
+    with pytest.raises(RanksHung, match="rank 0"):
+        run_ranks(_sleeper, 2, timeout=16.0)
+    assert time.time() - t0 < 45.0
+    assert not multiprocessing.active_children()

@@ -21,7 +21,8 @@ What is captured:
 
   <case>_generate.npz   the generation helpers (`_binary_from_logits`, `decoder(z, None)`, `mtp_from_logits`)
 
-Usage:  python oracle/make_golden.py [generate]     (from the repo root; `generate` rewrites only <case>_generate.npz)
+Usage:  python oracle/make_golden.py [generate|d128]     (from the repo root; `generate` rewrites only <case>_generate.npz,
+        `d128` only the slim d = 128 case)
 """
 import json
 import os
@@ -101,7 +102,7 @@ def build_batch(tmpdir, disk, n_bars):
     return Batch.from_data_list([ds[i] for i in range(len(ds))])
 
 
-def capture_case(name, cfg, batch_size, p, seed, corner=False):
+def capture_case(name, cfg, batch_size, p, seed, corner=False, slim=False):
     rng = np.random.default_rng(seed)
     nb = cfg["n_bars"]
     disk = [disk_sample(rng, nb, p) for _ in range(batch_size)]
@@ -133,8 +134,15 @@ def capture_case(name, cfg, batch_size, p, seed, corner=False):
     torch.manual_seed(0)
     vae = ref_model.VAE(**cfg, device=torch.device("cpu"))
     sd0 = {k: v.clone() for k, v in vae.state_dict().items()}
-    for k, v in sd0.items():
-        out[f"sd/{k}"] = v.numpy()
+    if slim:      # the state is the reference's default init under torch.manual_seed(0), which the product's module tree
+        import hashlib      # reproduces bit for bit (tests/test_model_cpu.py): store its digest instead of its 5 MB
+        h = hashlib.sha256()
+        for k, v in sd0.items():
+            h.update(k.encode()); h.update(v.numpy().tobytes())
+        out["sd_sha256"] = np.array(h.hexdigest())
+    else:
+        for k, v in sd0.items():
+            out[f"sd/{k}"] = v.numpy()
     out["param_names"] = np.array([n for n, _ in vae.named_parameters()])
     B = batch_size
     eps = torch.from_numpy(np.random.default_rng(seed + 1).standard_normal((B, cfg["d"])).astype(np.float32))
@@ -150,7 +158,9 @@ def capture_case(name, cfg, batch_size, p, seed, corner=False):
     vae.eval()
     with torch.no_grad():
         s_logits, c_logits, mu, lv = fwd(vae, graph)
-    out["eval/s_logits"], out["eval/c_logits"] = s_logits.numpy(), c_logits.numpy()
+    out["eval/s_logits"] = s_logits.numpy()
+    if not slim:
+        out["eval/c_logits"] = c_logits.numpy()
     out["eval/mu"], out["eval/log_var"] = mu.numpy(), lv.numpy()
 
     # ---- train mode, message dropout off, two optimizer steps ----------------
@@ -165,7 +175,7 @@ def capture_case(name, cfg, batch_size, p, seed, corner=False):
     trainer.beta = 0                                                     # training.py:116
     out["opt"] = np.array(json.dumps(dict(optimizer=tj["optimizer"], lr_scheduler=tj["lr_scheduler"])))
     opt.zero_grad()
-    for step in (1, 2):
+    for step in ((1,) if slim else (1, 2)):
         s_logits, c_logits, mu, lv = fwd(vae, graph)
         tot, losses = trainer._losses(graph.s_tensor, s_logits, graph.c_tensor, c_logits, mu, lv)
         tot.backward()                                                   # training.py:155
@@ -186,7 +196,8 @@ def capture_case(name, cfg, batch_size, p, seed, corner=False):
         opt.zero_grad()
         sched.step()                                                     # training.py:170
         for k, v in vae.state_dict().items():
-            out[f"{pre}/sd_after/{k}"] = v.numpy().copy()
+            if not slim or "running_" in k or k.endswith("num_batches_tracked"):
+                out[f"{pre}/sd_after/{k}"] = v.numpy().copy()
     # ---- evaluation metrics of the reference (training.py:349-497 `_accuracies`, `_losses` in eval mode) on the
     #      eval-mode outputs; kept in a separate small file
     vae.load_state_dict(sd0)
@@ -252,8 +263,18 @@ def capture_generation(name):
           f"corner on={int(out['corner/s_binary'].sum())}")
 
 
+def capture_d128():
+    """d = 128 (a multiple of 128: the GCL forward and input-gradient products of the native step take the B-direct
+    planes GEMM, the weight gradient the planes TN kernel) — the variant bench.py measures, pinned to the reference."""
+    capture_case("d128_l2", dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=128, n_bars=2, resolution=8),
+                 batch_size=4, p=0.2, seed=13, slim=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["d128"]:
+        capture_d128()
+        sys.exit(0)
     if sys.argv[1:] == ["generate"]:
         capture_generation("lmd2_tiny")
         capture_generation("nb3_tiny")
@@ -265,3 +286,5 @@ if __name__ == "__main__":
                  batch_size=6, p=0.05, seed=12)
     capture_generation("lmd2_tiny")
     capture_generation("nb3_tiny")
+    capture_d128()
+

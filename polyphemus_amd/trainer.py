@@ -181,6 +181,26 @@ class HipTrainer:
              ptr(self._plan_buf[off[i]:off[i] + 2]), vae.flat_counters.numel(), st)
         return self.loss_buf
 
+    def step_info(self) -> dict:
+        """Which variant of the native step the last `train_step` ran (`pm_vae_step_info`): compact GCL (K = 4d),
+        bf16-planes GEMM operands, active token slots S, fragment-major weight planes (B-direct GEMM), batch sizes."""
+        info = (ctypes.c_int32 * 8)()
+        call("pm_vae_step_info", ctypes.addressof(self._state), ctypes.cast(info, ctypes.c_void_p))
+        keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B")
+        return dict(zip(keys, (int(v) for v in info)))
+
+    def step_outputs(self):
+        """`((s_logits, c_logits), mu, log_var)` of the last native `train_step` — what `VAE.forward` returns
+        (model.py:676-678) — copied out of the workspace arena.  c_logits holds the active slots only: [N, S, 230]
+        (the remaining slots are PAD in every node of the batch; the fused step never computes them)."""
+        i = self.step_info()
+        dev, d, nb = self.grads.device, self.vae.cfg["d"], self.vae.cfg["n_bars"]
+        s_logits = torch.empty(i["B"], nb, 4, 32, device=dev)
+        c_logits = torch.empty(i["N"], i["n_slots"], 230, device=dev)
+        mu, lv = torch.empty(i["B"], d, device=dev), torch.empty(i["B"], d, device=dev)
+        call("pm_vae_step_outputs", ctypes.addressof(self._state), ptr(s_logits), ptr(c_logits), ptr(mu), ptr(lv), stream())
+        return (s_logits, c_logits), mu, lv
+
     def _python_forward_backward(self, graph, eps):
         vae, eng = self.vae, self.vae.engine
         eng.msg_dropout = vae.msg_dropout

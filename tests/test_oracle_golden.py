@@ -75,6 +75,27 @@ def test_two_train_steps(case):
                 assert torch.equal(got, v), (step, k)
 
 
+def test_train_step_d128_slim_case():
+    """The d = 128 case (fixture without the 5 MB state_dict: its sha256 pins the default init): one train step."""
+    z, cfg = load_case("d128_l2")
+    g = batch_from_golden(z, cfg)
+    names = [str(n) for n in z["param_names"]]
+    P, names = vae_cpu.split_state(state_dict_from_golden(z), names)
+    optcfg = json.loads(str(z["opt"]))
+    opt = torch.optim.Adam([P[n] for n in names], **optcfg["optimizer"])
+    outs, parts, grads = vae_cpu.train_step(g, P, names, cfg, opt, torch.from_numpy(z["in/eps"]), msg_dropout=0.0)
+    for k, v in json.loads(str(z["train1/losses"])).items():
+        assert abs(float(parts[k].detach()) - v) <= 1e-5 * max(1.0, abs(v)), k
+    for name, got in zip(("s_logits", "c_logits", "mu", "log_var"), outs):
+        assert rel_err(got.detach(), z[f"train1/{name}"]) < 1e-6, name
+    none = set(str(n) for n in z["train1/grad_none"])
+    for n in names:
+        if n not in none:
+            assert rel_err(grads[n], z[f"train1/grad/{n}"]) < 1e-5, n
+    for k, v in state_dict_from_golden(z, "train1/sd_after/").items():
+        assert (rel_err(P[k].detach(), v) < 2e-6) if v.dtype.is_floating_point else torch.equal(P[k].detach(), v), k
+
+
 def test_losses_quirk_structure_on_target():
     """training.py:307 replaces the logits by the target: the loss ignores s_logits."""
     z, cfg = load_case("lmd2_tiny")

@@ -46,6 +46,18 @@ def batch_from_golden(z, cfg) -> BarGraphBatch:
 
 
 def state_dict_from_golden(z, prefix="sd/"):
+    if prefix == "sd/" and "sd_sha256" in z.files:
+        # slim fixture: the initial state is the reference's default init under torch.manual_seed(0); the product's
+        # module tree reproduces it bit for bit, which the stored digest of the reference's tensors proves here
+        import hashlib
+        from polyphemus_amd.model import VAE
+        torch.manual_seed(0)
+        sd = {k: v.detach().clone() for k, v in VAE(**json.loads(str(z["cfg"])), device=torch.device("cpu")).state_dict().items()}
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            h.update(k.encode()); h.update(v.numpy().tobytes())
+        assert h.hexdigest() == str(z["sd_sha256"]), "default init differs from the reference's (fixture digest)"
+        return sd
     return {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
 
 
@@ -160,3 +172,108 @@ def run_ranks(fn, world, args=(), timeout=90.0):
             if p.is_alive():
                 p.kill()
                 p.join(timeout=5)
+
+
+# ---- full-size parity: the native HIP step against the CPU oracle in fp32 AND fp64 ------------------------------
+FULLSIZE = {
+    # BASELINE.json configs[1..2] and one GPU's shard of configs[4]; message dropout replayed where the mask is cheap
+    "configs1_lmd2_b256_d256": dict(B=256, nb=2, d=256, L=8, p=0.25, dense=False, msg_p=0.1, seed=1234),
+    "configs2_lmd16_b64_d256": dict(B=64, nb=16, d=256, L=8, p=0.25, dense=False, msg_p=0.1, seed=1234),
+    "configs4_dense_shard_b8_d512": dict(B=8, nb=2, d=512, L=8, p=1.0, dense=True, msg_p=0.0, seed=1234),
+}
+
+
+def _as_dtype(batch, dtype):
+    """The reference-format float inputs of a CPU batch (c_tensor, edge_attrs, s_tensor) in `dtype`."""
+    out = BarGraphBatch(**{k: v for k, v in batch.__dict__.items() if not k.startswith("_")})
+    out.__dict__["_c_tensor"] = batch.c_tensor.to(dtype)
+    out.__dict__["_edge_attrs"] = batch.edge_attrs.to(dtype)
+    out.s_tensor = batch.s_tensor.to(dtype)
+    return out
+
+
+def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
+    """One native HIP training step (the measured variant) and the same step through oracle/vae_cpu.py in fp32 and in
+    fp64 (same weights, eps and — replayed from the counter hash — the same message-dropout mask).  Returns the
+    relative errors (max|a-b| / max|b|) of every model output, loss and of the gradient against the fp64 oracle, for
+    both the HIP path and the fp32 oracle: the fp32 reference arithmetic is itself only defined up to its distance
+    from fp64, which is what the tolerances of the full-size tests are measured against."""
+    import time
+    from oracle import vae_cpu
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.synthetic import synthetic_batch
+    from polyphemus_amd.trainer import HipTrainer
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=spec["L"], d=spec["d"], n_bars=spec["nb"], resolution=8)
+    cpu = synthetic_batch(spec["B"], spec["nb"], p=spec["p"], seed=spec["seed"], dense=spec["dense"])
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=dev).to(dev)
+    vae.train()
+    vae.msg_dropout = spec["msg_p"]
+    sd = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
+    names = [n for n, _ in vae.named_parameters()]
+    eps = torch.randn(spec["B"], spec["d"], generator=torch.Generator().manual_seed(99))
+    tr = HipTrainer(vae, lr=5e-6)
+    step0 = vae._step
+    t0 = time.time()
+    got_l = tr.losses_dict(tr.train_step(cpu.to(dev), eps.to(dev)))
+    (s_h, c_h), mu_h, lv_h = tr.step_outputs()
+    info = tr.step_info()
+    S = info["n_slots"]
+    hip = dict(s_logits=s_h.cpu(), c_logits=c_h.cpu(), mu=mu_h.cpu(), log_var=lv_h.cpu())
+    hip_g = {n: tr._G[n].detach().cpu() for n in names}
+    t_hip = time.time() - t0
+    vae._step = step0
+    seeds = {"encoder": vae._next_seed(), "decoder": vae._next_seed()}
+    masks = {}
+
+    def keep(key, eids, dd):
+        k = (key, dd, eids.numel(), int(eids[0]) if eids.numel() else -1, int(eids[-1]) if eids.numel() else -1)
+        if k not in masks:
+            masks[k] = torch.from_numpy(dropout_keep_np(seeds[key.split(".")[0]], layer_uid_of(key), eids.numpy(), dd, spec["msg_p"]))
+        return masks[k]
+
+    res = {}
+    times = {}
+    for tag, dt in (("o64", torch.float64), ("o32", torch.float32)):
+        t0 = time.time()
+        P, _ = vae_cpu.split_state({k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}, names)
+        opt = torch.optim.SGD([P[n] for n in names], lr=0.0)
+        outs, parts, grads = vae_cpu.train_step(_as_dtype(cpu, dt), P, names, cfg, opt, eps.to(dt), msg_dropout=spec["msg_p"],
+                                                keep_mask=(lambda key, eids, dd, _dt=dt: keep(key, eids, dd).to(_dt)) if spec["msg_p"] > 0 else None)
+        res[tag] = (dict(zip(("s_logits", "c_logits", "mu", "log_var"), (o.detach() for o in outs))),
+                    {k: float(v.detach()) for k, v in parts.items()}, grads)
+        times[tag] = time.time() - t0
+    o64, l64, g64 = res["o64"]
+    o32, l32, g32 = res["o32"]
+    rep = {"info": info, "N": cpu.num_nodes, "E": int(cpu.edge_index.shape[1]), "seconds": {"hip_first_step": t_hip, **times},
+           "outputs": {}, "losses": {}, "grad": {}}
+    for k in ("s_logits", "c_logits", "mu", "log_var"):
+        ref64 = o64[k][:, :S] if k == "c_logits" else o64[k]
+        ref32 = o32[k][:, :S] if k == "c_logits" else o32[k]
+        rep["outputs"][k] = {"hip_vs_o64": rel_err(hip[k], ref64), "o32_vs_o64": rel_err(ref32, ref64), "hip_vs_o32": rel_err(hip[k], ref32)}
+    for k in ("pitch", "dur", "structure", "kld"):
+        den = max(1.0, abs(l64[k]))
+        rep["losses"][k] = {"hip_vs_o64": abs(got_l[k] - l64[k]) / den, "o32_vs_o64": abs(l32[k] - l64[k]) / den}
+    live = [n for n in names if g64[n] is not None]
+    gmax = max(float(g64[n].abs().max()) for n in live)
+    worst = {"hip_vs_o64": (0.0, ""), "o32_vs_o64": (0.0, ""), "hip_vs_o32": (0.0, "")}
+    num = {"hip_vs_o64": 0.0, "o32_vs_o64": 0.0, "hip_vs_o32": 0.0}
+    den2 = 0.0
+    for n in live:
+        a, b, c = hip_g[n].double(), g32[n].double(), g64[n].double()
+        den = max(float(c.abs().max()), 1e-2 * gmax)        # the metric of tests/test_model_gpu._grad_err
+        for tag, (x, y) in (("hip_vs_o64", (a, c)), ("o32_vs_o64", (b, c)), ("hip_vs_o32", (a, b))):
+            e = float((x - y).abs().max()) / den
+            if e > worst[tag][0]:
+                worst[tag] = (e, n)
+            num[tag] += float(((x - y) ** 2).sum())
+        den2 += float((c ** 2).sum())
+    for n in names:
+        if g64[n] is None:
+            assert float(hip_g[n].abs().max()) == 0.0, n
+    rep["grad"] = {tag: {"worst_tensor_err": worst[tag][0], "worst_tensor": worst[tag][1], "rel_l2": (num[tag] / den2) ** 0.5}
+                   for tag in worst}
+    rep["grad"]["gmax"] = gmax
+    return rep

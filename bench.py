@@ -103,6 +103,80 @@ def cpu_baseline(cfg, seconds_budget=20.0):
                       f"= {med * 1e3:.0f} ms"}
 
 
+def launch_ranks(argv, n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU, fresh
+    interpreters, rendezvous on 127.0.0.1 at a free port) BEFORE this process touches the GPU, forward rank 0's output,
+    and fail if any rank fails (the survivors are killed, never left waiting in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PM_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in list(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = rc or code
+                        sys.stderr.write(f"[bench] rank {r} exited with code {code}; stopping the other ranks\n")
+                        for q in live:
+                            procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def stub_main(args):
+    """`--stub-step` (tests only, no GPU, no HIP): the launcher, rendezvous, barrier / max-over-ranks timing and JSON
+    contract of the real bench with the training step replaced by a bucketed gloo all-reduce of a small CPU buffer."""
+    import torch.distributed as dist
+    from polyphemus_amd import parallel
+    rank, local, world = parallel.init_from_env("gloo")
+    flat = torch.full((1000,), float(rank + 1))
+    gb = parallel.GradBuckets(flat, [300, 700])
+
+    def step():
+        flat.fill_(float(rank + 1))
+        for i in (2, 1, 0):
+            gb.launch(i)
+        return gb.wait()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scale = step()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool((flat == world * (world + 1) / 2).all()) and scale == 1.0 / world
+    if os.environ.get("PM_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                                # (test hook: a dying rank must fail the whole launch)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": args.steps / float(t), "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t) / args.steps,
+                          "dp": {"ranks_seen": world, "backend": "gloo", "allreduce_checksum_ok": ok}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,7 +189,14 @@ def main():
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[4] dense-graph stress")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-batch", type=int, default=16, help=argparse.SUPPRESS)
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: be the launcher (nothing above has touched the GPU)
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
+    if args.stub_step:
+        return stub_main(args)
     if args.cpu_baseline_only:
         cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=args.layers, d=args.d, n_bars=args.n_bars, resolution=8)
         print(json.dumps(cpu_baseline(cfg)))
@@ -167,6 +248,48 @@ def main():
     # (in-library, on the launch stream): the per-class table and the choice of the dominant class.  An event pair costs
     # ~8 us of GPU idle time (all ~115 bracketed launches of a step: 12 % of the step), so the timed region brackets only
     # the dominant GEMM class and the segment-reduce forward, every EVENT_STRIDE-th launch of each.
+    # ---- data-parallel evidence (world > 1): who is here, does the exchange add up, what does it cost
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        probe = torch.arange(1024, dtype=torch.float32, device=dev) * float(rank + 1)
+        dist.all_reduce(probe)
+        ok = bool(torch.equal(probe, torch.arange(1024, dtype=torch.float32, device=dev) * (world * (world + 1) / 2)))
+        for _ in range(3):
+            trainer.train_step(batch)
+        reps = 5
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):                                   # the exchange alone: the three buckets back to back
+            for i in (2, 1, 0):
+                trainer.buckets.launch(i)
+            trainer.buckets.wait()
+        sync()
+        t_alone = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            trainer.train_step(batch)
+        sync()
+        t_dp = (time.perf_counter() - t0) / reps
+        trainer.buckets.disabled = True                         # same step without the exchange (ranks drift apart ...)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            trainer.train_step(batch)
+        sync()
+        t_nodp = (time.perf_counter() - t0) / reps
+        trainer.buckets.disabled = False
+        parallel.broadcast_([vae.flat_params, vae.flat_buffers, trainer.exp_avg, trainer.exp_avg_sq], 0)   # ... re-joined here
+        tt = torch.tensor([t_alone, t_dp, t_nodp], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_alone, t_dp, t_nodp = tt.tolist()
+        exposed = max(t_dp - t_nodp, 0.0)
+        dp = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_checksum_ok": ok,
+              "gradient_bytes": int(trainer.grads.numel() * 4), "buckets": [int(v.numel() * 4) for v in trainer.buckets.views],
+              "allreduce_alone_ms": round(1e3 * t_alone, 3), "step_ms_with_exchange": round(1e3 * t_dp, 3),
+              "step_ms_without_exchange": round(1e3 * t_nodp, 3), "allreduce_exposed_ms": round(1e3 * exposed, 3),
+              "overlapped_fraction": round(1.0 - min(exposed / t_alone, 1.0), 3) if t_alone > 0 else None,
+              "note": f"max over ranks, {reps} repetitions each, measured before the timed region"}
+
     SURVEY = 2
     EVENT_STRIDE = int(os.environ.get("PM_BENCH_EVENT_STRIDE", "5" if args.steps >= 5 else "1"))
     for _ in range(max(args.warmup - SURVEY, 0)):
@@ -194,6 +317,12 @@ def main():
         torch.distributed.all_reduce(tot_nodes)
     elapsed = float(t.item())
     losses = trainer.losses_dict(out)
+    if world > 1:                                                # every rank must hold the same parameters after the run
+        ck = vae.flat_params.double().sum().reshape(1)
+        lo, hi = ck.clone(), ck.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        dp["params_in_sync_after_run"] = bool(lo.item() == hi.item())
 
     if rank == 0:
         gemm_keys = [k for k in survey if k.startswith("gemm")]
@@ -253,6 +382,8 @@ def main():
             "losses": {k: round(v, 5) for k, v in losses.items()},
             "roofline": roof, "roofline_segreduce": roof_seg,
         }
+        if dp is not None:
+            line["dp"] = dp
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_subprocess(cfg)
             if line["cpu_baseline"].get("value"):

@@ -32,7 +32,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             torch.cuda.set_device(local)
         elif torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a rank that dies before / during the rendezvous fails the others after two minutes instead of the 30-minute default
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     return rank, local, world
 
 
@@ -54,9 +56,10 @@ class GradBuckets:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._work = []
         self.hold = False        # True: launches are skipped (micro-batches of a gradient accumulation)
+        self.disabled = False    # True: no exchange at all (bench.py: cost of the step without the all-reduce)
 
     def launch(self, i: int) -> None:
-        if self.world > 1 and not self.hold:
+        if self.world > 1 and not self.hold and not self.disabled:
             self._work.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> float:

@@ -88,3 +88,32 @@ def test_harness_reports_a_failing_rank_and_kills_the_others():
         run_ranks(_sleeper, 2, timeout=16.0)
     assert time.time() - t0 < 45.0
     assert not multiprocessing.active_children()
+
+
+def _bench(*extra, env=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step", "--steps", "3",
+                        "--warmup", "1", *extra], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, **(env or {})))
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, lines, r.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must start both ranks itself; the stub step keeps the launcher, the
+    rendezvous, the bucketed exchange and the JSON contract and drops only the GPU work."""
+    rc, lines, err = _bench()
+    assert rc == 0, err
+    assert len(lines) == 1, lines                                  # ONE line, from rank 0
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["dp"] == {"ranks_seen": 2, "backend": "gloo", "allreduce_checksum_ok": True}
+
+
+def test_bench_fails_when_a_rank_dies():
+    rc, _, err = _bench(env={"PM_BENCH_FAIL_RANK": "1"})
+    assert rc != 0 and "rank 1 exited" in err

@@ -28,12 +28,31 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak; a split-mode fp32 product costs SIX bf16 MFMA products
-# Memory-side bytes per launch of the dominant kernels at the DEFAULT workload, from separate `rocprofv3 --pmc FETCH_SIZE`
-# / `--pmc WRITE_SIZE` passes over this same command (profiles/r01_v7_kernel_stats.md, v5 for the LDS-staged tiles; reads doubled per the gfx950
-# FETCH_SIZE rule of MI355X_MICROARCH.md).  bench.py cannot read PMC counters itself; other workloads report null.
-PMC_TRAFFIC_DEFAULT = {"gemm_NT_planes:64x64x32": 99.7e6, "gemm_NN_planes:64x64x32": 119.6e6,
-                       "gemm_TN_planes:64x64x32": 152.7e6, "gemm_NT_planesB:64x128x32": 104.9e6,
-                       "gemm_NN_planesB:64x128x32": 117.9e6, "segreduce_fwd": 121.4e6}
+# Memory-side bytes per launch (`roofline.traffic`): bench.py cannot read PMC counters itself, so they come from the
+# committed result of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
+# (tools/pmc_traffic.py writes profiles/pmc_traffic.json: per kernel class the corrected bytes, the workload and a digest
+# of the kernel sources they were measured on).  A stale digest or another workload reports null, never an old number.
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def kernel_source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "segreduce.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "polyphemus_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_class, workload):
+    try:
+        rec = json.load(open(PMC_TRAFFIC_JSON))
+    except (OSError, ValueError):
+        return None
+    if rec.get("source_digest") != kernel_source_digest() or rec.get("workload") != workload:
+        return None
+    return rec.get("bytes_per_launch", {}).get(kernel_class)
+
+
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; ~6.3 TB/s achievable
 
 
@@ -74,13 +93,20 @@ def cpu_baseline_subprocess(cfg, timeout_s=240):
 
 
 def cpu_baseline(cfg, seconds_budget=20.0):
-    """The CPU oracle (oracle/vae_cpu.py: reference op sequence, fp32, stock torch Adam) on a bounded
-    sample of the same workload: B=16 samples of the same synthetic distribution, all host cores."""
+    """The CPU oracle (oracle/vae_cpu.py: reference op sequence, fp32, stock torch Adam) on bounded samples of the same
+    workload, all host cores: B = 64 samples of the same synthetic distribution for a stable rate
+    (`value`), B = 8 (BASELINE configs[0], the reference's own CPU-runnable case) beside it."""
+    rate = cpu_baseline_at(cfg, 64, seconds_budget)
+    small = cpu_baseline_at(cfg, 8, seconds_budget / 4)
+    rate["configs0_B8"] = {"value": small["value"], "unit": small["unit"], "sample": small["sample"]}
+    return rate
+
+
+def cpu_baseline_at(cfg, B, seconds_budget):
     from oracle import vae_cpu
     from polyphemus_amd.model import VAE
     from polyphemus_amd.synthetic import synthetic_batch
     torch.set_num_threads(host_cores())
-    B = 16
     batch = synthetic_batch(B, cfg["n_bars"], p=0.25, seed=1234)
     torch.manual_seed(0)
     ref = VAE(**cfg, device=torch.device("cpu"))
@@ -189,7 +215,6 @@ def main():
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[4] dense-graph stress")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-batch", type=int, default=16, help=argparse.SUPPRESS)
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -333,12 +358,12 @@ def main():
         split = dom[8:].startswith(("planes", "x6"))          # fp32 product = 6 bf16 MFMA products (fp32 accumulate)
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
         insn = "v_mfma_f32_32x32x16_bf16, 6 products per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
-        default_wl = (args.batch, args.d, args.n_bars, args.layers, args.dense) == (256, 256, 2, 8, False)
+        workload_key = f"B{args.batch}_d{args.d}_nb{args.n_bars}_L{args.layers}" + ("_dense" if args.dense else "")
         sampling = (f"HIP events around every {EVENT_STRIDE}-th launch of this kernel inside the timed region "
                     f"({ds['launches']} launches sampled)")
         roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[8:]},{dom[5:7]}> ({insn})",
                 "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(tf / peak, 4), "traffic": PMC_TRAFFIC_DEFAULT.get(dom) if default_wl else None,
+                "frac": round(tf / peak, 4), "traffic": pmc_traffic(dom, workload_key),
                 "peak_note": ("dense bf16 MFMA peak / 6 (fp32-equivalent flops)" if split else "dense fp32 MFMA peak")
                              + f"; {round(tf / PEAK_FP32_MFMA_TFLOPS, 3)} of the 157.3 TFLOP/s fp32 MFMA peak",
                 "launches_per_step": survey[dom]["launches"] / SURVEY, "avg_launch_us": round(ds["avg_us"], 2),
@@ -353,14 +378,18 @@ def main():
         gbs = ss["work"] / (ss["total_ms"] * 1e-3) / 1e9
         roof_seg = {"bound": "hbm", "kernel": "k_segreduce_fwd", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "traffic": PMC_TRAFFIC_DEFAULT.get("segreduce_fwd") if default_wl else None,
+                    "traffic": pmc_traffic("segreduce_fwd", workload_key),
                     "launches_per_step": survey["segreduce_fwd"]["launches"] / SURVEY, "avg_launch_us": round(ss["avg_us"], 2),
                     "algorithmic_bytes_per_launch": ss["work"] / ss["launches"],
                     "sampling": f"every {EVENT_STRIDE}-th launch inside the timed region ({ss['launches']} sampled)"}
         sb = survey.get("segreduce_bwd")
         if sb:
-            roof_seg["backward"] = {"GB/s": round(sb["work"] / (sb["total_ms"] * 1e-3) / 1e9, 1),
-                                    "avg_launch_us": round(sb["avg_us"], 2), "from": "survey steps"}
+            bgbs = sb["work"] / (sb["total_ms"] * 1e-3) / 1e9
+            roof_seg["backward"] = {"achieved": round(bgbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(bgbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(sb["avg_us"], 2),
+                                    "algorithmic_bytes_per_launch": sb["work"] / sb["launches"],
+                                    "traffic": pmc_traffic("segreduce_bwd", workload_key),
+                                    "from": "survey steps (every launch bracketed)"}
         bars_total = float(tot_nodes[1].item())
         value = bars_total * args.steps / elapsed
         fpb = flops_per_bar(float(tot_nodes[0].item()), bars_total, args.d, args.layers)

@@ -447,7 +447,10 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
                      pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes, pr); } while (0)
 #define LAUNCH2(NV, DR) do { if (nn) LAUNCH(NV, DR, true); else LAUNCH(NV, DR, false); } while (0)
   const int nv = (int)pm_cdiv(d, 256);
-  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 3 : PM_N_REL) + 1 + (nn ? 1 : 0)) + 12.0 * E + 128.0 * d);
+  // algorithmic bytes: read dA (all stored blocks, the root block included) and the residual gradient,
+  // write dx, + the pre-norm activations when the next norm's sums ride along, edge records, table gradient; the
+  // gathered x rows are L2 traffic and not counted
+  const int pe = pm_prof_open(st, PM_PROF_SEGREDUCE_BWD, 4.0 * d * (double)N * ((compact ? 4 : PM_N_REL + 1) + 1 + (dres ? 1 : 0) + (nn ? 1 : 0)) + 12.0 * E + 128.0 * d);
   if (nv == 1) { if (drop) LAUNCH2(1, true); else LAUNCH2(1, false); }
   else if (nv == 2) { if (drop) LAUNCH2(2, true); else LAUNCH2(2, false); }
   else { if (drop) LAUNCH2(4, true); else LAUNCH2(4, false); }

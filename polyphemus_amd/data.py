@@ -67,9 +67,20 @@ def collate_on_device(samples: Sequence[Tuple[np.ndarray, np.ndarray]], n_bars: 
     for i, (c, s) in enumerate(samples):
         tok_h[i] = torch.from_numpy(c)
         s_h[i] = torch.from_numpy(s)
+    # active token slots of the batch (`PmBatch.n_slots`): the last slot that holds a non-PAD token in any ACTIVE cell
+    # (an empty bar's cell [0,0] counts: the graph builder switches it on, data.py:152-153) — 4 MB of int16 on the host
+    s_np, tok_np = s_h.numpy().astype(bool), tok_h.numpy()
+    empty = ~s_np.any(axis=(-1, -2))
+    if empty.any():
+        s_np = s_np.copy()
+        s_np[..., 0, 0] |= empty
+    live = ((tok_np[..., 1:, 0] != C.PITCH_PAD) | (tok_np[..., 1:, 1] != C.DUR_PAD)) & s_np[..., None]
+    slots = np.nonzero(live.reshape(-1, C.MAX_SIMU_TOKENS - 1).any(axis=0))[0]
     tok = tok_h.to(device, non_blocking=True)
     s = s_h.to(device, non_blocking=True)
-    return device_batch_from_structure(s.view(B * n_bars, C.N_TRACKS, C.N_TIMESTEPS), n_bars, token_grid=tok)
+    batch = device_batch_from_structure(s.view(B * n_bars, C.N_TRACKS, C.N_TIMESTEPS), n_bars, token_grid=tok)
+    batch.n_slots = int(slots.max()) + 1 if slots.size else 1
+    return batch
 
 
 def _staging(B: int, n_bars: int, pin: bool):
@@ -86,7 +97,17 @@ class DeviceLoader:
     the reference uses)."""
 
     def __init__(self, dataset, batch_size: int, shuffle: bool = False, seed: int = 0, device="cuda",
-                 drop_last: bool = False, num_workers: int = 0):
+                 drop_last: bool = False, num_workers: int = 0, rank: Optional[int] = None, world: Optional[int] = None):
+        """`batch_size` is PER RANK.  Under data parallelism (`rank` / `world`, default: the torch.distributed default
+        group) the loader behaves like `DistributedSampler`: every rank draws the SAME permutation (seed + epoch),
+        pads it by wrap-around to a multiple of `world` and keeps every world-th index starting at its rank — disjoint
+        shards, the same number of batches on every rank (the gradient all-reduce needs the ranks in lock step)."""
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized()
+        self.rank = int(rank) if rank is not None else (dist.get_rank() if ddp else 0)
+        self.world = int(world) if world is not None else (dist.get_world_size() if ddp else 1)
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f"rank {self.rank} outside world {self.world}")
         self.dataset, self.batch_size, self.shuffle, self.seed = dataset, int(batch_size), shuffle, seed
         self.device, self.drop_last = torch.device(device), drop_last
         self._pool = ThreadPoolExecutor(num_workers) if num_workers > 0 else None
@@ -95,13 +116,20 @@ class DeviceLoader:
         self._stage = [_staging(self.batch_size, self.n_bars, pin=True) for _ in range(2)]
         self._stream = torch.cuda.Stream(device=self.device)
 
+    def _shard_len(self) -> int:
+        return (len(self.dataset) + self.world - 1) // self.world
+
     def __len__(self) -> int:
-        n = len(self.dataset)
+        n = self._shard_len()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _index_batches(self) -> List[np.ndarray]:
         n = len(self.dataset)
         order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        if self.world > 1:
+            total = self._shard_len() * self.world
+            order = np.concatenate([order, order[:total - n]])[self.rank::self.world]   # DistributedSampler's rule
+            n = order.shape[0]
         out = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
         if self.drop_last and out and len(out[-1]) < self.batch_size:
             out.pop()

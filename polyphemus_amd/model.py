@@ -328,7 +328,12 @@ class Decoder(nn.Module):
             # exactly as the reference does (model.py:646-650); needs a first structure-only pass.
             with torch.no_grad():
                 s_logits0 = vae.engine.structure_only(z.contiguous().float(), vae.training)
-            s = self._structure_from_logits(s_logits0.detach())
+            s_bin = self._binary_from_logits(s_logits0.detach())
+            # the content decoder runs on THIS thresholded structure; callers that lay the result out (generate_music)
+            # must use the same one: the logits this forward returns come from a second pass of the head GEMMs, whose
+            # split-K float atomics may differ in the last bits and flip a cell whose logit is ~0
+            self.__dict__["_last_structure"] = s_bin.clone()
+            s = self._structure_from_binary(s_bin)
         plan = vae._prepare(s)
         with torch.autocast("cuda", enabled=False):
             s_logits, c_logits = _DecoderFn.apply(vae, plan, z, *vae._tensors("decoder."))

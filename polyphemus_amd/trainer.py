@@ -96,6 +96,9 @@ class HipTrainer:
         self.grad_accum = torch.zeros_like(flat) if self.iters_to_accumulate > 1 else None
         self._accum_bucket = GradBuckets(self.grad_accum, [], process_group) if self.grad_accum is not None else None
         broadcast_([vae.flat_params, vae.flat_buffers], 0, process_group)
+        if self.world > 1:                      # every rank its own message-dropout stream (same seed = same masks)
+            import torch.distributed as dist
+            vae.seed = (vae.seed ^ (0x9E3779B9 * (dist.get_rank(process_group) + 1))) & 0xFFFFFFFF
         # native step plumbing
         self._layout = build_layout(vae)
         self._flat_ptr = flat.data_ptr()
@@ -367,7 +370,7 @@ class HipTrainer:
         'tot_batches'; `extra` carries the bookkeeping entries of the reference's loop (epoch, lrs, ...).
         `generate.load_model` of the reference reads 'model_state_dict' from it."""
         ckpt = dict(extra)
-        ckpt.update(tot_batches=self.micro_batches,
+        ckpt.update(tot_batches=self.micro_batches, dropout_stream={"seed": self.vae.seed, "step": self.vae._step},
                     model_state_dict={k: v.detach().cpu().clone() for k, v in self.vae.state_dict().items()},
                     optimizer_state_dict=self.optimizer_state_dict())
         torch.save(ckpt, path)
@@ -379,6 +382,9 @@ class HipTrainer:
         self.vae.load_state_dict(ckpt.pop("model_state_dict"))
         self.load_optimizer_state_dict(ckpt.pop("optimizer_state_dict"))
         self.micro_batches = int(ckpt.get("tot_batches", self.step_count * self.iters_to_accumulate))
+        ds = ckpt.pop("dropout_stream", None)           # position of the counter-based dropout stream: a resumed run
+        if ds is not None:                              # continues with fresh masks instead of replaying the old ones
+            self.vae.seed, self.vae._step = int(ds["seed"]), int(ds["step"])
         if self.sched is not None:
             self.sched.update_steps = self.step_count
         return ckpt

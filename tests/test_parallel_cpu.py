@@ -117,3 +117,29 @@ def test_bench_launches_its_own_ranks():
 def test_bench_fails_when_a_rank_dies():
     rc, _, err = _bench(env={"PM_BENCH_FAIL_RANK": "1"})
     assert rc != 0 and "rank 1 exited" in err
+
+
+def test_device_loader_shards_are_disjoint_and_in_lock_step():
+    """World-2 `DeviceLoader` index plan (no GPU needed for the plan itself): same permutation on both ranks, disjoint
+    shards, equal batch counts, every sample seen once per epoch (one wrapped duplicate when the size is odd)."""
+    import numpy as np
+    from polyphemus_amd.data import DeviceLoader
+
+    class DS:
+        n_bars = 2
+
+        def __len__(self):
+            return 11
+
+    plans = []
+    for rank in range(2):
+        ld = DeviceLoader.__new__(DeviceLoader)                   # the index plan only: no pinned buffers, no stream
+        ld.dataset, ld.batch_size, ld.shuffle, ld.seed, ld.drop_last, ld.epoch = DS(), 2, True, 5, False, 3
+        ld.rank, ld.world = rank, 2
+        plans.append(ld._index_batches())
+        assert len(plans[-1]) == len(ld) == 3
+    a, b = (np.concatenate(p) for p in plans)
+    assert len(a) == len(b) == 6
+    assert len(set(a) & set(b)) <= 1 and set(a) | set(b) == set(range(11))
+    order = np.random.default_rng(5 + 3).permutation(11)
+    assert list(a) == list(np.concatenate([order, order[:1]])[0::2])

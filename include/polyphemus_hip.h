@@ -291,6 +291,13 @@ int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const
 int pm_bn_counters_update(int64_t* counters /* [n] */, const int64_t* inc /* [n] */, const int64_t* sel /* [2,n] */,
                           const int32_t* group_cnt /* [2] */, int32_t n, pm_stream_t stream);
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
+/* y = relu(x) + res (res may be NULL): layer tail of a model built with batch_norm = False (model.py:203-206,219-230). */
+int pm_relu_residual_fwd(const float* x, const float* res, int64_t n, float* y, pm_stream_t stream);
+/* Element dropout of the cfg.dropout layers (model.py:160,199,244-247,267-270,389-390,473,479,558-559,640) on a
+ * row-major [rows, cols] tensor: y = x * keep(seed, site, row, col) / (1 - p) with the counter hash of the message
+ * dropout (pm_dropout_hash(seed, site, row, col)); y may alias x; the backward is the same call on the gradient. */
+int pm_dropout_rows(const float* x, int64_t rows, int32_t cols, float p, uint32_t seed, uint32_t site, float* y,
+                    pm_stream_t stream);
 int pm_add(const float* a, const float* b, int64_t n, float* out, pm_stream_t stream);
 int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out /* [C] += */, pm_stream_t stream);
 /* same over an indirect row set (rows = rowmap[r / rpe] * rpe + r % rpe, entry count read on device) */
@@ -346,7 +353,11 @@ int pm_attnpool_bwd(const float* x, const float* g, const float* g_mean, const f
                     const float* bn_g, const float* alpha, const float* dout /* [G,d] */, const float* gate_w,
                     const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx /* [N,d] */,
                     float* d_gate_w /* [d] += */, float* d_gate_b /* [1] += */, float* d_bn_g /* [1] += */,
-                    float* d_bn_b /* [1] += */, float* scratch /* [3*N + 8] */, pm_stream_t stream);
+                    float* d_bn_b /* [1] += */, float* scratch /* [3*N + 8] */,
+                    const float* x_gate /* NULL, or the gate MLP's own input when it differs from x (dropout in front of
+                                           the gate Linear, model.py:160): d_gate_w is then taken against it ... */,
+                    float* dx_gate /* ... and the gradient w.r.t. it is written here instead of being added to dx */,
+                    pm_stream_t stream);
 int pm_bar_broadcast_fwd(const float* bars /* [G,d] */, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                          int32_t d, float* x /* [N,d] */, pm_stream_t stream);
 int pm_bar_broadcast_bwd(const float* dx /* [N,d] */, const int32_t* plan, int32_t N, int32_t E, int32_t G,

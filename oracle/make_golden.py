@@ -263,6 +263,14 @@ def capture_generation(name):
           f"corner on={int(out['corner/s_binary'].sum())}")
 
 
+def capture_bnoff():
+    """A model built with batch_norm = False (model.py:176-188: no norm layers in the GCNs; :218-238,278-292: CNNs without
+    BatchNorm2d, so the Sequential indices of the second convolutions shift): state_dict keys and arithmetic of that
+    constructor switch, pinned to the reference."""
+    capture_case("bnoff_tiny", dict(dropout=0, batch_norm=False, gnn_n_layers=2, d=16, n_bars=2, resolution=8),
+                 batch_size=5, p=0.08, seed=14)
+
+
 def capture_d128():
     """d = 128 (a multiple of 128: the GCL forward and input-gradient products of the native step take the B-direct
     planes GEMM, the weight gradient the planes TN kernel) — the variant bench.py measures, pinned to the reference."""
@@ -274,6 +282,9 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["d128"]:
         capture_d128()
+        sys.exit(0)
+    if sys.argv[1:] == ["bnoff"]:
+        capture_bnoff()
         sys.exit(0)
     if sys.argv[1:] == ["generate"]:
         capture_generation("lmd2_tiny")
@@ -287,4 +298,5 @@ if __name__ == "__main__":
     capture_generation("lmd2_tiny")
     capture_generation("nb3_tiny")
     capture_d128()
+    capture_bnoff()
 

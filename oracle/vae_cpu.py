@@ -35,6 +35,25 @@ Params = Dict[str, torch.Tensor]
 
 
 # --------------------------------------------------------------------------- utils
+# Element dropout of the `cfg.dropout` layers.  The reference draws these masks from torch's global RNG (F.dropout /
+# nn.Dropout); to compare a run with dropout against the HIP path the tests install ELEM_KEEP(site, rows, cols) -> 0/1
+# mask [len(rows), cols] (the counter hash of csrc/common.h replayed in numpy), exactly like `keep_mask` does for the
+# message dropout.  `rows` are the global row ids of the tensor's rows (node ids where the reference splits a tensor
+# into drums / non-drums before the layer).  None = torch's own F.dropout.
+ELEM_KEEP: Optional[Callable] = None
+
+
+def _drop(x, p: float, training: bool, site: str, rows=None):
+    if not training or p == 0:
+        return x
+    if ELEM_KEEP is None:
+        return F.dropout(x, p, True)
+    flat = x.reshape(x.shape[0], -1)
+    rows = torch.arange(flat.shape[0]) if rows is None else rows
+    keep = ELEM_KEEP(site, rows, flat.shape[1]).to(x.dtype)
+    return (flat * keep / (1.0 - p)).reshape(x.shape)
+
+
 def _bn(x, P: Params, key: str, training: bool, eps=1e-5, momentum=0.1):
     """nn.BatchNorm1d/2d forward incl. running-stat update (in place in `P`)."""
     if x.shape[0] == 0:
@@ -88,7 +107,7 @@ def gcn_forward(x, graph, P: Params, key: str, cfg, training: bool, msg_dropout:
     edge_type, edge_attr = edge_attrs[:, 0], edge_attrs[:, 1:]             # model.py:193-194
     for i in range(cfg["gnn_n_layers"]):
         residual = x
-        x = F.dropout(x, p=cfg["dropout"], training=training)              # model.py:199
+        x = _drop(x, cfg["dropout"], training, f"{key.split('.')[0][:3]}_gcn.{i}")     # model.py:199
         x = gcl_forward(x, edge_index, edge_type, edge_attr, P, f"{key}.layers.{i}", training,
                         msg_dropout, keep_mask)
         if cfg["batch_norm"]:
@@ -114,9 +133,9 @@ def cnn_encoder(s, P: Params, key: str, cfg, training: bool):
         x = F.max_pool2d(x, (1, 4), stride=(1, 4))
         x = F.relu(F.conv2d(x, P[key + ".conv.3.weight"], P[key + ".conv.3.bias"], padding=1))
     x = x.flatten(1)
-    x = F.dropout(x, p, training)
+    x = _drop(x, p, training, "enc_cnn_in")
     x = F.relu(_lin(x, P, key + ".lin.1"))
-    x = F.dropout(x, p, training)
+    x = _drop(x, p, training, "enc_cnn_mid")
     return _lin(x, P, key + ".lin.4")
 
 
@@ -133,7 +152,7 @@ def attention_pool(x, seg, P: Params, key: str, cfg, training: bool):
     gate = BN1d(1)(Linear(d->1)(x)); softmax over the nodes of each bar with PyG's
     `exp(g - segmax) / (segsum + 1e-16)`; out[b] = sum_i gate_i * x_i."""
     size = int(seg[-1].item()) + 1
-    g = F.dropout(x, cfg["dropout"], training)                             # MLP.forward, model.py:160
+    g = _drop(x, cfg["dropout"], training, "enc_gate")                     # MLP.forward, model.py:160
     g = _lin(g, P, key + ".gate_nn.0.layers.0")
     g = _bn(g, P, key + ".gate_nn.1", training).view(-1, 1)
     gmax = torch.full((size, 1), float("-inf"), dtype=g.dtype).scatter_reduce(
@@ -164,7 +183,9 @@ def content_encoder(graph, P: Params, cfg, training: bool, msg_dropout: float, k
     non_drums = embed(non_drums, "non_drums_pitch_emb", "bn_non_drums")
     drums = F.relu(_lin(drums.view(-1, d * N_SLOTS), P, f"{k}.chord_encoder"))     # model.py:381-390
     non_drums = F.relu(_lin(non_drums.view(-1, d * N_SLOTS), P, f"{k}.chord_encoder"))
-    drums, non_drums = F.dropout(drums, p, training), F.dropout(non_drums, p, training)
+    node = torch.arange(c.size(0))
+    drums = _drop(drums, p, training, "enc_chord", node[is_drum])
+    non_drums = _drop(non_drums, p, training, "enc_chord", node[torch.logical_not(is_drum)])
     out = torch.zeros((c.size(0), d), dtype=drums.dtype)                   # model.py:394-397
     out[is_drum] = drums
     out[torch.logical_not(is_drum)] = non_drums
@@ -180,10 +201,10 @@ def encoder_forward(graph, P: Params, cfg, training: bool, msg_dropout: float = 
     z_s = structure_encoder(graph, P, cfg, training)
     z_c = content_encoder(graph, P, cfg, training, msg_dropout, keep_mask)
     z_g = torch.cat((z_c, z_s), dim=1)
-    z_g = F.dropout(z_g, p, training)
+    z_g = _drop(z_g, p, training, "enc_merge_in")
     z_g = _lin(z_g, P, "encoder.linear_merge")
     z_g = F.relu(_bn(z_g, P, "encoder.bn_linear_merge", training))
-    z_g = F.dropout(z_g, p, training)
+    z_g = _drop(z_g, p, training, "enc_merge_out")
     return _lin(z_g, P, "encoder.linear_mu"), _lin(z_g, P, "encoder.linear_log_var")
 
 
@@ -191,9 +212,9 @@ def encoder_forward(graph, P: Params, cfg, training: bool, msg_dropout: float = 
 def cnn_decoder(x, P: Params, key: str, cfg, training: bool):
     """`CNNDecoder.forward` (model.py:259-299)."""
     p = cfg["dropout"]
-    x = F.dropout(x, p, training)
+    x = _drop(x, p, training, "dec_cnn_in")
     x = F.relu(_lin(x, P, key + ".lin.1"))
-    x = F.dropout(x, p, training)
+    x = _drop(x, p, training, "dec_cnn_mid")
     x = F.relu(_lin(x, P, key + ".lin.4"))
     x = x.view(-1, 16, 4, 8)
     x = F.interpolate(x, scale_factor=(1, 4), mode="nearest")
@@ -227,7 +248,9 @@ def content_decoder(z_c, graph, P: Params, cfg, training: bool, msg_dropout: flo
     out = _lin(out, P, f"{k}.chord_decoder").view(-1, N_SLOTS, d)          # model.py:549-550
     is_drum = graph.is_drum
     drums, non_drums = out[is_drum], out[torch.logical_not(is_drum)]
-    non_drums, drums = F.dropout(non_drums, p, training), F.dropout(drums, p, training)
+    node = torch.arange(out.shape[0])
+    non_drums = _drop(non_drums, p, training, "dec_chord", node[torch.logical_not(is_drum)])
+    drums = _drop(drums, p, training, "dec_chord", node[is_drum])
     drums = torch.cat((_lin(drums[..., :d // 2], P, f"{k}.drums_pitch_emb"),
                        _lin(drums[..., d // 2:], P, f"{k}.dur_emb")), dim=-1)          # model.py:561-563
     non_drums = torch.cat((_lin(non_drums[..., :d // 2], P, f"{k}.non_drums_pitch_emb"),
@@ -243,7 +266,7 @@ def decoder_forward(z, graph, P: Params, cfg, training: bool, msg_dropout: float
     d = cfg["d"]
     z = _lin(z, P, "decoder.lin_decoder")
     z = F.relu(_bn(z, P, "decoder.batch_norm", training))
-    z = F.dropout(z, cfg["dropout"], training)
+    z = _drop(z, cfg["dropout"], training, "dec_in")
     z_s, z_c = z[:, :d], z[:, d:]
     s_logits = structure_decoder(z_s, P, cfg, training)
     c_logits = content_decoder(z_c, graph, P, cfg, training, msg_dropout, keep_mask)

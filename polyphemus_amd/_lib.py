@@ -61,7 +61,9 @@ _SIGS = {
     "pm_embed_tables_bwd": "ppppppppppppifpppppppppppps",
     "pm_gate_fwd": "pppiips",
     "pm_attnpool_fwd": "ppppfpppiiiipps",
-    "pm_attnpool_bwd": "ppppfpppppiiiipppppps",
+    "pm_attnpool_bwd": "ppppfpppppiiiipppppppps",
+    "pm_relu_residual_fwd": "pplps",
+    "pm_dropout_rows": "plifuups",
     "pm_bar_broadcast_fwd": "ppiiiips",
     "pm_bar_broadcast_bwd": "ppiiiips",
     "pm_conv3x3_fwd": "pppiiiiiips",

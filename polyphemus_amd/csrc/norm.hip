@@ -468,6 +468,36 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = a[i] + b[i];
 }
+// y = relu(x) (+ res): the layer tail of a model built with batch_norm = False (model.py:203-206 without the norm,
+// :219-230 / :279-285 without BatchNorm2d)
+__global__ void k_relu_res(const float* __restrict__ x, const float* __restrict__ res, int64_t n, float* y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fmaxf(x[i], 0.f) + (res ? res[i] : 0.f);
+}
+extern "C" int pm_relu_residual_fwd(const float* x, const float* res, int64_t n, float* y, pm_stream_t stream) {
+  if (!x || !y || n <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_relu_res, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, res, n, y);
+  return pm_check_launch();
+}
+// Element dropout of the `cfg.dropout` layers (nn.Dropout / F.dropout at model.py:160,199,244-247,267-270,389-390,473,479,
+// 558-559,640): y[r, c] = x[r, c] * keep(seed, site, r, c) / (1 - p), the same counter hash as the message dropout
+// (row in place of the edge id), so the backward (the same call on the gradient) and the oracle regenerate the mask.
+__global__ void k_dropout_rows(const float* __restrict__ x, int64_t n, int cols, uint32_t seed, uint32_t site,
+                               uint32_t thresh, float scale, float* y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = (uint32_t)(i / cols), c = (uint32_t)(i % cols);
+    const bool keep = (pm_elem_hash(pm_edge_key(seed, site, r), c) >> 8) >= thresh;
+    y[i] = keep ? x[i] * scale : 0.f;
+  }
+}
+extern "C" int pm_dropout_rows(const float* x, int64_t rows, int32_t cols, float p, uint32_t seed, uint32_t site, float* y,
+                               pm_stream_t stream) {
+  if (!x || !y || rows <= 0 || cols <= 0 || !(p >= 0.f) || p >= 1.f) return PM_E_INVALID;
+  const int64_t n = rows * cols;
+  hipLaunchKernelGGL(k_dropout_rows, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, cols, seed, site,
+                     pm_keep_threshold(p), 1.0f / (1.0f - p), y);
+  return pm_check_launch();
+}
 extern "C" int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream) {
   if (!dy || !y || !dx || n <= 0) return PM_E_INVALID;
   hipLaunchKernelGGL(k_relu_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
                                                        const float* __restrict__ w, const int* __restrict__ node_bar,
                                                        const float* __restrict__ dgn, const double* __restrict__ sums,
                                                        int N, int d, float* __restrict__ dx, float* dW, float* db,
-                                                       float* dbn_g, float* dbn_b) {
+                                                       float* dbn_g, float* dbn_b, const float* __restrict__ xg,
+                                                       float* __restrict__ dxg) {
   extern __shared__ __attribute__((aligned(16))) float sW[];   // [d] partial dW + 1 partial db
   for (int i = threadIdx.x; i <= d; i += blockDim.x) sW[i] = 0.f;
   __syncthreads();
@@ -152,9 +153,13 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
     for (int k = 0; k < 4; ++k) {
       const int c = lane * 4 + k * 256;
       if (c >= d) continue;
-      const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c);
+      const float4 xv = *reinterpret_cast<const float4*>(xg + (int64_t)n * d + c);
       const float4 dv = *reinterpret_cast<const float4*>(dout + (int64_t)b * d + c);
       const float4 wv = *reinterpret_cast<const float4*>(w + c);
+      if (dxg) {                       // gate input differs from the pooled input (cfg.dropout in the gate MLP)
+        *reinterpret_cast<float4*>(dx + (int64_t)n * d + c) = make_float4(a * dv.x, a * dv.y, a * dv.z, a * dv.w);
+        *reinterpret_cast<float4*>(dxg + (int64_t)n * d + c) = make_float4(dg * wv.x, dg * wv.y, dg * wv.z, dg * wv.w);
+      } else
       *reinterpret_cast<float4*>(dx + (int64_t)n * d + c) =
           make_float4(a * dv.x + dg * wv.x, a * dv.y + dg * wv.y, a * dv.z + dg * wv.z, a * dv.w + dg * wv.w);
       wacc[k].x += dg * xv.x; wacc[k].y += dg * xv.y; wacc[k].z += dg * xv.z; wacc[k].w += dg * xv.w;
@@ -177,7 +182,8 @@ extern "C" int pm_attnpool_bwd(const float* x, const float* g, const float* g_me
                                const float* bn_g, const float* alpha, const float* dout, const float* gate_w,
                                const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx,
                                float* d_gate_w, float* d_gate_b, float* d_bn_g, float* d_bn_b, float* scratch,
-                               pm_stream_t stream) {
+                               const float* x_gate, float* dx_gate, pm_stream_t stream) {
+  if ((x_gate == nullptr) != (dx_gate == nullptr)) return PM_E_INVALID;
   if (!x || !g || !g_mean || !g_var || !bn_g || !alpha || !dout || !gate_w || !plan || !dx || !d_gate_w || !d_gate_b ||
       !d_bn_g || !d_bn_b || !scratch || N <= 0 || G <= 0 || d <= 0 || (d & 3) || d > 1024 || ((uintptr_t)scratch & 7))
     return PM_E_INVALID;
@@ -191,7 +197,8 @@ extern "C" int pm_attnpool_bwd(const float* x, const float* g, const float* g_me
   int nb = (int)pm_cdiv(N, 4);
   if (nb > 256) nb = 256;
   hipLaunchKernelGGL(k_attnpool_bwd2, dim3(nb), dim3(256), sizeof(float) * (d + 1), st, x, g, g_mean, g_var, eps, bn_g,
-                     alpha, dout, gate_w, pv.node_bar, dgn, sums, N, d, dx, d_gate_w, d_gate_b, d_bn_g, d_bn_b);
+                     alpha, dout, gate_w, pv.node_bar, dgn, sums, N, d, dx, d_gate_w, d_gate_b, d_bn_g, d_bn_b,
+                     x_gate ? x_gate : x, dx_gate);
   return pm_check_launch();
 }
 

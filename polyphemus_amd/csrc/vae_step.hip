@@ -461,7 +461,7 @@ void backward_encoder(Ctx& c) {
   float* pscr = ar.f((size_t)3 * N + 8);
   c.chk(pm_attnpool_bwd(s.eg.x[c.L], s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, s.alpha, dpooled, c.P + Y.enc_gate.w,
                         s.plan, N, c.E, Gn, d, dxL, c.G + Y.enc_gate.w, c.G + Y.enc_gate.b, c.G + Y.enc_gate_bn.w,
-                        c.G + Y.enc_gate_bn.b, pscr, c.st));
+                        c.G + Y.enc_gate_bn.b, pscr, nullptr, nullptr, c.st));
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
   c.chk(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
   s.bk_dx0 = dx0; s.bk_dzcat = dzcat;

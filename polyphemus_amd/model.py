@@ -442,11 +442,6 @@ class VAE(nn.Module):
         return (self.seed * 0x9E3779B1 + self._step * 0x85EBCA77) & 0xFFFFFFFF
 
     def _prepare(self, graph) -> ops.Plan:
-        if not self.cfg["batch_norm"]:
-            raise NotImplementedError("HIP path: batch_norm=False is not implemented (reference default is True)")
-        if self.training and self.cfg["dropout"] != 0:
-            raise NotImplementedError("HIP path: cfg dropout != 0 in training mode is not implemented "
-                                      "(training.json uses dropout 0; GCL message dropout 0.1 IS implemented)")
         self._check_flat()
         self.engine.msg_dropout = self.msg_dropout
         return prepare_graph(graph, self.cfg["n_bars"])

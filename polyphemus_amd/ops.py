@@ -332,6 +332,21 @@ def relu_bwd(dy, y, out=None):
     return dx
 
 
+def relu_residual(x, res=None):
+    y = torch.empty_like(x)
+    call("pm_relu_residual_fwd", ptr(x), ptr(res), x.numel(), ptr(y), stream())
+    return y
+
+
+def dropout_rows(x, cols: int, p: float, seed: int, site: int, out=None):
+    """x viewed as [numel / cols, cols] times the counter-hash keep mask of (seed, site) / (1 - p); contiguous input."""
+    if not x.is_contiguous():
+        raise ValueError("dropout_rows needs a contiguous tensor")
+    y = out if out is not None else torch.empty_like(x)
+    call("pm_dropout_rows", ptr(x), x.numel() // cols, cols, float(p), seed & 0xFFFFFFFF, site, ptr(y), stream())
+    return y
+
+
 def add(a, b, out=None):
     o = out if out is not None else torch.empty_like(a)
     call("pm_add", ptr(a), ptr(b), a.numel(), ptr(o), stream())
@@ -383,14 +398,16 @@ def attnpool_fwd(x, g, g_mean, g_var, bn_g, bn_b, plan: Plan, eps=1e-5):
 
 
 def attnpool_bwd(x, g, g_mean, g_var, bn_g, alpha, dout, gate_w, plan: Plan, d_gate_w, d_gate_b, d_bn_g, d_bn_b,
-                 eps=1e-5):
+                 eps=1e-5, x_gate=None):
+    """Returns dx, or (dx, dx_gate) when the gate MLP saw `x_gate` instead of x (dropout in front of its Linear)."""
     N, d = x.shape
     dx = torch.empty_like(x)
+    dxg = torch.empty_like(x) if x_gate is not None else None
     scratch = torch.empty(3 * N + 8, dtype=F32, device=x.device)
     call("pm_attnpool_bwd", ptr(x), ptr(g), ptr(g_mean), ptr(g_var), eps, ptr(bn_g), ptr(alpha), ptr(dout),
          ptr(gate_w), ptr(plan.buf), N, plan.E, plan.G, d, ptr(dx), ptr(d_gate_w), ptr(d_gate_b), ptr(d_bn_g),
-         ptr(d_bn_b), ptr(scratch), stream())
-    return dx
+         ptr(d_bn_b), ptr(scratch), ptr(x_gate), ptr(dxg), stream())
+    return dx if x_gate is None else (dx, dxg)
 
 
 def bar_broadcast_fwd(bars, plan: Plan):

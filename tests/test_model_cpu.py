@@ -10,7 +10,7 @@ from polyphemus_amd._lib import HipExtensionError
 from util import batch_from_golden, load_case, state_dict_from_golden
 
 
-@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny", "bnoff_tiny"])
 def test_state_dict_keys_shapes_and_init_match_reference(case):
     z, cfg = load_case(case)
     ref = state_dict_from_golden(z)

@@ -77,7 +77,7 @@ def hip_forward(vae, g, eps):
     return s_logits, c_logits, mu, lv
 
 
-@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny", "bnoff_tiny"])
 def test_eval_forward_matches_reference_golden(case):
     z, cfg = load_case(case)
     vae = VAE(**cfg, device=DEV).to(DEV)
@@ -91,7 +91,7 @@ def test_eval_forward_matches_reference_golden(case):
         assert rel_err(got, z[f"eval/{name}"]) < REL_TOL, name
 
 
-@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny", "bnoff_tiny"])
 def test_train_step_matches_reference_golden(case):
     """forward + reference loss + backward + torch Adam through the drop-in module == golden."""
     z, cfg = load_case(case)
@@ -184,6 +184,74 @@ def test_train_forward_backward_with_message_dropout_matches_oracle(B, nb, d, L,
             assert int(sd2[k]) == int(P[k]), k
 
 
+@pytest.mark.parametrize("batch_norm,p_cfg", [(True, 0.2), (False, 0.0), (False, 0.3)])
+def test_constructor_switches_dropout_and_batch_norm_match_oracle(batch_norm, p_cfg):
+    """The two non-default constructor kwargs of the boundary (train.py:176): `dropout` != 0 (element dropout layers at
+    model.py:160,199,244-247,267-270,389-390,473,479,558-559,640) and `batch_norm` = False (model.py:176-188,218-238,
+    278-292).  The reference draws its dropout masks from torch's RNG; here the oracle replays the HIP path's counter
+    hash at every dropout layer (and for the message dropout), so outputs and every gradient are comparable."""
+    from polyphemus_amd.engine import SITE
+    B, nb, d, L = 6, 2, 32, 2
+    cfg = dict(dropout=p_cfg, batch_norm=batch_norm, gnn_n_layers=L, d=d, n_bars=nb, resolution=8)
+    torch.manual_seed(3)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.train()
+    cpu = synthetic_batch(B, nb, p=0.2, seed=17)
+    g = cpu.to(DEV)
+    eps = torch.randn(B, d)
+    sd = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
+    names = [n for n, _ in vae.named_parameters()]
+    s_logits, c_logits, mu, lv = hip_forward(vae, g, eps.to(DEV))
+    vae._step -= 2
+    seeds = {"enc": vae._next_seed(), "dec": vae._next_seed()}
+
+    def keep(key, eids, dd):
+        return torch.from_numpy(dropout_keep_np(seeds[key[:3]], layer_uid_of(key), eids.numpy(), dd, 0.1))
+
+    def elem_keep(site, rows, cols):
+        name, _, layer = site.partition(".")
+        uid = SITE[name] + (int(layer) if layer else 0)
+        return torch.from_numpy(dropout_keep_np(seeds[name[:3]], uid, rows.numpy(), cols, p_cfg))
+
+    P, names = vae_cpu.split_state(sd, names)
+    vae_cpu.ELEM_KEEP = elem_keep
+    try:
+        (rs, rc), rmu, rlv = vae_cpu.vae_forward(cpu, P, cfg, True, eps, msg_dropout=0.1, keep_mask=keep)
+    finally:
+        vae_cpu.ELEM_KEEP = None
+    for name, got, ref in (("s_logits", s_logits, rs), ("c_logits", c_logits, rc), ("mu", mu, rmu), ("log_var", lv, rlv)):
+        assert rel_err(got.detach(), ref.detach()) < REL_TOL, name
+    w = [torch.randn_like(t) for t in (rs, rc, rmu, rlv)]
+    (sum((a * b).sum() for a, b in zip((rs, rc, rmu, rlv), w)) / 100.0).backward()
+    (sum((a * b.to(DEV)).sum() for a, b in zip((s_logits, c_logits, mu, lv), w)) / 100.0).backward()
+    gp = dict(vae.named_parameters())
+    gmax = max(float(P[n].grad.abs().max()) for n in names)
+    for n in names:
+        assert grad_err(gp[n].grad, P[n].grad, gmax, n) < 5 * REL_TOL, n
+    sd2 = vae.state_dict()
+    assert list(sd2) == list(sd)
+    for k in sd2:
+        if "running_" in k:
+            assert rel_err(sd2[k], P[k]) < REL_TOL, k
+    # the fused trainer takes the same configuration through the Python orchestration of the same kernels
+    from polyphemus_amd.trainer import HipTrainer
+    tr = HipTrainer(vae, lr=1e-4)
+    assert not tr.native
+    out = tr.losses_dict(tr.train_step(g, eps.to(DEV)))
+    assert all(v == v for v in out.values())
+
+
+def test_element_dropout_kernel_keep_rate_and_scale():
+    from polyphemus_amd import ops
+    x = torch.ones(4096, 256, device=DEV)
+    y = ops.dropout_rows(x, 256, 0.3, 1234, 2001)
+    kept = (y != 0)
+    assert abs(float(kept.float().mean()) - 0.7) < 5e-3
+    assert torch.allclose(y[kept], torch.full_like(y[kept], 1 / 0.7))
+    assert torch.equal(y, ops.dropout_rows(x, 256, 0.3, 1234, 2001))             # pure function of (seed, site, row, col)
+    assert not torch.equal(y, ops.dropout_rows(x, 256, 0.3, 1234, 2002))
+
+
 def test_generation_path_builds_structure_on_host():
     """decoder(z, None) (generate.py:24): structure from thresholded logits, then content decoding."""
     z, cfg = load_case("lmd2_tiny")
@@ -218,7 +286,7 @@ def test_autocast_context_is_ignored_by_the_fp32_kernels():
     assert rel_err(mu, z["eval/mu"]) < REL_TOL
 
 
-@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny"])
+@pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny", "bnoff_tiny"])
 def test_fused_trainer_matches_reference_golden(case):
     """The sync-free train step (fused CE/KLD/BCE loss kernels + fused Adam on the flat buffer)
     reproduces the reference's losses and its parameters after 1 and 2 optimizer steps."""

@@ -412,6 +412,17 @@ int pm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
  * step every k-th batch): accum = (first ? 0 : accum) + scale * grads, scale = 1 / k. */
 int pm_grad_accumulate(const float* grads, float* accum, int64_t n, float scale, int32_t first, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ data-parallel exchange
+ * The reference is single-device (train.py:120-122).  Sum-all-reduce of the flat fp32 gradient buffer over RCCL / xGMI
+ * for hosts that do not go through torch.distributed: rank 0 makes a 128-byte id (pm_comm_unique_id), the host hands it
+ * to every rank, each rank creates its communicator on its current device (pm_comm_init) and then calls pm_allreduce —
+ * in place, on `stream`, ordered after the kernels that wrote `buf`.  RCCL is loaded at run time; without it these four
+ * return PM_E_UNSUPPORTED and nothing else is affected. */
+int pm_comm_unique_id(uint8_t* id128 /* [128] host, out */);
+int pm_comm_init(const uint8_t* id128 /* [128] host */, int32_t rank, int32_t world, void** comm /* out */);
+int pm_comm_destroy(void* comm);
+int pm_allreduce(float* buf, int64_t count, void* comm, pm_stream_t stream);
+
 /* Counter-based dropout mask shared by device code and the oracle (host-callable). */
 uint32_t pm_dropout_hash(uint32_t seed, uint32_t layer_uid, uint32_t eid, uint32_t channel);
 

@@ -77,6 +77,10 @@ _SIGS = {
     "pm_content_accuracy": "pppips",
     "pm_structure_metrics": "pplps",
     "pm_adam_step": "pppplffffifs",
+    "pm_comm_unique_id": "p",
+    "pm_comm_init": "piip",
+    "pm_comm_destroy": "p",
+    "pm_allreduce": "plps",
     "pm_prof_configure": "li",
     "pm_prof_begin": "i",
     "pm_prof_end": "ppp",

@@ -57,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(lambda a: _compile(*a), jobs))
     if jobs or not os.path.exists(LIB):
-        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -75,3 +75,50 @@ def broadcast_(tensors: Sequence[torch.Tensor], src: int = 0, group=None) -> Non
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for t in tensors:
             dist.broadcast(t, src=src, group=group)
+
+
+class NativeComm:
+    """RCCL communicator behind the C ABI (`pm_comm_*`, `pm_allreduce`, csrc/comm.hip): what a host that is not
+    PyTorch binds.  `NativeComm.from_torch_group()` bootstraps one next to an initialised torch.distributed group (the
+    128-byte id travels as a broadcast object); `NativeComm.single()` is the one-rank communicator."""
+
+    def __init__(self, id128: bytes, rank: int, world: int):
+        import ctypes
+        from ._lib import call
+        self.rank, self.world = rank, world
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(id128)
+        h = ctypes.c_void_p()
+        call("pm_comm_init", ctypes.cast(buf, ctypes.c_void_p), rank, world, ctypes.cast(ctypes.pointer(h), ctypes.c_void_p))
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from ._lib import call
+        buf = (ctypes.c_uint8 * 128)()
+        call("pm_comm_unique_id", ctypes.cast(buf, ctypes.c_void_p))
+        return bytes(buf)
+
+    @classmethod
+    def single(cls) -> "NativeComm":
+        return cls(cls.unique_id(), 0, 1)
+
+    @classmethod
+    def from_torch_group(cls, group=None) -> "NativeComm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, world)
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        """In-place sum of a contiguous fp32 cuda tensor over the ranks, on the current stream."""
+        from ._lib import call, ptr, stream
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("NativeComm.all_reduce needs a contiguous fp32 cuda tensor")
+        call("pm_allreduce", ptr(t), t.numel(), self._h, stream())
+
+    def close(self) -> None:
+        from ._lib import call
+        if self._h:
+            call("pm_comm_destroy", self._h)
+            self._h = None

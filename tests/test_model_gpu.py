@@ -91,10 +91,15 @@ def test_eval_forward_matches_reference_golden(case):
         assert rel_err(got, z[f"eval/{name}"]) < REL_TOL, name
 
 
+@pytest.mark.parametrize("amp", [False, True])
 @pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny", "bnoff_tiny"])
-def test_train_step_matches_reference_golden(case):
-    """forward + reference loss + backward + torch Adam through the drop-in module == golden."""
+def test_train_step_matches_reference_golden(case, amp):
+    """forward + reference loss + backward + torch Adam through the drop-in module == golden.  `amp`: the iteration
+    exactly as the unchanged `PolyphemusTrainer.train` runs it on a cuda device (training.py:123,137-166): forward and
+    `_losses` inside fp16 autocast, `GradScaler.scale(tot_loss).backward()`, `scaler.step`, `scaler.update` — the fp32
+    kernels ignore the autocast context and the power-of-two loss scale is exact, so the result is the golden's."""
     z, cfg = load_case(case)
+    scaler = torch.cuda.amp.GradScaler() if amp else None
     vae = VAE(**cfg, device=DEV).to(DEV)
     sd0 = state_dict_from_golden(z)
     vae.load_state_dict(sd0)
@@ -107,12 +112,17 @@ def test_train_step_matches_reference_golden(case):
     lr_sum = 0.0
     for step in (1, 2):
         lr_sum += opt.param_groups[0]["lr"]
-        s_logits, c_logits, mu, lv = hip_forward(vae, g, eps)
-        tot, parts = vae_cpu.losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, lv)   # training.py:298-347
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):                    # training.py:137
+            s_logits, c_logits, mu, lv = hip_forward(vae, g, eps)
+            tot, parts = vae_cpu.losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, lv)   # training.py:298-347
         want = json.loads(str(z[f"train{step}/losses"]))
         for k, v in want.items():
             assert abs(float(parts[k]) - v) <= REL_TOL * max(1.0, abs(v)), (step, k)
-        tot.backward()
+        if amp:
+            scaler.scale(tot).backward()                                                 # training.py:153
+            scaler.unscale_(opt)            # (scaler.step would do it: unscaled here so the gradients can be compared)
+        else:
+            tot.backward()
         if step == 1:
             for name, got in zip(("s_logits", "c_logits", "mu", "log_var"), (s_logits, c_logits, mu, lv)):
                 assert rel_err(got.detach(), z[f"train1/{name}"]) < REL_TOL, name
@@ -123,7 +133,11 @@ def test_train_step_matches_reference_golden(case):
                     assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
                 else:
                     assert grad_err(p.grad, z[f"train1/grad/{n}"], gmax, n) < 5 * REL_TOL, n
-        opt.step()
+        if amp:
+            scaler.step(opt)                                                             # training.py:161-162
+            scaler.update()
+        else:
+            opt.step()
         opt.zero_grad()
         for pg in opt.param_groups:
             pg["lr"] = vae_cpu.exp_decay_lr(step, **optcfg["lr_scheduler"])

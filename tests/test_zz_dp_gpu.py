@@ -76,3 +76,39 @@ def test_two_rank_step_matches_mean_gradient_step():
     # noise-driven elements may differ by the full Adam step (2 * lr); everything else must agree tightly
     diff = (p.cpu() - p0).abs()
     assert float(diff.max()) <= 2.5e-3 and float((diff > 1e-5).float().mean()) < 0.02
+
+
+def test_native_rccl_allreduce_single_rank():
+    """`pm_comm_*` / `pm_allreduce` (the C-ABI exchange, csrc/comm.hip) on a one-rank communicator: RCCL loads, the
+    communicator binds to this GPU, the collective runs on the caller's stream after the producing kernel."""
+    from polyphemus_amd.parallel import NativeComm
+    comm = NativeComm.single()
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    y = x * 2.0                                        # producer on the current stream
+    comm.all_reduce(y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, x * 2.0)
+    comm.close()
+
+
+def _native_worker(rank, world):
+    import datetime
+    import torch.distributed as dist
+    from polyphemus_amd.parallel import NativeComm
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        comm = NativeComm.from_torch_group()
+        t = torch.full((4096,), float(rank + 1), device="cuda")
+        comm.all_reduce(t)
+        torch.cuda.synchronize()
+        comm.close()
+        return float(t[0]), float(t[-1])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_allreduce_two_gpus():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    assert run_ranks(_native_worker, 2, timeout=120.0) == [(3.0, 3.0), (3.0, 3.0)]

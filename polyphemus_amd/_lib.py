@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpolyphemus_hip.so")
+# PM_LIB_PATH: development only — load a differently built library (kernel A/B variants of tools/build_variants.py)
+LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "libpolyphemus_hip.so")
 
 PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", "csc_reldist", "csc_eid",
                "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "row_list", "node_trel", "trk_list", "trk_cnt", "scratch"]

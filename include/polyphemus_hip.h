@@ -178,6 +178,8 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] o
  *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
  *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
 enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2,
+       PM_GEMM_ZEROED = 8 /* C is known to hold zeros (a pre-cleared arena region): the split-K path of the small head
+                             products skips its own clear */,
        PM_GEMM_PARTITION = 4 /* grouped + row lists + device counts: the groups' lists partition at most M (K when
                                 transA) rows IN TOTAL; the launch then only enumerates live row panels */ };
 /* tile configuration pm_gemm_f32 picks for a shape (host only).  fp32 MFMA: 0 = 64x64x16, 1 = 128x128x16,

@@ -892,7 +892,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
       !(flags & (PM_GEMM_RELU | PM_GEMM_ACCUM)) && !q->col_stats && !q->rowmap && !planes) {
     split_k = K / 64 < 8 ? K / 64 : 8;
     if (split_k > 1) {
-      hipMemsetAsync(q->C, 0, sizeof(float) * (size_t)M * N, st);
+      if (!(flags & PM_GEMM_ZEROED)) hipMemsetAsync(q->C, 0, sizeof(float) * (size_t)M * N, st);
       flags |= PM_GEMM_ACCUM;
       g.flags = flags;
     } else split_k = 1;

@@ -14,17 +14,32 @@
 
 namespace {
 
+// Bump allocator over the caller's workspace.  The first `zcap` bytes are the ZERO REGION: every small buffer that must
+// start the step cleared (accumulators, split-K outputs of the head products, atomics targets) is carved from it with
+// z() / zf() / zdbl() and the whole region is cleared by ONE memset at the start of pm_vae_step_forward — the step
+// used to issue ~45 separate clears (2.7 % of its kernel time).  Everything else comes from the region behind it.
 struct Arena {
   char* base; size_t cap, used; bool overflow;
+  size_t zcap, zused;
   void* take(size_t bytes) {
     const size_t a = (used + 255) & ~size_t(255);
     used = a + bytes;
     if (!base) return nullptr;                 // measuring pass
-    if (used > cap) { overflow = true; return base; }
+    if (zcap + used > cap) { overflow = true; return base + zcap; }
+    return base + zcap + a;
+  }
+  void* z(size_t bytes) {
+    const size_t a = (zused + 255) & ~size_t(255);
+    zused = a + bytes;
+    if (!base) return nullptr;
+    if (zused > zcap) { overflow = true; return base; }
     return base + a;
   }
+  bool zeroed(const void* p) const { return base && (const char*)p >= base && (const char*)p < base + zcap; }
   float* f(size_t n) { return (float*)take(n * sizeof(float)); }
   double* dbl(size_t n) { return (double*)take(n * sizeof(double)); }
+  float* zf(size_t n) { return (float*)z(n * sizeof(float)); }
+  double* zdbl(size_t n) { return (double*)z(n * sizeof(double)); }
 };
 
 struct GcnSaved {
@@ -77,7 +92,7 @@ struct Ctx {
 // y[M, Nout] = x @ W^T + b      (x: leading dim lda, y: leading dim ldc)
 void lin(Ctx& c, const float* x, PmLin l, int M, int Nout, int Kin, float* y, bool relu, int lda = 0, int ldc = 0) {
   c.chk(pm_gemm_f32(0, 1, M, Nout, Kin, x, lda ? lda : Kin, c.P + l.w, Kin, y, ldc ? ldc : Nout, c.P + l.b,
-                    relu ? PM_GEMM_RELU : 0, 1, nullptr, 0, nullptr, c.st));
+                    (relu ? PM_GEMM_RELU : 0) | (c.s->ar.zeroed(y) ? PM_GEMM_ZEROED : 0), 1, nullptr, 0, nullptr, c.st));
 }
 // dW += dy^T x ; db += colsum(dy) ; dx = dy @ W
 void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, int Kin, float* dx, int lddy = 0,
@@ -86,8 +101,8 @@ void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, 
   c.chk(pm_gemm_f32(1, 0, Nout, Kin, M, dy, lddy, x, ldx ? ldx : Kin, c.G + l.w, Kin, nullptr, PM_GEMM_ACCUM, 0,
                     nullptr, 0, nullptr, c.st));
   if (want_bias) c.chk(pm_colsum_acc(dy, M, Nout, lddy, c.G + l.b, c.st));
-  if (dx) c.chk(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr, 0, 1, nullptr,
-                            0, nullptr, c.st));
+  if (dx) c.chk(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
+                            c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
 }
 // training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
 void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
@@ -129,8 +144,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
   }
   sv.x[0] = x0;
-  sv.pool = ar.dbl((size_t)c.L * 5 * d * PM_BN_REPL);
-  if (ar.base) hipMemsetAsync(sv.pool, 0, sizeof(double) * c.L * 5 * d * PM_BN_REPL, c.st);
+  sv.pool = ar.zdbl((size_t)c.L * 5 * d * PM_BN_REPL);
   const int64_t aps = (int64_t)N * nb * d;                // plane stride of the aggregates (elements)
   if (c.planes) {                                         // the GCL weights of this stack, split once per step
     sv.wp_base = g.weight[0];
@@ -203,7 +217,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   Arena& ar = c.s->ar;
   const int N = c.N, d = c.d, nb = c.compact ? 4 : 7;
   const int64_t dd = (int64_t)d * d;
-  float* dT = ar.f((size_t)PM_N_DIST * d);
+  float* dT = ar.zf((size_t)PM_N_DIST * d);
   float* dh = ar.f((size_t)N * d);
   float* dA = ar.f((size_t)N * nb * d);
   const int64_t aps = (int64_t)N * nb * d, dps = (int64_t)N * d;
@@ -211,7 +225,6 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   float* dxa = ar.f((size_t)N * d);
   float* dxb = ar.f((size_t)N * d);
   PmPlanView pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
-  hipMemsetAsync(dT, 0, sizeof(float) * PM_N_DIST * d, c.st);
   // the segment-reduce backward of layer i also accumulates the column sums of the norm backward of layer i-1; beyond
   // d = 512 that variant spills (16-wave workgroups: 128 VGPRs), so wider models take the separate column-sum pass
   const bool fuse_sums = d <= 512;
@@ -290,7 +303,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.zcat = ar.f((size_t)B * 2 * d);
   s.c0 = ar.f((size_t)Gn * 8 * 128); s.a0 = ar.f((size_t)Gn * 8 * 128); s.m0 = ar.f(8); s.v0 = ar.f(8);
   s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
-  s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.f((size_t)Gn * d);
+  s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.zf((size_t)Gn * d);
   if (run) {
     c.chk(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
     bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
@@ -333,8 +346,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);            // z_c = zcat[:, :d]
   }
   // ---------------- merge + heads (model.py:472-481), reparametrisation (model.py:671-673)
-  s.m = ar.f((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
-  s.mu = ar.f((size_t)B * d); s.lv = ar.f((size_t)B * d); s.z = ar.f((size_t)B * d);
+  s.m = ar.zf((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
+  s.mu = ar.zf((size_t)B * d); s.lv = ar.zf((size_t)B * d); s.z = ar.f((size_t)B * d);
   if (run) {
     lin(c, s.zcat, Y.enc_merge, B, d, 2 * d, s.m, false);
     bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
@@ -343,10 +356,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     c.chk(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
   }
   // ---------------- decoder (model.py:634-655)
-  s.zd = ar.f((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
-  s.sb = ar.f((size_t)Gn * d); s.u1 = ar.f((size_t)Gn * d); s.u2 = ar.f((size_t)Gn * 512);
+  s.zd = ar.zf((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
+  s.sb = ar.zf((size_t)Gn * d); s.u1 = ar.f((size_t)Gn * d); s.u2 = ar.f((size_t)Gn * 512);
   s.c2 = ar.f((size_t)Gn * 8 * 128); s.a2 = ar.f((size_t)Gn * 8 * 128); s.m2 = ar.f(8); s.v2 = ar.f(8);
-  s.s_logits = ar.f((size_t)Gn * 128); s.cb = ar.f((size_t)Gn * d);
+  s.s_logits = ar.f((size_t)Gn * 128); s.cb = ar.zf((size_t)Gn * d);
   float* xd0 = ar.f((size_t)N * d);
   if (run) {
     lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
@@ -364,7 +377,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
-  s.dmu = ar.f((size_t)B * d); s.dlv = ar.f((size_t)B * d);
+  s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   if (run) {
     lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);            // rows [0, S*d) of chord_decoder.weight
     // duration logits for every (node, slot) row; pitch logits per drum / non-drum node list (model.py:561-576)
@@ -378,8 +391,6 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     // (also accumulates the three un-embedding bias gradients: column sums of d_logits per node group)
     c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.dc_logits, c.G + Y.dec_pitch_d.b,
                         c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
-    hipMemsetAsync(s.dmu, 0, sizeof(float) * B * d, c.st);
-    hipMemsetAsync(s.dlv, 0, sizeof(float) * B * d, c.st);
     c.chk(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
     if (s.fix_structure)
       c.chk(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
@@ -396,8 +407,7 @@ void backward_decoder(Ctx& c) {
   PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
   const int S = c.S;
   const int64_t R = (int64_t)N * S;
-  float* dzr = ar.f((size_t)B * 2 * d);
-  hipMemsetAsync(dzr, 0, sizeof(float) * B * 2 * d, c.st);
+  float* dzr = ar.zf((size_t)B * 2 * d);
   // ---- content decoder
   float* dH = ar.f((size_t)R * d);
   c.chk(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
@@ -422,7 +432,7 @@ void backward_decoder(Ctx& c) {
   // ---- structure decoder (only when the structure loss reaches the logits)
   if (s.fix_structure) {
     float* da2 = ar.f((size_t)Gn * 8 * 128); float* dc2 = ar.f((size_t)Gn * 8 * 128);
-    float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.f((size_t)Gn * d); float* dsb = ar.f((size_t)Gn * d);
+    float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.zf((size_t)Gn * d); float* dsb = ar.zf((size_t)Gn * d);
     c.chk(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
     c.chk(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
     bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
@@ -436,7 +446,7 @@ void backward_decoder(Ctx& c) {
   }
   float* dzd = ar.f((size_t)B * 2 * d);
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
-  s.dz = ar.f((size_t)B * d);
+  s.dz = ar.zf((size_t)B * d);
   lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz);
   c.chk(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
 }
@@ -446,16 +456,16 @@ void backward_encoder(Ctx& c) {
   Arena& ar = s.ar;
   const PmVaeLayout& Y = s.lay;
   const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
-  float* dzg = ar.f((size_t)B * d); float* dzg2 = ar.f((size_t)B * d);
+  float* dzg = ar.zf((size_t)B * d); float* dzg2 = ar.zf((size_t)B * d);
   lin_bwd(c, s.dmu, s.zg, Y.enc_mu, B, d, d, dzg);
   lin_bwd(c, s.dlv, s.zg, Y.enc_lv, B, d, d, dzg2);
   c.chk(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
   float* dm = ar.f((size_t)B * d);
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
-  float* dzcat = ar.f((size_t)B * 2 * d);
+  float* dzcat = ar.zf((size_t)B * 2 * d);
   lin_bwd(c, dm, s.zcat, Y.enc_merge, B, d, 2 * d, dzcat);
   // ---- content branch (z_c = zcat[:, :d])
-  float* dpooled = ar.f((size_t)Gn * d);
+  float* dpooled = ar.zf((size_t)Gn * d);
   lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d);
   float* dxL = ar.f((size_t)N * d);
   float* pscr = ar.f((size_t)3 * N + 8);
@@ -497,7 +507,7 @@ void backward_encoder_tail(Ctx& c) {
                             c.G + Y.enc_dur.b, c.G + Y.enc_bn_d.w, c.G + Y.enc_bn_d.b, c.G + Y.enc_bn_nd.w,
                             c.G + Y.enc_bn_nd.b, c.G + Y.enc_bn_dur.w, c.G + Y.enc_bn_dur.b, c.st));
   // ---- structure branch (z_s = zcat[:, d:])
-  float* dh2 = ar.f((size_t)Gn * d); float* dh1 = ar.f((size_t)Gn * d); float* da1 = ar.f((size_t)Gn * 512);
+  float* dh2 = ar.zf((size_t)Gn * d); float* dh1 = ar.zf((size_t)Gn * d); float* da1 = ar.zf((size_t)Gn * 512);
   float* dc1 = ar.f((size_t)Gn * 512); float* dp0 = ar.f((size_t)Gn * 8 * 32); float* da0 = ar.f((size_t)Gn * 8 * 128);
   float* dc0 = ar.f((size_t)Gn * 8 * 128);
   lin_bwd(c, dzcat + d, s.h2, Y.enc_s_bars, B, d, nb * d, dh2, 2 * d, nb * d, nb * d);
@@ -522,6 +532,9 @@ void measure_backward(Ctx& c) {
                   2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + R * d + 2 * d + 4 * PM_N_PITCH * dh +
                   (2 * Gn * d + 2 * Gn * 512 + Gn * 8 * 32 + 2 * Gn * 8 * 128);
   ar.take(floats * sizeof(float) + 256 * 256);    // + alignment slack of the ~60 carve-outs
+  // zero-region carve-outs of the backward: dT x2, dzr, du1, dsb, dz, dzg x2, dzcat, dpooled, dh2, dh1, da1 (+ slack)
+  ar.z((2 * PM_N_DIST * d + B * 2 * d + 2 * Gn * d + B * d + 2 * B * d + B * 2 * d + Gn * d + 2 * Gn * d + Gn * 512) *
+           sizeof(float) + 16 * 256);
   ar.take((size_t)2 * c.L * (7 * d * d + 64 * d) * 6);   // planes mode: bf16 planes of the two GCN weight ranges
 }
 
@@ -530,23 +543,35 @@ void measure_backward(Ctx& c) {
 extern "C" int64_t pm_vae_layout_bytes(void) { return (int64_t)sizeof(PmVaeLayout); }
 extern "C" int64_t pm_vae_step_state_bytes(void) { return (int64_t)sizeof(StepState); }
 
+// Arena requirement of a step, by a launch-free pass over the carve-outs: bytes of the zero region (rounded to 4 KiB)
+// and of the region behind it.
+static void measure_step(const PmVaeLayout* lay, const PmBatch& bt, size_t* zero_bytes, size_t* main_bytes) {
+  StepState s;
+  memset(&s, 0, sizeof(s));
+  s.lay = *lay; s.bt = bt;
+  s.ar.base = nullptr; s.ar.cap = 0; s.ar.used = 0; s.ar.zcap = 0; s.ar.zused = 0;
+  Ctx c = make_ctx(&s, nullptr);
+  forward(c, 0.f, 0, 0);
+  measure_backward(c);
+  *zero_bytes = (s.ar.zused + 4095) & ~size_t(4095);
+  *main_bytes = s.ar.used;
+}
+
 extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B,
                                                int32_t n_slots) {      // sized for the non-compact (7d) aggregates
   if (!lay || N <= 0 || E <= 0 || G <= 0 || B <= 0 || lay->n_layers > PM_MAX_LAYERS || n_slots < 1 ||
       n_slots > PM_N_SLOTS)
     return -1;
-  StepState s;
-  memset(&s, 0, sizeof(s));
-  s.lay = *lay; s.bt.N = N; s.bt.E = E; s.bt.G = G; s.bt.B = B; s.bt.n_slots = n_slots;
-  s.ar.base = nullptr; s.ar.cap = 0; s.ar.used = 0;
-  Ctx c = make_ctx(&s, nullptr);
-  forward(c, 0.f, 0, 0);
-  measure_backward(c);
+  PmBatch bt;
+  memset(&bt, 0, sizeof(bt));
+  bt.N = N; bt.E = E; bt.G = G; bt.B = B; bt.n_slots = n_slots;
+  size_t zb, mb;
+  measure_step(lay, bt, &zb, &mb);
   // the measuring pass runs the fp32 7-block layout; the planes layout additionally keeps the GCL weights of both
   // stacks as bf16 planes (row-major + two fragment-major copies): 3 x 6 bytes per stored weight element
   const int64_t d = lay->d, per_layer = 7 * d * d + 64 * d + 256;
   const int64_t weight_planes = 2 * (int64_t)lay->n_layers * per_layer * 6 * 3 + (1 << 16);
-  return (int64_t)s.ar.used + weight_planes + 4096;
+  return (int64_t)(zb + mb) + weight_planes + 4096;
 }
 
 extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,
@@ -565,6 +590,15 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
   s->eps = eps; s->losses = losses; s->beta = beta; s->fix_structure = structure_loss_on_logits;
   s->ar.base = (char*)workspace; s->ar.cap = (size_t)workspace_bytes; s->ar.used = 0; s->ar.overflow = false;
   hipStream_t st = (hipStream_t)stream;
+  // size check BEFORE anything is launched (a short workspace used to surface only after the whole pass had been
+  // enqueued on aliased memory), then the one clear of the zero region
+  size_t zb, mb;
+  measure_step(lay, *batch, &zb, &mb);
+  if ((size_t)pm_vae_step_workspace_bytes(lay, batch->N, batch->E, batch->G, batch->B, batch->n_slots) > (size_t)workspace_bytes ||
+      zb + mb > (size_t)workspace_bytes)
+    return PM_E_INVALID;
+  s->ar.zcap = zb; s->ar.zused = 0;
+  if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess) return PM_E_LAUNCH;
   Ctx c = make_ctx(s, st);
   c.chk(pm_plan_build(batch->edge_index, batch->edge_type, batch->edge_dist, batch->bars, batch->batch, batch->is_drum,
                       batch->tokens, lay->n_bars, batch->n_slots, batch->N, batch->E, batch->G, plan, stream));

@@ -178,6 +178,8 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] o
  *   and applies to A and C (!transA) or to A and B (transA); `dyn_entries` (device int,
  *   optional) overrides the entry count so no host sync is needed for data-dependent sizes. */
 enum { PM_GEMM_RELU = 1, PM_GEMM_ACCUM = 2,
+       PM_GEMM_RELU_ADD = 16 /* C = C + relu(op(A) op(B) + bias): the residual tail x + relu(.) of an eval-mode GCL layer
+                                whose BatchNorm is folded into the weights (pm_bn_fold_weights); no split-K */,
        PM_GEMM_ZEROED = 8 /* C is known to hold zeros (a pre-cleared arena region): the split-K path of the small head
                              products skips its own clear */,
        PM_GEMM_PARTITION = 4 /* grouped + row lists + device counts: the groups' lists partition at most M (K when
@@ -287,6 +289,14 @@ int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const
                     int64_t plane_stride /* elements */,
                     int32_t sums_ready /* != 0: acc3 already holds the sums (pm_segreduce_bwd_norm) */,
                     pm_stream_t stream);
+/* Eval-mode BatchNorm folded into the linear map in front of it (model.py:203 under `vae.eval()`,
+ * generate.py:112): with s = gamma / sqrt(running_var + eps), t = beta - running_mean * s,
+ *   W_out[k, n] = W[k, n] * s[n]      (W [rows, cols] row-major, the GCL operand [weight; root] [7d, d])
+ *   b_out[n]    = bias[n] * s[n] + t[n]
+ * so BN(A @ W + b) = A @ W_out + b_out and the normalisation pass over [N, d] disappears from the forward. */
+int pm_bn_fold_weights(const float* W, int32_t rows, int32_t cols, const float* bias, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, float eps, float* W_out, float* b_out,
+                       pm_stream_t stream);
 /* `num_batches_tracked` of all BatchNorm modules after a training forward: counters[i] += inc[i] + [group_cnt[0] > 0] *
  * sel[0][i] + [group_cnt[1] > 0] * sel[1][i] (the embedding norms only count when their node group — drums / non-drums,
  * plan field GROUP_CNT — is non-empty, model.py:362,375). */

@@ -64,6 +64,7 @@ _SIGS = {
     "pm_attnpool_fwd": "ppppfpppiiiipps",
     "pm_attnpool_bwd": "ppppfpppppiiiipppppppps",
     "pm_relu_residual_fwd": "pplps",
+    "pm_bn_fold_weights": "piipppppfpps",
     "pm_dropout_rows": "plifuups",
     "pm_bar_broadcast_fwd": "ppiiiips",
     "pm_bar_broadcast_bwd": "ppiiiips",

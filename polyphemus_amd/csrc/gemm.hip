@@ -688,6 +688,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
   const bool atomic = gridDim.z > 1;
   const bool accum = (g.flags & PM_GEMM_ACCUM) != 0;
   const bool relu = (g.flags & PM_GEMM_RELU) != 0;
+  const bool relu_add = (g.flags & PM_GEMM_RELU_ADD) != 0;      // C = C + relu(acc + bias): residual GCL tail, eval mode
   const bool add_bias = g.bias != nullptr && zs == 0;
   const int32_t* mapC = TA ? nullptr : g.rowmap;
   const bool stats = g.colstats != nullptr;
@@ -715,8 +716,11 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
         if (add_bias) v += g.bias[col];
         if (at) atomicAdd(crow + col, v);
         else {
-          if (accum) v += crow[col];
-          if (relu) v = fmaxf(v, 0.f);
+          if (relu_add) v = fmaxf(v, 0.f) + crow[col];
+          else {
+            if (accum) v += crow[col];
+            if (relu) v = fmaxf(v, 0.f);
+          }
           crow[col] = v;
           if (stats) { cs[j] += (double)v; cq[j] += (double)v * (double)v; }
         }
@@ -889,7 +893,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   // split it over the otherwise idle CUs.  C is cleared first and accumulated with atomics (bias by slice 0);
   // only for a plainly stored contiguous C (no ReLU / statistics / row map / accumulate).
   if (!transA && q->split_k == 1 && n_groups == 1 && tiles <= 64 && K >= 256 && ldc_contig(q, N) &&
-      !(flags & (PM_GEMM_RELU | PM_GEMM_ACCUM)) && !q->col_stats && !q->rowmap && !planes) {
+      !(flags & (PM_GEMM_RELU | PM_GEMM_ACCUM | PM_GEMM_RELU_ADD)) && !q->col_stats && !q->rowmap && !planes) {
     split_k = K / 64 < 8 ? K / 64 : 8;
     if (split_k > 1) {
       if (!(flags & PM_GEMM_ZEROED)) hipMemsetAsync(q->C, 0, sizeof(float) * (size_t)M * N, st);
@@ -897,7 +901,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
       g.flags = flags;
     } else split_k = 1;
   }
-  if (split_k > 1 && ((flags & PM_GEMM_RELU) || !(flags & PM_GEMM_ACCUM))) return PM_E_INVALID;  // needs += semantics
+  if (split_k > 1 && ((flags & (PM_GEMM_RELU | PM_GEMM_RELU_ADD)) || !(flags & PM_GEMM_ACCUM))) return PM_E_INVALID;  // needs += semantics
   if (g.c_split > 0 && n_groups > 1 && !(flags & PM_GEMM_ACCUM)) return PM_E_INVALID;
   const int kper = (int)pm_cdiv(pm_cdiv(K, split_k), BK) * BK;
   g.kper = kper;

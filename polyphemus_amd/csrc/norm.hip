@@ -468,6 +468,27 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = a[i] + b[i];
 }
+__global__ void __launch_bounds__(256) k_bn_fold(const float* __restrict__ W, int64_t n, int cols, const float* __restrict__ bias,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                                 float* __restrict__ Wo, float* __restrict__ bo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    const float s = gamma[c] * rsqrtf(rv[c] + eps);
+    Wo[i] = W[i] * s;
+    if (i < cols) bo[c] = bias[c] * s + (beta[c] - rm[c] * s);
+  }
+}
+extern "C" int pm_bn_fold_weights(const float* W, int32_t rows, int32_t cols, const float* bias, const float* gamma,
+                                  const float* beta, const float* running_mean, const float* running_var, float eps,
+                                  float* W_out, float* b_out, pm_stream_t stream) {
+  if (!W || !bias || !gamma || !beta || !running_mean || !running_var || !W_out || !b_out || rows <= 0 || cols <= 0)
+    return PM_E_INVALID;
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(k_bn_fold, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, W, n, cols, bias, gamma, beta,
+                     running_mean, running_var, eps, W_out, b_out);
+  return pm_check_launch();
+}
 // y = relu(x) (+ res): the layer tail of a model built with batch_norm = False (model.py:203-206 without the norm,
 // :219-230 / :279-285 without BatchNorm2d)
 __global__ void k_relu_res(const float* __restrict__ x, const float* __restrict__ res, int64_t n, float* y) {

@@ -105,6 +105,14 @@ class Engine:
     def dropping(self, training) -> bool:
         return bool(training and self.cfg["dropout"])
 
+    def _gcl_operand(self, lk: str) -> torch.Tensor:
+        """[weight; root] of a GCL as ONE [7d, d] matrix: the two parameters are adjacent in the flat buffer."""
+        W, R = self.T[lk + ".weight"], self.T[lk + ".root"]
+        d = self.d
+        if R.data_ptr() != W.data_ptr() + 4 * 6 * d * d:
+            raise RuntimeError("GCL weight / root are not adjacent in the flat parameter buffer")
+        return torch.as_strided(W, (7 * d, d), (d, 1))
+
     # ------------------------------------------------------------------ GCN (model.py:167-208)
     def gcn_forward(self, x, plan, key, training, seed, uid0):
         d, N = self.d, plan.N
@@ -116,6 +124,19 @@ class Engine:
             lk = f"{key}.layers.{i}"
             xin = self.drop(x, d, site0 + i, seed, training)        # model.py:199 (the residual keeps the undropped x)
             A = ops.segreduce_fwd(xin, T, plan, p, seed, uid0 + i)
+            if not training and self.cfg["batch_norm"]:
+                # eval mode (generate.py:112): the norm is an affine map of running statistics, folded into the layer's
+                # weights — x' = x + relu(A @ (W s) + (b s + t)) in ONE product whose epilogue adds the residual; the
+                # normalisation pass over [N, d] is gone.  Folded per call: 7 d^2 floats per layer.
+                nk = f"{key}.norm_layers.{i}.module"
+                Wf, bf = ops.bn_fold_weights(self._gcl_operand(lk),
+                                             self.T[lk + ".bias"], self.T[nk + ".weight"], self.T[nk + ".bias"],
+                                             self.T[nk + ".running_mean"], self.T[nk + ".running_var"], EPS)
+                xn = x.clone() if i == 0 else x          # (in place from layer 1 on: x is this loop's own buffer)
+                ops.gemm(A, Wf, xn, N, d, 7 * d, 7 * d, d, d, bias=bf, relu_add=True)
+                layers.append((xin, A, None, None, None))
+                x = xn
+                continue
             h = torch.empty(N, d, dtype=F32, device=x.device)
             # weight [6,d,d] and root [d,d] are adjacent in the flat buffer: B = [W_0;..;W_5;root], K = 7d
             ops.gemm(A, self.T[lk + ".weight"], h, N, d, 7 * d, 7 * d, d, d, bias=self.T[lk + ".bias"])

@@ -219,14 +219,24 @@ def segreduce_bwd(x, T, dA, dres, plan: Plan, dropout_p: float, seed: int, layer
     return dx
 
 
-GEMM_RELU, GEMM_ACCUM, GEMM_PARTITION = 1, 2, 4
+GEMM_RELU, GEMM_ACCUM, GEMM_PARTITION, GEMM_RELU_ADD = 1, 2, 4, 16
+
+
+def bn_fold_weights(W, bias, gamma, beta, running_mean, running_var, eps=1e-5):
+    """(W * s, bias * s + t) with s = gamma / sqrt(running_var + eps), t = beta - running_mean * s (columns of W)."""
+    W2 = W.reshape(-1, W.shape[-1])
+    Wo, bo = torch.empty_like(W2), torch.empty_like(bias)
+    call("pm_bn_fold_weights", ptr(W2), W2.shape[0], W2.shape[1], ptr(bias), ptr(gamma), ptr(beta), ptr(running_mean),
+         ptr(running_var), eps, ptr(Wo), ptr(bo), stream())
+    return Wo, bo
 
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
-         split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None):
+         split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None, relu_add=False):
     """out[M,N] (=|+=) op(A) op(B) (+bias)(relu); A/B/out may be views with an element offset
-    (pass the sliced tensor: its data_ptr() carries the offset) and explicit leading dimensions."""
-    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0)
+    (pass the sliced tensor: its data_ptr() carries the offset) and explicit leading dimensions.
+    relu_add: out = out + relu(op(A) op(B) + bias)."""
+    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_RELU_ADD if relu_add else 0)
     cls = gemm_class(transA, transB, M, N, K) if PROF is not None else ""
     e0 = _prof_begin(cls)
     call("pm_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),

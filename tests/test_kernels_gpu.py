@@ -762,3 +762,20 @@ def test_launch_profiler_class_mask_and_stride():
         assert L.pm_prof_configure(-1, 0) != 0
     finally:
         L.pm_prof_configure(-1, 1)
+
+
+def test_eval_batchnorm_folded_into_weights():
+    """pm_bn_fold_weights + the RELU_ADD epilogue: x + relu(BN_eval(A @ W + b)) in one product."""
+    from polyphemus_amd import ops
+    torch.manual_seed(5)
+    N, K, d = 777, 7 * 64, 64
+    A, W, b, x = (torch.randn(N, K, device=DEV), torch.randn(K, d, device=DEV) * 0.1, torch.randn(d, device=DEV),
+                  torch.randn(N, d, device=DEV))
+    gamma, beta, rm, rv = (torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV), torch.randn(d, device=DEV),
+                           torch.rand(d, device=DEV) + 0.1)
+    Wf, bf = ops.bn_fold_weights(W, b, gamma, beta, rm, rv, 1e-5)
+    out = x.clone()
+    ops.gemm(A, Wf, out, N, d, K, K, d, d, bias=bf, relu_add=True)
+    h = A.double() @ W.double() + b.double()
+    ref = x.double() + torch.relu((h - rm.double()) / torch.sqrt(rv.double() + 1e-5) * gamma.double() + beta.double())
+    assert rel_err(out, ref) < 1e-5

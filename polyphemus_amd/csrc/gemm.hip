@@ -27,6 +27,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef PM_BD_DUAL
+#define PM_BD_DUAL 0
+#endif
+#ifndef PM_TN_DUAL
+#define PM_TN_DUAL 1
+#endif
+#ifndef PM_PL_WAVES
+#define PM_PL_WAVES 5          // waves per SIMD the 64x64 planes kernel is register-budgeted for
+#endif
 #ifndef PM_BD_WAVES
 #define PM_BD_WAVES 5
 #endif
@@ -320,8 +329,8 @@ struct PlaneStage {
 //  contraction then run as one resident wave of workgroups instead of 1024 + a 12-tile tail)
 template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
 __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
-    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? PM_BD_WAVES : 1),
-                                       (MODE == 2 && BM * BN <= 64 * 64) ? 5 : (MODE == 3 ? PM_BD_WAVES : 8))))
+    __attribute__((amdgpu_waves_per_eu((MODE == 2 && BM * BN <= 64 * 64) ? PM_PL_WAVES : (MODE == 3 ? PM_BD_WAVES : 1),
+                                       (MODE == 2 && BM * BN <= 64 * 64) ? PM_PL_WAVES : (MODE == 3 ? PM_BD_WAVES : 8))))
     k_gemm(GemmArgs g) {
   constexpr bool X6 = MODE == 1, PL = MODE >= 2, BD = MODE == 3;
   static_assert(MODE == 0 || (VA && VB && BK % 16 == 0), "split modes stage with 16-byte loads");
@@ -474,6 +483,16 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
       const int q = v / kblk;
       return (q == 0 ? 0 : q == 1 ? s1 : q == 2 ? s2 : 3) * kblk + (v - q * kblk);
     };
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    f32x16 accb[PM_BD_DUAL ? TM : 1][PM_BD_DUAL ? TN : 1];
+#pragma unroll
+    for (int i = 0; i < (PM_BD_DUAL ? TM : 1); ++i)
+#pragma unroll
+      for (int j = 0; j < (PM_BD_DUAL ? TN : 1); ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][j][r] = 0.f;
     if constexpr (BD) {
       // B direct (MODE 3): B is a weight matrix kept as FRAGMENT-MAJOR planes (pm_split_planes_frag): the 1 KiB that a
       // wave needs for one (32-row tile, 16-wide k-step, plane) MFMA operand is contiguous, so every wave takes its B
@@ -530,13 +549,25 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks][PB[t6]][j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < TN; ++j) {
+                if (PM_BD_DUAL && (t6 & 1))      // odd products to a second accumulator set: twice the independent chains
+                  accb[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks][PB[t6]][j], accb[i][j], 0, 0, 0);
+                else
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks][PB[t6]][j], acc[i][j], 0, 0, 0);
+              }
           bload(bq[ks], kn < kend ? kn + ks * 16 : kend);
         }
         __syncthreads();
         if (v0 + BK < kv_end) pa.store(Ax0);
         __syncthreads();
+      }
+      if (PM_BD_DUAL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += accb[PM_BD_DUAL ? i : 0][PM_BD_DUAL ? j : 0][r];
       }
     } else {
     pa.prime(kbeg, kend);
@@ -550,6 +581,24 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     for (int v0 = 0; v0 < kv_end; v0 += BK) {
       pa.load(kmap(v0 + BK), kend);            // (past the end: out-of-range offsets, returns 0, no traffic)
       pb.load(kmap(v0 + BK), kend);
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+      if constexpr (PM_TN_DUAL && TM * TN == 1 && BK == 32) {
+        // one 32x32 tile per wave: its six products per k-step form ONE dependent MFMA chain; the two k-steps of the
+        // tile go to two accumulators (added in the epilogue), so two independent chains interleave
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            a[ks][p] = PA_::frag(Ax0 + p * PA_::PPLANE, wr * WM, ks, lane);
+            b[ks][p] = PB_::frag(Bx1 + p * PB_::PPLANE, wc * WN, ks, lane);
+          }
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[t6]], b[0][PB[t6]], acc[0][0], 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[t6]], b[1][PB[t6]], acc2, 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 a[3][TM], b[3][TN];
@@ -560,7 +609,6 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
 #pragma unroll
           for (int j = 0; j < TN; ++j) b[p][j] = PB_::frag(Bx1 + p * PB_::PPLANE, wc * WN + j * 32, ks, lane);
         }
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
         for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
@@ -569,6 +617,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
       }
+      }
       __syncthreads();
       if (v0 + BK < kv_end) {
         pa.store(Ax0);
@@ -576,6 +625,10 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
       }
       __syncthreads();
     }
+    }
+    if constexpr (PM_TN_DUAL && TM * TN == 1 && BK == 32 && !BD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
     }
   } else {
   sa.init(g.A, g.lda, m0, M, mapA, g.rpe);

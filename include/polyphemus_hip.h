@@ -399,6 +399,13 @@ int pm_content_ce(const float* c_logits /* [N,15,230] */, const int32_t* tokens 
                   int32_t n_slots /* c_logits is [N,S,230] */, float grad_scale,
                   float* d_logits /* or NULL */, float* db_pitch_drum /* [131] or NULL */,
                   float* db_pitch_nd /* [131] */, float* db_dur /* [99] */, double* out, pm_stream_t stream);
+/* Same with per-term gradient weights read on the device: dev_scale [2] = {pitch, duration} multiplies d_logits (not the
+ * reported loss values).  Data parallel: with dev_scale = n_valid_local * world / n_valid_global the mean of the ranks'
+ * gradients is the gradient of the token mean over the GLOBAL batch (training.py:316-323). */
+int pm_content_ce_scaled(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist, const uint8_t* is_drum,
+                         int32_t N, int32_t n_slots, float grad_scale, const float* dev_scale /* [2] device, or NULL */,
+                         float* d_logits, float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out,
+                         pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
            float* dlog_var, double* out, pm_stream_t stream);
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,
@@ -489,6 +496,8 @@ typedef struct PmBatch {                                    /* device pointers o
   int32_t n_slots;                                          /* active token slots S (1..15), see pm_plan_build */
   int32_t flags;                                            /* bit 0: every node receives edges of at most one track
                                                                relation (host-verified) -> compact GCL, K = 4d */
+  const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
+                                                               gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
 int64_t pm_vae_layout_bytes(void);
 int64_t pm_vae_step_state_bytes(void);

@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ l
                                                     const int* __restrict__ hist, const uint8_t* __restrict__ is_drum,
                                                     int64_t rows, int S, float grad_scale, float* __restrict__ dlogits,
                                                     float* db_pitch_d, float* db_pitch_nd, float* db_dur,
-                                                    double* __restrict__ out) {
+                                                    double* __restrict__ out, const float* __restrict__ dev_scale) {
   __shared__ double sh[2][16];
   __shared__ float sb[16][2][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -22,7 +22,9 @@ __global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ l
   const double rows15 = (double)(rows / S) * PM_N_SLOTS;
   const double np = rows15 - (double)(hist[0 * PM_N_PITCH + 130] + hist[1 * PM_N_PITCH + 130]);
   const double nd = rows15 - (double)(hist[2 * PM_N_PITCH + 98] + hist[3 * PM_N_PITCH + 98]);
-  const float inv_p = (float)(1.0 / np), inv_d = (float)(1.0 / nd);
+  // dev_scale (data parallel, optional): per-rank weights n_local * world / n_global of the pitch / duration terms, so
+  // that the mean of the ranks' gradients is the gradient of the GLOBAL token mean (CE ignore_index means, training.py:316-323)
+  const float inv_p = (float)(1.0 / np) * (dev_scale ? dev_scale[0] : 1.f), inv_d = (float)(1.0 / nd) * (dev_scale ? dev_scale[1] : 1.f);
   const bool want_b = db_pitch_d != nullptr && dlogits != nullptr;
   double lp = 0, ld = 0;
   float bacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // [drum?][column lane + 64 j]
@@ -93,6 +95,13 @@ __global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ l
 extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist,
                              const uint8_t* is_drum, int32_t N, int32_t n_slots, float grad_scale, float* d_logits,
                              float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream) {
+  return pm_content_ce_scaled(c_logits, tokens, tok_hist, is_drum, N, n_slots, grad_scale, nullptr, d_logits, db_pitch_drum,
+                              db_pitch_nd, db_dur, out, stream);
+}
+extern "C" int pm_content_ce_scaled(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist,
+                                    const uint8_t* is_drum, int32_t N, int32_t n_slots, float grad_scale,
+                                    const float* dev_scale, float* d_logits, float* db_pitch_drum, float* db_pitch_nd,
+                                    float* db_dur, double* out, pm_stream_t stream) {
   if (!c_logits || !tokens || !tok_hist || !out || N <= 0 || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   if (db_pitch_drum && (!db_pitch_nd || !db_dur || !is_drum || !d_logits)) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -105,7 +114,7 @@ extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const
   int nb = (int)pm_cdiv(rows, (threads / 64) * 8);
   if (nb > 512) nb = 512;
   hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(threads), 0, st, c_logits, tokens, tok_hist, is_drum, rows, n_slots, grad_scale,
-                     d_logits, db_pitch_drum, db_pitch_nd, db_dur, out);
+                     d_logits, db_pitch_drum, db_pitch_nd, db_dur, out, dev_scale);
   return pm_check_launch();
 }
 

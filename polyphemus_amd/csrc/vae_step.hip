@@ -389,8 +389,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                       c.P + Y.dec_pitch_nd.b, 0, 1, pv.row_list + (int64_t)N * PM_N_SLOTS, 1, pv.group_cnt + 3, c.st));
     // ---------------- losses (training.py:298-347) and their gradients w.r.t. the model outputs
     // (also accumulates the three un-embedding bias gradients: column sums of d_logits per node group)
-    c.chk(pm_content_ce(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.dc_logits, c.G + Y.dec_pitch_d.b,
-                        c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
+    c.chk(pm_content_ce_scaled(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.bt.ce_scale, s.dc_logits,
+                               c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     c.chk(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
     if (s.fix_structure)
       c.chk(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));

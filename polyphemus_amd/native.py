@@ -63,7 +63,7 @@ class PmBatch(C.Structure):
     _fields_ = [("edge_index", C.c_void_p), ("edge_type", C.c_void_p), ("edge_dist", C.c_void_p), ("bars", C.c_void_p),
                 ("batch", C.c_void_p), ("is_drum", C.c_void_p), ("tokens", C.c_void_p), ("s_tensor", C.c_void_p),
                 ("N", C.c_int32), ("E", C.c_int32), ("G", C.c_int32), ("B", C.c_int32), ("n_slots", C.c_int32),
-                ("flags", C.c_int32)]
+                ("flags", C.c_int32), ("ce_scale", C.c_void_p)]
 
 
 def build_layout(vae) -> PmVaeLayout:

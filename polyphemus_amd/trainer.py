@@ -52,13 +52,18 @@ class ExpDecayLR:
 class HipTrainer:
     def __init__(self, vae: VAE, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler: Optional[dict] = None,
                  structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None, native: bool = True,
-                 iters_to_accumulate: int = 1):
+                 iters_to_accumulate: int = 1, global_token_mean: bool = False):
         self.vae = vae
         self.lr, self.betas, self.eps = lr, betas, eps
         self.sched = ExpDecayLR(**lr_scheduler) if lr_scheduler else None
         self.fix_structure_loss = structure_loss_on_logits
         self.beta = beta
         self.pg = process_group
+        # Data parallel: the reference's CE losses are means over the non-PAD tokens of the batch (training.py:316-323),
+        # so the mean of per-rank gradients weights every rank equally whatever its token count.  With
+        # `global_token_mean` each rank's CE gradient is weighted n_local * world / n_global (one all-reduce of two
+        # counts per step, no host sync): the averaged gradient is then that of the token mean over the GLOBAL batch.
+        self.global_token_mean = bool(global_token_mean)
         # the C++ step covers the configuration of training.json (batch_norm = True, dropout = 0: what bench.py measures);
         # the two non-default constructor switches of the model (model.py:176,188,218,278) run the same kernels through
         # the Python orchestration (engine.py)
@@ -145,6 +150,9 @@ class HipTrainer:
                 from .graphs import batch_flags
                 n_slots, unique = batch_flags(tok, ei, et, tok.shape[0])
             c = (et, ed, tok, drum, ei, bars, bat, int(n_slots), bool(unique))
+            if self.global_token_mean:        # non-PAD (pitch, duration) tokens of slots 1..15, on the device
+                nv = torch.stack([(tok[:, 1:, 0] != 130).sum(), (tok[:, 1:, 1] != 98).sum()]).to(torch.float32)
+                c = c + (nv,)
             try:
                 graph.__dict__["_pm_inputs"] = c
             except Exception:
@@ -154,11 +162,21 @@ class HipTrainer:
     def _native_forward_backward(self, graph, eps):
         vae = self.vae
         L = lib()
-        et, ed, tok, drum, ei, bars, bat, n_slots, unique = self._prep_inputs(graph)
+        inputs = self._prep_inputs(graph)
+        et, ed, tok, drum, ei, bars, bat, n_slots, unique = inputs[:9]
         s_tensor = graph.s_tensor
         if s_tensor.dtype != torch.float32 or not s_tensor.is_contiguous():
             s_tensor = s_tensor.float().contiguous()
         bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, n_slots, unique)
+        ce_scale = None
+        if self.global_token_mean and self.world > 1:
+            import torch.distributed as dist
+            if len(inputs) < 10:
+                raise RuntimeError("batch was prepared before global_token_mean was switched on")
+            tot = inputs[9].clone()
+            dist.all_reduce(tot, group=self.pg)
+            ce_scale = (inputs[9] * float(self.world) / tot).contiguous()      # stays on the device
+            bt.ce_scale = ce_scale.data_ptr()
         bt.B = bt.G // vae.cfg["n_bars"]
         need = int(L.pm_vae_step_workspace_bytes(ctypes.byref(self._layout), bt.N, bt.E, bt.G, bt.B, bt.n_slots))
         if self._ws is None or self._ws.numel() < need:
@@ -208,6 +226,8 @@ class HipTrainer:
         return (s_logits, c_logits), mu, lv
 
     def _python_forward_backward(self, graph, eps):
+        if self.global_token_mean and self.world > 1:
+            raise NotImplementedError("global_token_mean is implemented by the native step only")
         vae, eng = self.vae, self.vae.engine
         eng.msg_dropout = vae.msg_dropout
         graph.__dict__.pop("_pm_plan", None)                 # the plan is part of the step (new batch every step)

@@ -112,3 +112,61 @@ def test_native_rccl_allreduce_two_gpus():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     assert run_ranks(_native_worker, 2, timeout=120.0) == [(3.0, 3.0), (3.0, 3.0)]
+
+
+def _gtm_batch(rank):
+    from polyphemus_amd.synthetic import synthetic_batch
+    return synthetic_batch(4 + 4 * rank, 2, p=0.25, seed=60 + rank)      # 4 and 8 samples: different token counts
+
+
+def _gtm_worker(rank, world, backend):
+    import datetime
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from polyphemus_amd.model import VAE
+        from polyphemus_amd.trainer import HipTrainer
+        torch.manual_seed(100)
+        vae = VAE(**CFG, device=dev).to(dev)
+        vae.train()
+        vae.msg_dropout = 0.0
+        tr = HipTrainer(vae, lr=1e-3, global_token_mean=True)
+        b = _gtm_batch(rank)
+        eps = torch.randn(b.s_tensor.shape[0] // 2, CFG["d"], generator=torch.Generator().manual_seed(7 + rank)).to(dev)
+        tr.train_step(b.to(dev), eps)
+        torch.cuda.synchronize()
+        return tr.grads.detach().cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_token_mean_weights_the_ranks_by_their_token_counts():
+    """CE `ignore_index` means (training.py:316-323) under data parallelism: with `global_token_mean` the summed
+    gradient equals sum_r (n_r * world / n_total) * g_r, g_r = the rank's own local-mean gradient — i.e. its mean over the
+    ranks is the gradient of the token mean over the global batch (per-replica BatchNorm statistics apart)."""
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    try:
+        res = run_ranks(_gtm_worker, 2, (backend,), timeout=120.0)
+    except RanksHung as e:
+        pytest.skip(f"2-rank {backend} run did not complete on this box:\n{e}")
+    got = torch.from_numpy(res[0])
+    assert torch.equal(got, torch.from_numpy(res[1]))
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.trainer import HipTrainer
+    grads, counts = [], []
+    for rank in range(2):
+        torch.manual_seed(100)
+        vae = VAE(**CFG, device="cuda").to("cuda")
+        vae.train()
+        vae.msg_dropout = 0.0
+        tr = HipTrainer(vae, lr=1e-3)
+        b = _gtm_batch(rank)
+        eps = torch.randn(b.s_tensor.shape[0] // 2, CFG["d"], generator=torch.Generator().manual_seed(7 + rank)).cuda()
+        tr.train_step(b.to("cuda"), eps)
+        grads.append(tr.grads.detach().cpu().double())
+        counts.append(float((b.tokens[:, 1:, 0] != 130).sum()))
+    assert counts[0] != counts[1]
+    want = sum(g * (n * 2.0 / sum(counts)) for g, n in zip(grads, counts))
+    assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())

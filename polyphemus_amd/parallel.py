@@ -23,7 +23,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # PM_DP_FORCE=1 (tests): take the exchange path with a single rank too, so that the RCCL stream semantics of the
+    # bucketed all-reduce can be exercised on a one-GPU box
+    if (world > 1 or os.environ.get("PM_DP_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend is None:
@@ -54,12 +56,13 @@ class GradBuckets:
         edges = [0] + list(boundaries) + [flat_grads.numel()]
         self.views: List[torch.Tensor] = [flat_grads[a:b] for a, b in zip(edges[:-1], edges[1:])]
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (os.environ.get("PM_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
         self._work = []
         self.hold = False        # True: launches are skipped (micro-batches of a gradient accumulation)
         self.disabled = False    # True: no exchange at all (bench.py: cost of the step without the all-reduce)
 
     def launch(self, i: int) -> None:
-        if self.world > 1 and not self.hold and not self.disabled:
+        if self.active and not self.hold and not self.disabled:
             self._work.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> float:

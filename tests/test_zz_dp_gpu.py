@@ -170,3 +170,52 @@ def test_global_token_mean_weights_the_ranks_by_their_token_counts():
     assert counts[0] != counts[1]
     want = sum(g * (n * 2.0 / sum(counts)) for g, n in zip(grads, counts))
     assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def _nccl1_worker(rank, world):
+    """One rank, backend nccl (RCCL), exchange path forced on: the three gradient buckets really travel through
+    ncclAllReduce on RCCL's stream while the backward continues on the compute stream."""
+    import datetime
+    import os
+    import torch.distributed as dist
+    os.environ["PM_DP_FORCE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=60))
+    try:
+        from polyphemus_amd.model import VAE
+        from polyphemus_amd.synthetic import synthetic_batch
+        from polyphemus_amd.trainer import HipTrainer
+        cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=4, d=128, n_bars=2, resolution=8)
+        batch = synthetic_batch(64, 2, p=0.25, seed=5).to("cuda")
+        eps = torch.randn(64, 128, generator=torch.Generator().manual_seed(1)).cuda()
+        out = []
+        for force in (True, False):
+            torch.manual_seed(0)
+            vae = VAE(**cfg, device="cuda").to("cuda")
+            vae.train()
+            vae.msg_dropout = 0.0
+            tr = HipTrainer(vae, lr=1e-3)
+            assert tr.buckets.active
+            tr.buckets.disabled = not force
+            g1 = None
+            for i in range(3):
+                tr.train_step(batch, eps)
+                if i == 0:
+                    g1 = tr.grads.detach().cpu().numpy()      # same weights in both runs: comparable to rounding noise
+            torch.cuda.synchronize()
+            out.append((vae.flat_params.detach().cpu().numpy(), g1))
+        return out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_exchange_over_rccl_single_rank():
+    """RCCL has never run with more than one rank on the builder's one-GPU boxes; this at least runs the real
+    `ncclAllReduce` launches of the trainer (three async buckets overlapping the backward, then the fused Adam) on
+    backend "nccl" and checks that the result equals the same steps without the exchange: a stream-ordering bug
+    (all-reduce reading a bucket before its producers finished, Adam reading it before the all-reduce) would show."""
+    (p_dp, g_dp), (p_ref, g_ref) = run_ranks(_nccl1_worker, 1, timeout=150.0)[0]
+    gd, gr = torch.from_numpy(g_dp), torch.from_numpy(g_ref)
+    assert float((gd - gr).abs().max()) <= 2e-4 * float(gr.abs().max())        # (atomics-order noise between two runs)
+    assert float((torch.from_numpy(p_dp) - torch.from_numpy(p_ref)).abs().max()) <= 6.5e-3   # 3 Adam steps at lr 1e-3
+    assert float((torch.from_numpy(p_dp) - torch.from_numpy(p_ref)).abs().mean()) < 2e-4      # (Adam at lr 1e-3 amplifies rounding noise)

@@ -103,16 +103,9 @@ def test_measured_native_path_matches_reference_golden(case):
     # reproduces the golden bit for bit in fp32 (tests/test_oracle_golden.py): every gradient tensor of the HIP path
     # within 1e-4 of the fp64 result (measured <= 3e-5), and no further from the reference's fp32 tensor than that
     # tensor is from fp64 (+ the 1e-4 bar).  No carve-out for analytically-zero gradients is needed against fp64.
-    from oracle import vae_cpu
-    from util import _as_dtype
+    from util import fp64_oracle_grads
     names = [n for n, _ in vae.named_parameters()]
-    sd0 = state_dict_from_golden(z)
-    P64, _ = vae_cpu.split_state({k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}, names)
-    nthreads = torch.get_num_threads()
-    torch.set_num_threads(1)
-    _, _, g64 = vae_cpu.train_step(_as_dtype(batch_from_golden(z, cfg), torch.float64), P64, names, cfg,
-                                   torch.optim.SGD([P64[n] for n in names], lr=0.0), eps.cpu().double(), msg_dropout=0.0)
-    torch.set_num_threads(nthreads)
+    g64 = fp64_oracle_grads(z, cfg)
     none = set(str(n) for n in z["train1/grad_none"])
     gmax = max(float(g64[n].abs().max()) for n in names if g64[n] is not None)
     for n in names:

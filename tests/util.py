@@ -174,6 +174,25 @@ def run_ranks(fn, world, args=(), timeout=90.0):
                 p.join(timeout=5)
 
 
+def fp64_oracle_grads(z, cfg):
+    """Gradients of the reference training step of a golden case, computed by oracle/vae_cpu.py in fp64 (one thread):
+    the anchor of the gradient tolerances (the golden's own fp32 gradients sit up to 2.7e-2 of a tensor's scale from
+    exact arithmetic; tools/golden_fp64_diag.py)."""
+    from oracle import vae_cpu
+    names = [str(n) for n in z["param_names"]]
+    sd0 = state_dict_from_golden(z)
+    P, _ = vae_cpu.split_state({k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}, names)
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _, _, g = vae_cpu.train_step(_as_dtype(batch_from_golden(z, cfg), torch.float64), P, names, cfg,
+                                     torch.optim.SGD([P[k] for k in names], lr=0.0),
+                                     torch.from_numpy(z["in/eps"]).double(), msg_dropout=0.0)
+    finally:
+        torch.set_num_threads(n)
+    return g
+
+
 # ---- full-size parity: the native HIP step against the CPU oracle in fp32 AND fp64 ------------------------------
 FULLSIZE = {
     # BASELINE.json configs[1..2] and one GPU's shard of configs[4]; message dropout replayed where the mask is cheap

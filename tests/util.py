@@ -278,6 +278,7 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
     live = [n for n in names if g64[n] is not None]
     gmax = max(float(g64[n].abs().max()) for n in live)
     worst = {"hip_vs_o64": (0.0, ""), "o32_vs_o64": (0.0, ""), "hip_vs_o32": (0.0, "")}
+    per_tensor = []
     num = {"hip_vs_o64": 0.0, "o32_vs_o64": 0.0, "hip_vs_o32": 0.0}
     den2 = 0.0
     for n in live:
@@ -287,6 +288,8 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
             e = float((x - y).abs().max()) / den
             if e > worst[tag][0]:
                 worst[tag] = (e, n)
+            if tag == "hip_vs_o64":
+                per_tensor.append((e, n, float(c.abs().max()) / gmax))
             num[tag] += float(((x - y) ** 2).sum())
         den2 += float((c ** 2).sum())
     for n in names:
@@ -295,4 +298,5 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
     rep["grad"] = {tag: {"worst_tensor_err": worst[tag][0], "worst_tensor": worst[tag][1], "rel_l2": (num[tag] / den2) ** 0.5}
                    for tag in worst}
     rep["grad"]["gmax"] = gmax
+    rep["grad"]["hip_worst_tensors"] = [{"err": round(e, 6), "tensor": n, "scale_vs_gmax": round(sc, 5)} for e, n, sc in sorted(per_tensor, reverse=True)[:10]]
     return rep

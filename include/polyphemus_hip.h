@@ -406,6 +406,17 @@ int pm_content_ce_scaled(const float* c_logits, const int32_t* tokens, const int
                          int32_t N, int32_t n_slots, float grad_scale, const float* dev_scale /* [2] device, or NULL */,
                          float* d_logits, float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out,
                          pm_stream_t stream);
+/* Fused un-embedding + cross-entropy: the three Linear(d/2 -> 131 | 131 | 99) products of
+ * ContentDecoder.forward (model.py:561-567; pitch per drum / non-drum row list of the plan, duration on all rows) and the
+ * two CrossEntropyLoss(ignore_index = PAD) terms of `_losses` (training.py:316-323) in one launch: the logits of a
+ * 64-row tile stay in the MFMA accumulators, only d_logits [N,S,230] is written (and `logits` when not NULL).
+ * H [N,S,d] is the chord decoder's output; out[0] / out[1] receive the pitch / duration loss (zeroed by the call);
+ * db_* (all or none) += the bias gradients; dev_scale as in pm_content_ce_scaled. */
+int pm_unembed_ce(const float* H, const float* w_pitch_drum /* [131,d/2] */, const float* b_pitch_drum,
+                  const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur /* [99,d/2] */, const float* b_dur,
+                  const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
+                  float grad_scale, const float* dev_scale, float* logits /* or NULL */, float* d_logits,
+                  float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
            float* dlog_var, double* out, pm_stream_t stream);
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,
@@ -495,7 +506,10 @@ typedef struct PmBatch {                                    /* device pointers o
   int32_t N, E, G, B;
   int32_t n_slots;                                          /* active token slots S (1..15), see pm_plan_build */
   int32_t flags;                                            /* bit 0: every node receives edges of at most one track
-                                                               relation (host-verified) -> compact GCL, K = 4d */
+                                                               relation (host-verified) -> compact GCL, K = 4d;
+                                                               bit 1: GCL GEMM operands as pre-split bf16 planes;
+                                                               bit 2: also store the content logits (pm_vae_step_outputs)
+                                                               — the fused un-embedding + CE otherwise writes d_logits only */
   const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;

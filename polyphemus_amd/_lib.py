@@ -75,6 +75,7 @@ _SIGS = {
     "pm_maxpool4_bwd": "pplps",
     "pm_content_ce": "ppppiifppppps",
     "pm_content_ce_scaled": "ppppiifpppppps",
+    "pm_unembed_ce": "pppppppppiiiiifppppppps",
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
     "pm_content_accuracy": "pppips",

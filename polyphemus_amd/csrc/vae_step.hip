@@ -380,17 +380,26 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   if (run) {
     lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);            // rows [0, S*d) of chord_decoder.weight
-    // duration logits for every (node, slot) row; pitch logits per drum / non-drum node list (model.py:561-576)
+    // un-embedding (model.py:561-576: duration logits for every (node, slot) row, pitch logits per drum / non-drum row
+    // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits stay in the MFMA
+    // accumulators, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
+    // (opt-in, PM_FUSED_CE=1: measured 195-220 us against 159 us for the three products + the loss kernel, csrc/unembed.hip)
+    static const bool fused_ce = getenv("PM_FUSED_CE") && atoi(getenv("PM_FUSED_CE")) != 0;
+    if (fused_ce) {
+      c.chk(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
+                          c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
+                          (s.bt.flags & 4) ? s.c_logits : nullptr, s.dc_logits, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b,
+                          c.G + Y.dec_dur.b, s.losses, c.st));
+    } else {
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
                       c.P + Y.dec_dur.b, 0, 1, nullptr, 0, nullptr, c.st));
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_d.w, dh, s.c_logits, PM_N_TOK,
                       c.P + Y.dec_pitch_d.b, 0, 1, pv.row_list, 1, pv.group_cnt + 2, c.st));
     c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_nd.w, dh, s.c_logits, PM_N_TOK,
                       c.P + Y.dec_pitch_nd.b, 0, 1, pv.row_list + (int64_t)N * PM_N_SLOTS, 1, pv.group_cnt + 3, c.st));
-    // ---------------- losses (training.py:298-347) and their gradients w.r.t. the model outputs
-    // (also accumulates the three un-embedding bias gradients: column sums of d_logits per node group)
     c.chk(pm_content_ce_scaled(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.bt.ce_scale, s.dc_logits,
                                c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
+    }
     c.chk(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
     if (s.fix_structure)
       c.chk(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
@@ -630,6 +639,8 @@ extern "C" int pm_vae_step_outputs(const void* state, float* s_logits, float* c_
   const size_t N = s->bt.N, S = s->bt.n_slots, G = s->bt.G, B = s->bt.B, d = s->lay.d;
   hipError_t e = hipSuccess;
   if (s_logits && e == hipSuccess) e = hipMemcpyAsync(s_logits, s->s_logits, sizeof(float) * G * 128, hipMemcpyDeviceToDevice, st);
+  static const bool fused_ce = getenv("PM_FUSED_CE") && atoi(getenv("PM_FUSED_CE")) != 0;
+  if (c_logits && fused_ce && !(s->bt.flags & 4)) return PM_E_INVALID;      // the step was told not to keep the logits
   if (c_logits && e == hipSuccess) e = hipMemcpyAsync(c_logits, s->c_logits, sizeof(float) * N * S * PM_N_TOK, hipMemcpyDeviceToDevice, st);
   if (mu && e == hipSuccess) e = hipMemcpyAsync(mu, s->mu, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
   if (log_var && e == hipSuccess) e = hipMemcpyAsync(log_var, s->lv, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);

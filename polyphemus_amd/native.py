@@ -97,7 +97,8 @@ def build_layout(vae) -> PmVaeLayout:
     return lay
 
 
-def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_slots: int, track_unique: bool) -> PmBatch:
+def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_slots: int, track_unique: bool,
+               keep_logits: bool = False) -> PmBatch:
     """Batch descriptor of the native step; every tensor is a checked device tensor of the dtype the C side reads
     (int64 edge_index / bars / batch, int32 ids, uint8 is_drum, fp32 s_tensor: `HipTrainer._prep_inputs`)."""
     for t, dt in ((edge_index, torch.int64), (bars, torch.int64), (batch, torch.int64), (s_tensor, torch.float32),
@@ -113,5 +114,6 @@ def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_
         raise ValueError(f"n_slots must be in 1..15, got {n_slots}")
     b.n_slots = int(n_slots)
     # bit 0: one track relation per node (compact GCL); bit 1: GCL GEMM operands as pre-split bf16 planes
-    b.flags = (1 if track_unique else 0) | (2 if _PLANES else 0)
+    # bit 2: the fused un-embedding + CE also stores the content logits (step_outputs, evaluation)
+    b.flags = (1 if track_unique else 0) | (2 if _PLANES else 0) | (4 if keep_logits else 0)
     return b

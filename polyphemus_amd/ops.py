@@ -474,6 +474,20 @@ def content_ce(c_logits, plan: Plan, grad_scale=1.0, want_grad=True, out=None, d
     return out, dl
 
 
+def unembed_ce(H, w_pd, b_pd, w_pnd, b_pnd, w_dur, b_dur, plan: Plan, grad_scale=1.0, want_logits=False, out=None,
+               dbias=None, dev_scale=None):
+    """Fused un-embedding + cross-entropy (`pm_unembed_ce`): H [N,15,d] -> (out, d_logits [N,15,230], logits or None)."""
+    N, S, d = H.shape
+    out = out if out is not None else torch.empty(4, dtype=F64, device=H.device)
+    dl = torch.empty(N, S, C.D_TOKEN_PAIR, dtype=F32, device=H.device)
+    lg = torch.empty_like(dl) if want_logits else None
+    b = dbias if dbias is not None else (None, None, None)
+    call("pm_unembed_ce", ptr(H), ptr(w_pd), ptr(b_pd), ptr(w_pnd), ptr(b_pnd), ptr(w_dur), ptr(b_dur), ptr(plan.tokens),
+         ptr(plan.buf), N, plan.E, plan.G, d, S, grad_scale, ptr(dev_scale), ptr(lg), ptr(dl), ptr(b[0]), ptr(b[1]), ptr(b[2]),
+         ptr(out), stream())
+    return out, dl, lg
+
+
 def kld(mu, log_var, out, beta=0.0, dmu=None, dlog_var=None):
     B, d = mu.shape
     call("pm_kld", ptr(mu), ptr(log_var), B, d, beta, ptr(dmu), ptr(dlog_var), ptr(out), stream())

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -64,6 +65,9 @@ class HipTrainer:
         # `global_token_mean` each rank's CE gradient is weighted n_local * world / n_global (one all-reduce of two
         # counts per step, no host sync): the averaged gradient is then that of the token mean over the GLOBAL batch.
         self.global_token_mean = bool(global_token_mean)
+        # True: the native step also stores the content logits (`step_outputs`); off by default — the fused un-embedding +
+        # cross-entropy then writes d(loss)/d(logits) only
+        self.keep_logits = False
         # the C++ step covers the configuration of training.json (batch_norm = True, dropout = 0: what bench.py measures);
         # the two non-default constructor switches of the model (model.py:176,188,218,278) run the same kernels through
         # the Python orchestration (engine.py)
@@ -167,7 +171,7 @@ class HipTrainer:
         s_tensor = graph.s_tensor
         if s_tensor.dtype != torch.float32 or not s_tensor.is_contiguous():
             s_tensor = s_tensor.float().contiguous()
-        bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, n_slots, unique)
+        bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, n_slots, unique, keep_logits=self.keep_logits)
         ce_scale = None
         if self.global_token_mean and self.world > 1:
             import torch.distributed as dist
@@ -217,6 +221,9 @@ class HipTrainer:
         """`((s_logits, c_logits), mu, log_var)` of the last native `train_step` — what `VAE.forward` returns
         (model.py:676-678) — copied out of the workspace arena.  c_logits holds the active slots only: [N, S, 230]
         (the remaining slots are PAD in every node of the batch; the fused step never computes them)."""
+        if not self.keep_logits and os.environ.get("PM_FUSED_CE", "0") not in ("", "0"):
+            raise RuntimeError("step_outputs needs trainer.keep_logits = True before the step (the fused un-embedding + "
+                               "cross-entropy does not store the logits otherwise)")
         i = self.step_info()
         dev, d, nb = self.grads.device, self.vae.cfg["d"], self.vae.cfg["n_bars"]
         s_logits = torch.empty(i["B"], nb, 4, 32, device=dev)

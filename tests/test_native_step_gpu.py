@@ -75,6 +75,7 @@ def test_measured_native_path_matches_reference_golden(case):
     eps = torch.from_numpy(z["in/eps"]).to(DEV)
     optcfg = json.loads(str(z["opt"]))
     tr = HipTrainer(vae, lr_scheduler=optcfg["lr_scheduler"], **optcfg["optimizer"])
+    tr.keep_logits = True                                       # (the fused un-embedding + CE also stores the logits)
     L = lib()
     L.pm_prof_configure(-1, 1)
     L.pm_prof_begin(512)
@@ -344,3 +345,41 @@ def test_evaluate_loop_and_checkpoint_round_trip(tmp_path):
     assert abs(tr2.lr - want_lr) < 1e-15
     diff = (vae2.flat_params - want).abs()
     assert float(diff.max()) <= 2.5e-4 and float(diff.mean()) < 2e-6
+
+
+def _fused_ce_worker(rank, world, case):
+    """Fresh process (the switch is read once): the native step with the fused un-embedding + cross-entropy kernel."""
+    import os
+    os.environ["PM_FUSED_CE"] = "1"
+    z, cfg = load_case(case)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.load_state_dict(state_dict_from_golden(z))
+    vae.train()
+    vae.msg_dropout = 0.0
+    tr = HipTrainer(vae)
+    tr.keep_logits = True
+    out = tr.losses_dict(tr.train_step(batch_from_golden(z, cfg).to(DEV), torch.from_numpy(z["in/eps"]).to(DEV)))
+    (_, c_logits), _, _ = tr.step_outputs()
+    return out, tr.grads.detach().cpu().numpy(), c_logits.cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["lmd2_tiny", "d128_l2"])
+def test_native_step_with_fused_unembed_ce_matches_the_unfused_step(case):
+    """PM_FUSED_CE=1 (csrc/unembed.hip) against the default step — three un-embedding products + the
+    loss kernel — on a reference-captured batch: same losses (and the goldens'), logits, and gradients."""
+    from util import run_ranks
+    (lf, gf, cf), = run_ranks(_fused_ce_worker, 1, (case,), timeout=120.0)
+    z, cfg = load_case(case)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.load_state_dict(state_dict_from_golden(z))
+    vae.train()
+    vae.msg_dropout = 0.0
+    tr = HipTrainer(vae)
+    tr.keep_logits = True
+    lu = tr.losses_dict(tr.train_step(batch_from_golden(z, cfg).to(DEV), torch.from_numpy(z["in/eps"]).to(DEV)))
+    (_, cu), _, _ = tr.step_outputs()
+    for k, v in json.loads(str(z["train1/losses"])).items():
+        assert abs(lf[k] - v) <= REL_TOL * max(1.0, abs(v)), k
+        assert abs(lf[k] - lu[k]) <= 1e-6 * max(1.0, abs(lu[k])), k
+    assert rel_err(torch.from_numpy(cf), cu) < 1e-5
+    assert rel_err(torch.from_numpy(gf), tr.grads) < 1e-4

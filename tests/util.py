@@ -234,6 +234,7 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
     names = [n for n, _ in vae.named_parameters()]
     eps = torch.randn(spec["B"], spec["d"], generator=torch.Generator().manual_seed(99))
     tr = HipTrainer(vae, lr=5e-6)
+    tr.keep_logits = True
     step0 = vae._step
     t0 = time.time()
     got_l = tr.losses_dict(tr.train_step(cpu.to(dev), eps.to(dev)))

@@ -262,6 +262,7 @@ def main():
              "x6:128x128x32", "planes:64x64x32", "planesB:64x128x32", "planes:128x128x32")
     lay = ("NN", "NT", "TN")
     names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(33)] + ["segreduce_fwd", "segreduce_bwd"]
+    names[9 * 3] = "gemm_NN_planesB:64x128x64"            # (the B-direct forward product takes k-tiles of 64)
 
     def prof_collect():
         ms_a, work_a, cnt_a = (ctypes.c_double * NCLS)(), (ctypes.c_double * NCLS)(), (ctypes.c_int64 * NCLS)()

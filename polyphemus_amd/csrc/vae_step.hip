@@ -89,30 +89,34 @@ struct Ctx {
   }
 };
 
+// Launch (or any call that returns a PM_* code) — skipped in the measuring pass (null arena base), where the same code
+// only walks the carve-outs: the workspace requirement is measured by the code that uses it, forward AND backward.
+#define RUN(expr) do { if (c.s->ar.base) c.chk(expr); } while (0)
+
 // y[M, Nout] = x @ W^T + b      (x: leading dim lda, y: leading dim ldc)
 void lin(Ctx& c, const float* x, PmLin l, int M, int Nout, int Kin, float* y, bool relu, int lda = 0, int ldc = 0) {
-  c.chk(pm_gemm_f32(0, 1, M, Nout, Kin, x, lda ? lda : Kin, c.P + l.w, Kin, y, ldc ? ldc : Nout, c.P + l.b,
+  RUN(pm_gemm_f32(0, 1, M, Nout, Kin, x, lda ? lda : Kin, c.P + l.w, Kin, y, ldc ? ldc : Nout, c.P + l.b,
                     (relu ? PM_GEMM_RELU : 0) | (c.s->ar.zeroed(y) ? PM_GEMM_ZEROED : 0), 1, nullptr, 0, nullptr, c.st));
 }
 // dW += dy^T x ; db += colsum(dy) ; dx = dy @ W
 void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, int Kin, float* dx, int lddy = 0,
              int ldx = 0, int lddx = 0, bool want_bias = true) {
   lddy = lddy ? lddy : Nout;
-  c.chk(pm_gemm_f32(1, 0, Nout, Kin, M, dy, lddy, x, ldx ? ldx : Kin, c.G + l.w, Kin, nullptr, PM_GEMM_ACCUM, 0,
+  RUN(pm_gemm_f32(1, 0, Nout, Kin, M, dy, lddy, x, ldx ? ldx : Kin, c.G + l.w, Kin, nullptr, PM_GEMM_ACCUM, 0,
                     nullptr, 0, nullptr, c.st));
-  if (want_bias) c.chk(pm_colsum_acc(dy, M, Nout, lddy, c.G + l.b, c.st));
-  if (dx) c.chk(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
+  if (want_bias) RUN(pm_colsum_acc(dy, M, Nout, lddy, c.G + l.b, c.st));
+  if (dx) RUN(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
                             c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
 }
 // training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
 void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
             float* var) {
-  c.chk(pm_bn_stats(x, O, C, I, mean, var, c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.s->bn_scratch, c.st));
-  c.chk(pm_bn_apply(x, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, res, relu ? 1 : 0, y, c.st));
+  RUN(pm_bn_stats(x, O, C, I, mean, var, c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.s->bn_scratch, c.st));
+  RUN(pm_bn_apply(x, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, res, relu ? 1 : 0, y, c.st));
 }
 void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn bn, const float* mean, const float* var,
             bool relu, float* dx, float* dbias_pre = nullptr) {
-  c.chk(pm_bn_bwd(x, dy, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, relu ? 1 : 0, c.G + bn.w, c.G + bn.b,
+  RUN(pm_bn_bwd(x, dy, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, relu ? 1 : 0, c.G + bn.w, c.G + bn.b,
                   dbias_pre, dx, c.s->bn_scratch, c.st));
 }
 
@@ -140,7 +144,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
   sv.seed = seed; sv.uid0 = uid0; sv.p = p;
   PmPlanView pv;
   if (ar.base) {
-    c.chk(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
+    RUN(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
     pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
   }
   sv.x[0] = x0;
@@ -150,9 +154,9 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     sv.wp_base = g.weight[0];
     sv.wp_stride = (g.weight[c.L - 1] + 7 * dd - g.weight[0] + 7) & ~(int64_t)7;
     for (int i = 0; i < c.L; ++i)
-      if (g.weight[i] < sv.wp_base || ((g.weight[i] - sv.wp_base) & 7)) c.chk(PM_E_INVALID);
+      if (g.weight[i] < sv.wp_base || ((g.weight[i] - sv.wp_base) & 7)) RUN(PM_E_INVALID);
     sv.Wp = (uint16_t*)ar.take((size_t)sv.wp_stride * 6);
-    if (ar.base) c.chk(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
+    if (ar.base) RUN(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
     // fragment-major copies for the B-direct mode (d a multiple of 32, the layers' matrices equally spaced)
     sv.Wfn = sv.Wft = nullptr; sv.wf_stride = 7 * dd * 3;
     // (layer 0 is followed by the shared edge_nn parameters, so it is converted on its own; layers 1.. are equally
@@ -166,9 +170,9 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       if (ar.base) {
         for (int kind = 0; kind < 2; ++kind) {
           uint16_t* dst = kind ? sv.Wfn : sv.Wft;
-          c.chk(pm_split_planes_frag(c.P + g.weight[0], 7 * d, d, kind, 1, 7 * dd, sv.wf_stride, dst, c.st));
+          RUN(pm_split_planes_frag(c.P + g.weight[0], 7 * d, d, kind, 1, 7 * dd, sv.wf_stride, dst, c.st));
           if (c.L > 1)
-            c.chk(pm_split_planes_frag(c.P + g.weight[1], 7 * d, d, kind, c.L - 1, lstride, sv.wf_stride,
+            RUN(pm_split_planes_frag(c.P + g.weight[1], 7 * d, d, kind, c.L - 1, lstride, sv.wf_stride,
                                        dst + sv.wf_stride, c.st));
         }
       }
@@ -182,9 +186,9 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     if (!ar.base) continue;
     const float* W = c.P + g.weight[i];
     if (c.planes)
-      c.chk(pm_segreduce_fwd_planes(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
+      RUN(pm_segreduce_fwd_planes(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
     else
-      c.chk(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
+      RUN(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
     double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
     if (!c.compact) {
       PmGemmDesc q;
@@ -192,7 +196,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       q.M = N; q.N = d; q.K = 7 * d; q.split_k = 1; q.n_groups = 1;
       q.A = sv.A[i]; q.lda = 7 * d; q.B = W; q.ldb = d; q.C = sv.h[i]; q.ldc = d; q.bias = c.P + g.bias[i];
       q.col_stats = sums;
-      c.chk(pm_gemm_f32_desc(&q, c.st));
+      RUN(pm_gemm_f32_desc(&q, c.st));
     } else {
       PmGemmDesc q = gcl_desc(pv, N, d);                  // h[rows_t] = A'[rows_t] @ [W_t; W_4; W_5; root] + b
       q.M = N; q.N = d; q.K = 4 * d;
@@ -204,10 +208,10 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
         if (sv.Wfn) q.b_frag = sv.Wfn + (int64_t)i * sv.wf_stride;
       }
-      c.chk(pm_gemm_f32_desc(&q, c.st));
+      RUN(pm_gemm_f32_desc(&q, c.st));
     }
     const PmBn& bn = g.norm[i];                           // x' = x + relu(BN(h))   (model.py:203-206)
-    c.chk(pm_bn_apply_fused(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
+    RUN(pm_bn_apply_fused(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
                             sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.st));
   }
   return sv.x[c.L];
@@ -232,12 +236,12 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const float* W = c.P + g.weight[i];
     float* dW = c.G + g.weight[i];
     const PmBn& bn = g.norm[i];
-    c.chk(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
+    RUN(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
                           c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
                           sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1 && fuse_sums) ? 1 : 0, c.st));
     if (!c.compact) {
-      c.chk(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
-      c.chk(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
+      RUN(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
+      RUN(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
     } else {
       PmGemmDesc q = gcl_desc(pv, N, d);                  // dA'[rows_t] = dh[rows_t] @ [W_t; W_4; W_5; root]^T
       q.transB = 1; q.M = N; q.N = 4 * d; q.K = d;
@@ -248,7 +252,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
         if (sv.Wft) q.b_frag = sv.Wft + (int64_t)i * sv.wf_stride;
       }
-      c.chk(pm_gemm_f32_desc(&q, c.st));
+      RUN(pm_gemm_f32_desc(&q, c.st));
       PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
       w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM | PM_GEMM_PARTITION; w.split_k = 0;
       w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;
@@ -257,7 +261,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
         w.B = (const float*)dhp; w.b_plane_stride = dps;
       }
-      c.chk(pm_gemm_f32_desc(&w, c.st));
+      RUN(pm_gemm_f32_desc(&w, c.st));
     }
     float* out = (dx == dxa) ? dxb : dxa;
     if (i > 0 && fuse_sums) {                             // + the column sums of the norm backward of layer i-1
@@ -265,15 +269,15 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
       nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
-      c.chk(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact,
+      RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact,
                                   out, dT, &nn, c.st));
     } else {
-      c.chk(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out,
+      RUN(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out,
                              dT, c.st));
     }
     dx = out;
   }
-  c.chk(pm_edge_table_bwd(dT, d, c.G + g.nn_w, c.G + g.nn_b, c.st));
+  RUN(pm_edge_table_bwd(dT, d, c.G + g.nn_w, c.G + g.nn_b, c.st));
   return dx;
 }
 
@@ -305,10 +309,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
   s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.zf((size_t)Gn * d);
   if (run) {
-    c.chk(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
+    RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
     bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
-    c.chk(pm_maxpool4_fwd(s.a0, (int64_t)Gn * 8 * 32, s.p0, c.st));
-    c.chk(pm_conv3x3_fwd(s.p0, c.P + Y.enc_conv4.w, c.P + Y.enc_conv4.b, Gn, 8, 16, 4, 8, 0, s.c1, c.st));
+    RUN(pm_maxpool4_fwd(s.a0, (int64_t)Gn * 8 * 32, s.p0, c.st));
+    RUN(pm_conv3x3_fwd(s.p0, c.P + Y.enc_conv4.w, c.P + Y.enc_conv4.b, Gn, 8, 16, 4, 8, 0, s.c1, c.st));
     bn_fwd(c, s.c1, Gn, 16, 32, Y.enc_bn5, true, nullptr, s.a1, s.m1, s.v1);
     lin(c, s.a1, Y.enc_lin1, Gn, d, 512, s.h1, true);
     lin(c, s.h1, Y.enc_lin4, Gn, d, d, s.h2, false);
@@ -322,26 +326,26 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
   if (run) {
-    c.chk(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
+    RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                           c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_d.b,
                           c.P + Y.enc_bn_nd.w, c.P + Y.enc_bn_nd.b, c.P + Y.enc_bn_dur.w, c.P + Y.enc_bn_dur.b,
                           c.Bf + Y.enc_bn_d.rm, c.Bf + Y.enc_bn_d.rv, c.Bf + Y.enc_bn_nd.rm, c.Bf + Y.enc_bn_nd.rv,
                           c.Bf + Y.enc_bn_dur.rm, c.Bf + Y.enc_bn_dur.rv, pv.tok_hist, d, 1, 1e-5f, 0.1f, tables,
                           s.emb_stats, c.st));
-    c.chk(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
+    RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
     if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
     else {             // x0 = relu(X[:, :S] @ Wc[:, :S*d]^T + (bias + all-PAD tail slots, one vector per node group))
-      c.chk(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
+      RUN(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
                         nullptr, 0, nullptr, c.st));
-      c.chk(pm_chord_pad_fwd(tables, c.P + Y.enc_chord.w, c.P + Y.enc_chord.b, s.bt.is_drum, N, d, S, s.cvec, s.x0, c.st));
+      RUN(pm_chord_pad_fwd(tables, c.P + Y.enc_chord.w, c.P + Y.enc_chord.b, s.bt.is_drum, N, d, S, s.cvec, s.x0, c.st));
     }
   }
   float* xL = gcn_forward(c, s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
   s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);
   if (run) {
-    c.chk(pm_gate_fwd(xL, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
-    c.chk(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, s.bn_scratch, c.st));
-    c.chk(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
+    RUN(pm_gate_fwd(xL, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
+    RUN(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, s.bn_scratch, c.st));
+    RUN(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
                           s.alpha, s.pooled, c.st));
     lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);            // z_c = zcat[:, :d]
   }
@@ -353,7 +357,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
     lin(c, s.zg, Y.enc_mu, B, d, d, s.mu, false);
     lin(c, s.zg, Y.enc_lv, B, d, d, s.lv, false);
-    c.chk(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
+    RUN(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
   }
   // ---------------- decoder (model.py:634-655)
   s.zd = ar.zf((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
@@ -367,11 +371,11 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                      // A = zr[:, :d]
     lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
     lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
-    c.chk(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
+    RUN(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
     bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
-    c.chk(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
+    RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
     lin(c, s.zr + d, Y.dec_c_bars, B, nb * d, d, s.cb, false, 2 * d, 0);                  // A = zr[:, d:]
-    c.chk(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
+    RUN(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
   }
   float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
@@ -386,25 +390,25 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     // (opt-in, PM_FUSED_CE=1: measured 195-220 us against 159 us for the three products + the loss kernel, csrc/unembed.hip)
     static const bool fused_ce = getenv("PM_FUSED_CE") && atoi(getenv("PM_FUSED_CE")) != 0;
     if (fused_ce) {
-      c.chk(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
+      RUN(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
                           c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
                           (s.bt.flags & 4) ? s.c_logits : nullptr, s.dc_logits, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b,
                           c.G + Y.dec_dur.b, s.losses, c.st));
     } else {
-    c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
+    RUN(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
                       c.P + Y.dec_dur.b, 0, 1, nullptr, 0, nullptr, c.st));
-    c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_d.w, dh, s.c_logits, PM_N_TOK,
+    RUN(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_d.w, dh, s.c_logits, PM_N_TOK,
                       c.P + Y.dec_pitch_d.b, 0, 1, pv.row_list, 1, pv.group_cnt + 2, c.st));
-    c.chk(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_nd.w, dh, s.c_logits, PM_N_TOK,
+    RUN(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_nd.w, dh, s.c_logits, PM_N_TOK,
                       c.P + Y.dec_pitch_nd.b, 0, 1, pv.row_list + (int64_t)N * PM_N_SLOTS, 1, pv.group_cnt + 3, c.st));
-    c.chk(pm_content_ce_scaled(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.bt.ce_scale, s.dc_logits,
+    RUN(pm_content_ce_scaled(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.bt.ce_scale, s.dc_logits,
                                c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     }
-    c.chk(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
+    RUN(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
     if (s.fix_structure)
-      c.chk(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
+      RUN(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
     else      // training.py:307 evaluates the BCE on the target itself: a constant, no gradient (SURVEY B-1)
-      c.chk(pm_bce_logits(s.bt.s_tensor, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, nullptr, s.losses, c.st));
+      RUN(pm_bce_logits(s.bt.s_tensor, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, nullptr, s.losses, c.st));
   }
 }
 
@@ -419,37 +423,37 @@ void backward_decoder(Ctx& c) {
   float* dzr = ar.zf((size_t)B * 2 * d);
   // ---- content decoder
   float* dH = ar.f((size_t)R * d);
-  c.chk(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
+  RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
                     nullptr, 0, 1, nullptr, 0, nullptr, c.st));
-  c.chk(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
+  RUN(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
                     nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
   const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
   for (int g = 0; g < 2; ++g) {
     const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);   // (node, slot) rows of the group
     const int32_t* cnt = pv.group_cnt + 2 + g;
-    c.chk(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
+    RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
                       1, cnt, c.st));
-    c.chk(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
+    RUN(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
                       PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
   lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);          // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
   float* dcb = ar.f((size_t)Gn * d);
-  c.chk(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
+  RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
   lin_bwd(c, dcb, s.zr + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d);
   // ---- structure decoder (only when the structure loss reaches the logits)
   if (s.fix_structure) {
     float* da2 = ar.f((size_t)Gn * 8 * 128); float* dc2 = ar.f((size_t)Gn * 8 * 128);
     float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.zf((size_t)Gn * d); float* dsb = ar.zf((size_t)Gn * d);
-    c.chk(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
-    c.chk(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
+    RUN(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
+    RUN(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
     bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
-    c.chk(pm_conv3x3_bwd_weight(s.u2, dc2, Gn, 16, 8, 4, 32, 1, c.G + Y.dec_conv1.w, c.G + Y.dec_conv1.b, c.st));
-    c.chk(pm_conv3x3_bwd_data(dc2, c.P + Y.dec_conv1.w, Gn, 16, 8, 4, 32, 1, du2, c.st));
-    c.chk(pm_relu_bwd(du2, s.u2, (int64_t)Gn * 512, du2, c.st));
+    RUN(pm_conv3x3_bwd_weight(s.u2, dc2, Gn, 16, 8, 4, 32, 1, c.G + Y.dec_conv1.w, c.G + Y.dec_conv1.b, c.st));
+    RUN(pm_conv3x3_bwd_data(dc2, c.P + Y.dec_conv1.w, Gn, 16, 8, 4, 32, 1, du2, c.st));
+    RUN(pm_relu_bwd(du2, s.u2, (int64_t)Gn * 512, du2, c.st));
     lin_bwd(c, du2, s.u1, Y.dec_s_lin4, Gn, 512, d, du1);
-    c.chk(pm_relu_bwd(du1, s.u1, (int64_t)Gn * d, du1, c.st));
+    RUN(pm_relu_bwd(du1, s.u1, (int64_t)Gn * d, du1, c.st));
     lin_bwd(c, du1, s.sb, Y.dec_s_lin1, Gn, d, d, dsb);
     lin_bwd(c, dsb, s.zr, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
   }
@@ -457,7 +461,7 @@ void backward_decoder(Ctx& c) {
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
   s.dz = ar.zf((size_t)B * d);
   lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz);
-  c.chk(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
+  RUN(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
 }
 
 void backward_encoder(Ctx& c) {
@@ -468,7 +472,7 @@ void backward_encoder(Ctx& c) {
   float* dzg = ar.zf((size_t)B * d); float* dzg2 = ar.zf((size_t)B * d);
   lin_bwd(c, s.dmu, s.zg, Y.enc_mu, B, d, d, dzg);
   lin_bwd(c, s.dlv, s.zg, Y.enc_lv, B, d, d, dzg2);
-  c.chk(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
+  RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
   float* dm = ar.f((size_t)B * d);
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
   float* dzcat = ar.zf((size_t)B * 2 * d);
@@ -478,11 +482,11 @@ void backward_encoder(Ctx& c) {
   lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d);
   float* dxL = ar.f((size_t)N * d);
   float* pscr = ar.f((size_t)3 * N + 8);
-  c.chk(pm_attnpool_bwd(s.eg.x[c.L], s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, s.alpha, dpooled, c.P + Y.enc_gate.w,
+  RUN(pm_attnpool_bwd(s.eg.x[c.L], s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, s.alpha, dpooled, c.P + Y.enc_gate.w,
                         s.plan, N, c.E, Gn, d, dxL, c.G + Y.enc_gate.w, c.G + Y.enc_gate.b, c.G + Y.enc_gate_bn.w,
                         c.G + Y.enc_gate_bn.b, pscr, nullptr, nullptr, c.st));
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
-  c.chk(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
+  RUN(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
   s.bk_dx0 = dx0; s.bk_dzcat = dzcat;
 }
 // Second half of the encoder backward: chord encoder, embeddings, structure branch.  Split off so that the gradients
@@ -500,16 +504,16 @@ void backward_encoder_tail(Ctx& c) {
   float* gsum = ar.f((size_t)2 * d);
   if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
-    c.chk(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
+    RUN(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
                       nullptr, 0, nullptr, c.st));
-    c.chk(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
-    c.chk(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
+    RUN(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
+    RUN(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
                       nullptr, c.st));
   }
-  c.chk(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
-  c.chk(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
+  RUN(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
+  RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
   PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
-  c.chk(pm_embed_tables_bwd(Stab, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
+  RUN(pm_embed_tables_bwd(Stab, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                             c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_nd.w,
                             c.P + Y.enc_bn_dur.w, s.emb_stats, pv.tok_hist, d, 1e-5f, c.G + Y.enc_pitch_d.w,
                             c.G + Y.enc_pitch_d.b, c.G + Y.enc_pitch_nd.w, c.G + Y.enc_pitch_nd.b, c.G + Y.enc_dur.w,
@@ -521,30 +525,22 @@ void backward_encoder_tail(Ctx& c) {
   float* dc0 = ar.f((size_t)Gn * 8 * 128);
   lin_bwd(c, dzcat + d, s.h2, Y.enc_s_bars, B, d, nb * d, dh2, 2 * d, nb * d, nb * d);
   lin_bwd(c, dh2, s.h1, Y.enc_lin4, Gn, d, d, dh1);
-  c.chk(pm_relu_bwd(dh1, s.h1, (int64_t)Gn * d, dh1, c.st));
+  RUN(pm_relu_bwd(dh1, s.h1, (int64_t)Gn * d, dh1, c.st));
   lin_bwd(c, dh1, s.a1, Y.enc_lin1, Gn, d, 512, da1);
   bn_bwd(c, s.c1, da1, Gn, 16, 32, Y.enc_bn5, s.m1, s.v1, true, dc1);
-  c.chk(pm_conv3x3_bwd_weight(s.p0, dc1, Gn, 8, 16, 4, 8, 0, c.G + Y.enc_conv4.w, c.G + Y.enc_conv4.b, c.st));
-  c.chk(pm_conv3x3_bwd_data(dc1, c.P + Y.enc_conv4.w, Gn, 8, 16, 4, 8, 0, dp0, c.st));
-  c.chk(pm_maxpool4_bwd(s.a0, dp0, (int64_t)Gn * 8 * 32, da0, c.st));
+  RUN(pm_conv3x3_bwd_weight(s.p0, dc1, Gn, 8, 16, 4, 8, 0, c.G + Y.enc_conv4.w, c.G + Y.enc_conv4.b, c.st));
+  RUN(pm_conv3x3_bwd_data(dc1, c.P + Y.enc_conv4.w, Gn, 8, 16, 4, 8, 0, dp0, c.st));
+  RUN(pm_maxpool4_bwd(s.a0, dp0, (int64_t)Gn * 8 * 32, da0, c.st));
   bn_bwd(c, s.c0, da0, Gn, 8, 128, Y.enc_bn1, s.m0, s.v0, true, dc0);
-  c.chk(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
+  RUN(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
 }
 
-// arena use of the two backward passes, measured with a null base
+// arena use of the backward passes: the real carve-out code, launches skipped (RUN)
 void measure_backward(Ctx& c) {
-  // mirrors the ar.f() calls of backward_decoder / backward_encoder / gcn_backward (x2)
-  Arena& ar = c.s->ar;
-  const size_t N = c.N, Gn = c.Gn, B = c.B, d = c.d, dh = d / 2, R = N * c.S;
-  size_t floats = B * 2 * d + R * d + N * d + 2 * (PM_N_DIST * d + N * d + N * 7 * d + 2 * N * d + 2 * N * d) + Gn * d +   // (7d: upper bound)
-                  (Gn * 8 * 128 * 2 + Gn * 512 + 2 * Gn * d) + B * 2 * d + B * d +
-                  2 * B * d + B * d + B * 2 * d + Gn * d + N * d + (3 * N + 8) + R * d + 2 * d + 4 * PM_N_PITCH * dh +
-                  (2 * Gn * d + 2 * Gn * 512 + Gn * 8 * 32 + 2 * Gn * 8 * 128);
-  ar.take(floats * sizeof(float) + 256 * 256);    // + alignment slack of the ~60 carve-outs
-  // zero-region carve-outs of the backward: dT x2, dzr, du1, dsb, dz, dzg x2, dzcat, dpooled, dh2, dh1, da1 (+ slack)
-  ar.z((2 * PM_N_DIST * d + B * 2 * d + 2 * Gn * d + B * d + 2 * B * d + B * 2 * d + Gn * d + 2 * Gn * d + Gn * 512) *
-           sizeof(float) + 16 * 256);
-  ar.take((size_t)2 * c.L * (7 * d * d + 64 * d) * 6);   // planes mode: bf16 planes of the two GCN weight ranges
+  c.s->fix_structure = 1;                         // the larger variant (structure decoder backward included)
+  backward_decoder(c);
+  backward_encoder(c);
+  backward_encoder_tail(c);
 }
 
 }  // namespace
@@ -574,13 +570,14 @@ extern "C" int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N
   PmBatch bt;
   memset(&bt, 0, sizeof(bt));
   bt.N = N; bt.E = E; bt.G = G; bt.B = B; bt.n_slots = n_slots;
-  size_t zb, mb;
-  measure_step(lay, bt, &zb, &mb);
-  // the measuring pass runs the fp32 7-block layout; the planes layout additionally keeps the GCL weights of both
-  // stacks as bf16 planes (row-major + two fragment-major copies): 3 x 6 bytes per stored weight element
-  const int64_t d = lay->d, per_layer = 7 * d * d + 64 * d + 256;
-  const int64_t weight_planes = 2 * (int64_t)lay->n_layers * per_layer * 6 * 3 + (1 << 16);
-  return (int64_t)(zb + mb) + weight_planes + 4096;
+  size_t need = 0;                                  // the caller does not know yet which variant the batch will take
+  for (int flags : {0, 1, 3}) {                     // 7-block fp32 | compact fp32 | compact + bf16 planes
+    bt.flags = flags;
+    size_t zb, mb;
+    measure_step(lay, bt, &zb, &mb);
+    if (zb + mb > need) need = zb + mb;
+  }
+  return (int64_t)need + 4096;
 }
 
 extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,
@@ -603,13 +600,11 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
   // enqueued on aliased memory), then the one clear of the zero region
   size_t zb, mb;
   measure_step(lay, *batch, &zb, &mb);
-  if ((size_t)pm_vae_step_workspace_bytes(lay, batch->N, batch->E, batch->G, batch->B, batch->n_slots) > (size_t)workspace_bytes ||
-      zb + mb > (size_t)workspace_bytes)
-    return PM_E_INVALID;
+  if (zb + mb > (size_t)workspace_bytes) return PM_E_INVALID;
   s->ar.zcap = zb; s->ar.zused = 0;
   if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess) return PM_E_LAUNCH;
   Ctx c = make_ctx(s, st);
-  c.chk(pm_plan_build(batch->edge_index, batch->edge_type, batch->edge_dist, batch->bars, batch->batch, batch->is_drum,
+  RUN(pm_plan_build(batch->edge_index, batch->edge_type, batch->edge_dist, batch->bars, batch->batch, batch->is_drum,
                       batch->tokens, lay->n_bars, batch->n_slots, batch->N, batch->E, batch->G, plan, stream));
   forward(c, msg_dropout, seed_enc, seed_dec);
   if (s->ar.overflow) return PM_E_INVALID;

@@ -270,6 +270,20 @@ int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, 
               float* dgamma /* += */, float* dbeta /* += */, float* dbias_pre /* NULL or += */, float* dx,
               double* scratch /* [PM_BN_SCRATCH(C)] */, pm_stream_t stream);
 #define PM_BN_SCRATCH(C) (256 * 3 * (C) + 4 * (C))
+/* Split forms for synchronised BatchNorm under data parallelism (the reference is single-device, so its
+ * BatchNorm statistics span what is here the GLOBAL batch): the column sums of one rank come out as `sums` [3][C] fp64 —
+ * statistics mode (dy == NULL): {sum x, sum x^2, 0}; backward mode: {sum du, sum du*xhat, sum xhat} —, the host adds them
+ * over the ranks (one all-reduce) and hands the totals back with the global row count O_global * I. */
+int pm_bn_partial_sums(const float* x, const float* dy /* or NULL */, int32_t O, int32_t C, int32_t I, const float* mean,
+                       const float* var, float eps, const float* gamma, const float* beta, int relu,
+                       double* sums /* [3][C] out */, double* scratch /* [PM_BN_SCRATCH(C)] */, pm_stream_t stream);
+int pm_bn_stats_from_sums(const double* sums /* [3][C] */, double count, int32_t C, float* mean, float* var,
+                          float* running_mean /* or NULL */, float* running_var, float momentum, pm_stream_t stream);
+int pm_bn_bwd_from_sums(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
+                        const float* var, float eps, const float* gamma, const float* beta, int relu,
+                        const double* sums_local /* [3][C] this rank */, const double* sums_global /* [3][C] all ranks */,
+                        double count_global, float* dgamma /* += */, float* dbeta /* += */, float* dbias_pre /* NULL or += */,
+                        float* dx, double* scratch /* [2C] */, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ element-wise helpers */
 /* Fused forms for row-major [O, C] (I = 1, C % 4 == 0, 16-byte aligned), used by the native step for the GCL norms:
@@ -353,6 +367,18 @@ int pm_embed_tables_bwd(const float* S, const float* w_pitch_drum, const float* 
                         float* dbeta_drum, float* dg_nd, float* dbeta_nd, float* dg_dur, float* dbeta_dur,
                         pm_stream_t stream);
 
+/* Synchronised form (data parallel, BatchNorm statistics over the global batch): call once with sums_out [4][2][d/2] fp64
+ * (only the local sums {sum_v S[v], sum_v S[v] xhat[v]} per table and channel are written), add them and the token
+ * histograms over the ranks, then call again with sums_global / hist_global (sums_out NULL).  All three NULL = the plain
+ * form above. */
+int pm_embed_tables_bwd_sync(const float* S, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
+                             const float* b_pitch_nd, const float* w_dur, const float* b_dur, const float* bn_drum_g,
+                             const float* bn_nd_g, const float* bn_dur_g, const float* stats, const int32_t* tok_hist,
+                             int32_t d, float eps, float* dw_pitch_drum, float* db_pitch_drum, float* dw_pitch_nd,
+                             float* db_pitch_nd, float* dw_dur, float* db_dur, float* dg_drum, float* dbeta_drum,
+                             float* dg_nd, float* dbeta_nd, float* dg_dur, float* dbeta_dur, double* sums_out,
+                             const double* sums_global, const int32_t* hist_global, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ bar pooling / broadcast
  * PyG GlobalAttention over the nodes of each bar (model.py:335-340,408-409) and the
  * bar -> node broadcast `repeat_interleave(out, counts)` (model.py:543-545). */
@@ -370,6 +396,18 @@ int pm_attnpool_bwd(const float* x, const float* g, const float* g_mean, const f
                                            the gate Linear, model.py:160): d_gate_w is then taken against it ... */,
                     float* dx_gate /* ... and the gradient w.r.t. it is written here instead of being added to dx */,
                     pm_stream_t stream);
+/* The same in two phases for synchronised BatchNorm of the gate (BatchNorm1d(1) over ALL nodes, model.py:338): phase 1
+ * leaves the two local sums {sum dgn, sum dgn * ghat} as fp64 at the head of `scratch` (the host adds them over the
+ * ranks), phase 2 takes the global sums and node count. */
+int pm_attnpool_bwd_sums(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                         const float* alpha, const float* dout, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                         int32_t d, float* scratch /* [3*N + 8] */, pm_stream_t stream);
+int pm_attnpool_bwd_from_sums(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                              const float* bn_g, const float* alpha, const float* dout, const float* gate_w,
+                              const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx, float* d_gate_w,
+                              float* d_gate_b, float* d_bn_g, float* d_bn_b, float* scratch, const float* x_gate,
+                              float* dx_gate, const double* sums_global /* [2] */, double count_global,
+                              pm_stream_t stream);
 int pm_bar_broadcast_fwd(const float* bars /* [G,d] */, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                          int32_t d, float* x /* [N,d] */, pm_stream_t stream);
 int pm_bar_broadcast_bwd(const float* dx /* [N,d] */, const int32_t* plan, int32_t N, int32_t E, int32_t G,

@@ -41,6 +41,9 @@ _SIGS = {
     "pm_gemm_force_config": "i",
     "pm_bn_stats": "piiippppfps",
     "pm_bn_apply": "piiippfpppips",
+    "pm_bn_partial_sums": "ppiiippfppipps",
+    "pm_bn_stats_from_sums": "pDippppfs",
+    "pm_bn_bwd_from_sums": "ppiiippfppippDppppps",
     "pm_bn_bwd": "ppiiippfppippppps",
     "pm_bn_apply_fused": "piipfpppipppppfs",
     "pm_bn_bwd_fused": "ppiippfppipppppplis",
@@ -60,9 +63,12 @@ _SIGS = {
     "pm_chord_pad_bwd": "ppiiippppps",
     "pm_embed_bwd_scatter": "pppiiiiips",
     "pm_embed_tables_bwd": "ppppppppppppifpppppppppppps",
+    "pm_embed_tables_bwd_sync": "ppppppppppppifppppppppppppppps",
     "pm_gate_fwd": "pppiips",
     "pm_attnpool_fwd": "ppppfpppiiiipps",
     "pm_attnpool_bwd": "ppppfpppppiiiipppppppps",
+    "pm_attnpool_bwd_sums": "ppppfpppiiiips",
+    "pm_attnpool_bwd_from_sums": "ppppfpppppiiiipppppppppDs",
     "pm_relu_residual_fwd": "pplps",
     "pm_bn_fold_weights": "piipppppfpps",
     "pm_dropout_rows": "plifuups",
@@ -96,7 +102,7 @@ _SIGS = {
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",
 }
-_CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p}
+_CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes"}
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])

@@ -211,7 +211,12 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
 struct EmbGrads { float* dw[3]; float* db[3]; float* dg[3]; float* dbe[3]; };
 __global__ void __launch_bounds__(256) k_embed_tables_bwd(const float* __restrict__ S, EmbParams P, EmbGrads Gd,
                                                           const float* __restrict__ stats,
-                                                          const int* __restrict__ hist, int dh, float eps) {
+                                                          const int* __restrict__ hist, int dh, float eps,
+                                                          double* __restrict__ sums_out, const double* __restrict__ gsums,
+                                                          const int* __restrict__ ghist) {
+  // sums_out (phase 1 of the synchronised form): only the local {sum_v S[v], sum_v S[v] xhat[v]} per (table, channel)
+  // are written, [4][2][dh]; gsums / ghist (phase 2): those sums and the token histogram over ALL ranks — they enter
+  // the two batch means of the BatchNorm backward, the parameter gradients keep the local sums
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;   // one wave per (kind, channel)
   if (i >= 3 * dh) return;
   const int kind = i / dh, c = i % dh;
@@ -231,11 +236,21 @@ __global__ void __launch_bounds__(256) k_embed_tables_bwd(const float* __restric
       cnt += h[v]; db += sv; dg += sv * (double)(((w[v] + bias) - mean) * rstd);
     }
     cnt = pm_wave_sum_d(cnt); db = pm_wave_sum_d(db); dg = pm_wave_sum_d(dg);
-    if (cnt < 1) continue;
-    if (lane == 0) {
+    if (sums_out) {
+      if (lane == 0) { sums_out[(t * 2) * dh + c] = db; sums_out[(t * 2 + 1) * dh + c] = dg; }
+      continue;
+    }
+    if (lane == 0 && cnt >= 1) {
       Gd.dbe[wsel][c] += (float)db;
       Gd.dg[wsel][c] += (float)dg;
     }
+    if (gsums) {
+      double gc = 0;
+      for (int v = lane; v < V; v += 64) gc += ghist[t * EMB_V + v];
+      cnt = pm_wave_sum_d(gc);
+      db = gsums[(t * 2) * dh + c]; dg = gsums[(t * 2 + 1) * dh + c];
+    }
+    if (cnt < 1) continue;
     double dbias = 0;
     float* dw = Gd.dw[wsel] + (int64_t)c * V;
     for (int v = lane; v < V; v += 64) {
@@ -254,7 +269,19 @@ extern "C" int pm_embed_tables_bwd(const float* S, const float* w_pd, const floa
                                    int32_t d, float eps, float* dw_pd, float* db_pd, float* dw_pn, float* db_pn,
                                    float* dw_du, float* db_du, float* dg_d, float* dbe_d, float* dg_n, float* dbe_n,
                                    float* dg_u, float* dbe_u, pm_stream_t stream) {
+  return pm_embed_tables_bwd_sync(S, w_pd, b_pd, w_pn, b_pn, w_du, b_du, g_d, g_n, g_u, stats, tok_hist, d, eps, dw_pd,
+                                  db_pd, dw_pn, db_pn, dw_du, db_du, dg_d, dbe_d, dg_n, dbe_n, dg_u, dbe_u, nullptr,
+                                  nullptr, nullptr, stream);
+}
+extern "C" int pm_embed_tables_bwd_sync(const float* S, const float* w_pd, const float* b_pd, const float* w_pn,
+                                        const float* b_pn, const float* w_du, const float* b_du, const float* g_d,
+                                        const float* g_n, const float* g_u, const float* stats, const int32_t* tok_hist,
+                                        int32_t d, float eps, float* dw_pd, float* db_pd, float* dw_pn, float* db_pn,
+                                        float* dw_du, float* db_du, float* dg_d, float* dbe_d, float* dg_n, float* dbe_n,
+                                        float* dg_u, float* dbe_u, double* sums_out, const double* sums_global,
+                                        const int32_t* hist_global, pm_stream_t stream) {
   if (!S || !stats || !tok_hist || d <= 0 || (d & 7)) return PM_E_INVALID;
+  if ((sums_global == nullptr) != (hist_global == nullptr) || (sums_out && sums_global)) return PM_E_INVALID;
   EmbParams P;
   P.w[0] = w_pd; P.w[1] = w_pn; P.w[2] = w_du; P.b[0] = b_pd; P.b[1] = b_pn; P.b[2] = b_du;
   P.g[0] = g_d; P.g[1] = g_n; P.g[2] = g_u;
@@ -264,7 +291,7 @@ extern "C" int pm_embed_tables_bwd(const float* S, const float* w_pd, const floa
   Gd.dg[0] = dg_d; Gd.dg[1] = dg_n; Gd.dg[2] = dg_u; Gd.dbe[0] = dbe_d; Gd.dbe[1] = dbe_n; Gd.dbe[2] = dbe_u;
   const int dh = d / 2;
   hipLaunchKernelGGL(k_embed_tables_bwd, dim3(pm_cdiv(3 * dh, 4)), dim3(256), 0, (hipStream_t)stream, S, P, Gd, stats,
-                     tok_hist, dh, eps);
+                     tok_hist, dh, eps, sums_out, sums_global, hist_global);
   return pm_check_launch();
 }
 

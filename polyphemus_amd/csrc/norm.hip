@@ -282,6 +282,71 @@ extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, 
   return pm_check_launch();
 }
 
+// ---------------------------------------------------------------- split forms (synchronised BatchNorm)
+// Data parallel with statistics over the GLOBAL batch: the column sums are produced here, summed over the ranks by the
+// host (an all-reduce of [3][C] doubles) and consumed by the *_from_sums calls together with the global row count.
+__global__ void __launch_bounds__(1024) k_bn_collect(const double* __restrict__ partial, int nchunk, int C, int nacc,
+                                                    double* __restrict__ sums) {
+  __shared__ double sh[BN_FIN_WAVES][64][BN_NACC];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s[BN_NACC];
+  sum_chunks(partial, nchunk, C, c, nacc, sh, s);
+  if (threadIdx.x >= 64 || c >= C) return;
+  for (int a = 0; a < BN_NACC; ++a) sums[(int64_t)a * C + c] = a < nacc ? s[a] : 0.0;
+}
+extern "C" int pm_bn_partial_sums(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
+                                  const float* var, float eps, const float* gamma, const float* beta, int relu,
+                                  double* sums, double* scratch, pm_stream_t stream) {
+  if (!x || !sums || !scratch || O <= 0 || C <= 0 || I <= 0) return PM_E_INVALID;
+  if (dy && (!mean || !var || !gamma || !beta)) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {mean, var, gamma, beta, eps, relu};
+  int nchunk = 1;
+  if (dy) run_reduce<1>(x, dy, O, C, I, ctx, scratch, &nchunk, st);
+  else run_reduce<0>(x, nullptr, O, C, I, ctx, scratch, &nchunk, st);
+  hipLaunchKernelGGL(k_bn_collect, dim3(pm_cdiv(C, 64)), dim3(1024), 0, st, scratch, nchunk, C, dy ? 3 : 2, sums);
+  return pm_check_launch();
+}
+extern "C" int pm_bn_stats_from_sums(const double* sums, double count, int32_t C, float* mean, float* var,
+                                     float* running_mean, float* running_var, float momentum, pm_stream_t stream) {
+  if (!sums || !mean || !var || C <= 0 || !(count > 0)) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_bn_finalize_stats, dim3(pm_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, sums, 1, C, count, mean,
+                     var, running_mean, running_var, momentum);
+  return pm_check_launch();
+}
+// dgamma / dbeta / dbias_pre take the LOCAL sums (they are summed over the ranks with the other gradients), the two
+// batch means of the backward formula the GLOBAL ones.
+__global__ void __launch_bounds__(256) k_bn_finalize_bwd_sync(const double* __restrict__ loc, const double* __restrict__ glob,
+                                                              int C, double count_local, double count_global, BnCtx ctx,
+                                                              float* dgamma, float* dbeta, float* dbias_pre, double* means) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] += (float)loc[c];
+  if (dgamma) dgamma[c] += (float)loc[C + c];
+  const double m0 = glob[c] / count_global, m1 = glob[C + c] / count_global;
+  means[c] = m0;
+  means[C + c] = m1;
+  if (dbias_pre) {
+    const double rstd = 1.0 / sqrt((double)ctx.var[c] + (double)ctx.eps);
+    dbias_pre[c] += (float)((double)ctx.gamma[c] * rstd * ((loc[c] - count_local * m0) - m1 * loc[2 * C + c]));
+  }
+}
+extern "C" int pm_bn_bwd_from_sums(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, const float* mean,
+                                   const float* var, float eps, const float* gamma, const float* beta, int relu,
+                                   const double* sums_local, const double* sums_global, double count_global, float* dgamma,
+                                   float* dbeta, float* dbias_pre, float* dx, double* scratch, pm_stream_t stream) {
+  if (!x || !dy || !mean || !var || !gamma || !beta || !sums_local || !sums_global || !dx || !scratch || O <= 0 || C <= 0 ||
+      I <= 0 || !(count_global > 0))
+    return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {mean, var, gamma, beta, eps, relu};
+  hipLaunchKernelGGL(k_bn_finalize_bwd_sync, dim3(pm_cdiv(C, 256)), dim3(256), 0, st, sums_local, sums_global, C,
+                     (double)O * (double)I, count_global, ctx, dgamma, dbeta, dbias_pre, scratch);
+  const int64_t n = (int64_t)O * C * I;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n)), dim3(256), 0, st, x, dy, n, C, I, ctx, scratch, dx);
+  return pm_check_launch();
+}
+
 // ---------------------------------------------------------------- fused variants for [M, C] rows (I == 1)
 // The column sums come from somewhere else (the epilogue of the producing GEMM, pm_gemm_f32_desc col_stats) or go
 // straight into a caller-zeroed fp64 accumulator with atomics, and mean / variance / the backward means are

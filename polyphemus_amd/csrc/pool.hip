@@ -130,13 +130,16 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
                                                        const float* __restrict__ dgn, const double* __restrict__ sums,
                                                        int N, int d, float* __restrict__ dx, float* dW, float* db,
                                                        float* dbn_g, float* dbn_b, const float* __restrict__ xg,
-                                                       float* __restrict__ dxg) {
+                                                       float* __restrict__ dxg, const double* __restrict__ gsums,
+                                                       double gcount) {
   extern __shared__ __attribute__((aligned(16))) float sW[];   // [d] partial dW + 1 partial db
   for (int i = threadIdx.x; i <= d; i += blockDim.x) sW[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float mean = gm[0], rstd = rsqrtf(gv[0] + eps), ga = bg[0];
-  const float m0 = (float)(sums[0] / N), m1 = (float)(sums[1] / N);
+  // the two batch means of the BatchNorm1d(1) backward: over this rank's nodes, or (synchronised BatchNorm) over all ranks'
+  const float m0 = gsums ? (float)(gsums[0] / gcount) : (float)(sums[0] / N);
+  const float m1 = gsums ? (float)(gsums[1] / gcount) : (float)(sums[1] / N);
   if (blockIdx.x == 0 && threadIdx.x == 0) { dbn_b[0] += (float)sums[0]; dbn_g[0] += (float)sums[1]; }
   // the gate-weight gradient of the wave's nodes is summed in registers (LDS float atomics run at about one lane per
   // clock: one per node and element cost most of this kernel); d <= 1024: four float4 per lane
@@ -178,28 +181,57 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
   for (int i = threadIdx.x; i < d; i += blockDim.x) atomicAdd(&dW[i], sW[i]);
   if (threadIdx.x == 0) atomicAdd(&db[0], sW[d]);
 }
+static int attnpool_bwd_impl(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                             const float* bn_g, const float* alpha, const float* dout, const float* gate_w,
+                             const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx, float* d_gate_w,
+                             float* d_gate_b, float* d_bn_g, float* d_bn_b, float* scratch, const float* x_gate,
+                             float* dx_gate, int phase, const double* gsums, double gcount, pm_stream_t stream) {
+  if ((x_gate == nullptr) != (dx_gate == nullptr)) return PM_E_INVALID;
+  if (!x || !g || !g_mean || !g_var || !alpha || !dout || !plan || !scratch || N <= 0 || G <= 0 || d <= 0 || (d & 3) ||
+      d > 1024 || ((uintptr_t)scratch & 7))
+    return PM_E_INVALID;
+  if (phase != 1 && (!bn_g || !gate_w || !dx || !d_gate_w || !d_gate_b || !d_bn_g || !d_bn_b)) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  double* sums = reinterpret_cast<double*>(scratch);
+  float* dgn = scratch + 4;
+  if (phase != 2) {                                     // phase 1: per-node gate gradients + the two local sums
+    hipMemsetAsync(sums, 0, 2 * sizeof(double), st);
+    hipLaunchKernelGGL(k_attnpool_bwd1, dim3(G), dim3(256), 0, st, x, g, g_mean, g_var, eps, alpha, dout, pv.bar_ptr, d,
+                       dgn, sums);
+  }
+  if (phase != 1) {                                     // phase 2: dx, gate / norm parameter gradients
+    int nb = (int)pm_cdiv(N, 4);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(k_attnpool_bwd2, dim3(nb), dim3(256), sizeof(float) * (d + 1), st, x, g, g_mean, g_var, eps, bn_g,
+                       alpha, dout, gate_w, pv.node_bar, dgn, sums, N, d, dx, d_gate_w, d_gate_b, d_bn_g, d_bn_b,
+                       x_gate ? x_gate : x, dx_gate, gsums, gcount);
+  }
+  return pm_check_launch();
+}
 extern "C" int pm_attnpool_bwd(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
                                const float* bn_g, const float* alpha, const float* dout, const float* gate_w,
                                const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx,
                                float* d_gate_w, float* d_gate_b, float* d_bn_g, float* d_bn_b, float* scratch,
                                const float* x_gate, float* dx_gate, pm_stream_t stream) {
-  if ((x_gate == nullptr) != (dx_gate == nullptr)) return PM_E_INVALID;
-  if (!x || !g || !g_mean || !g_var || !bn_g || !alpha || !dout || !gate_w || !plan || !dx || !d_gate_w || !d_gate_b ||
-      !d_bn_g || !d_bn_b || !scratch || N <= 0 || G <= 0 || d <= 0 || (d & 3) || d > 1024 || ((uintptr_t)scratch & 7))
-    return PM_E_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  PmPlanView pv = pm_plan_view(plan, N, E, G);
-  double* sums = reinterpret_cast<double*>(scratch);
-  float* dgn = scratch + 4;
-  hipMemsetAsync(sums, 0, 2 * sizeof(double), st);
-  hipLaunchKernelGGL(k_attnpool_bwd1, dim3(G), dim3(256), 0, st, x, g, g_mean, g_var, eps, alpha, dout, pv.bar_ptr, d,
-                     dgn, sums);
-  int nb = (int)pm_cdiv(N, 4);
-  if (nb > 256) nb = 256;
-  hipLaunchKernelGGL(k_attnpool_bwd2, dim3(nb), dim3(256), sizeof(float) * (d + 1), st, x, g, g_mean, g_var, eps, bn_g,
-                     alpha, dout, gate_w, pv.node_bar, dgn, sums, N, d, dx, d_gate_w, d_gate_b, d_bn_g, d_bn_b,
-                     x_gate ? x_gate : x, dx_gate);
-  return pm_check_launch();
+  return attnpool_bwd_impl(x, g, g_mean, g_var, eps, bn_g, alpha, dout, gate_w, plan, N, E, G, d, dx, d_gate_w, d_gate_b,
+                           d_bn_g, d_bn_b, scratch, x_gate, dx_gate, 0, nullptr, 0.0, stream);
+}
+extern "C" int pm_attnpool_bwd_sums(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                                    const float* alpha, const float* dout, const int32_t* plan, int32_t N, int32_t E,
+                                    int32_t G, int32_t d, float* scratch, pm_stream_t stream) {
+  return attnpool_bwd_impl(x, g, g_mean, g_var, eps, nullptr, alpha, dout, nullptr, plan, N, E, G, d, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, scratch, nullptr, nullptr, 1, nullptr, 0.0, stream);
+}
+extern "C" int pm_attnpool_bwd_from_sums(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
+                                         const float* bn_g, const float* alpha, const float* dout, const float* gate_w,
+                                         const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float* dx,
+                                         float* d_gate_w, float* d_gate_b, float* d_bn_g, float* d_bn_b, float* scratch,
+                                         const float* x_gate, float* dx_gate, const double* sums_global,
+                                         double count_global, pm_stream_t stream) {
+  if (!sums_global || !(count_global > 0)) return PM_E_INVALID;
+  return attnpool_bwd_impl(x, g, g_mean, g_var, eps, bn_g, alpha, dout, gate_w, plan, N, E, G, d, dx, d_gate_w, d_gate_b,
+                           d_bn_g, d_bn_b, scratch, x_gate, dx_gate, 2, sums_global, count_global, stream);
 }
 
 // x[n] = bars[node_bar[n]]

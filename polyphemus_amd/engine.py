@@ -46,6 +46,34 @@ class Engine:
         self.T = tensors
         self.d, self.nb, self.L = cfg["d"], cfg["n_bars"], cfg["gnn_n_layers"]
         self.msg_dropout = 0.1
+        # synchronised BatchNorm (data parallel): a torch.distributed group, or None = per-replica statistics.
+        # The reference is single-device: its statistics span what is here the GLOBAL batch.  With a group set, every
+        # training-mode norm of this engine (GCL norms, CNN norms, heads, the gate's BatchNorm1d(1), the embedding norms)
+        # sums its column sums over the ranks — one small all-reduce per norm and direction, one host read of the global
+        # row counts per step.  Used by the DP-vs-single-device parity test; throughput runs keep per-replica statistics.
+        self.sync_group = None
+        self._sync_on = False
+        self._rows = {}
+
+    # ------------------------------------------------------------------ synchronised BatchNorm
+    def set_sync_bn(self, group, on: bool = True):
+        self.sync_group, self._sync_on = group, bool(on)
+
+    def _reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=self.sync_group)
+        return t
+
+    def _sync_rows(self, plan):
+        """Global row counts of the three row spaces (nodes, bars, samples), keyed by the local count."""
+        if plan.N in (plan.G, plan.B):
+            raise NotImplementedError("synchronised BatchNorm: degenerate batch (one node per bar)")
+        t = torch.tensor([plan.N, plan.G, plan.B], dtype=torch.float64, device=plan.buf.device)
+        gN, gG, gB = self._reduce(t).tolist()                    # the one host read of the step
+        self._rows = {plan.N: gN, plan.G: gG, plan.B: gB}
+
+    def syncing(self, training) -> bool:
+        return bool(training and self._sync_on)
 
     # ------------------------------------------------------------------ small helpers
     def p(self, name: str) -> torch.Tensor:
@@ -81,7 +109,12 @@ class Engine:
     def bn_train_or_eval(self, x, key, O, Cn, I, training, relu, residual=None):
         """BatchNorm (+ReLU, + residual) forward; returns (y, mean, var) — batch stats when training
         (running stats updated), running stats otherwise."""
-        if training:
+        if self.syncing(training):
+            sums = self._reduce(ops.bn_partial_sums(x, O, Cn, I))
+            mean, var = ops.bn_stats_from_sums(sums, self._rows[O] * I, Cn, self.T[key + ".running_mean"],
+                                               self.T[key + ".running_var"], MOM)
+            self._bump(key, True)
+        elif training:
             mean, var = ops.bn_stats(x, O, Cn, I, self.T[key + ".running_mean"], self.T[key + ".running_var"], MOM)
             self._bump(key, True)
         else:
@@ -90,6 +123,12 @@ class Engine:
         return y, mean, var
 
     def bn_back(self, x, dy, key, O, Cn, I, mean, var, relu, G, dbias_pre=None):
+        if self._sync_on:
+            ga, be = self.T[key + ".weight"], self.T[key + ".bias"]
+            loc = ops.bn_partial_sums(x, O, Cn, I, dy=dy.contiguous(), mean=mean, var=var, gamma=ga, beta=be, eps=EPS, relu=relu)
+            glob = self._reduce(loc.clone())
+            return ops.bn_bwd_from_sums(x, dy.contiguous(), O, Cn, I, mean, var, ga, be, loc, glob, self._rows[O] * I,
+                                        G[key + ".weight"], G[key + ".bias"], EPS, relu, dbias_pre=dbias_pre)
         return ops.bn_bwd(x, dy, O, Cn, I, mean, var, self.T[key + ".weight"], self.T[key + ".bias"],
                           G[key + ".weight"], G[key + ".bias"], EPS, relu, dbias_pre=dbias_pre)
 
@@ -177,6 +216,8 @@ class Engine:
         d, nb, N, G_, B = self.d, self.nb, plan.N, plan.G, plan.B
         dev = s_tensor.device
         sv = {}
+        if self.syncing(training):
+            self._sync_rows(plan)
         zcat = torch.empty(B, 2 * d, dtype=F32, device=dev)          # [z_c | z_s]  (model.py:472)
         # --- structure encoder: CNN over the [G,1,4,32] grids
         k = "encoder.s_encoder.cnn_encoder"
@@ -207,6 +248,9 @@ class Engine:
         tables = torch.empty(4, C.N_PITCH_TOKENS, dh, dtype=F32, device=dev)
         stats = torch.empty(4, 2, dh, dtype=F32, device=dev)
         Tn = self.T
+        hist = plan.tok_hist
+        if self.syncing(training):                       # the embedding norms see the token histogram of ALL ranks
+            hist = self._reduce(plan.tok_hist.clone())
         call("pm_embed_tables", ptr(Tn[k + ".drums_pitch_emb.weight"]), ptr(Tn[k + ".drums_pitch_emb.bias"]),
              ptr(Tn[k + ".non_drums_pitch_emb.weight"]), ptr(Tn[k + ".non_drums_pitch_emb.bias"]),
              ptr(Tn[k + ".dur_emb.weight"]), ptr(Tn[k + ".dur_emb.bias"]),
@@ -216,10 +260,12 @@ class Engine:
              ptr(Tn[k + ".bn_drums.running_mean"]), ptr(Tn[k + ".bn_drums.running_var"]),
              ptr(Tn[k + ".bn_non_drums.running_mean"]), ptr(Tn[k + ".bn_non_drums.running_var"]),
              ptr(Tn[k + ".bn_dur.running_mean"]), ptr(Tn[k + ".bn_dur.running_var"]),
-             ptr(plan.tok_hist), d, int(training), EPS, MOM, ptr(tables), ptr(stats), stream())
+             ptr(hist), d, int(training), EPS, MOM, ptr(tables), ptr(stats), stream())
         if training:
             # one update per non-empty group; bn_dur is applied to both groups (model.py:362,375)
             cnt = plan.group_cnt[:2].to(torch.int64)
+            if self.syncing(training):
+                cnt = hist.view(4, -1)[:2].sum(dim=1).to(torch.int64)
             has = (cnt > 0).to(torch.int64)
             Tn[k + ".bn_drums.num_batches_tracked"] += has[0]
             Tn[k + ".bn_non_drums.num_batches_tracked"] += has[1]
@@ -232,14 +278,18 @@ class Engine:
         gk = k + ".graph_attention.gate_nn"
         xLg = self.drop(xL, d, SITE["enc_gate"], seed, training)                  # MLP.forward, model.py:160
         g = ops.gate_fwd(xLg, Tn[gk + ".0.layers.0.weight"].view(-1), Tn[gk + ".0.layers.0.bias"])
-        if training:
+        if self.syncing(training):
+            gs = self._reduce(ops.bn_partial_sums(g, N, 1, 1))
+            gm, gv = ops.bn_stats_from_sums(gs, self._rows[N], 1, Tn[gk + ".1.running_mean"], Tn[gk + ".1.running_var"], MOM)
+            self._bump(gk + ".1", True)
+        elif training:
             gm, gv = ops.bn_stats(g, N, 1, 1, Tn[gk + ".1.running_mean"], Tn[gk + ".1.running_var"], MOM)
             self._bump(gk + ".1", True)
         else:
             gm, gv = Tn[gk + ".1.running_mean"], Tn[gk + ".1.running_var"]
         alpha, pooled = ops.attnpool_fwd(xL, g, gm, gv, Tn[gk + ".1.weight"], Tn[gk + ".1.bias"], plan, EPS)
         self.lin(pooled, k + ".bars_encoder", out=zcat, M=B, lda=nb * d, ldc=2 * d)
-        sv.update(stats=stats, X=X, x0=x0, gcn=gsv, xL=xL, xLg=xLg, g=g, gm=gm, gv=gv, alpha=alpha, pooled=pooled)
+        sv.update(stats=stats, X=X, x0=x0, gcn=gsv, xL=xL, xLg=xLg, g=g, gm=gm, gv=gv, alpha=alpha, pooled=pooled, hist=hist)
         # --- merge + heads (model.py:472-481)
         zcat_d = self.drop(zcat, 2 * d, SITE["enc_merge_in"], seed, training)
         m = self.lin(zcat_d, "encoder.linear_merge")
@@ -271,11 +321,14 @@ class Engine:
         k = "encoder.c_encoder"
         dpooled = self.lin_bwd(dzcat, sv["pooled"], k + ".bars_encoder", G, M=B, ldx=nb * d, lddy=2 * d)
         gk = k + ".graph_attention.gate_nn"
-        dxL = ops.attnpool_bwd(sv["xL"], sv["g"], sv["gm"], sv["gv"], Tn[gk + ".1.weight"], sv["alpha"],
-                               dpooled.view(G_, d), Tn[gk + ".0.layers.0.weight"].view(-1), plan,
-                               G[gk + ".0.layers.0.weight"].view(-1), G[gk + ".0.layers.0.bias"],
-                               G[gk + ".1.weight"], G[gk + ".1.bias"], EPS,
-                               x_gate=sv["xLg"] if self.dropping(True) else None)
+        pool_args = (sv["xL"], sv["g"], sv["gm"], sv["gv"], Tn[gk + ".1.weight"], sv["alpha"], dpooled.view(G_, d),
+                     Tn[gk + ".0.layers.0.weight"].view(-1), plan, G[gk + ".0.layers.0.weight"].view(-1),
+                     G[gk + ".0.layers.0.bias"], G[gk + ".1.weight"], G[gk + ".1.bias"])
+        xg = sv["xLg"] if self.dropping(True) else None
+        if self._sync_on:
+            dxL = ops.attnpool_bwd_sync(*pool_args, self._reduce, self._rows[N], EPS, x_gate=xg)
+        else:
+            dxL = ops.attnpool_bwd(*pool_args, EPS, x_gate=xg)
         if self.dropping(True):            # pooled path + masked gate path
             dxL = ops.add(dxL[0], self.drop(dxL[1], d, SITE["enc_gate"], seed, tr))
         dx0 = self.gcn_backward(dxL, sv["gcn"], plan, k + ".graph_encoder", G)
@@ -285,15 +338,22 @@ class Engine:
         dh = d // 2
         S = torch.empty(4, C.N_PITCH_TOKENS, dh, dtype=F32, device=dev)
         call("pm_embed_bwd_scatter", ptr(dX), ptr(plan.tokens), ptr(plan.buf), N, plan.E, G_, d, C.N_SLOTS, ptr(S), stream())
-        call("pm_embed_tables_bwd", ptr(S), ptr(Tn[k + ".drums_pitch_emb.weight"]), ptr(Tn[k + ".drums_pitch_emb.bias"]),
-             ptr(Tn[k + ".non_drums_pitch_emb.weight"]), ptr(Tn[k + ".non_drums_pitch_emb.bias"]),
-             ptr(Tn[k + ".dur_emb.weight"]), ptr(Tn[k + ".dur_emb.bias"]), ptr(Tn[k + ".bn_drums.weight"]),
-             ptr(Tn[k + ".bn_non_drums.weight"]), ptr(Tn[k + ".bn_dur.weight"]), ptr(sv["stats"]), ptr(plan.tok_hist),
-             d, EPS, ptr(G[k + ".drums_pitch_emb.weight"]), ptr(G[k + ".drums_pitch_emb.bias"]),
-             ptr(G[k + ".non_drums_pitch_emb.weight"]), ptr(G[k + ".non_drums_pitch_emb.bias"]),
-             ptr(G[k + ".dur_emb.weight"]), ptr(G[k + ".dur_emb.bias"]), ptr(G[k + ".bn_drums.weight"]),
-             ptr(G[k + ".bn_drums.bias"]), ptr(G[k + ".bn_non_drums.weight"]), ptr(G[k + ".bn_non_drums.bias"]),
-             ptr(G[k + ".bn_dur.weight"]), ptr(G[k + ".bn_dur.bias"]), stream())
+        emb_args = (ptr(S), ptr(Tn[k + ".drums_pitch_emb.weight"]), ptr(Tn[k + ".drums_pitch_emb.bias"]),
+                    ptr(Tn[k + ".non_drums_pitch_emb.weight"]), ptr(Tn[k + ".non_drums_pitch_emb.bias"]),
+                    ptr(Tn[k + ".dur_emb.weight"]), ptr(Tn[k + ".dur_emb.bias"]), ptr(Tn[k + ".bn_drums.weight"]),
+                    ptr(Tn[k + ".bn_non_drums.weight"]), ptr(Tn[k + ".bn_dur.weight"]), ptr(sv["stats"]), ptr(plan.tok_hist),
+                    d, EPS, ptr(G[k + ".drums_pitch_emb.weight"]), ptr(G[k + ".drums_pitch_emb.bias"]),
+                    ptr(G[k + ".non_drums_pitch_emb.weight"]), ptr(G[k + ".non_drums_pitch_emb.bias"]),
+                    ptr(G[k + ".dur_emb.weight"]), ptr(G[k + ".dur_emb.bias"]), ptr(G[k + ".bn_drums.weight"]),
+                    ptr(G[k + ".bn_drums.bias"]), ptr(G[k + ".bn_non_drums.weight"]), ptr(G[k + ".bn_non_drums.bias"]),
+                    ptr(G[k + ".bn_dur.weight"]), ptr(G[k + ".bn_dur.bias"]))
+        if self._sync_on:        # the two batch means of the embedding norms' backward over all ranks (two phases)
+            es = torch.empty(4, 2, dh, dtype=torch.float64, device=dev)
+            call("pm_embed_tables_bwd_sync", *emb_args, ptr(es), None, None, stream())
+            self._reduce(es)
+            call("pm_embed_tables_bwd_sync", *emb_args, None, ptr(es), ptr(sv["hist"]), stream())
+        else:
+            call("pm_embed_tables_bwd", *emb_args, stream())
         # --- structure branch: z_s = zcat[:, d:]
         k = "encoder.s_encoder.cnn_encoder"
         dh2 = self.lin_bwd(dzcat[:, d:], sv["h2"], "encoder.s_encoder.bars_encoder", G, M=B, ldx=nb * d, lddy=2 * d)
@@ -361,6 +421,8 @@ class Engine:
         d, nb, N, G_, B = self.d, self.nb, plan.N, plan.G, plan.B
         dev = z.device
         Tn = self.T
+        if self.syncing(training) and plan.N not in self._rows:
+            self._sync_rows(plan)
         zd = self.lin(z, "decoder.lin_decoder")
         zr0, dm, dv = self.bn_train_or_eval(zd, "decoder.batch_norm", B, 2 * d, 1, training, True)
         zr = self.drop(zr0, 2 * d, SITE["dec_in"], seed, training)                  # model.py:640

@@ -336,6 +336,33 @@ def bn_bwd(x, dy, O, C_, I, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, rel
     return dx
 
 
+# ---- split forms for synchronised BatchNorm (data parallel, statistics over the global batch) -----------------------------
+def bn_partial_sums(x, O, C_, I, dy=None, mean=None, var=None, gamma=None, beta=None, eps=1e-5, relu=False):
+    """[3][C] fp64 column sums of this rank: {sum x, sum x^2, 0}, or with dy {sum du, sum du*xhat, sum xhat}."""
+    sums = torch.empty(3, C_, dtype=F64, device=x.device)
+    call("pm_bn_partial_sums", ptr(x), ptr(dy), O, C_, I, ptr(mean), ptr(var), eps, ptr(gamma), ptr(beta), int(relu),
+         ptr(sums), ptr(bn_scratch(C_, x.device)), stream())
+    return sums
+
+
+def bn_stats_from_sums(sums, count, C_, running_mean=None, running_var=None, momentum=0.1):
+    mean = torch.empty(C_, dtype=F32, device=sums.device)
+    var = torch.empty(C_, dtype=F32, device=sums.device)
+    call("pm_bn_stats_from_sums", ptr(sums), float(count), C_, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+         momentum, stream())
+    return mean, var
+
+
+def bn_bwd_from_sums(x, dy, O, C_, I, mean, var, gamma, beta, sums_local, sums_global, count_global, dgamma, dbeta, eps=1e-5,
+                     relu=False, dbias_pre=None):
+    dx = torch.empty_like(x)
+    scratch = torch.empty(2 * C_, dtype=F64, device=x.device)
+    call("pm_bn_bwd_from_sums", ptr(x), ptr(dy), O, C_, I, ptr(mean), ptr(var), eps, ptr(gamma), ptr(beta), int(relu),
+         ptr(sums_local), ptr(sums_global), float(count_global), ptr(dgamma), ptr(dbeta), ptr(dbias_pre), ptr(dx),
+         ptr(scratch), stream())
+    return dx
+
+
 def relu_bwd(dy, y, out=None):
     dx = out if out is not None else torch.empty_like(dy)
     call("pm_relu_bwd", ptr(dy), ptr(y), dy.numel(), ptr(dx), stream())
@@ -417,6 +444,24 @@ def attnpool_bwd(x, g, g_mean, g_var, bn_g, alpha, dout, gate_w, plan: Plan, d_g
     call("pm_attnpool_bwd", ptr(x), ptr(g), ptr(g_mean), ptr(g_var), eps, ptr(bn_g), ptr(alpha), ptr(dout),
          ptr(gate_w), ptr(plan.buf), N, plan.E, plan.G, d, ptr(dx), ptr(d_gate_w), ptr(d_gate_b), ptr(d_bn_g),
          ptr(d_bn_b), ptr(scratch), ptr(x_gate), ptr(dxg), stream())
+    return dx if x_gate is None else (dx, dxg)
+
+
+def attnpool_bwd_sync(x, g, g_mean, g_var, bn_g, alpha, dout, gate_w, plan: Plan, d_gate_w, d_gate_b, d_bn_g, d_bn_b, reduce_,
+                      count_global, eps=1e-5, x_gate=None):
+    """`attnpool_bwd` with the BatchNorm1d(1) of the gate synchronised over the ranks: `reduce_(t)` sums a tensor in place
+    over the ranks, `count_global` is the global node count."""
+    N, d = x.shape
+    dx = torch.empty_like(x)
+    dxg = torch.empty_like(x) if x_gate is not None else None
+    scratch = torch.empty(3 * N + 8, dtype=F32, device=x.device)
+    call("pm_attnpool_bwd_sums", ptr(x), ptr(g), ptr(g_mean), ptr(g_var), eps, ptr(alpha), ptr(dout), ptr(plan.buf), N,
+         plan.E, plan.G, d, ptr(scratch), stream())
+    gs = scratch[:4].view(F64).clone()                     # the two local sums (fp64 at the head of the scratch)
+    reduce_(gs)
+    call("pm_attnpool_bwd_from_sums", ptr(x), ptr(g), ptr(g_mean), ptr(g_var), eps, ptr(bn_g), ptr(alpha), ptr(dout),
+         ptr(gate_w), ptr(plan.buf), N, plan.E, plan.G, d, ptr(dx), ptr(d_gate_w), ptr(d_gate_b), ptr(d_bn_g), ptr(d_bn_b),
+         ptr(scratch), ptr(x_gate), ptr(dxg), ptr(gs), float(count_global), stream())
     return dx if x_gate is None else (dx, dxg)
 
 

@@ -53,7 +53,7 @@ class ExpDecayLR:
 class HipTrainer:
     def __init__(self, vae: VAE, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler: Optional[dict] = None,
                  structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None, native: bool = True,
-                 iters_to_accumulate: int = 1, global_token_mean: bool = False):
+                 iters_to_accumulate: int = 1, global_token_mean: bool = False, sync_bn: bool = False):
         self.vae = vae
         self.lr, self.betas, self.eps = lr, betas, eps
         self.sched = ExpDecayLR(**lr_scheduler) if lr_scheduler else None
@@ -71,7 +71,12 @@ class HipTrainer:
         # the C++ step covers the configuration of training.json (batch_norm = True, dropout = 0: what bench.py measures);
         # the two non-default constructor switches of the model (model.py:176,188,218,278) run the same kernels through
         # the Python orchestration (engine.py)
-        self.native = bool(native and vae.cfg["batch_norm"] and not vae.cfg["dropout"])
+        self.native = bool(native and vae.cfg["batch_norm"] and not vae.cfg["dropout"] and not sync_bn)
+        # Synchronised BatchNorm: every training-mode norm takes its statistics over the GLOBAL batch, so that
+        # — together with global_token_mean — a data-parallel step equals the single-device step on the concatenated
+        # batch.  Runs through the Python orchestration (one small all-reduce per norm and direction, one host read per
+        # step); an option for parity checks, not for throughput runs.
+        self.sync_bn = bool(sync_bn)
         if iters_to_accumulate < 1:
             raise ValueError("iters_to_accumulate must be >= 1")
         self.iters_to_accumulate = int(iters_to_accumulate)            # training.py:83,149,158
@@ -108,6 +113,7 @@ class HipTrainer:
         self.grad_accum = torch.zeros_like(flat) if self.iters_to_accumulate > 1 else None
         self._accum_bucket = GradBuckets(self.grad_accum, [], process_group) if self.grad_accum is not None else None
         broadcast_([vae.flat_params, vae.flat_buffers], 0, process_group)
+        vae.engine.set_sync_bn(process_group, self.sync_bn and self.world > 1)
         if self.world > 1:                      # every rank its own message-dropout stream (same seed = same masks)
             import torch.distributed as dist
             vae.seed = (vae.seed ^ (0x9E3779B9 * (dist.get_rank(process_group) + 1))) & 0xFFFFFFFF
@@ -233,8 +239,6 @@ class HipTrainer:
         return (s_logits, c_logits), mu, lv
 
     def _python_forward_backward(self, graph, eps):
-        if self.global_token_mean and self.world > 1:
-            raise NotImplementedError("global_token_mean is implemented by the native step only")
         vae, eng = self.vae, self.vae.engine
         eng.msg_dropout = vae.msg_dropout
         graph.__dict__.pop("_pm_plan", None)                 # the plan is part of the step (new batch every step)
@@ -246,7 +250,15 @@ class HipTrainer:
             eps = torch.randn_like(mu)
         z = ops.reparam_fwd(mu, lv, eps)
         s_logits, c_logits, dsv = eng.decoder_forward(plan, z, True, vae._next_seed())
-        out, dc = ops.content_ce(c_logits, plan, grad_scale=1.0, want_grad=True, out=self.loss_buf)
+        ce_scale = 1.0
+        if self.global_token_mean and self.world > 1:          # weight n_local * world / n_global (a host read: this
+            import torch.distributed as dist                   # orchestration is the parity path, not the measured one)
+            tok = plan.tokens
+            n_loc = (tok[:, 1:, 0] != 130).sum().double().reshape(1)
+            n_all = n_loc.clone()
+            dist.all_reduce(n_all, group=self.pg)
+            ce_scale = float(n_loc.item()) * self.world / float(n_all.item())
+        out, dc = ops.content_ce(c_logits, plan, grad_scale=ce_scale, want_grad=True, out=self.loss_buf)
         dmu, dlv = torch.zeros_like(mu), torch.zeros_like(lv)
         ops.kld(mu, lv, out, beta=self.beta, dmu=dmu, dlog_var=dlv)
         if self.fix_structure_loss:

@@ -33,6 +33,8 @@ def header_prototypes():
                 codes += "u"
             elif a.startswith("float"):
                 codes += "f"
+            elif a.startswith("double"):
+                codes += "D"
             elif a.startswith("int32_t") or a.startswith("int "):
                 codes += "i"
             else:

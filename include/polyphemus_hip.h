@@ -149,6 +149,19 @@ int pm_segreduce_fwd(const float* x /* [N,d] */, const float* T /* [32,d] */, co
 int pm_segreduce_fwd_planes(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                             int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, int32_t compact,
                             uint16_t* planes, int64_t plane_stride, pm_stream_t stream);
+/* GCL.forward (model.py:55-121) of one layer as ONE kernel (gcl.hip): the compact aggregate of 64 rows of a track
+ * group is built chunk by chunk in LDS by four producer waves (gather of x rows, GCL.message model.py:123-135,
+ * scatter-mean) while four consumer waves contract the previous chunk with the stacked weight [W_t; W_4; W_5; root]
+ * (bf16 planes, six products, B fragments straight from `w_frag` = pm_split_planes_frag kind 1 of the layer's [7d, d]
+ * weight).  h[n] = A'[n] @ W + bias, bit-identical to pm_segreduce_fwd_planes followed by the grouped planes product;
+ * `col_stats` as PmGemmDesc.col_stats; `planes` (optional) receives the A' planes the weight gradient of the backward
+ * pass contracts (blocks of row tiles without onset / next receivers are not written when use_classes != 0: the
+ * backward never reads them).  d in {128, 256}; the batch must satisfy the compact-GCL premise (track_unique). */
+int pm_gcl_forward_fused(const float* x /* [N,d] */, const float* T /* [32,d] */, const int32_t* plan, int32_t N,
+                         int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid,
+                         const uint16_t* w_frag, const float* bias /* [d] or NULL */, int32_t use_classes,
+                         float* h /* [N,d] */, double* col_stats /* [PM_BN_REPL][2][d] += or NULL */,
+                         uint16_t* planes /* or NULL */, int64_t plane_stride, pm_stream_t stream);
 /* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
  * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
  * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */

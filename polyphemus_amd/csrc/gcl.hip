@@ -1,0 +1,455 @@
+// gcl.hip — one graph-convolution layer's forward product as ONE kernel: message aggregation feeding the matrix
+// cores through LDS, without the [N, 4d] aggregate making a round trip through HBM.
+//
+// Reference: GCL.forward (model.py:55-121): propagate (gather x[src], GCL.message model.py:123-135, scatter-mean)
+// per relation, then the per-relation weight products and the root product summed with the bias.  The unfused pair
+// (segreduce.hip k_segreduce_fwd -> gemm.hip planesB NN product) writes the compact aggregate A' = [track | onset |
+// next | x] as three bf16 planes (6 B per element: 100 MB at N = 16.3 k, d = 256) and reads it straight back; the
+// product then waits on that HBM stream with one k-tile of prefetch.  Here a workgroup owns 64 rows of one track
+// group's node list (the same tiles, row classes and k order as the grouped GEMM) and
+//   * waves 4..7 (producers) build the aggregate of the next 128-feature chunk of one relation block: x rows gathered
+//     from L2 (x is 16.7 MB and stays cache resident), times the distance table (LDS), ReLU, dropout, mean; split
+//     into the three bf16 planes; written into an XOR-swizzled LDS image — and, for the weight gradient of the
+//     backward pass, to the A' planes in HBM (write only: nothing in the forward reads them);
+//   * waves 0..3 (consumers) run the six-product bf16 MFMA chain on the previous chunk: A fragments from LDS, B
+//     fragments straight from the fragment-major weight planes in L2 (as the B-direct GEMM), each wave all 64 rows
+//     by a quarter of the d output columns, so every weight byte is loaded once per workgroup;
+// one workgroup barrier per chunk, two LDS images.  The arithmetic (edge order of the mean, k order and product order
+// of the MFMA chain) is that of the unfused pair, so h and the A' planes are bit-identical to it.
+//
+// HBM bytes per layer: x 4dN (+ gathered rows from L2) + h 4dN + A' planes 24dN (kept for the backward) + W planes;
+// the unfused pair moves 24dN more (the read of A').
+#include "common.h"
+#include <stdlib.h>
+#include "prof.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define GCL_OOB ((int)0x80000000)
+#ifndef GCL_BDEPTH
+#define GCL_BDEPTH 2          // k-steps of weight fragments in flight per consumer wave
+#endif
+#ifndef GCL_TRACE
+#define GCL_TRACE 0           // development: workgroup 0 writes s_memtime stamps into col_stats instead of the sums
+#endif
+#if GCL_TRACE
+#define STAMP() do { if (blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4) && nst < 60) \
+    reinterpret_cast<long long*>(g.colstats)[wave * 16 + nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+#ifndef GCL_PRIO
+#define GCL_PRIO 0
+#endif
+#ifndef GCL_ABL
+#define GCL_ABL 0             // development ablations: 1 no gather, 2 no MFMA, 4 no A' store, 8 no weight loads
+#endif
+
+namespace {
+constexpr int BM = 64;        // rows (nodes) per workgroup
+constexpr int CH = 128;       // features of one relation block per chunk
+constexpr int EC = 12;        // edges per node cached in LDS (the reference's graphs: <= 8); beyond: read from global
+constexpr int EMAX = 3;       // edges per (node, relation) gathered in one go (beyond: a serial tail loop)
+#ifndef GCL_NPW
+#define GCL_NPW 8
+#endif
+constexpr int NPW = GCL_NPW;               // producer waves (waves 4 .. 4 + NPW - 1); two image rows per wave and pass
+constexpr int NTHR = (4 + NPW) * 64;       // threads per workgroup
+constexpr int RPP = NPW * 2;               // image rows per producer pass
+constexpr int NPS = BM / RPP;              // passes per chunk
+constexpr int ROWB = CH * 2;  // bytes of one image row (one plane)
+constexpr int PLANE = BM * ROWB;
+constexpr int IMG = 3 * PLANE;
+
+struct GclArgs {
+  const float* x; const float* T; const float* bias;
+  const int* rowptr; const int* csr_src; const int* csr_dist; const int* csr_eid;
+  const int* trk_list; const int* trk_cnt;
+  const char* wfrag;             // fragment-major planes of the layer's [7d, d] weight (kind 1: [k-step][column tile][plane])
+  uint16_t* planes; int64_t plane_stride;   // A' planes (optional)
+  float* h; double* colstats;
+  int N, use_classes;
+  uint32_t seed, layer_uid, thresh; float scale;
+};
+}  // namespace
+
+template <int D, bool DROP>
+__global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + NPW) / 4, (4 + NPW) / 4))) k_gcl_fwd(GclArgs g) {
+  constexpr int NCH = D / CH;            // chunks per relation block
+  constexpr int TN = D / 128;            // 32-column MFMA tiles per consumer wave (its D/4 columns)
+  constexpr int BFN = D / 32;            // column tiles of the weight
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const img0 = smem;                                   // two images
+  float* const sT = reinterpret_cast<float*>(smem + 2 * IMG);  // [32][D] distance table
+  int* const sNode = reinterpret_cast<int*>(sT + PM_N_DIST * D);   // [BM] node of the row (-1: past the end)
+  int* const sPtr = sNode + BM;                              // [BM][7] CSR offsets of the node's six relations
+  int* const sEdge = sPtr + BM * 7;                          // [BM][EC] source node | distance << 27
+  int* const sEid = sEdge + BM * EC;                         // [BM][EC] (DROP)
+  constexpr int HS = D + 8;
+  float* const sH = reinterpret_cast<float*>(smem);          // [BM][HS] output tile (epilogue; over the images)
+
+  // ---- tile -> (track group, first row): the packed tile list of the grouped GEMM, XCD-contiguous
+  int cnt[4], nt[4], nwg = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { cnt[q] = g.trk_cnt[q]; nt[q] = (cnt[q] + BM - 1) / BM; nwg += nt[q]; }
+  int t = blockIdx.x;
+  if (t >= nwg) return;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int grp = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (grp == q && t >= nt[q]) { t -= nt[q]; grp = q + 1; }
+  const int M = grp == 0 ? cnt[0] : grp == 1 ? cnt[1] : grp == 2 ? cnt[2] : cnt[3];
+  const int m0 = t * BM;
+  const int* list = g.trk_list + (int64_t)grp * g.N;
+  bool use_on = true, use_nx = true;
+  if (g.use_classes) {
+    const int* cb = g.trk_cnt + 8 + grp * 5;
+    use_on = m0 < cb[3] && m0 + BM > cb[1];
+    use_nx = m0 < cb[4] && m0 + BM > cb[2];
+  }
+  // block sequence [self, track, onset?, next?]; chunk c -> (block, half).  The self block comes first: its gather needs
+  // the node list only, so it runs while the consumer waves fetch the rows' CSR offsets and edge lists.
+  const int nblk = 2 + (use_on ? 1 : 0) + (use_nx ? 1 : 0), nchunk = nblk * NCH;
+  auto chunk_blk = [&](int c) { const int q = c / NCH; return q == 0 ? 3 : (q == 1 ? 0 : (q == 2 ? (use_on ? 1 : 2) : 2)); };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int nst = 0;
+  STAMP();
+#if GCL_TRACE
+  if (blockIdx.x == 8 && tid == 0) reinterpret_cast<long long*>(g.colstats)[200] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- prologue (all waves): the rows' nodes; the distance table
+  if (tid < BM) {
+    const int row = m0 + tid;
+    sNode[tid] = row < M ? list[row] : -1;
+  }
+  for (int i = tid; i < PM_N_DIST * D / 4; i += NTHR)
+    reinterpret_cast<float4*>(sT)[i] = reinterpret_cast<const float4*>(g.T)[i];
+  __syncthreads();
+  // Row metadata (consumer waves, while the producers build the self block): four threads per row fetch the row's CSR
+  // offsets and its first EC edges — a chain of two global reads per thread, no barrier in between.
+  auto load_metadata = [&]() {
+    const int rr = tid >> 2, j = tid & 3, n = sNode[rr];
+    int b0 = 0, b6 = 0;
+    if (n >= 0) {
+      const int* rp = g.rowptr + n * PM_N_REL;
+      b0 = rp[0]; b6 = rp[6];
+      sPtr[rr * 7 + j] = j == 0 ? b0 : rp[j];
+      if (j < 3) sPtr[rr * 7 + 4 + j] = j == 2 ? b6 : rp[4 + j];
+    } else {
+      sPtr[rr * 7 + j] = 0;
+      if (j < 3) sPtr[rr * 7 + 4 + j] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < EC / 4; ++k) {
+      const int e = j + 4 * k, p = b0 + e;
+      if (p < b6) {
+        sEdge[rr * EC + e] = g.csr_src[p] | (g.csr_dist[p] << 27);
+        if (DROP) sEid[rr * EC + e] = g.csr_eid[p];
+      }
+    }
+  };
+
+  STAMP();
+  // ---- producer: aggregate of chunk c into image (c & 1)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, GCL_OOB, 0x00020000);
+  // A' planes of chunk c (kept for the weight gradient of the backward pass): copied from its LDS image, 16 bytes per lane.
+  // Issued AFTER the gathers of the next chunk: vmcnt retires in order, so a store in front of a gather would put its
+  // write latency into the gather's wait.  Rows past the end of the list: out-of-range offset, the store is dropped.
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
+  auto store_planes = [&](int c) {
+    if (!g.planes || (GCL_ABL & 4)) return;
+    const int blk = chunk_blk(c), half = c % NCH;
+    const char* img = img0 + (c & 1) * IMG;
+    const int pt = tid - 256, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
+    const int ps_b = (int)(g.plane_stride * 2);
+#pragma unroll
+    for (int ps = 0; ps < BM / (NPW * 4); ++ps) {
+      const int rr = ps * (NPW * 4) + r0, n = sNode[rr];
+      const int off = n >= 0 ? (n * 4 * D + blk * D + half * CH + ch * 8) * 2 : GCL_OOB;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(img + p * PLANE + rr * ROWB + ((ch ^ (rr & 15)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? off + p * ps_b : GCL_OOB, 0, 0);
+      }
+    }
+  };
+  // Image row of one lane's four consecutive values: split into the three planes, 8 bytes each
+  auto put = [&](char* img, int rr, int q, float4 o) {
+    unsigned l1, l2, l3, u1, u2, u3;
+    pm_split3_pair(o.x, o.y, l1, l2, l3);
+    pm_split3_pair(o.z, o.w, u1, u2, u3);
+    const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+    char* dst = img + rr * ROWB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
+    *reinterpret_cast<pm_u32x2*>(dst) = p1;
+    *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
+    *reinterpret_cast<pm_u32x2*>(dst + 2 * PLANE) = p3;
+  };
+  // Straight-line gather (no branch inside the eight row passes): a missing edge takes a cached word that may hold
+  // anything, loads from an out-of-range offset (returns 0, no traffic) and contributes relu(0 * t) = +0 to the sum —
+  // the same value as skipping it.  Rows whose list does not fit this scheme (more than EMAX edges of the relation, or a
+  // list longer than the LDS copy) are redone afterwards by a serial loop that reads the CSR arrays from global.
+  auto build = [&](int c) {
+#pragma clang fp contract(off)   // (bit-identical to k_segreduce_fwd, whatever the code shape around the adds)
+    const int blk = chunk_blk(c), half = c % NCH;
+    char* const img = img0 + (c & 1) * IMG;
+    const int pt = tid - 256, q = pt & 31, prow = pt >> 5;      // 32 lanes per row, RPP rows per pass
+    const int f = half * CH + q * 4;                             // first of this lane's four features
+    if (blk == 3) {                                              // self block: the node's own row
+      float4 xs[NPS];
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int n = sNode[ps * RPP + prow];
+        xs[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, n >= 0 ? (n * D + f) * 4 : GCL_OOB, 0, 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP();
+      if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
+      STAMP();
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) put(img, ps * RPP + prow, q, xs[ps]);
+      return;
+    }
+    const int rel = blk == 0 ? grp : (blk == 1 ? 4 : 5);
+    float4 xv[NPS][EMAX];
+    int ew[NPS][EMAX], ecnt[NPS], npre[NPS];
+    bool redo = false;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int rr = ps * RPP + prow;
+      const int b0 = sPtr[rr * 7], b = sPtr[rr * 7 + rel], e_ = sPtr[rr * 7 + rel + 1];
+      const int eb = b - b0;
+      ecnt[ps] = e_ - b;                                         // (rows past the end: all offsets 0, no edges)
+      const bool fits = eb + EMAX <= EC;
+      redo = redo || ecnt[ps] > EMAX || (!fits && ecnt[ps] > 0);
+      npre[ps] = fits ? ecnt[ps] : 0;
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        ew[ps][e] = sEdge[rr * EC + (fits ? eb : 0) + e];        // source node | distance << 27
+        xv[ps][e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+            xrs, (e < npre[ps] && !(GCL_ABL & 16)) ? ((ew[ps][e] & 0x7ffffff) * D + f) * 4 : GCL_OOB, 0, 0));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);       // every gather of the chunk is in flight before the first one is waited for
+    STAMP();
+    if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
+    STAMP();
+    auto msg = [&](float4 xe, int dist, int eid) {
+      const float4 tv = *reinterpret_cast<const float4*>(sT + dist * D + f);
+      float4 m = make_float4(fmaxf(xe.x * tv.x, 0.f), fmaxf(xe.y * tv.y, 0.f), fmaxf(xe.z * tv.z, 0.f),
+                             fmaxf(xe.w * tv.w, 0.f));
+      if (DROP) {
+        const uint32_t key = pm_edge_key(g.seed, g.layer_uid, (uint32_t)eid);
+        m.x = (pm_elem_hash(key, f + 0) >> 8) >= g.thresh ? m.x * g.scale : 0.f;
+        m.y = (pm_elem_hash(key, f + 1) >> 8) >= g.thresh ? m.y * g.scale : 0.f;
+        m.z = (pm_elem_hash(key, f + 2) >> 8) >= g.thresh ? m.z * g.scale : 0.f;
+        m.w = (pm_elem_hash(key, f + 3) >> 8) >= g.thresh ? m.w * g.scale : 0.f;
+      }
+      return m;
+    };
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int rr = ps * RPP + prow;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        // (slot empty in both rows of the wave: nothing to add — skipping it saves the dropout hashes)
+        if (__builtin_amdgcn_ballot_w64(e < npre[ps]) == 0) continue;
+        const int eb = sPtr[rr * 7 + rel] - sPtr[rr * 7];
+        const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? sEid[rr * EC + (eb + EMAX <= EC ? eb : 0) + e] : 0);
+        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+      }
+      // 1 / max(count, 1) for count <= 3: the correctly rounded quotients, as the division gives them
+      const float inv = ecnt[ps] == 2 ? 0.5f : (ecnt[ps] == 3 ? 1.0f / 3.0f : 1.0f);
+      put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+      if (ps == 0) STAMP();
+    }
+    if (redo) {
+#pragma unroll 1
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int rr = ps * RPP + prow;
+        const int b0 = sPtr[rr * 7], b = sPtr[rr * 7 + rel], cnt = sPtr[rr * 7 + rel + 1] - b;
+        if (cnt <= EMAX && (b - b0 + EMAX <= EC || cnt == 0)) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int e = 0; e < cnt; ++e) {
+          const int sn = g.csr_src[b + e];
+          const float4 m = msg(*reinterpret_cast<const float4*>(g.x + (int64_t)sn * D + f), g.csr_dist[b + e],
+                               DROP ? g.csr_eid[b + e] : 0);
+          acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+        }
+        const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+        put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+      }
+    }
+  };
+
+  if (wave >= 4) {                                             // producers: one image ahead of the consumers
+#pragma unroll 1
+    for (int c = 0; c <= nchunk; ++c) {
+      if (c < nchunk && !((GCL_ABL & 1) && c > 0)) build(c);
+      else store_planes(c - 1);
+      STAMP();
+      __syncthreads();
+      STAMP();
+    }
+  } else {
+  // ---- consumers (same barrier sequence: one after the first image, one per chunk)
+#if GCL_PRIO
+  __builtin_amdgcn_s_setprio(GCL_PRIO);    // MFMA issue ahead of the producers' vector ALU work on the same SIMD
+#endif
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.wfrag), 0, GCL_OOB, 0x00020000);
+  const int ct0 = wave * TN;                                    // first column tile of this consumer wave
+  auto krow0 = [&](int c) {                                      // first weight row of chunk c (stacked [W_t; W_4; W_5; root])
+    const int blk = chunk_blk(c);
+    return (blk == 0 ? grp * D : (3 + blk) * D) + (c % NCH) * CH;
+  };
+  auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global k-step gs (16 rows of the weight)
+    const int c = gs >> 3, ks = gs & 7;
+    int off = GCL_OOB;
+    if (c < nchunk) off = (((krow0(c) >> 4) + ks) * BFN + ct0) * 3072 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, off == GCL_OOB ? off : off + j * 3072 + p * 1024, 0, 0));
+  };
+  bf16x8 bq[GCL_BDEPTH][3][TN];
+#pragma unroll
+  for (int s = 0; s < GCL_BDEPTH; ++s) bload(bq[s], s);
+  load_metadata();
+  STAMP();
+  __syncthreads();
+  STAMP();
+  for (int c = 0; c < nchunk; ++c) {
+    const char* img = img0 + (c & 1) * IMG;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 a[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int rr = i * 32 + li;
+          a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
+        }
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (!(GCL_ABL & 2))
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+      if (!(GCL_ABL & 8)) bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
+    }
+    STAMP();
+    __syncthreads();
+    STAMP();
+  }
+
+  // ---- h tile (+ bias) to LDS, over the images: C/D map of the 32x32 MFMA: col = lane & 31,
+  // row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5); row stride HS = D + 8 floats (the two half-waves 32 banks apart)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const float bv = g.bias ? g.bias[(ct0 + j) * 32 + li] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sH[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * HS + (ct0 + j) * 32 + li] = acc[i][j][r] + bv;
+  }
+  }
+  STAMP();
+  __syncthreads();
+  // ---- epilogue (all waves): rows scattered to their nodes, one 4*D-byte row per store; fp64 column sums for the
+  // BatchNorm that follows (partial per row group, combined through LDS, one atomic pair per column)
+  constexpr int NG = 512 / D, RG = BM / NG;                    // row groups, rows per group
+  double cs = 0.0, cq = 0.0;
+  const int col = tid % D, rg = tid / D;
+  if (tid < 512) {
+#pragma unroll 4
+    for (int k = 0; k < RG; ++k) {
+      const int rr = rg * RG + k, n = sNode[rr];
+      if (n < 0) continue;
+      const float v = sH[rr * HS + col];
+      g.h[(int64_t)n * D + col] = v;
+      cs += (double)v; cq += (double)v * (double)v;
+    }
+  }
+  STAMP();
+#if GCL_TRACE
+  if (blockIdx.x == 8 && tid == 0) reinterpret_cast<long long*>(g.colstats)[201] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  if (g.colstats && !GCL_TRACE) {
+    double* sS = reinterpret_cast<double*>(sT);                // [NG][2][D] (the distance table is no longer needed)
+    if (tid < 512) { sS[(rg * 2) * D + col] = cs; sS[(rg * 2 + 1) * D + col] = cq; }
+    __syncthreads();
+    if (tid < 2 * D) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < NG; ++k) v += sS[k * 2 * D + tid];
+      atomicAdd(g.colstats + (int64_t)(blockIdx.x % PM_BN_REPL) * 2 * D + tid, v);
+    }
+  }
+}
+
+static size_t gcl_lds_bytes(int d, bool drop) {
+  return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 7 + BM * EC * (drop ? 2 : 1)) * 4;
+}
+
+extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                    int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag,
+                                    const float* bias, int32_t use_classes, float* h, double* col_stats, uint16_t* planes,
+                                    int64_t plane_stride, pm_stream_t stream) {
+  if (!x || !T || !plan || !w_frag || !h || N <= 0 || (d != 128 && d != 256) || dropout_p < 0.f || dropout_p >= 1.f ||
+      ((uintptr_t)w_frag % 16) || ((uintptr_t)x % 16) || ((uintptr_t)T % 16) || (int64_t)N * d * 4 >= 0x7fffffffLL || N >= (1 << 27))
+    return PM_E_INVALID;
+  if (planes && (plane_stride < (int64_t)N * 4 * d || (plane_stride & 7) || ((uintptr_t)planes % 16) ||
+                 plane_stride * 6 >= 0x7fffffffLL))
+    return PM_E_INVALID;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  GclArgs a;
+  a.x = x; a.T = T; a.bias = bias; a.rowptr = pv.rowptr; a.csr_src = pv.csr_src; a.csr_dist = pv.csr_dist;
+  a.csr_eid = pv.csr_eid; a.trk_list = pv.trk_list; a.trk_cnt = pv.trk_cnt;
+  a.wfrag = reinterpret_cast<const char*>(w_frag); a.planes = planes; a.plane_stride = plane_stride; a.h = h;
+  a.colstats = col_stats; a.N = N; a.use_classes = use_classes;
+  const bool drop = dropout_p > 0.f;
+  a.seed = seed; a.layer_uid = layer_uid; a.thresh = pm_keep_threshold(dropout_p);
+  a.scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(pm_cdiv(N, BM) + 4)), block(NTHR);
+  const size_t lds = gcl_lds_bytes(d, drop);
+  // algorithmic bytes: x read + h written + A' planes written (when kept) + edges + the weight planes once
+  const double work = 8.0 * d * (double)N + (planes ? 24.0 * d * (double)N : 0.0) + 12.0 * E + 42.0 * d * (double)d;
+  const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, work);
+#define LAUNCH(DD, DR)                                                                                                 \
+  do {                                                                                                                 \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      hipFuncSetAttribute((const void*)k_gcl_fwd<DD, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_gcl_fwd<DD, DR>), grid, block, lds, st, a);                                                  \
+  } while (0)
+  if (d == 256) { if (drop) LAUNCH(256, true); else LAUNCH(256, false); }
+  else { if (drop) LAUNCH(128, true); else LAUNCH(128, false); }
+#undef LAUNCH
+  pm_prof_close(st, pe);
+  return pm_check_launch();
+}

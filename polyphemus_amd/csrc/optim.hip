@@ -4,8 +4,11 @@
 // training.json:11-18), stepped at training.py:160-166 as 152 per-tensor updates.  Here all
 // parameters, gradients and moments live in four flat buffers (also the unit of the data-parallel
 // gradient all-reduce), so the step is one HBM-bound pass: 16 B read + 12 B written per parameter.
-// Parameters whose gradient is identically zero (the structure decoder under the reference's
-// loss quirk, SURVEY B-1) are left unchanged, like torch's `grad is None` skip.
+// Parameters whose gradient has been zero on EVERY step so far (the structure decoder under the
+// reference's loss quirk, SURVEY B-1) stay bit-identical: m = v = 0 gives an update of 0 / eps = 0,
+// the same end state as torch's `grad is None` skip.  This is not a general skip: a parameter with
+// non-zero moments and a zero gradient on one step still moves here (torch.optim.Adam does the same
+// for a zero-valued, non-None gradient); the reference never produces that case on this path.
 #include "common.h"
 #include <math.h>
 

@@ -9,7 +9,8 @@ enum {
   PM_PROF_GEMM0 = 0,            // 33 GEMM classes: tile config (0..10) * 3 + {NN, NT, TN}
   PM_PROF_SEGREDUCE_FWD = 33,
   PM_PROF_SEGREDUCE_BWD = 34,
-  PM_PROF_NCLASS = 35
+  PM_PROF_GCL_FWD = 35,         // fused aggregate + product of one GCL layer (gcl.hip)
+  PM_PROF_NCLASS = 36
 };
 struct PmProfEvent { hipEvent_t a, b; int cls; double work; };
 struct PmProfState {

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
                                                        uint32_t thresh, float scale, const int* __restrict__ node_trel,
                                                        float* __restrict__ A, uint16_t* __restrict__ planes,
                                                        int64_t plane_stride, int xcd_chunk) {
+#pragma clang fp contract(off)   // (the fused layer kernel, gcl.hip, reproduces this arithmetic bit for bit)
   const int lane = threadIdx.x & 63;
   // XCD-aware node order: workgroup b runs on XCD b % 8, which has its own L2.  The neighbours of a node are the nodes
   // of its own bar, so each XCD takes one CONTIGUOUS eighth of the nodes (whole bars) and the x[src] rows of a bar are

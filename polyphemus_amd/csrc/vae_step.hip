@@ -120,6 +120,11 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
                   dbias_pre, dx, c.s->bn_scratch, c.st));
 }
 
+// A/B switch: PM_GCL_FUSED=0 restores the unfused pair (segment-reduce forward, then the grouped planes product)
+static bool gcl_fused_on() {
+  static const bool on = !(getenv("PM_GCL_FUSED") && atoi(getenv("PM_GCL_FUSED")) == 0);
+  return on;
+}
 // descriptor skeleton of the compact GCL contractions: four track-relation groups, rows of group t listed in
 // plan.trk_list[t*N ..], live count plan.trk_cnt[t]
 PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
@@ -185,12 +190,19 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     sv.mean[i] = ar.f(d); sv.var[i] = ar.f(d);
     if (!ar.base) continue;
     const float* W = c.P + g.weight[i];
-    if (c.planes)
+    double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
+    // one kernel for aggregate + product (gcl.hip) where it applies: compact planes path, fragment-major weights
+    const bool fused = c.planes && c.compact && sv.Wfn && (d == 128 || d == 256) && gcl_fused_on();
+    if (fused)
+      RUN(pm_gcl_forward_fused(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
+                                 sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], getenv("PM_GCL_NO_CLASSES") ? 0 : 1,
+                                 sv.h[i], sums, sv.Ap[i], aps, c.st));
+    else if (c.planes)
       RUN(pm_segreduce_fwd_planes(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
     else
       RUN(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
-    double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
-    if (!c.compact) {
+    if (fused) {
+    } else if (!c.compact) {
       PmGemmDesc q;
       memset(&q, 0, sizeof(q));
       q.M = N; q.N = d; q.K = 7 * d; q.split_k = 1; q.n_groups = 1;

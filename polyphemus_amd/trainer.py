@@ -202,6 +202,14 @@ class HipTrainer:
              vae._next_seed(), vae._next_seed(), float(self.beta), int(self.fix_structure_loss), ptr(self._ws),
              self._ws.numel(), ctypes.addressof(self._state), ptr(self.loss_buf), st)
         state = ctypes.addressof(self._state)
+        if unique and os.environ.get("PM_DEBUG", "0") not in ("", "0"):
+            # the plan kernels count the nodes that break the one-track-relation-per-node rule the compact GCL
+            # relies on (plan.hip k_node_class, cnt[4]); a host read, hence only under PM_DEBUG
+            j = PLAN_FIELDS.index("trk_cnt")
+            bad = int(self._plan_buf[off[j] + 4].item())
+            if bad:
+                raise RuntimeError(f"{bad} nodes receive track edges of more than one track but the batch was "
+                                   "flagged track_unique (graphs.batch_flags); the compact GCL would be wrong")
         call("pm_vae_step_backward_decoder", state, st)
         self.buckets.launch(2)                               # decoder gradients: overlapped with the encoder backward
         call("pm_vae_step_backward_encoder", state, st)

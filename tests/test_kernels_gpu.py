@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from polyphemus_amd import constants as C
 from polyphemus_amd import ops
-from polyphemus_amd._lib import call, lib, ptr, stream
+from polyphemus_amd._lib import PROF_NCLASS, call, lib, ptr, stream
 from polyphemus_amd.synthetic import synthetic_batch
 from util import REL_TOL, rel_err, dropout_keep_np
 
@@ -733,6 +733,63 @@ def _masked_contractions(plan, N, on, nx, d, bfrag):
     assert rel_err(dA1[keep], dA0[keep]) < 1e-6
 
 
+@pytest.mark.parametrize("d,p,dense", [(128, 0.0, False), (256, 0.0, False), (256, 0.15, False), (128, 0.1, True),
+                                       (256, 0.0, True)])
+def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
+    """`pm_gcl_forward_fused` (aggregate built in LDS, contracted in the same kernel) against the unfused pair it
+    replaces — `pm_segreduce_fwd_planes` then the grouped planes product with row classes: same edge order and message
+    arithmetic, so the A' planes it leaves for the backward are BIT-identical to the pair's wherever the backward reads
+    them; h agrees to fp32 accumulation order (the fused kernel contracts the self block first) and against an fp64
+    product of the exact planes; the BatchNorm column sums agree with its own h.  dense: up to 127 edges per node (the edge
+    lists overflow the LDS cache and the in-flight gather: the serial tail paths)."""
+    cpu = synthetic_batch(3 if dense else 40, 2, p=0.3, seed=17, dense=dense)
+    assert cpu.track_unique
+    b, plan = make_plan(cpu)
+    N, dd = cpu.num_nodes, d * d
+    torch.manual_seed(3)
+    x = torch.randn(N, d, device=DEV)
+    T = ops.edge_table(torch.randn(d, 32, device=DEV) * 0.5, torch.randn(d, device=DEV) * 0.1)
+    W = torch.randn(7 * d, d, device=DEV) / d ** 0.5
+    bias = torch.randn(d, device=DEV)
+    Wp, Wf = ops.split_planes(W), ops.split_planes_frag(W, 1)
+    tl, tc = plan.field("trk_list"), plan.field("trk_cnt")
+    # unfused pair
+    P0 = torch.zeros(3, N * 4 * d, dtype=torch.int16, device=DEV)
+    call("pm_segreduce_fwd_planes", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, 1, ptr(P0), N * 4 * d,
+         stream())
+    h0 = torch.zeros(N, d, device=DEV)
+    s0 = torch.zeros(8, 2, d, dtype=torch.float64, device=DEV)
+    ops.gemm_desc(P0, Wp, h0, N, d, 4 * d, 4 * d, d, d, bias=bias, b_group_stride=dd, b_split_rows=d, b_shared_off=3 * dd,
+                  a_plane_stride=N * 4 * d, b_plane_stride=W.numel(), rowmap=tl, rows_per_entry=1, dyn_entries=tc,
+                  n_groups=4, map_group_stride=N, dyn_group_stride=1, partition=True, planes=True, class_ptr=tc[8:],
+                  class_block=d, b_frag=Wf, col_stats=s0)
+    # fused
+    P1 = torch.full((3, N * 4 * d), 0x7fc0, dtype=torch.int16, device=DEV)       # NaN pattern: unwritten blocks show
+    s1 = torch.zeros(8, 2, d, dtype=torch.float64, device=DEV)
+    h1 = ops.gcl_forward_fused(x, T, plan, p, 5, 2, Wf, bias, col_stats=s1, planes=P1)
+    assert rel_err(h1, h0) < 5e-6
+    A64 = _planes_value(P0).double().view(N, 4 * d)
+    trel_t = plan.field("node_trel").long()[:N]
+    Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()
+    want = torch.einsum("nk,nkj->nj", A64, Wn[trel_t]) + bias.double()
+    assert rel_err(h1, want) < 5e-6 and rel_err(h0, want) < 5e-6
+    assert rel_err(s1.sum(0)[0], h1.double().sum(0)) < 1e-12 and rel_err(s1.sum(0)[1], (h1.double() ** 2).sum(0)) < 1e-12
+    # A' planes: track and self blocks everywhere; onset / next blocks for the rows that receive such edges
+    dst, et = cpu.edge_index[1], cpu.edge_type
+    on, nx = torch.zeros(N, dtype=torch.bool), torch.zeros(N, dtype=torch.bool)
+    on[dst[et == 4]] = True
+    nx[dst[et == 5]] = True
+    keep = torch.ones(N, 4, d, dtype=torch.bool)
+    keep[~on, 1] = False
+    keep[~nx, 2] = False
+    keep = keep.view(-1).to(DEV)
+    for k in range(3):
+        assert torch.equal(P1[k][keep], P0[k][keep])
+    # without the planes output and without row classes: same h
+    h2 = ops.gcl_forward_fused(x, T, plan, p, 5, 2, Wf, bias, use_classes=False)
+    assert torch.equal(h2, h1)
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""
@@ -748,7 +805,7 @@ def test_launch_profiler_class_mask_and_stride():
         for _ in range(launches):
             ops.gemm(A, B, out, 256, 64, 128, 128, 64, 64)            # NN, 64x64x16 tiles: class 0
         torch.cuda.synchronize()
-        ms, work, cnt = (ctypes.c_double * 35)(), (ctypes.c_double * 35)(), (ctypes.c_int64 * 35)()
+        ms, work, cnt = (ctypes.c_double * PROF_NCLASS)(), (ctypes.c_double * PROF_NCLASS)(), (ctypes.c_int64 * PROF_NCLASS)()
         assert L.pm_prof_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p),
                              ctypes.cast(cnt, ctypes.c_void_p)) == 0
         return list(ms), list(work), list(cnt)

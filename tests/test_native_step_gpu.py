@@ -7,6 +7,7 @@ import json
 import pytest
 import torch
 
+from polyphemus_amd._lib import PROF_NCLASS
 from polyphemus_amd.model import VAE
 from polyphemus_amd.synthetic import synthetic_batch
 from polyphemus_amd.trainer import HipTrainer
@@ -80,15 +81,15 @@ def test_measured_native_path_matches_reference_golden(case):
     L.pm_prof_configure(-1, 1)
     L.pm_prof_begin(512)
     got = tr.losses_dict(tr.train_step(g, eps))
-    ms, work, cnt = (ctypes.c_double * 35)(), (ctypes.c_double * 35)(), (ctypes.c_int64 * 35)()
+    ms, work, cnt = (ctypes.c_double * PROF_NCLASS)(), (ctypes.c_double * PROF_NCLASS)(), (ctypes.c_int64 * PROF_NCLASS)()
     L.pm_prof_end(*(ctypes.cast(a, ctypes.c_void_p) for a in (ms, work, cnt)))
     info = tr.step_info()
     d, nl = cfg["d"], cfg["gnn_n_layers"]
     assert info["compact"] == 1 and info["planes"] == 1 and info["n_slots"] == g.n_slots, info
     planes_tn, planesb_nn, planesb_nt, planes_nn, planes_nt = cnt[8 * 3 + 2], cnt[9 * 3], cnt[9 * 3 + 1], cnt[8 * 3], cnt[8 * 3 + 1]
     assert planes_tn == 2 * nl, list(cnt)                       # GCL weight gradients of both stacks
-    if d % 128 == 0:
-        assert info["b_frag"] == 1 and planesb_nn == 2 * nl and planesb_nt == 2 * nl, (info, list(cnt))
+    if d % 128 == 0:                                            # forward: the fused layer kernel (gcl.hip)
+        assert info["b_frag"] == 1 and cnt[35] == 2 * nl and planesb_nn == 0 and planesb_nt == 2 * nl, (info, list(cnt))
     else:
         assert planes_nn == 2 * nl and planes_nt == 2 * nl, list(cnt)
     for k, v in json.loads(str(z["train1/losses"])).items():
@@ -210,6 +211,28 @@ def test_native_step_on_foreign_graphs_takes_the_seven_block_path():
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(lb[k])), k
     assert rel_err(ga, gb) < 1e-4
+
+
+def test_debug_mode_rejects_a_wrong_track_unique_flag(monkeypatch):
+    """A caller that attaches `track_unique = True` to a batch that breaks the rule would silently get a wrong compact
+    GCL; under PM_DEBUG=1 the trainer reads the violation count the plan kernels keep (plan.hip cnt[4]) and raises."""
+    monkeypatch.setenv("PM_DEBUG", "1")
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    batch = synthetic_batch(6, 2, p=0.3, seed=4)
+    et = batch.edge_type.clone()
+    trk = torch.nonzero(et < 4).flatten()
+    et[trk[::3]] = (et[trk[::3]] + 1) % 4
+    batch.edge_type = et
+    batch.track_unique = True                                      # wrong on purpose
+    batch.__dict__.pop("_edge_attrs", None)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.train()
+    tr = HipTrainer(vae, lr=5e-6, native=True)
+    with pytest.raises(RuntimeError, match="more than one track"):
+        tr.train_step(batch.to(DEV), torch.randn(6, 32, device=DEV))
+    good = synthetic_batch(6, 2, p=0.3, seed=4).to(DEV)             # a well-formed batch passes the same check
+    tr.train_step(good, torch.randn(6, 32, device=DEV))
 
 
 def test_native_step_with_all_fifteen_slots_active():

@@ -49,8 +49,17 @@ __host__ __device__ static inline uint32_t pm_mix32(uint32_t x) {
 __host__ __device__ static inline uint32_t pm_edge_key(uint32_t seed, uint32_t layer_uid, uint32_t eid) {
   return pm_mix32(pm_mix32(seed ^ (layer_uid + 1u) * 0x9E3779B9U) ^ (eid * 0x85EBCA6BU + 0x27D4EB2FU));
 }
+// One full mix per GROUP of four consecutive channels; the four channels of a group take the group's word times four
+// different odd constants (x -> x*K mod 2^32 is a bijection, so each is uniform; the keep decision reads the top 24
+// bits).  The kernels own four consecutive channels per lane, so a lane pays one mix per edge instead of four.
+__host__ __device__ static inline uint32_t pm_group_hash(uint32_t edge_key, uint32_t group) {
+  return pm_mix32(edge_key + group * 0xC2B2AE35U);
+}
+__host__ __device__ static inline uint32_t pm_lane_hash(uint32_t group_hash, uint32_t j) {
+  return group_hash * (j == 0 ? 1u : j == 1 ? 0x9E3779B1U : j == 2 ? 0x85EBCA77U : 0xC2B2AE3DU);
+}
 __host__ __device__ static inline uint32_t pm_elem_hash(uint32_t edge_key, uint32_t channel) {
-  return pm_mix32(edge_key + channel * 0xC2B2AE35U);
+  return pm_lane_hash(pm_group_hash(edge_key, channel >> 2), channel & 3u);
 }
 // keep iff top 24 bits >= p * 2^24
 __host__ __device__ static inline uint32_t pm_keep_threshold(float p) {

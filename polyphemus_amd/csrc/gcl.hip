@@ -31,10 +31,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define GCL_BDEPTH 2          // k-steps of weight fragments in flight per consumer wave
 #endif
 #ifndef GCL_TRACE
-#define GCL_TRACE 0           // development: workgroup 0 writes s_memtime stamps into col_stats instead of the sums
+#define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
 #endif
 #if GCL_TRACE
-#define STAMP() do { if (blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4) && nst < 60) \
+#define STAMP() do { if (blockIdx.x == (GCL_TRACE - 1) && lane == 0 && (wave == 0 || wave == 4) && nst < 60) \
     reinterpret_cast<long long*>(g.colstats)[wave * 16 + nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP() do {} while (0)
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   int nst = 0;
   STAMP();
 #if GCL_TRACE
-  if (blockIdx.x == 8 && tid == 0) reinterpret_cast<long long*>(g.colstats)[200] = (long long)__builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == (GCL_TRACE - 1) && tid == 0) reinterpret_cast<long long*>(g.colstats)[200] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   // ---- prologue (all waves): the rows' nodes; the distance table
   if (tid < BM) {
@@ -245,10 +245,11 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
                              fmaxf(xe.w * tv.w, 0.f));
       if (DROP) {
         const uint32_t key = pm_edge_key(g.seed, g.layer_uid, (uint32_t)eid);
-        m.x = (pm_elem_hash(key, f + 0) >> 8) >= g.thresh ? m.x * g.scale : 0.f;
-        m.y = (pm_elem_hash(key, f + 1) >> 8) >= g.thresh ? m.y * g.scale : 0.f;
-        m.z = (pm_elem_hash(key, f + 2) >> 8) >= g.thresh ? m.z * g.scale : 0.f;
-        m.w = (pm_elem_hash(key, f + 3) >> 8) >= g.thresh ? m.w * g.scale : 0.f;
+        const uint32_t gh = pm_group_hash(key, f >> 2);
+        m.x = (pm_lane_hash(gh, 0) >> 8) >= g.thresh ? m.x * g.scale : 0.f;
+        m.y = (pm_lane_hash(gh, 1) >> 8) >= g.thresh ? m.y * g.scale : 0.f;
+        m.z = (pm_lane_hash(gh, 2) >> 8) >= g.thresh ? m.z * g.scale : 0.f;
+        m.w = (pm_lane_hash(gh, 3) >> 8) >= g.thresh ? m.w * g.scale : 0.f;
       }
       return m;
     };
@@ -382,19 +383,19 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   constexpr int NG = 512 / D, RG = BM / NG;                    // row groups, rows per group
   double cs = 0.0, cq = 0.0;
   const int col = tid % D, rg = tid / D;
-  if (tid < 512) {
-#pragma unroll 4
+  if (tid < 512) {                                             // (rows past the end: dropped store, +0 to the sums)
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(g.h, 0, GCL_OOB, 0x00020000);
+#pragma unroll 8
     for (int k = 0; k < RG; ++k) {
       const int rr = rg * RG + k, n = sNode[rr];
-      if (n < 0) continue;
-      const float v = sH[rr * HS + col];
-      g.h[(int64_t)n * D + col] = v;
+      const float v = n >= 0 ? sH[rr * HS + col] : 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), hrs, n >= 0 ? (n * D + col) * 4 : GCL_OOB, 0, 0);
       cs += (double)v; cq += (double)v * (double)v;
     }
   }
   STAMP();
 #if GCL_TRACE
-  if (blockIdx.x == 8 && tid == 0) reinterpret_cast<long long*>(g.colstats)[201] = (long long)__builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == (GCL_TRACE - 1) && tid == 0) reinterpret_cast<long long*>(g.colstats)[201] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   if (g.colstats && !GCL_TRACE) {
     double* sS = reinterpret_cast<double*>(sT);                // [NG][2][D] (the distance table is no longer needed)

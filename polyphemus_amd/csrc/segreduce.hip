@@ -101,10 +101,11 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
         float4 m = make_float4(fmaxf(xv.x * tv.x, 0.f), fmaxf(xv.y * tv.y, 0.f), fmaxf(xv.z * tv.z, 0.f),
                                fmaxf(xv.w * tv.w, 0.f));
         if (DROP) {
-          m.x = (pm_elem_hash(key, c[v] + 0) >> 8) >= thresh ? m.x * scale : 0.f;
-          m.y = (pm_elem_hash(key, c[v] + 1) >> 8) >= thresh ? m.y * scale : 0.f;
-          m.z = (pm_elem_hash(key, c[v] + 2) >> 8) >= thresh ? m.z * scale : 0.f;
-          m.w = (pm_elem_hash(key, c[v] + 3) >> 8) >= thresh ? m.w * scale : 0.f;
+          const uint32_t gh = pm_group_hash(key, c[v] >> 2);
+          m.x = (pm_lane_hash(gh, 0) >> 8) >= thresh ? m.x * scale : 0.f;
+          m.y = (pm_lane_hash(gh, 1) >> 8) >= thresh ? m.y * scale : 0.f;
+          m.z = (pm_lane_hash(gh, 2) >> 8) >= thresh ? m.z * scale : 0.f;
+          m.w = (pm_lane_hash(gh, 3) >> 8) >= thresh ? m.w * scale : 0.f;
         }
         acc[v].x += m.x; acc[v].y += m.y; acc[v].z += m.z; acc[v].w += m.w;
       }
@@ -295,10 +296,11 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
           const float g[4] = {g4[u].x * w[u], g4[u].y * w[u], g4[u].z * w[u], g4[u].w * w[u]};
           const float ts[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
           float gt[4];
+          const uint32_t gh = DROP ? pm_group_hash(key[u], c[v] >> 2) : 0u;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             bool on = xs[j] * ts[j] > 0.f;
-            if (DROP) on = on && ((pm_elem_hash(key[u], c[v] + j) >> 8) >= thresh);
+            if (DROP) on = on && ((pm_lane_hash(gh, j) >> 8) >= thresh);
             const float gg = on ? g[j] : 0.f;
             ap[j] += gg * ts[j];
             gt[j] = gg * xs[j];

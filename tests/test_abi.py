@@ -74,3 +74,31 @@ def test_dropout_hash_is_host_callable_and_stable():
     a = L.pm_dropout_hash(1234, 3, 17, 5)
     assert a == L.pm_dropout_hash(1234, 3, 17, 5) and 0 <= a < (1 << 24)
     assert a != L.pm_dropout_hash(1234, 3, 17, 6)
+
+
+def test_dropout_stream_statistics_and_numpy_replica():
+    """The counter-based dropout stream (common.h: one 32-bit mix per (edge, group of four channels), the four channels
+    of a group = that word times four odd constants): the numpy restatement the oracle replays equals the library's
+    host entry bit for bit; the keep rate is 1 - p; the four channels of a group, neighbouring groups and neighbouring
+    edges drop independently (joint drop rate = p^2 within sampling error)."""
+    import numpy as np
+    from util import dropout_keep_np
+    L = _lib.lib()
+    p, d = 0.1, 64
+    eids = np.arange(20000)
+    keep = dropout_keep_np(77, 3, eids, d, p).astype(bool)                       # [E, d]
+    thr = int(np.float32(p) * np.float32(16777216.0))
+    for e in (0, 1, 4097, 19999):
+        for c in (0, 1, 2, 3, 4, 7, 62, 63):
+            assert (L.pm_dropout_hash(77, 3, int(e), c) >= thr) == bool(keep[e, c])
+    drop = ~keep
+    n = drop.size
+    assert abs(drop.mean() - p) < 4 * (p * (1 - p) / n) ** 0.5
+    sig2 = 4 * (p * p * (1 - p * p) / (drop.shape[0] * (d // 4))) ** 0.5          # 4 sigma of a joint rate
+    for a in range(4):
+        for b in range(a + 1, 4):                                                 # channels a, b of the same group
+            assert abs((drop[:, a::4] & drop[:, b::4]).mean() - p * p) < sig2, (a, b)
+    assert abs((drop[:, :-4] & drop[:, 4:]).mean() - p * p) < sig2                # same lane, next group
+    assert abs((drop[:-1] & drop[1:]).mean() - p * p) < sig2                      # same channel, next edge
+    other = dropout_keep_np(77, 4, eids, d, p).astype(bool)                       # next layer: another stream
+    assert abs((drop & ~other).mean() - p * p) < sig2

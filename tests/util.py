@@ -78,8 +78,9 @@ def dropout_keep_np(seed, layer_uid, eids, d, p):
     eids = np.asarray(eids, dtype=np.uint64)
     k0 = _mix32(np.array([(seed & 0xFFFFFFFF) ^ (((layer_uid + 1) * 0x9E3779B9) & 0xFFFFFFFF)], np.uint64))[0]
     ek = _mix32(k0 ^ ((eids * np.uint64(0x85EBCA6B) + np.uint64(0x27D4EB2F)) & _M32))
-    ch = (np.arange(d, dtype=np.uint64) * np.uint64(0xC2B2AE35)) & _M32
-    h = _mix32((ek[:, None] + ch[None, :]) & _M32)
+    grp = ((np.arange(d, dtype=np.uint64) >> np.uint64(2)) * np.uint64(0xC2B2AE35)) & _M32    # one mix per 4 channels,
+    lane = np.array([1, 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D], np.uint64)[np.arange(d) & 3]        # times a per-lane odd constant
+    h = (_mix32((ek[:, None] + grp[None, :]) & _M32) * lane[None, :]) & _M32
     thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
     return ((h >> np.uint64(8)) >= thresh).astype(np.float32)
 

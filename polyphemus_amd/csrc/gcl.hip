@@ -49,7 +49,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int BM = 64;        // rows (nodes) per workgroup
 constexpr int CH = 128;       // features of one relation block per chunk
-constexpr int EC = 12;        // edges per node cached in LDS (the reference's graphs: <= 8); beyond: read from global
 constexpr int EMAX = 3;       // edges per (node, relation) gathered in one go (beyond: a serial tail loop)
 #ifndef GCL_NPW
 #define GCL_NPW 8
@@ -83,9 +82,9 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   char* const img0 = smem;                                   // two images
   float* const sT = reinterpret_cast<float*>(smem + 2 * IMG);  // [32][D] distance table
   int* const sNode = reinterpret_cast<int*>(sT + PM_N_DIST * D);   // [BM] node of the row (-1: past the end)
-  int* const sPtr = sNode + BM;                              // [BM][7] CSR offsets of the node's six relations
-  int* const sEdge = sPtr + BM * 7;                          // [BM][EC] source node | distance << 27
-  int* const sEid = sEdge + BM * EC;                         // [BM][EC] (DROP)
+  // per (row, relation block track / onset / next): the first EMAX edges as source node | distance << 27, then the
+  // edge count and the CSR position of the first edge (longer lists are redone from global)
+  int* const sSlot = sNode + BM;                             // [BM][3][8]: w0 w1 w2 count | first eid0 eid1 eid2
   constexpr int HS = D + 8;
   float* const sH = reinterpret_cast<float*>(smem);          // [BM][HS] output tile (epilogue; over the images)
 
@@ -131,28 +130,29 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   for (int i = tid; i < PM_N_DIST * D / 4; i += NTHR)
     reinterpret_cast<float4*>(sT)[i] = reinterpret_cast<const float4*>(g.T)[i];
   __syncthreads();
-  // Row metadata (consumer waves, while the producers build the self block): four threads per row fetch the row's CSR
-  // offsets and its first EC edges — a chain of two global reads per thread, no barrier in between.
+  // Row metadata (consumer waves, while the producers build the self block): four threads per row, three of them fetch
+  // one relation block's CSR range and its first EMAX edges — a chain of two global reads per thread, no barrier between.
   auto load_metadata = [&]() {
     const int rr = tid >> 2, j = tid & 3, n = sNode[rr];
-    int b0 = 0, b6 = 0;
+    if (j == 3) return;
+    const int rel = j == 0 ? grp : 3 + j;
+    int b = 0, cnt = 0;
     if (n >= 0) {
-      const int* rp = g.rowptr + n * PM_N_REL;
-      b0 = rp[0]; b6 = rp[6];
-      sPtr[rr * 7 + j] = j == 0 ? b0 : rp[j];
-      if (j < 3) sPtr[rr * 7 + 4 + j] = j == 2 ? b6 : rp[4 + j];
-    } else {
-      sPtr[rr * 7 + j] = 0;
-      if (j < 3) sPtr[rr * 7 + 4 + j] = 0;
+      b = g.rowptr[n * PM_N_REL + rel];
+      cnt = g.rowptr[n * PM_N_REL + rel + 1] - b;
     }
+    int w[EMAX], id[EMAX];
 #pragma unroll
-    for (int k = 0; k < EC / 4; ++k) {
-      const int e = j + 4 * k, p = b0 + e;
-      if (p < b6) {
-        sEdge[rr * EC + e] = g.csr_src[p] | (g.csr_dist[p] << 27);
-        if (DROP) sEid[rr * EC + e] = g.csr_eid[p];
+    for (int e = 0; e < EMAX; ++e) {
+      w[e] = 0; id[e] = 0;
+      if (e < cnt) {
+        w[e] = g.csr_src[b + e] | (g.csr_dist[b + e] << 27);
+        if (DROP) id[e] = g.csr_eid[b + e];
       }
     }
+    int4* dst = reinterpret_cast<int4*>(sSlot + (rr * 3 + j) * 8);
+    dst[0] = make_int4(w[0], w[1], w[2], cnt);
+    dst[1] = make_int4(b, id[0], id[1], id[2]);
   };
 
   STAMP();
@@ -215,25 +215,19 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
       for (int ps = 0; ps < NPS; ++ps) put(img, ps * RPP + prow, q, xs[ps]);
       return;
     }
-    const int rel = blk == 0 ? grp : (blk == 1 ? 4 : 5);
     float4 xv[NPS][EMAX];
-    int ew[NPS][EMAX], ecnt[NPS], npre[NPS];
+    int ew[NPS][EMAX], ecnt[NPS];
     bool redo = false;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
-      const int rr = ps * RPP + prow;
-      const int b0 = sPtr[rr * 7], b = sPtr[rr * 7 + rel], e_ = sPtr[rr * 7 + rel + 1];
-      const int eb = b - b0;
-      ecnt[ps] = e_ - b;                                         // (rows past the end: all offsets 0, no edges)
-      const bool fits = eb + EMAX <= EC;
-      redo = redo || ecnt[ps] > EMAX || (!fits && ecnt[ps] > 0);
-      npre[ps] = fits ? ecnt[ps] : 0;
+      const int4 sl = *reinterpret_cast<const int4*>(sSlot + ((ps * RPP + prow) * 3 + blk) * 8);
+      ew[ps][0] = sl.x; ew[ps][1] = sl.y; ew[ps][2] = sl.z;      // source node | distance << 27
+      ecnt[ps] = sl.w;                                           // (rows past the end: no edges)
+      redo = redo || ecnt[ps] > EMAX;
 #pragma unroll
-      for (int e = 0; e < EMAX; ++e) {
-        ew[ps][e] = sEdge[rr * EC + (fits ? eb : 0) + e];        // source node | distance << 27
+      for (int e = 0; e < EMAX; ++e)
         xv[ps][e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-            xrs, (e < npre[ps] && !(GCL_ABL & 16)) ? ((ew[ps][e] & 0x7ffffff) * D + f) * 4 : GCL_OOB, 0, 0));
-      }
+            xrs, (e < ecnt[ps] && !(GCL_ABL & 16)) ? ((ew[ps][e] & 0x7ffffff) * D + f) * 4 : GCL_OOB, 0, 0));
     }
     __builtin_amdgcn_sched_barrier(0);       // every gather of the chunk is in flight before the first one is waited for
     STAMP();
@@ -260,9 +254,8 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
 #pragma unroll
       for (int e = 0; e < EMAX; ++e) {
         // (slot empty in both rows of the wave: nothing to add — skipping it saves the dropout hashes)
-        if (__builtin_amdgcn_ballot_w64(e < npre[ps]) == 0) continue;
-        const int eb = sPtr[rr * 7 + rel] - sPtr[rr * 7];
-        const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? sEid[rr * EC + (eb + EMAX <= EC ? eb : 0) + e] : 0);
+        if (__builtin_amdgcn_ballot_w64(e < ecnt[ps]) == 0) continue;
+        const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? sSlot[(rr * 3 + blk) * 8 + 5 + e] : 0);
         acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
       }
       // 1 / max(count, 1) for count <= 3: the correctly rounded quotients, as the division gives them
@@ -274,8 +267,8 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
 #pragma unroll 1
       for (int ps = 0; ps < NPS; ++ps) {
         const int rr = ps * RPP + prow;
-        const int b0 = sPtr[rr * 7], b = sPtr[rr * 7 + rel], cnt = sPtr[rr * 7 + rel + 1] - b;
-        if (cnt <= EMAX && (b - b0 + EMAX <= EC || cnt == 0)) continue;
+        const int cnt = sSlot[(rr * 3 + blk) * 8 + 3], b = sSlot[(rr * 3 + blk) * 8 + 4];
+        if (cnt <= EMAX) continue;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int e = 0; e < cnt; ++e) {
@@ -411,7 +404,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
 }
 
 static size_t gcl_lds_bytes(int d, bool drop) {
-  return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 7 + BM * EC * (drop ? 2 : 1)) * 4;
+  return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 3 * 8) * 4;
 }
 
 extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,

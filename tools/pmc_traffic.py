@@ -24,7 +24,7 @@ from tools.trace_summary import short  # noqa: E402
 
 
 def klass(kernel_name):
-    """bench.py's class name of a kernel (gemm_<layout>_<tile> / segreduce_fwd / segreduce_bwd) or None."""
+    """bench.py's class name of a kernel (gemm_<layout>_<tile> / segreduce_fwd / segreduce_bwd / gcl_fwd) or None."""
     s = short(kernel_name)
     if s.startswith("k_gemm<"):
         body = s[len("k_gemm<"):-1].split(",")
@@ -33,6 +33,8 @@ def klass(kernel_name):
         return "segreduce_fwd"
     if s.startswith("k_segreduce_bwd"):
         return "segreduce_bwd"
+    if s.startswith("k_gcl_fwd"):
+        return "gcl_fwd"
     return None
 
 

@@ -162,6 +162,14 @@ int pm_gcl_forward_fused(const float* x /* [N,d] */, const float* T /* [32,d] */
                          const uint16_t* w_frag, const float* bias /* [d] or NULL */, int32_t use_classes,
                          float* h /* [N,d] */, double* col_stats /* [PM_BN_REPL][2][d] += or NULL */,
                          uint16_t* planes /* or NULL */, int64_t plane_stride, pm_stream_t stream);
+/* Input gradient of that product, dA'[rows_t] = dh[rows_t] @ [W_t; W_4; W_5; root]^T (the autograd of model.py:104-119),
+ * A-stationary (gcl.hip): a workgroup keeps the dh planes of 64 rows of a track group in LDS and walks all 4d output
+ * columns; `w_frag_t` = pm_split_planes_frag kind 0 of the layer's [7d, d] weight.  Same result as the grouped planes
+ * product with transB (blocks of row tiles without onset / next receivers are not written when use_classes != 0: the
+ * segment-reduce backward never reads them).  d in {128, 256}, compact graphs. */
+int pm_gcl_input_grad_fused(const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t plane_stride, const int32_t* plan,
+                            int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
+                            float* dA /* [N,4d] */, pm_stream_t stream);
 /* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
  * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
  * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */

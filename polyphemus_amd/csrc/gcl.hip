@@ -403,6 +403,216 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Input gradient of the layer's product: dA'[rows_t] = dh[rows_t] @ [W_t; W_4; W_5; root]^T, one kernel, A-stationary.
+// Reference: the autograd of GCL.forward's weight products (model.py:104-119).  The grouped planes product it
+// replaces (gemm.hip planesB NT, 64x128 tiles, K = d) is a short-K GEMM: 2072 workgroups that each stage their dh rows,
+// run 8 k-steps and leave.  Here a workgroup owns 64 rows of a track group's list for ALL 4d output columns: the dh
+// planes of its rows (64 x d x 3 bf16) are loaded into LDS once, then the four waves walk the output blocks
+// [track | onset | next | self] (a block = d columns; blocks no row of the tile receives edges of are skipped, as the
+// grouped product skips them), each wave 64 rows by d/4 columns, B fragments straight from the fragment-major
+// transposed weight planes in L2, GCL_BDEPTH k-steps ahead.  Same products, same k order as the grouped product.
+#if GCL_TRACE
+__device__ long long g_gcl_trace[256];
+extern "C" int pm_debug_read_trace(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gcl_trace), sizeof(long long) * 256) == hipSuccess ? 0 : 1;
+}
+#define STAMP2() do { if (blockIdx.x == (GCL_TRACE - 1) && lane == 0 && (wave == 0 || wave == 4) && nst < 60) \
+    g_gcl_trace[wave * 16 + nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP2() do {} while (0)
+#endif
+// The output never leaves through the MFMA waves: vmcnt retires in order, so 64 row-segment stores in front of the next
+// block's weight-fragment loads would put the write latency into every block.  Waves 4..7 take each finished block
+// from an LDS stage (64 x d fp32) and store it as whole 4*d-byte rows.
+template <int D>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_list, const int* __restrict__ trk_cnt,
+           const char* __restrict__ wfrag, float* __restrict__ dA, int N, int use_classes) {
+  constexpr int TN = D / 128;            // 32-column MFMA tiles per wave (its D/4 columns of a block)
+  constexpr int KS = D / 16;             // k-steps
+  constexpr int RB = D * 2;              // bytes of one image row (one plane)
+  constexpr int PL = BM * RB;            // one plane of the image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
+  int* const sNode = reinterpret_cast<int*>(sC);               // the rows' nodes (until the first block is staged)
+
+  int cnt[4], nt[4], nwg = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { cnt[q] = trk_cnt[q]; nt[q] = (cnt[q] + BM - 1) / BM; nwg += nt[q]; }
+  int t = blockIdx.x;
+  if (t >= nwg) return;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int grp = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (grp == q && t >= nt[q]) { t -= nt[q]; grp = q + 1; }
+  const int M = grp == 0 ? cnt[0] : grp == 1 ? cnt[1] : grp == 2 ? cnt[2] : cnt[3];
+  const int m0 = t * BM;
+  const int* list = trk_list + (int64_t)grp * N;
+  bool use_on = true, use_nx = true;
+  if (use_classes) {
+    const int* cb = trk_cnt + 8 + grp * 5;
+    use_on = m0 < cb[3] && m0 + BM > cb[1];
+    use_nx = m0 < cb[4] && m0 + BM > cb[2];
+  }
+  const int nblk = 2 + (use_on ? 1 : 0) + (use_nx ? 1 : 0);
+  auto blk_of = [&](int q) { return q == 0 ? 0 : (q == nblk - 1 ? 3 : (q == 1 ? (use_on ? 1 : 2) : 2)); };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  int nst = 0;
+  STAMP2();
+  if (tid < BM) sNode[tid] = m0 + tid < M ? list[m0 + tid] : -1;
+  __syncthreads();
+  STAMP2();
+  if (wave >= 4) {
+    // ---- store waves: block q of the stage -> dA rows (one 16-byte piece per lane: a whole 4*D-byte row per D/4 lanes)
+    constexpr int LPR = D / 4, RPW = 64 / LPR, NR = BM / (4 * RPW);     // lanes per row, rows per wave-instruction, per thread
+    const int st = tid - 256, c4 = st % LPR, r0 = st / LPR;
+    int node[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) node[k] = sNode[r0 + k * 4 * RPW];
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(dA, 0, GCL_OOB, 0x00020000);
+    __syncthreads();                                           // (image filled; the stage may be written from here on)
+#pragma unroll 1
+    for (int qb = 0; qb < nblk; ++qb) {
+      __syncthreads();                                         // consumers: stage free -> they fill it
+      __syncthreads();                                         // stage holds block qb
+      STAMP2();
+      const int blk = blk_of(qb);
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int rr = r0 + k * 4 * RPW;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sC + rr * D + c4 * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(v, crs, node[k] >= 0 ? (int)(((int64_t)node[k] * 4 * D + blk * D + c4 * 4) * 4) : GCL_OOB, 0, 0);
+      }
+      STAMP2();
+    }
+    return;
+  }
+  // ---- the rows' dh planes -> XOR-swizzled LDS image (16-byte chunk c of row r at chunk c ^ (r & 15))
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
+    constexpr int CPR = D / 8, NCHK = BM * CPR / 256;            // chunks per row, chunks per thread and plane
+    u32x4 v[3][NCHK];
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR, n = sNode[rr];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        v[p][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<u32x4*>(smem + p * PL + rr * RB + ((ch ^ (rr & 15)) << 4)) = v[p][k];
+    }
+  }
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
+  auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global step gs = block index * KS + k-step
+    const int qb = gs / KS, ks = gs % KS;
+    int off = GCL_OOB;
+    if (qb < nblk) {
+      const int blk = blk_of(qb);
+      const int wrow = (blk == 0 ? grp * D : (3 + blk) * D) + wave * (D / 4);   // first stacked weight row of this wave's columns
+      off = ((wrow >> 5) * KS + ks) * 3072 + lane * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, off == GCL_OOB ? off : off + j * KS * 3072 + p * 1024, 0, 0));
+  };
+  bf16x8 bq[GCL_BDEPTH][3][TN];
+#pragma unroll
+  for (int s = 0; s < GCL_BDEPTH; ++s) bload(bq[s], s);
+  STAMP2();
+  __syncthreads();
+  STAMP2();
+  // A fragments of k-step ks (both 32-row blocks, three planes); read one step ahead of the MFMAs that use them
+  auto aload = [&](bf16x8 (&a)[3][2], int ks) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rr = i * 32 + li;
+        a[p][i] = *reinterpret_cast<const bf16x8*>(smem + p * PL + rr * RB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
+      }
+  };
+  bf16x8 af[2][3][2];
+  aload(af[0], 0);
+#pragma unroll 1
+  for (int qb = 0; qb < nblk; ++qb) {
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      aload(af[(ks + 1) & 1], (ks + 1) % KS);                    // (the last step: step 0 of the next block, same image)
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+      bload(bq[ks % GCL_BDEPTH], qb * KS + ks + GCL_BDEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    STAMP2();
+    __syncthreads();                                             // the store waves have read the previous block
+    STAMP2();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / 4) + j * 32 + li] = acc[i][j][r];
+    STAMP2();
+    __syncthreads();
+  }
+}
+
+extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
+                                       int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
+                                       float* dA, pm_stream_t stream) {
+  if (!dh_planes || !plan || !w_frag_t || !dA || N <= 0 || (d != 128 && d != 256) || plane_stride < (int64_t)N * d ||
+      (plane_stride & 7) || ((uintptr_t)dh_planes % 16) || ((uintptr_t)w_frag_t % 16) || ((uintptr_t)dA % 16) ||
+      plane_stride * 6 >= 0x7fffffffLL || (int64_t)N * 4 * d * 4 >= 0x7fffffffLL)
+    return PM_E_INVALID;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(pm_cdiv(N, BM) + 4)), block(512);
+  const size_t lds = (size_t)3 * BM * d * 2 + (size_t)BM * d * 4;
+  const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
+#define LAUNCH(DD)                                                                                                     \
+  do {                                                                                                                 \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      hipFuncSetAttribute((const void*)k_gcl_dagg<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_gcl_dagg<DD>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt,       \
+                       reinterpret_cast<const char*>(w_frag_t), dA, N, use_classes);                                   \
+  } while (0)
+  if (d == 256) LAUNCH(256); else LAUNCH(128);
+#undef LAUNCH
+  pm_prof_close(st, pe);
+  return pm_check_launch();
+}
+
 static size_t gcl_lds_bytes(int d, bool drop) {
   return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 3 * 8) * 4;
 }

@@ -264,7 +264,11 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
         if (sv.Wft) q.b_frag = sv.Wft + (int64_t)i * sv.wf_stride;
       }
-      RUN(pm_gemm_f32_desc(&q, c.st));
+      if (c.planes && sv.Wft && (d == 128 || d == 256) && gcl_fused_on())      // A-stationary kernel (gcl.hip)
+        RUN(pm_gcl_input_grad_fused(dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
+                                      getenv("PM_GCL_NO_CLASSES") ? 0 : 1, dA, c.st));
+      else
+        RUN(pm_gemm_f32_desc(&q, c.st));
       PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
       w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM | PM_GEMM_PARTITION; w.split_k = 0;
       w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;

@@ -212,6 +212,16 @@ def gcl_forward_fused(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: 
     return h
 
 
+def gcl_input_grad_fused(dh_planes, plan: Plan, d: int, w_frag_t, use_classes: bool = True, out=None):
+    """`pm_gcl_input_grad_fused`: dA' [N, 4d] = dh @ [W_t; W_4; W_5; root]^T per track group, A-stationary;
+    `dh_planes` int16 [3, N*d] (`split_planes(dh)`), `w_frag_t` = `split_planes_frag(W, 0)`."""
+    N = plan.N
+    dA = out if out is not None else torch.empty(N, 4 * d, dtype=F32, device=dh_planes.device)
+    call("pm_gcl_input_grad_fused", ptr(dh_planes), dh_planes.shape[1], ptr(plan.buf), N, plan.E, plan.G, d, ptr(w_frag_t),
+         1 if use_classes else 0, ptr(dA), stream())
+    return dA
+
+
 def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int, out=None):
     _chk(x, F32, "x"); _chk(T, F32, "T")
     N, d = x.shape

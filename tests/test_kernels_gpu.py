@@ -790,6 +790,42 @@ def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     assert torch.equal(h2, h1)
 
 
+@pytest.mark.parametrize("d", [128, 256])
+def test_gcl_input_grad_fused_equals_grouped_product(d):
+    """`pm_gcl_input_grad_fused` (dh rows resident in LDS, all 4d output columns per workgroup) against the grouped planes
+    product with transB it replaces: same six products in the same k order -> BIT-identical wherever the segment-reduce
+    backward reads dA' (track and self blocks of every row, onset / next blocks of the rows that receive such edges)."""
+    cpu = synthetic_batch(40, 2, p=0.3, seed=19)
+    b, plan = make_plan(cpu)
+    N, dd = cpu.num_nodes, d * d
+    torch.manual_seed(4)
+    dh = torch.randn(N, d, device=DEV)
+    W = torch.randn(7 * d, d, device=DEV) / d ** 0.5
+    dhp, Wp, Wft = ops.split_planes(dh), ops.split_planes(W), ops.split_planes_frag(W, 0)
+    tl, tc = plan.field("trk_list"), plan.field("trk_cnt")
+    dA0 = torch.zeros(N, 4 * d, device=DEV)
+    ops.gemm_desc(dhp, Wp, dA0, N, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
+                  b_shared_off=3 * dd, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), rowmap=tl, rows_per_entry=1,
+                  dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1, partition=True, planes=True,
+                  class_ptr=tc[8:], class_block=d, b_frag=Wft)
+    dA1 = ops.gcl_input_grad_fused(dhp, plan, d, Wft, out=torch.full((N, 4 * d), float("nan"), device=DEV))
+    dst, et = cpu.edge_index[1], cpu.edge_type
+    on, nx = torch.zeros(N, dtype=torch.bool), torch.zeros(N, dtype=torch.bool)
+    on[dst[et == 4]] = True
+    nx[dst[et == 5]] = True
+    keep = torch.ones(N, 4, d, dtype=torch.bool)
+    keep[~on, 1] = False
+    keep[~nx, 2] = False
+    keep = keep.view(N, 4 * d).to(DEV)
+    assert torch.equal(dA1[keep], dA0[keep])
+    trel_t = plan.field("node_trel").long()[:N]
+    Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()       # [4, 4d, d]
+    want = torch.einsum("nk,njk->nj", dh.double(), Wn[trel_t])
+    assert rel_err(dA1[keep], want[keep]) < 2e-6
+    dA2 = ops.gcl_input_grad_fused(dhp, plan, d, Wft, use_classes=False)
+    assert torch.equal(dA2[keep], dA1[keep]) and bool(torch.isfinite(dA2).all())
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

@@ -40,14 +40,34 @@ def main():
         for _ in range(n): fn()
         e.record(); torch.cuda.synchronize()
         return a.elapsed_time(e) / n * 1e3
+    dh = torch.randn(N, d, device="cuda")
+    dhp, Wft = ops.split_planes(dh), ops.split_planes_frag(W, 0)
+    dA = torch.empty(N, 4 * d, device="cuda")
+    def nt_unfused():
+        ops.gemm_desc(dhp, Wp, dA, N, 4 * d, d, d, d, 4 * d, transB=True, b_group_stride=dd, b_split_rows=d,
+                      b_shared_off=3 * dd, a_plane_stride=dh.numel(), b_plane_stride=W.numel(), rowmap=tl, rows_per_entry=1,
+                      dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1, partition=True, planes=True,
+                      class_ptr=tc[8:], class_block=d, b_frag=Wft)
+    def nt_fused(): ops.gcl_input_grad_fused(dhp, plan, d, Wft, out=dA)
     tag = os.path.basename(os.environ.get("PM_LIB_PATH", "default"))
-    which = os.environ.get("WHICH", "ufp")
+    which = os.environ.get("WHICH", "ufpn")
     out = [tag, f"N={N}"]
     if "u" in which: out.append(f"unfused {timeit(unfused):.1f} us")
     if "f" in which: out.append(f"fused {timeit(fused):.1f} us")
     if "p" in which: out.append(f"fused(no A' out) {timeit(fused_np):.1f} us")
+    if "n" in which: out.append(f"dA' grouped {timeit(nt_unfused):.1f} us  A-stationary {timeit(nt_fused):.1f} us")
     print("  ".join(out), flush=True)
-    if os.environ.get("TRACE"):
+    if os.environ.get("TRACE") == "n":
+        import ctypes
+        from polyphemus_amd._lib import lib
+        nt_fused(); torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * 256)()
+        lib().pm_debug_read_trace(buf)
+        tr = list(buf)
+        for w in (0, 4):
+            st = [v for v in tr[w * 16: w * 16 + 60] if v]
+            print("dagg wave", w, [round((v - st[0]) / 100.0, 2) for v in st])
+    elif os.environ.get("TRACE"):
         s.zero_()
         fused()
         torch.cuda.synchronize()

@@ -170,6 +170,14 @@ int pm_gcl_forward_fused(const float* x /* [N,d] */, const float* T /* [32,d] */
 int pm_gcl_input_grad_fused(const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t plane_stride, const int32_t* plan,
                             int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
                             float* dA /* [N,4d] */, pm_stream_t stream);
+/* Weight gradient of that product, d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t] (gcl.hip): 128x128 output tiles,
+ * one workgroup per (tile, track group, K slice), operands streamed by loader waves through an LDS ring, K slices added
+ * with float atomics; `dW` is the layer's [7d, d] gradient (+=).  Same result as the grouped planes product with transA
+ * up to the order of the atomic adds.  d in {128, 256}, compact graphs. */
+int pm_gcl_weight_grad_fused(const uint16_t* a_planes /* 3 planes [N,4d] */, int64_t a_plane_stride,
+                             const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t dh_plane_stride, const int32_t* plan,
+                             int32_t N, int32_t E, int32_t G, int32_t d, int32_t use_classes, float* dW /* [7d,d] += */,
+                             pm_stream_t stream);
 /* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
  * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
  * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */

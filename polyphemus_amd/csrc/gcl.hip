@@ -613,6 +613,214 @@ extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_
   return pm_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the layer's product: d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]  (autograd of model.py:104-119).
+// The contraction runs over the NODES of a track group (K = 4 k rows at the bench sizes), both operands are activations
+// streamed from HBM.  The grouped planes product it replaces uses 64x64 output tiles (1024 workgroups, each re-reading
+// its operand slices: 0.8 GB of L2 -> LDS traffic per launch).  Here an output tile is 128 features x 128 columns
+// (half the operand traffic per flop), one workgroup per (feature tile, column tile, track group, K slice):
+//   * waves 4..7 (loaders) keep the slice's row list in LDS and stream 32-row tiles of the A' planes and the dh
+//     planes, two tiles ahead in registers, into a two-stage LDS ring (row pitch 320 bytes: conflict-free
+//     transposing reads);
+//   * waves 0..3 run the six-product MFMA chain on a 64x64 quarter each, both operands read transposed from LDS
+//     (ds_read_b64_tr_b16: the image is [node][feature], the MFMA wants 8 consecutive nodes per lane);
+// K slices add their tiles with float atomics (as the grouped product's split-K), onset / next feature blocks contract
+// only over the rows that receive such edges (row classes).
+namespace {
+constexpr int DW_T = 128;                 // output tile edge
+constexpr int DW_KT = 32;                 // node rows per LDS tile
+#ifndef GCL_DW_PAD
+#define GCL_DW_PAD 64
+#endif
+constexpr int DW_PITCH = DW_T * 2 + GCL_DW_PAD;   // bytes per image row (+64: the 4 rows x 2 column halves a 32-lane transposing read touches fall into 64 different banks)
+constexpr int DW_PLANE = DW_KT * DW_PITCH;
+constexpr int DW_STAGE = 2 * 3 * DW_PLANE;          // A' image + dh image, three planes each
+constexpr int DW_MAP = 4096;              // row-list entries of a K slice kept in LDS
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+// operand fragment of the 32-wide block starting at image column `c0` for k-step ks (16 nodes): 8 consecutive nodes per lane
+__device__ inline bf16x8 dw_frag(const char* S, int c0, int ks, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2;
+  const int k = ks * 16 + 8 * (g >> 1) + q;
+  const int colb = (c0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+  typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4;
+  const char* p0 = S + k * DW_PITCH + colb;
+  const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+  const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * DW_PITCH));
+  const s16x8_t t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, t);
+}
+}  // namespace
+
+template <int D>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restrict__ dhp, int64_t dps,
+         const int* __restrict__ trk_list, const int* __restrict__ trk_cnt, float* __restrict__ dW, int N, int nsplit,
+         int use_classes) {
+  constexpr int NFT = 4 * D / DW_T, NCT = D / DW_T, PER = NFT * NCT;       // tiles per (group, slice)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* const sMap = reinterpret_cast<int*>(smem + 2 * DW_STAGE);
+  // XCD-aware order: the PER tiles of one (group, slice) share its operand rows -> consecutive slabs on one XCD
+  const int total = PER * 4 * nsplit;
+  int L = blockIdx.x;
+  {
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int slab = L / PER, within = L % PER;
+  const int grp = slab % 4, zs = slab / 4, ft = within / NCT, ct = within % NCT;
+  const int blk = ft * DW_T / D;                                 // feature block of this tile: track | onset | next | self
+  int lo = 0, hi = trk_cnt[grp];
+  if (use_classes && (blk == 1 || blk == 2)) {
+    const int* cb = trk_cnt + 8 + grp * 5;
+    lo = blk == 1 ? cb[1] : cb[2];
+    hi = blk == 1 ? cb[3] : cb[4];
+  }
+  const int K = hi - lo;
+  if (K <= 0) return;
+  const int kper = (((K + nsplit - 1) / nsplit + DW_KT - 1) / DW_KT) * DW_KT;
+  const int kbeg = zs * kper, kend = min(kbeg + kper, K);
+  if (kbeg >= kend) return;
+  const int nt = (kend - kbeg + DW_KT - 1) / DW_KT;
+  const int* list = trk_list + (int64_t)grp * N + lo + kbeg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int nst = 0;
+  STAMP2();
+  for (int i = tid; i < nt * DW_KT; i += 512) sMap[i] = i < kend - kbeg ? list[i] : -1;
+  __syncthreads();
+  STAMP2();
+
+  if (wave >= 4) {
+    // ---- loaders: thread -> 16-byte chunk ch of rows r0 and r0 + 16 of each tile, three planes, both operands
+    const int lt = tid - 256, ch = lt & 15, r0 = lt >> 4;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ap), 0, GCL_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
+    const int acol = (ft * DW_T + ch * 8) * 2, dcol = (ct * DW_T + ch * 8) * 2;
+    const int aps_b = (int)(aps * 2), dps_b = (int)(dps * 2);
+    auto issue = [&](u32x4 (&v)[2][2][3], int t) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = t < nt ? sMap[t * DW_KT + r0 + j * 16] : -1;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          v[j][0][p] = __builtin_amdgcn_raw_buffer_load_b128(ars, n >= 0 ? n * (4 * D * 2) + acol + p * aps_b : GCL_OOB, 0, 0);
+          v[j][1][p] = __builtin_amdgcn_raw_buffer_load_b128(drs, n >= 0 ? n * (D * 2) + dcol + p * dps_b : GCL_OOB, 0, 0);
+        }
+      }
+    };
+    auto put = [&](const u32x4 (&v)[2][2][3], int t) {
+      char* st = smem + (t & 1) * DW_STAGE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<u32x4*>(st + (o * 3 + p) * DW_PLANE + (r0 + j * 16) * DW_PITCH + ch * 16) = v[j][o][p];
+    };
+    u32x4 va[2][2][3], vb[2][2][3];
+    issue(va, 0);
+    issue(vb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    put(va, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nt; t += 2) {
+      issue(va, t + 2);                                          // (past the end: out-of-range offsets, zeros, no traffic)
+      __builtin_amdgcn_sched_barrier(0);
+      put(vb, t + 1);                                            // waits for tile t+1 only: tile t+2 stays in flight
+      __syncthreads();
+      if (t + 1 >= nt) break;
+      issue(vb, t + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      put(va, t + 2);
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- MFMA waves: 64x64 quarter (wr, wc) of the tile
+  const int li = lane & 31, lh = lane >> 5, wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();                                               // tile 0 staged
+  STAMP2();
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    if ((t & 7) == 0) STAMP2();
+    const char* st = smem + (t & 1) * DW_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < DW_KT / 16; ++ks) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
+          b[p][i] = dw_frag(st + (3 + p) * DW_PLANE, wc * 64 + i * 32, ks, lane);
+        }
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  STAMP2();
+  // ---- epilogue: the tile is one K slice's (and, for the shared blocks, one group's) term: float atomics
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int fr = ft * DW_T + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;        // row of the stacked [4d, d] gradient
+      float* crow = dW + (int64_t)(fr < D ? grp * D + fr : 3 * D + fr) * D + ct * DW_T + wc * 64 + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
+    }
+  STAMP2();
+}
+
+extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
+                                        int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                        int32_t d, int32_t use_classes, float* dW, pm_stream_t stream) {
+  if (!a_planes || !dh_planes || !plan || !dW || N <= 0 || (d != 128 && d != 256) || a_plane_stride < (int64_t)N * 4 * d ||
+      dh_plane_stride < (int64_t)N * d || (a_plane_stride & 7) || (dh_plane_stride & 7) || ((uintptr_t)a_planes % 16) ||
+      ((uintptr_t)dh_planes % 16) || a_plane_stride * 6 >= 0x7fffffffLL)
+    return PM_E_INVALID;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  hipStream_t st = (hipStream_t)stream;
+  // K slices: four (256 workgroups at d = 256), more when a slice's row list would not fit its LDS copy
+  int nsplit = d == 256 ? 4 : 16;
+  while ((int64_t)nsplit * (DW_MAP - DW_KT) < N) nsplit *= 2;
+  const int per = (4 * d / DW_T) * (d / DW_T);
+  const dim3 grid((unsigned)(per * 4 * nsplit)), block(512);
+  const size_t lds = 2 * DW_STAGE + DW_MAP * 4;
+  const int pe = pm_prof_open(st, PM_PROF_GCL_DW, 2.0 * N * 4.0 * d * d);
+#define LAUNCH(DD)                                                                                                     \
+  do {                                                                                                                 \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      hipFuncSetAttribute((const void*)k_gcl_dw<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_gcl_dw<DD>), grid, block, lds, st, a_planes, a_plane_stride, dh_planes, dh_plane_stride,     \
+                       pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes);                                           \
+  } while (0)
+  if (d == 256) LAUNCH(256); else LAUNCH(128);
+#undef LAUNCH
+  pm_prof_close(st, pe);
+  return pm_check_launch();
+}
+
 static size_t gcl_lds_bytes(int d, bool drop) {
   return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 3 * 8) * 4;
 }

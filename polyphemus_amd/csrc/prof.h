@@ -11,7 +11,8 @@ enum {
   PM_PROF_SEGREDUCE_BWD = 34,
   PM_PROF_GCL_FWD = 35,         // fused aggregate + product of one GCL layer (gcl.hip)
   PM_PROF_GCL_DAGG = 36,        // input gradient of a GCL layer's product, A-stationary (gcl.hip)
-  PM_PROF_NCLASS = 37
+  PM_PROF_GCL_DW = 37,          // weight gradient of a GCL layer's product, 128x128 tiles (gcl.hip)
+  PM_PROF_NCLASS = 38
 };
 struct PmProfEvent { hipEvent_t a, b; int cls; double work; };
 struct PmProfState {

@@ -277,7 +277,11 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
         w.B = (const float*)dhp; w.b_plane_stride = dps;
       }
-      RUN(pm_gemm_f32_desc(&w, c.st));
+      if (c.planes && (d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_GCL_NO_DW"))      // 128x128 tiles (gcl.hip)
+        RUN(pm_gcl_weight_grad_fused(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d,
+                                       getenv("PM_GCL_NO_CLASSES") ? 0 : 1, dW, c.st));
+      else
+        RUN(pm_gemm_f32_desc(&w, c.st));
     }
     float* out = (dx == dxa) ? dxb : dxa;
     if (i > 0 && fuse_sums) {                             // + the column sums of the norm backward of layer i-1

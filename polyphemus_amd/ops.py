@@ -222,6 +222,15 @@ def gcl_input_grad_fused(dh_planes, plan: Plan, d: int, w_frag_t, use_classes: b
     return dA
 
 
+def gcl_weight_grad_fused(a_planes, dh_planes, plan: Plan, d: int, dW, use_classes: bool = True):
+    """`pm_gcl_weight_grad_fused`: dW [7d, d] += A'^T dh per track group (stacked [W_t; W_4; W_5; root] rows);
+    `a_planes` int16 [3, N*4d], `dh_planes` int16 [3, N*d]."""
+    _chk(dW, F32, "dW")
+    call("pm_gcl_weight_grad_fused", ptr(a_planes), a_planes.shape[1], ptr(dh_planes), dh_planes.shape[1], ptr(plan.buf),
+         plan.N, plan.E, plan.G, d, 1 if use_classes else 0, ptr(dW), stream())
+    return dW
+
+
 def segreduce_fwd(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int, out=None):
     _chk(x, F32, "x"); _chk(T, F32, "T")
     N, d = x.shape

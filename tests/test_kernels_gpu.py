@@ -826,6 +826,44 @@ def test_gcl_input_grad_fused_equals_grouped_product(d):
     assert torch.equal(dA2[keep], dA1[keep]) and bool(torch.isfinite(dA2).all())
 
 
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 3)])
+def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
+    """`pm_gcl_weight_grad_fused` (128x128 tiles, loader waves + LDS ring, K slices by atomics) against the grouped planes
+    product with transA it replaces and against an fp64 contraction of the exact planes; accumulates into dW (+=)."""
+    cpu = synthetic_batch(B, 2, p=0.3, seed=23)
+    b, plan = make_plan(cpu)
+    N, dd = cpu.num_nodes, d * d
+    torch.manual_seed(5)
+    A = torch.randn(N, 4 * d, device=DEV)
+    dst, et = cpu.edge_index[1], cpu.edge_type
+    on, nx = torch.zeros(N, dtype=torch.bool), torch.zeros(N, dtype=torch.bool)
+    on[dst[et == 4]] = True
+    nx[dst[et == 5]] = True
+    A[(~on).to(DEV), d:2 * d] = 0                                     # the aggregate's zero blocks
+    A[(~nx).to(DEV), 2 * d:3 * d] = 0
+    dh = torch.randn(N, d, device=DEV)
+    Ap, dhp = ops.split_planes(A), ops.split_planes(dh)
+    tl, tc = plan.field("trk_list"), plan.field("trk_cnt")
+    base = torch.randn(7 * d, d, device=DEV)
+    dW0 = base.clone()
+    ops.gemm_desc(Ap, dhp, dW0, 4 * d, d, N, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
+                  c_split_rows=d, c_shared_off=3 * dd, a_plane_stride=A.numel(), b_plane_stride=dh.numel(), rowmap=tl,
+                  rows_per_entry=1, dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1, partition=True,
+                  planes=True, class_ptr=tc[8:], class_block=d)
+    dW1 = ops.gcl_weight_grad_fused(Ap, dhp, plan, d, base.clone())
+    trel = plan.field("node_trel").long()[:N]
+    want = base.double().clone()
+    for t in range(4):
+        rows = trel == t
+        want[t * d:(t + 1) * d] += A[rows, :d].double().T @ dh[rows].double()
+    want[4 * d:] += A[:, d:].double().T @ dh.double()
+    scale = float((want - base.double()).abs().max())
+    assert float((dW1.double() - want).abs().max()) < 2e-6 * scale
+    assert float((dW0.double() - want).abs().max()) < 2e-6 * scale
+    dW2 = ops.gcl_weight_grad_fused(Ap, dhp, plan, d, base.clone(), use_classes=False)
+    assert float((dW2.double() - want).abs().max()) < 2e-6 * scale
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

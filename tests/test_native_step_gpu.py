@@ -89,11 +89,10 @@ def test_measured_native_path_matches_reference_golden(case):
     d, nl = cfg["d"], cfg["gnn_n_layers"]
     assert info["compact"] == 1 and info["planes"] == 1 and info["n_slots"] == g.n_slots, info
     planes_tn, planesb_nn, planesb_nt, planes_nn, planes_nt = cnt[8 * 3 + 2], cnt[9 * 3], cnt[9 * 3 + 1], cnt[8 * 3], cnt[8 * 3 + 1]
-    assert planes_tn == 2 * nl, list(cnt)                       # GCL weight gradients of both stacks
-    if d % 128 == 0:                                            # forward and input gradient: the kernels of gcl.hip
-        assert info["b_frag"] == 1 and cnt[35] == 2 * nl and cnt[36] == 2 * nl and planesb_nn == 0 and planesb_nt == 0, (info, list(cnt))
+    if d % 128 == 0:                                            # the three layer products: the kernels of gcl.hip
+        assert info["b_frag"] == 1 and cnt[35] == 2 * nl and cnt[36] == 2 * nl and cnt[37] == 2 * nl and planesb_nn == 0 and planesb_nt == 0 and planes_tn == 0, (info, list(cnt))
     else:
-        assert planes_nn == 2 * nl and planes_nt == 2 * nl, list(cnt)
+        assert planes_nn == 2 * nl and planes_nt == 2 * nl and planes_tn == 2 * nl, list(cnt)
     for k, v in json.loads(str(z["train1/losses"])).items():
         assert abs(got[k] - v) <= REL_TOL * max(1.0, abs(v)), k
     (s_logits, c_logits), mu, lv = tr.step_outputs()

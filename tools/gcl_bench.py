@@ -49,15 +49,34 @@ def main():
                       dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1, partition=True, planes=True,
                       class_ptr=tc[8:], class_block=d, b_frag=Wft)
     def nt_fused(): ops.gcl_input_grad_fused(dhp, plan, d, Wft, out=dA)
+    Aagg = torch.randn(N, 4 * d, device="cuda")
+    Ap = ops.split_planes(Aagg)
+    dWb = torch.zeros(7 * d, d, device="cuda")
+    def tn_unfused():
+        ops.gemm_desc(Ap, dhp, dWb, 4 * d, d, N, 4 * d, d, d, transA=True, accum=True, split_k=0, c_group_stride=dd,
+                      c_split_rows=d, c_shared_off=3 * dd, a_plane_stride=Aagg.numel(), b_plane_stride=dh.numel(), rowmap=tl,
+                      rows_per_entry=1, dyn_entries=tc, n_groups=4, map_group_stride=N, dyn_group_stride=1, partition=True,
+                      planes=True, class_ptr=tc[8:], class_block=d)
+    def tn_fused(): ops.gcl_weight_grad_fused(Ap, dhp, plan, d, dWb)
     tag = os.path.basename(os.environ.get("PM_LIB_PATH", "default"))
-    which = os.environ.get("WHICH", "ufpn")
+    which = os.environ.get("WHICH", "ufpnw")
     out = [tag, f"N={N}"]
     if "u" in which: out.append(f"unfused {timeit(unfused):.1f} us")
     if "f" in which: out.append(f"fused {timeit(fused):.1f} us")
     if "p" in which: out.append(f"fused(no A' out) {timeit(fused_np):.1f} us")
+    if "w" in which: out.append(f"dW grouped {timeit(tn_unfused):.1f} us  128x128 {timeit(tn_fused):.1f} us")
     if "n" in which: out.append(f"dA' grouped {timeit(nt_unfused):.1f} us  A-stationary {timeit(nt_fused):.1f} us")
     print("  ".join(out), flush=True)
-    if os.environ.get("TRACE") == "n":
+    if os.environ.get("TRACE") == "w":
+        import ctypes
+        from polyphemus_amd._lib import lib
+        tn_fused(); torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * 256)()
+        lib().pm_debug_read_trace(buf)
+        tr = list(buf)
+        st = [v for v in tr[0:60] if v]
+        print("dw wave 0", [round((v - st[0]) / 100.0, 2) for v in st])
+    elif os.environ.get("TRACE") == "n":
         import ctypes
         from polyphemus_amd._lib import lib
         nt_fused(); torch.cuda.synchronize()

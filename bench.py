@@ -326,7 +326,8 @@ def main():
         trainer.train_step(batch)
     sync()
     survey = prof_collect()
-    dom = max((k for k in survey if k.startswith("gemm")), key=lambda k: survey[k]["total_ms"])
+    mfma_classes = [k for k in survey if k.startswith(("gemm", "gcl"))]       # every kernel class that runs on the matrix cores
+    dom = max(mfma_classes, key=lambda k: survey[k]["total_ms"])
     # the aggregation kernel of the forward: the fused layer kernel (gcl.hip) where it runs, else the segment-reduce
     seg_key = "gcl_fwd" if "gcl_fwd" in survey else "segreduce_fwd"
     L.pm_prof_configure((1 << names.index(dom)) | (1 << names.index(seg_key)), EVENT_STRIDE)
@@ -353,18 +354,21 @@ def main():
         dp["params_in_sync_after_run"] = bool(lo.item() == hi.item())
 
     if rank == 0:
-        gemm_keys = [k for k in survey if k.startswith("gemm")]
+        gemm_keys = mfma_classes
         ds = gst[dom]                                          # timed region, sampled launches of the dominant class
         tf = ds["work"] / (ds["total_ms"] * 1e-3) / 1e12
         gemm_ms = sum(survey[k]["total_ms"] for k in gemm_keys)
         gemm_tf = sum(survey[k]["work"] for k in gemm_keys) / (gemm_ms * 1e-3) / 1e12
-        split = dom[8:].startswith(("planes", "x6"))          # fp32 product = 6 bf16 MFMA products (fp32 accumulate)
+        split = dom.startswith("gcl") or dom[8:].startswith(("planes", "x6"))   # fp32 product = 6 bf16 MFMA products (fp32 accumulate)
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
         insn = "v_mfma_f32_32x32x16_bf16, 6 products per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
         workload_key = f"B{args.batch}_d{args.d}_nb{args.n_bars}_L{args.layers}" + ("_dense" if args.dense else "")
         sampling = (f"HIP events around every {EVENT_STRIDE}-th launch of this kernel inside the timed region "
                     f"({ds['launches']} launches sampled)")
-        roof = {"bound": "mfma", "kernel": f"k_gemm<{dom[8:]},{dom[5:7]}> ({insn})",
+        gcl_names = {"gcl_fwd": "k_gcl_fwd: GCL forward, aggregate built in LDS + weight product in one kernel",
+                     "gcl_dagg": "k_gcl_dagg: GCL input gradient, A-stationary", "gcl_dw": "k_gcl_dw: GCL weight gradient, 128x128 tiles"}
+        kname = f"{gcl_names[dom]} ({insn})" if dom in gcl_names else f"k_gemm<{dom[8:]},{dom[5:7]}> ({insn})"
+        roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4), "traffic": pmc_traffic(dom, workload_key),
                 "peak_note": ("dense bf16 MFMA peak / 6 (fp32-equivalent flops)" if split else "dense fp32 MFMA peak")
@@ -378,13 +382,17 @@ def main():
                                            "launches_per_step": survey[k]["launches"] / SURVEY}
                                        for k in gemm_keys if k != dom}}
         ss = gst[seg_key]
-        gbs = ss["work"] / (ss["total_ms"] * 1e-3) / 1e9
+        if seg_key == "gcl_fwd":        # algorithmic HBM bytes of the fused layer kernel (its profiler work is the product's flops)
+            seg_bytes = 8.0 * args.d * n_nodes + 24.0 * args.d * n_nodes + 12.0 * n_edges + 42.0 * args.d * args.d
+        else:
+            seg_bytes = ss["work"] / ss["launches"]
+        gbs = seg_bytes / (ss["avg_us"] * 1e-6) / 1e9
         roof_seg = {"bound": "hbm", "kernel": "k_gcl_fwd (aggregate built in LDS + weight product, one kernel)"
                     if seg_key == "gcl_fwd" else "k_segreduce_fwd", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                     "traffic": pmc_traffic(seg_key, workload_key),
                     "launches_per_step": survey[seg_key]["launches"] / SURVEY, "avg_launch_us": round(ss["avg_us"], 2),
-                    "algorithmic_bytes_per_launch": ss["work"] / ss["launches"],
+                    "algorithmic_bytes_per_launch": seg_bytes,
                     "sampling": f"every {EVENT_STRIDE}-th launch inside the timed region ({ss['launches']} sampled)"}
         if seg_key == "gcl_fwd":
             # the fused kernel is no longer bounded by HBM alone: it also carries the layer's forward product

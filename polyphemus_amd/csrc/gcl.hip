@@ -847,9 +847,9 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(pm_cdiv(N, BM) + 4)), block(NTHR);
   const size_t lds = gcl_lds_bytes(d, drop);
-  // algorithmic bytes: x read + h written + A' planes written (when kept) + edges + the weight planes once
-  const double work = 8.0 * d * (double)N + (planes ? 24.0 * d * (double)N : 0.0) + 12.0 * E + 42.0 * d * (double)d;
-  const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, work);
+  // profiler work: the product's flops (as the GEMM classes); the kernel's algorithmic HBM bytes are x read + h written
+  // + A' planes written (when kept) + edges + the weight planes once = 8dN (+ 24dN) + 12E + 42d^2 (bench.py)
+  const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD, DR)                                                                                                 \
   do {                                                                                                                 \
     static bool once = false;                                                                                          \

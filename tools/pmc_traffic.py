@@ -33,8 +33,9 @@ def klass(kernel_name):
         return "segreduce_fwd"
     if s.startswith("k_segreduce_bwd"):
         return "segreduce_bwd"
-    if s.startswith("k_gcl_fwd"):
-        return "gcl_fwd"
+    for k in ("gcl_fwd", "gcl_dagg", "gcl_dw"):
+        if s.startswith("k_" + k):
+            return k
     return None
 
 

@@ -39,12 +39,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define STAMP() do {} while (0)
 #endif
-#ifndef GCL_PRIO
-#define GCL_PRIO 0
-#endif
-#ifndef GCL_ABL
-#define GCL_ABL 0             // development ablations: 1 no gather, 2 no MFMA, 4 no A' store, 8 no weight loads
-#endif
 
 namespace {
 constexpr int BM = 64;        // rows (nodes) per workgroup
@@ -163,7 +157,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   // write latency into the gather's wait.  Rows past the end of the list: out-of-range offset, the store is dropped.
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
   auto store_planes = [&](int c) {
-    if (!g.planes || (GCL_ABL & 4)) return;
+    if (!g.planes) return;
     const int blk = chunk_blk(c), half = c % NCH;
     const char* img = img0 + (c & 1) * IMG;
     const int pt = tid - 256, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
@@ -227,7 +221,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
 #pragma unroll
       for (int e = 0; e < EMAX; ++e)
         xv[ps][e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-            xrs, (e < ecnt[ps] && !(GCL_ABL & 16)) ? ((ew[ps][e] & 0x7ffffff) * D + f) * 4 : GCL_OOB, 0, 0));
+            xrs, e < ecnt[ps] ? ((ew[ps][e] & 0x7ffffff) * D + f) * 4 : GCL_OOB, 0, 0));
     }
     __builtin_amdgcn_sched_barrier(0);       // every gather of the chunk is in flight before the first one is waited for
     STAMP();
@@ -286,7 +280,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   if (wave >= 4) {                                             // producers: one image ahead of the consumers
 #pragma unroll 1
     for (int c = 0; c <= nchunk; ++c) {
-      if (c < nchunk && !((GCL_ABL & 1) && c > 0)) build(c);
+      if (c < nchunk) build(c);
       else store_planes(c - 1);
       STAMP();
       __syncthreads();
@@ -294,9 +288,6 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
     }
   } else {
   // ---- consumers (same barrier sequence: one after the first image, one per chunk)
-#if GCL_PRIO
-  __builtin_amdgcn_s_setprio(GCL_PRIO);    // MFMA issue ahead of the producers' vector ALU work on the same SIMD
-#endif
   const int li = lane & 31, lh = lane >> 5;
   f32x16 acc[2][TN];
 #pragma unroll
@@ -347,9 +338,8 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            if (!(GCL_ABL & 2))
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
-      if (!(GCL_ABL & 8)) bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+      bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
       __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
     }
     STAMP();

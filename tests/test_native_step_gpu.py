@@ -407,3 +407,42 @@ def test_native_step_with_fused_unembed_ce_matches_the_unfused_step(case):
         assert abs(lf[k] - lu[k]) <= 1e-6 * max(1.0, abs(lu[k])), k
     assert rel_err(torch.from_numpy(cf), cu) < 1e-5
     assert rel_err(torch.from_numpy(gf), tr.grads) < 1e-4
+
+
+def _unfused_gcl_worker(rank, world, d, L, seed):
+    """Fresh process (the switch is read once): the native step with PM_GCL_FUSED=0 — segment-reduce forward + the three
+    grouped planes products instead of the kernels of csrc/gcl.hip; message dropout ON (same counter stream)."""
+    import os
+    os.environ["PM_GCL_FUSED"] = "0"
+    return _synthetic_step(d, L, seed)
+
+
+def _synthetic_step(d, L, seed):
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=L, d=d, n_bars=2, resolution=8)
+    batch = synthetic_batch(24, 2, p=0.25, seed=seed).to(DEV)
+    eps = torch.randn(24, d, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=DEV).to(DEV)
+    vae.train()
+    tr = HipTrainer(vae, lr=5e-6)
+    tr.keep_logits = True
+    out = tr.losses_dict(tr.train_step(batch, eps))
+    (s_logits, c_logits), mu, _ = tr.step_outputs()
+    info = tr.step_info()
+    return out, tr.grads.detach().cpu().numpy(), c_logits.cpu().numpy(), mu.cpu().numpy(), info
+
+
+@pytest.mark.parametrize("d,L", [(128, 2), (256, 3)])
+def test_gcl_kernels_match_the_segment_reduce_plus_grouped_product_step(d, L):
+    """The measured step (csrc/gcl.hip: fused forward, A-stationary input gradient, 128x128 weight gradient) against
+    the same step built from the round-1 kernels (PM_GCL_FUSED=0, child process), message dropout p = 0.1 on: same losses,
+    outputs and gradients up to fp32 accumulation order and the order of the atomic adds."""
+    from util import run_ranks
+    (lu, gu, cu, mu_u, info_u), = run_ranks(_unfused_gcl_worker, 1, (d, L, 31), timeout=180.0)
+    lf, gf, cf, mu_f, info_f = _synthetic_step(d, L, 31)
+    assert info_f["compact"] == 1 and info_f["planes"] == 1 and info_f == info_u
+    for k in lf:
+        assert abs(lf[k] - lu[k]) <= 2e-6 * max(1.0, abs(lu[k])), k
+    assert rel_err(torch.from_numpy(cf), torch.from_numpy(cu)) < 2e-5
+    assert rel_err(torch.from_numpy(mu_f), torch.from_numpy(mu_u)) < 2e-5
+    assert rel_err(torch.from_numpy(gf), torch.from_numpy(gu)) < 2e-4

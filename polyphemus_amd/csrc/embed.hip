@@ -185,6 +185,105 @@ __global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restr
     if (v != 0.f) atomicAdd(&out[i], v);
   }
 }
+// The same sums on the matrix cores (d/2 a multiple of 32): S[t] = OneHot(tokens)^T x dX, the reference's own formulation
+// (the backward of Linear(131 -> d/2) on one-hot rows, model.py:344-360).  LDS float atomics run at about one lane per
+// clock, so the scatter above is bounded by its adds (110 us at the bench sizes); here a one-hot A operand is built in
+// registers from the token ids (1.0 is exact in bf16) and the dX rows are split into three bf16 planes on the fly
+// (x = p1 + p2 + p3 exactly), so the three products per k-step add exactly the fp32 values the scatter adds.
+// Workgroup = a slice of the group's (node, slot) rows for one table; wave w owns 32 columns, all token tiles.
+typedef float e_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 e_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int e_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int EMM_ROWS = 2048;            // rows of a workgroup's slice staged in LDS at a time
+constexpr int NVT = 5;                    // token tiles of 32: 5 for the pitch tables (131), 4 of them for the duration tables (99)
+__global__ void __launch_bounds__(512) k_embed_bwd_mfma(const float* __restrict__ dX, const int* __restrict__ tok,
+                                                       const int* __restrict__ group_list,
+                                                       const int* __restrict__ group_cnt, int N, int d, int NS,
+                                                       float* __restrict__ S) {
+  __shared__ int sTok[EMM_ROWS + 16], sOff[EMM_ROWS + 16];
+  const int grp = blockIdx.y, kind = blockIdx.z, dh = d / 2, t = kind * 2 + grp;
+  const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
+  const int cnt = grp == 0 ? group_cnt[0] : group_cnt[1];
+  const int* list = group_list + (grp == 0 ? 0 : N);
+  const int per = (cnt + gridDim.x - 1) / gridDim.x;              // nodes of this workgroup
+  const int i0 = blockIdx.x * per, i1 = min(cnt, i0 + per);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  e_f32x16 acc[NVT];
+#pragma unroll
+  for (int q = 0; q < NVT; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dX), 0, (int)0x80000000, 0x00020000);
+  const int colb = (kind * dh + wave * 32 + li) * 4;
+  const int nrows = (i1 > i0 ? (i1 - i0) : 0) * NS;
+  for (int r0 = 0; r0 < nrows; r0 += EMM_ROWS) {
+    const int nr = min(EMM_ROWS, nrows - r0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < EMM_ROWS + 16; k += blockDim.x) {       // row k of the slice: token, byte offset of its dX row
+      int tk = -1, off = (int)0x80000000;
+      if (k < nr) {
+        const int n = list[i0 + (r0 + k) / NS], sl = (r0 + k) % NS;
+        tk = tok[(int64_t)n * 32 + 2 + kind + sl * 2];
+        off = (n * NS + sl) * d * 4;
+      }
+      sTok[k] = tk; sOff[k] = off;
+    }
+    __syncthreads();
+    // k-step = 16 rows; the 8 row values a lane needs for the NEXT step are loaded before this step's MFMAs
+    auto fetch = [&](int (&tk)[8], float (&x)[8], int k0) {
+      const int kb = k0 + lh * 8;                                  // this half-wave's 8 rows of the k-step
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        tk[i] = sTok[kb + i];
+        const int of = sOff[kb + i];
+        x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, of == (int)0x80000000 ? of : of + colb, 0, 0));
+      }
+    };
+    auto step = [&](const int (&tk)[8], const float (&x)[8]) {
+      unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pm_split3_pair(x[2 * i], x[2 * i + 1], p1[i], p2[i], p3[i]);
+      const e_bf16x8 b1 = __builtin_bit_cast(e_bf16x8, e_u32x4{p1[0], p1[1], p1[2], p1[3]});
+      const e_bf16x8 b2 = __builtin_bit_cast(e_bf16x8, e_u32x4{p2[0], p2[1], p2[2], p2[3]});
+      const e_bf16x8 b3 = __builtin_bit_cast(e_bf16x8, e_u32x4{p3[0], p3[1], p3[2], p3[3]});
+#pragma unroll
+      for (int q = 0; q < NVT; ++q) {
+        if (q * 32 >= V) break;                                    // (duration tables: four tiles)
+        const int v = q * 32 + li;
+        unsigned a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = (tk[2 * i] == v ? 0x3F80u : 0u) | (tk[2 * i + 1] == v ? 0x3F800000u : 0u);
+        const e_bf16x8 av = __builtin_bit_cast(e_bf16x8, e_u32x4{a[0], a[1], a[2], a[3]});
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b3, acc[q], 0, 0, 0);      // smallest plane first
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b2, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[q], 0, 0, 0);
+      }
+    };
+    int tka[8], tkb[8];
+    float xa[8], xb[8];
+    fetch(tka, xa, 0);
+    for (int k0 = 0; k0 < nr; k0 += 32) {                          // (rows past nr: token -1, out-of-range offset -> 0)
+      fetch(tkb, xb, min(k0 + 16, EMM_ROWS));
+      __builtin_amdgcn_sched_barrier(0);
+      step(tka, xa);
+      if (k0 + 16 >= nr) break;
+      fetch(tka, xa, min(k0 + 32, EMM_ROWS));
+      __builtin_amdgcn_sched_barrier(0);
+      step(tkb, xb);
+    }
+  }
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  float* out = S + (int64_t)t * EMB_V * dh + wave * 32 + li;
+#pragma unroll
+  for (int q = 0; q < NVT; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int v = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float val = acc[q][r];
+      if (v < V && val != 0.f) atomicAdd(out + (int64_t)v * dh, val);
+    }
+}
+
 extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E,
                                     int32_t G, int32_t d, int32_t n_slots, float* S, pm_stream_t stream) {
   if (!dX || !tokens || !plan || !S || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
@@ -195,6 +294,17 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
   hipStream_t st = (hipStream_t)stream;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipMemsetAsync(S, 0, sizeof(float) * 4 * EMB_V * dh, st);
+  static const bool mfma_on = !(getenv("PM_EMBED_MFMA") && atoi(getenv("PM_EMBED_MFMA")) == 0);
+  if (mfma_on && dh % 32 == 0 && dh <= 256 && (int64_t)N * n_slots * d * 4 < 0x7fffffffLL) {
+    // ~640 rows of the larger group per workgroup (measured at 81 k rows: 32 / 64 / 80 / 128 / 192 / 256 workgroups per
+    // table: 86 / 51 / 47 / 43 / 43 / 46 us — fewer leave CUs idle, more flush more partial tables)
+    int nb = (int)pm_cdiv((int64_t)N * n_slots, 640);
+    if (nb > 160) nb = 160;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_embed_bwd_mfma, dim3(nb, 2, 2), dim3(64 * (dh / 32)), 0, st, dX, tokens, pv.group_list,
+                       pv.group_cnt, N, d, n_slots, S);
+    return pm_check_launch();
+  }
   if (lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);

@@ -302,15 +302,16 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
     const int blk = chunk_blk(c);
     return (blk == 0 ? grp * D : (3 + blk) * D) + (c % NCH) * CH;
   };
+  // (the block offset is wave-uniform: it rides in the instruction's scalar offset, the lane part never changes — no
+  //  vector ALU work per load; past the end the last chunk is re-read and never used)
   auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global k-step gs (16 rows of the weight)
-    const int c = gs >> 3, ks = gs & 7;
-    int off = GCL_OOB;
-    if (c < nchunk) off = (((krow0(c) >> 4) + ks) * BFN + ct0) * 3072 + lane * 16;
+    const int c = min(gs >> 3, nchunk - 1), ks = gs & 7;
+    const int soff = __builtin_amdgcn_readfirstlane((((krow0(c) >> 4) + ks) * BFN + ct0) * 3072);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, off == GCL_OOB ? off : off + j * 3072 + p * 1024, 0, 0));
+        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * 3072 + p * 1024, 0));
   };
   bf16x8 bq[GCL_BDEPTH][3][TN];
 #pragma unroll
@@ -504,19 +505,17 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
     }
   }
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
+  // (wave-uniform block offset in the instruction's scalar offset; past the end the last block is re-read, never used)
   auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global step gs = block index * KS + k-step
-    const int qb = gs / KS, ks = gs % KS;
-    int off = GCL_OOB;
-    if (qb < nblk) {
-      const int blk = blk_of(qb);
-      const int wrow = (blk == 0 ? grp * D : (3 + blk) * D) + wave * (D / 4);   // first stacked weight row of this wave's columns
-      off = ((wrow >> 5) * KS + ks) * 3072 + lane * 16;
-    }
+    const int qb = min(gs / KS, nblk - 1), ks = gs % KS;
+    const int blk = blk_of(qb);
+    const int wrow = (blk == 0 ? grp * D : (3 + blk) * D) + wave * (D / 4);     // first stacked weight row of this wave's columns
+    const int soff = __builtin_amdgcn_readfirstlane(((wrow >> 5) * KS + ks) * 3072);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, off == GCL_OOB ? off : off + j * KS * 3072 + p * 1024, 0, 0));
+        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * KS * 3072 + p * 1024, 0));
   };
   bf16x8 bq[GCL_BDEPTH][3][TN];
 #pragma unroll

@@ -178,6 +178,14 @@ int pm_gcl_weight_grad_fused(const uint16_t* a_planes /* 3 planes [N,4d] */, int
                              const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t dh_plane_stride, const int32_t* plan,
                              int32_t N, int32_t E, int32_t G, int32_t d, int32_t use_classes, float* dW /* [7d,d] += */,
                              pm_stream_t stream);
+/* C[N, Nout] = X[N, K] @ W (+ bias) for a plain linear layer with a short inner dimension, K in {128, 256}, Nout a
+ * multiple of K (chord decoder forward model.py:555-559; chord encoder input gradient, autograd of model.py:384-390),
+ * A-stationary (gcl.hip k_rows_w): the 64 fp32 rows of a tile are split into bf16 planes once and kept in LDS for all
+ * output columns.  `w_frag` = pm_split_planes_frag of the weight: kind 0 for W [Nout, K] (y = x W^T), kind 1 for
+ * W [K, 32*w_tiles] (y = x W; only the first Nout columns are used). */
+int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
+                         int32_t w_tiles, int32_t Nout, const float* bias /* [Nout] or NULL */, float* C, int32_t ldc,
+                         pm_stream_t stream);
 /* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
  * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
  * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */

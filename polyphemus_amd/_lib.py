@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PM_LIB_PATH: development only — load a differently built library (kernel A/B variants of tools/build_variants.py)
 LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "libpolyphemus_hip.so")
 
-PROF_NCLASS = 38        # prof.h: 33 GEMM classes, segreduce_fwd, segreduce_bwd, gcl_fwd, gcl_dagg, gcl_dw
+PROF_NCLASS = 39        # prof.h: 33 GEMM classes, segreduce_fwd, segreduce_bwd, gcl_fwd, gcl_dagg, gcl_dw, rows_w
 PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", "csc_reldist", "csc_eid",
                "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "row_list", "node_trel", "trk_list", "trk_cnt", "scratch"]
 
@@ -36,6 +36,7 @@ _SIGS = {
     "pm_gcl_forward_fused": "pppiiiifuuppipppls",
     "pm_gcl_input_grad_fused": "plpiiiipips",
     "pm_gcl_weight_grad_fused": "plplpiiiiips",
+    "pm_rows_times_weight": "piiipiiippis",
     "pm_segreduce_bwd": "pppppiiiifuuipps",
     "pm_segreduce_bwd_norm": "pppppiiiifuuippps",
     "pm_gemm_f32": "iiiiipipipipiipips",

@@ -810,6 +810,170 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
   return pm_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The A-stationary shape for a PLAIN linear layer with a short inner dimension: C[N, Nout] = X[N, K] @ W (+ bias),
+// K = d in {128, 256}, Nout a multiple of K (chord decoder forward, model.py:555-559, and the chord encoder's input
+// gradient, autograd of model.py:384-390; Nout = S*d).  X is fp32: the 64 rows of a tile are split into the three
+// bf16 planes ONCE, in the prologue, into the LDS image the MFMA waves then read for every block of K output columns;
+// the weight comes as fragment-major planes (pm_split_planes_frag; kind 0: W [Nout, K] used as B[n][k], kind 1: W [K, ldw]
+// used as B[k][n]); store waves write finished blocks (+ bias) as whole rows.  The in-kernel split (x6) tile kernel
+// it replaces re-splits every operand element once per 128x128 tile that uses it.
+template <int D, int BKIND>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ wfrag, int wtiles, int nblk,
+         const float* __restrict__ bias, float* __restrict__ C, int ldc) {
+  constexpr int TN = D / 128, KS = D / 16, RB = D * 2, PL = BM * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
+  const int ntile = (N + BM - 1) / BM;
+  int t = blockIdx.x;
+  {
+    const int q = ntile >> 3, r = ntile & 7, xcd = t & 7, idx = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = t * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  if (wave >= 4) {
+    // ---- store waves: block q of the stage (+ bias) -> C rows, 16 bytes per lane
+    constexpr int LPR = D / 4, RPW = 64 / LPR, NR = BM / (4 * RPW);
+    const int st = tid - 256, c4 = st % LPR, r0 = st / LPR;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, GCL_OOB, 0x00020000);
+    __syncthreads();                                           // (image filled)
+#pragma unroll 1
+    for (int qb = 0; qb < nblk; ++qb) {
+      __syncthreads();                                         // consumers: stage free -> they fill it
+      __syncthreads();                                         // stage holds block qb
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bv = *reinterpret_cast<const float4*>(bias + qb * D + c4 * 4);
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int rr = r0 + k * 4 * RPW, row = m0 + rr;
+        float4 v = *reinterpret_cast<const float4*>(sC + rr * D + c4 * 4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crs,
+            row < N ? (int)(((int64_t)row * ldc + qb * D + c4 * 4) * 4) : GCL_OOB, 0, 0);
+      }
+    }
+    return;
+  }
+  // ---- the tile's rows: fp32 -> three bf16 planes -> XOR-swizzled LDS image (16-byte chunk c of row r at c ^ (r & 15))
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, GCL_OOB, 0x00020000);
+    constexpr int CPR = D / 8, NCHK = BM * CPR / 256;            // 8-value chunks per row, chunks per thread
+    u32x4 v[NCHK][2];
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR, row = m0 + rr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        v[k][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, row < N ? (int)(((int64_t)row * ldx + ch * 8 + h * 4) * 4) : GCL_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR;
+      unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pm_split3_pair(__uint_as_float(v[k][h][0]), __uint_as_float(v[k][h][1]), p1[2 * h], p2[2 * h], p3[2 * h]);
+        pm_split3_pair(__uint_as_float(v[k][h][2]), __uint_as_float(v[k][h][3]), p1[2 * h + 1], p2[2 * h + 1], p3[2 * h + 1]);
+      }
+      char* dst = smem + rr * RB + ((ch ^ (rr & 15)) << 4);
+      *reinterpret_cast<u32x4*>(dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+      *reinterpret_cast<u32x4*>(dst + PL) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+      *reinterpret_cast<u32x4*>(dst + 2 * PL) = u32x4{p3[0], p3[1], p3[2], p3[3]};
+    }
+  }
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
+  auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global step gs = block index * KS + k-step
+    const int qb = min(gs / KS, nblk - 1), ks = gs % KS;
+    const int n0 = qb * D + wave * (D / 4);                      // first output column of this wave in block qb
+    // kind 0: blocks ordered [32-column tile of W rows][k-step]; kind 1: [k-step][32-column tile], wtiles tiles per k-step
+    const int soff = __builtin_amdgcn_readfirstlane(BKIND == 0 ? ((n0 >> 5) * KS + ks) * 3072 : (ks * wtiles + (n0 >> 5)) * 3072);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * (BKIND == 0 ? KS : 1) * 3072 + p * 1024, 0));
+  };
+  bf16x8 bq[GCL_BDEPTH][3][TN];
+#pragma unroll
+  for (int s2 = 0; s2 < GCL_BDEPTH; ++s2) bload(bq[s2], s2);
+  __syncthreads();
+  auto aload = [&](bf16x8 (&a)[3][2], int ks) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rr = i * 32 + li;
+        a[p][i] = *reinterpret_cast<const bf16x8*>(smem + p * PL + rr * RB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
+      }
+  };
+  bf16x8 af[2][3][2];
+  aload(af[0], 0);
+#pragma unroll 1
+  for (int qb = 0; qb < nblk; ++qb) {
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      aload(af[(ks + 1) & 1], (ks + 1) % KS);
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+      bload(bq[ks % GCL_BDEPTH], qb * KS + ks + GCL_BDEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                             // the store waves have read the previous block
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / 4) + j * 32 + li] = acc[i][j][r];
+    __syncthreads();
+  }
+}
+
+extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
+                                    int32_t w_tiles, int32_t Nout, const float* bias, float* C, int32_t ldc,
+                                    pm_stream_t stream) {
+  if (!X || !w_frag || !C || N <= 0 || (K != 128 && K != 256) || Nout <= 0 || (Nout % K) || (kind != 0 && kind != 1) ||
+      ldx < K || ldc < Nout || (ldx & 3) || (ldc & 3) || ((uintptr_t)X % 16) || ((uintptr_t)C % 16) ||
+      ((uintptr_t)w_frag % 16) || (bias && ((uintptr_t)bias % 16)) || (int64_t)N * ldx * 4 >= 0x7fffffffLL ||
+      (int64_t)N * ldc * 4 >= 0x7fffffffLL || (kind == 1 && w_tiles * 32 < Nout))
+    return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
+  const size_t lds = (size_t)3 * BM * K * 2 + (size_t)BM * K * 4;
+  const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
+#define LAUNCH(DD, KD)                                                                                                 \
+  do {                                                                                                                 \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      hipFuncSetAttribute((const void*)k_rows_w<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_rows_w<DD, KD>), grid, block, lds, st, X, ldx, N, reinterpret_cast<const char*>(w_frag),     \
+                       w_tiles, Nout / K, bias, C, ldc);                                                               \
+  } while (0)
+  if (K == 256) { if (kind == 0) LAUNCH(256, 0); else LAUNCH(256, 1); }
+  else { if (kind == 0) LAUNCH(128, 0); else LAUNCH(128, 1); }
+#undef LAUNCH
+  pm_prof_close(st, pe);
+  return pm_check_launch();
+}
+
 static size_t gcl_lds_bytes(int d, bool drop) {
   return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 3 * 8) * 4;
 }

@@ -402,8 +402,15 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
+  // chord decoder (K = d, S*d output columns): A-stationary kernel of gcl.hip, its weight rows as fragment-major planes
+  const bool rows_w = (d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W");
+  uint16_t* wf_dec = rows_w ? (uint16_t*)ar.take((size_t)S * d * d * 6) : nullptr;
   if (run) {
-    lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);            // rows [0, S*d) of chord_decoder.weight
+    if (rows_w) {
+      RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, 0, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3, wf_dec, c.st));
+      RUN(pm_rows_times_weight(xdL, d, N, d, wf_dec, 0, 0, S * d, c.P + Y.dec_chord.b, s.H, S * d, c.st));
+    } else
+      lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);          // rows [0, S*d) of chord_decoder.weight
     // un-embedding (model.py:561-576: duration logits for every (node, slot) row, pitch logits per drum / non-drum row
     // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits stay in the MFMA
     // accumulators, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
@@ -527,8 +534,14 @@ void backward_encoder_tail(Ctx& c) {
     RUN(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
                       nullptr, 0, nullptr, c.st));
     RUN(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
-    RUN(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
-                      nullptr, c.st));
+    if ((d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W")) {      // dX = dx0 @ Wc[:, :S*d], A-stationary
+      uint16_t* wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
+      RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 1, 1, (int64_t)PM_N_SLOTS * d * d,
+                                 (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));
+      RUN(pm_rows_times_weight(dx0, d, N, d, wf_enc, 1, PM_N_SLOTS * d / 32, S * d, nullptr, dX, S * d, c.st));
+    } else
+      RUN(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
+                        nullptr, c.st));
   }
   RUN(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
   RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));

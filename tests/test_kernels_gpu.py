@@ -864,6 +864,31 @@ def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
     assert float((dW2.double() - want).abs().max()) < 2e-6 * scale
 
 
+@pytest.mark.parametrize("K,Nout,N,kind", [(256, 1280, 16271, 0), (256, 1280, 5000, 1), (128, 384, 77, 0), (128, 256, 64, 1)])
+def test_rows_times_weight_matches_fp64(K, Nout, N, kind):
+    """`pm_rows_times_weight` (A-stationary: the fp32 rows of a 64-row tile split into bf16 planes once, all output columns
+    from that LDS image) for both weight orientations: y = x W^T + b (kind 0, W [Nout, K]) and y = x W[:, :Nout] (kind 1,
+    W [K, ldw]); fp32-exact products against an fp64 product; strided x and y; rows past N untouched."""
+    torch.manual_seed(9)
+    ldx, ldc = K + 8, Nout + 4
+    X = torch.randn(N, ldx, device=DEV)
+    bias = torch.randn(Nout, device=DEV) if kind == 0 else None
+    if kind == 0:
+        W = torch.randn(Nout, K, device=DEV) / K ** 0.5
+        want = X[:, :K].double() @ W.double().T + bias.double()
+        tiles = 0
+    else:
+        ldw = Nout + 3 * K                                             # the product uses the first Nout columns of W [K, ldw]
+        W = torch.randn(K, ldw, device=DEV) / K ** 0.5
+        want = X[:, :K].double() @ W[:, :Nout].double()
+        tiles = ldw // 32
+    Wf = ops.split_planes_frag(W, kind)
+    C = torch.full((N, ldc), 7.0, device=DEV)
+    call("pm_rows_times_weight", ptr(X), ldx, N, K, ptr(Wf), kind, tiles, Nout, ptr(bias), ptr(C), ldc, stream())
+    assert rel_err(C[:, :Nout], want) < 2e-6
+    assert bool((C[:, Nout:] == 7.0).all())
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

@@ -186,6 +186,12 @@ int pm_gcl_weight_grad_fused(const uint16_t* a_planes /* 3 planes [N,4d] */, int
 int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
                          int32_t w_tiles, int32_t Nout, const float* bias /* [Nout] or NULL */, float* C, int32_t ldc,
                          pm_stream_t stream);
+/* The same for a long inner dimension and d output columns: C[N, Nout] = X[N, K] @ W, K a multiple of 128, Nout in
+ * {128, 256} (chord encoder forward model.py:384-390 without its bias; chord decoder input gradient): producer waves split
+ * 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves contract them (gcl.hip k_rows_wk).  `w_frag`: kind 0
+ * for W [Nout, 16*w_pitch] (y = x W[:, :K]^T), kind 1 for W [K, Nout] (y = x W). */
+int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
+                               int32_t w_pitch, int32_t Nout, float* C, int32_t ldc, pm_stream_t stream);
 /* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
  * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
  * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */

@@ -37,6 +37,7 @@ _SIGS = {
     "pm_gcl_input_grad_fused": "plpiiiipips",
     "pm_gcl_weight_grad_fused": "plplpiiiiips",
     "pm_rows_times_weight": "piiipiiippis",
+    "pm_rows_times_weight_longk": "piiipiiipis",
     "pm_segreduce_bwd": "pppppiiiifuuipps",
     "pm_segreduce_bwd_norm": "pppppiiiifuuippps",
     "pm_gemm_f32": "iiiiipipipipiipips",

@@ -345,6 +345,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
+  uint16_t* wf_enc = ((d == 128 || d == 256) && S < PM_N_SLOTS && gcl_fused_on() && !getenv("PM_NO_ROWS_W"))
+                         ? (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6) : nullptr;
   if (run) {
     RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                           c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_d.b,
@@ -355,8 +357,13 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
     if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
     else {             // x0 = relu(X[:, :S] @ Wc[:, :S*d]^T + (bias + all-PAD tail slots, one vector per node group))
-      RUN(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
-                        nullptr, 0, nullptr, c.st));
+      if (wf_enc) {                // long-K kernel of gcl.hip: Wc [d, 15d] as fragment-major planes (kind 0), columns [0, S*d)
+        RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 0, 1, (int64_t)PM_N_SLOTS * d * d,
+                                   (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));
+        RUN(pm_rows_times_weight_longk(s.X, S * d, N, S * d, wf_enc, 0, PM_N_SLOTS * d / 16, d, s.x0, d, c.st));
+      } else
+        RUN(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
+                          nullptr, 0, nullptr, c.st));
       RUN(pm_chord_pad_fwd(tables, c.P + Y.enc_chord.w, c.P + Y.enc_chord.b, s.bt.is_drum, N, d, S, s.cvec, s.x0, c.st));
     }
   }
@@ -464,7 +471,14 @@ void backward_decoder(Ctx& c) {
                       PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
-  lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);          // slots >= S: zero gradient (all PAD)
+  if ((d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W")) {
+    // dxL = dH @ W[:S*d, :] by the long-K kernel of gcl.hip (weight rows as fragment-major planes, kind 1)
+    uint16_t* wf = (uint16_t*)ar.take((size_t)S * d * d * 6);
+    lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);    // weight and bias gradients
+    RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, 1, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3, wf, c.st));
+    RUN(pm_rows_times_weight_longk(dH, S * d, N, S * d, wf, 1, 0, d, dxL, d, c.st));
+  } else
+    lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);        // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
   float* dcb = ar.f((size_t)Gn * d);
   RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));

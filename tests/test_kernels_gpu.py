@@ -889,6 +889,29 @@ def test_rows_times_weight_matches_fp64(K, Nout, N, kind):
     assert bool((C[:, Nout:] == 7.0).all())
 
 
+@pytest.mark.parametrize("K,Nout,N,kind", [(1280, 256, 16271, 0), (1280, 256, 5000, 1), (384, 128, 77, 0), (128, 128, 64, 1)])
+def test_rows_times_weight_longk_matches_fp64(K, Nout, N, kind):
+    """`pm_rows_times_weight_longk` (producer waves split 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves
+    contract them): y = x W[:, :K]^T (kind 0, W [Nout, ldw]) and y = x W (kind 1, W [K, Nout]) against an fp64 product."""
+    torch.manual_seed(10)
+    ldx, ldc = K + 4, Nout + 4
+    X = torch.randn(N, ldx, device=DEV)
+    if kind == 0:
+        ldw = K + 256                                                  # the product uses the first K columns of W [Nout, ldw]
+        W = torch.randn(Nout, ldw, device=DEV) / K ** 0.5
+        want = X[:, :K].double() @ W[:, :K].double().T
+        pitch = ldw // 16
+    else:
+        W = torch.randn(K, Nout, device=DEV) / K ** 0.5
+        want = X[:, :K].double() @ W.double()
+        pitch = 0
+    Wf = ops.split_planes_frag(W, kind)
+    C = torch.full((N, ldc), 7.0, device=DEV)
+    call("pm_rows_times_weight_longk", ptr(X), ldx, N, K, ptr(Wf), kind, pitch, Nout, ptr(C), ldc, stream())
+    assert rel_err(C[:, :Nout], want) < 3e-6
+    assert bool((C[:, Nout:] == 7.0).all())
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

@@ -734,7 +734,7 @@ def _masked_contractions(plan, N, on, nx, d, bfrag):
 
 
 @pytest.mark.parametrize("d,p,dense", [(128, 0.0, False), (256, 0.0, False), (256, 0.15, False), (128, 0.1, True),
-                                       (256, 0.0, True)])
+                                       (256, 0.0, True), (128, 0.1, "tiny"), (256, 0.0, "tiny")])
 def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     """`pm_gcl_forward_fused` (aggregate built in LDS, contracted in the same kernel) against the unfused pair it
     replaces — `pm_segreduce_fwd_planes` then the grouped planes product with row classes: same edge order and message
@@ -742,7 +742,10 @@ def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     them; h agrees to fp32 accumulation order (the fused kernel contracts the self block first) and against an fp64
     product of the exact planes; the BatchNorm column sums agree with its own h.  dense: up to 127 edges per node (the edge
     lists overflow the LDS cache and the in-flight gather: the serial tail paths)."""
-    cpu = synthetic_batch(3 if dense else 40, 2, p=0.3, seed=17, dense=dense)
+    if dense == "tiny":                # one sparse sample: a few dozen nodes, tiles far from full, class ranges partly empty
+        cpu = synthetic_batch(1, 2, p=0.12, seed=41)
+    else:
+        cpu = synthetic_batch(3 if dense else 40, 2, p=0.3, seed=17, dense=dense)
     assert cpu.track_unique
     b, plan = make_plan(cpu)
     N, dd = cpu.num_nodes, d * d
@@ -790,12 +793,12 @@ def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     assert torch.equal(h2, h1)
 
 
-@pytest.mark.parametrize("d", [128, 256])
-def test_gcl_input_grad_fused_equals_grouped_product(d):
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 1)])
+def test_gcl_input_grad_fused_equals_grouped_product(d, B):
     """`pm_gcl_input_grad_fused` (dh rows resident in LDS, all 4d output columns per workgroup) against the grouped planes
     product with transB it replaces: same six products in the same k order -> BIT-identical wherever the segment-reduce
     backward reads dA' (track and self blocks of every row, onset / next blocks of the rows that receive such edges)."""
-    cpu = synthetic_batch(40, 2, p=0.3, seed=19)
+    cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=19)
     b, plan = make_plan(cpu)
     N, dd = cpu.num_nodes, d * d
     torch.manual_seed(4)
@@ -826,11 +829,11 @@ def test_gcl_input_grad_fused_equals_grouped_product(d):
     assert torch.equal(dA2[keep], dA1[keep]) and bool(torch.isfinite(dA2).all())
 
 
-@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 3)])
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 3), (128, 1)])
 def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
     """`pm_gcl_weight_grad_fused` (128x128 tiles, loader waves + LDS ring, K slices by atomics) against the grouped planes
     product with transA it replaces and against an fp64 contraction of the exact planes; accumulates into dW (+=)."""
-    cpu = synthetic_batch(B, 2, p=0.3, seed=23)
+    cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=23)
     b, plan = make_plan(cpu)
     N, dd = cpu.num_nodes, d * d
     torch.manual_seed(5)

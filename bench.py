@@ -38,7 +38,7 @@ PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 def kernel_source_digest():
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "common.h"):
+    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "gcl_tiles.h", "common.h"):
         h.update(open(os.path.join(ROOT, "polyphemus_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -180,7 +180,7 @@ int pm_gcl_weight_grad_fused(const uint16_t* a_planes /* 3 planes [N,4d] */, int
                              pm_stream_t stream);
 /* C[N, Nout] = X[N, K] @ W (+ bias) for a plain linear layer with a short inner dimension, K in {128, 256}, Nout a
  * multiple of K (chord decoder forward model.py:555-559; chord encoder input gradient, autograd of model.py:384-390),
- * A-stationary (gcl.hip k_rows_w): the 64 fp32 rows of a tile are split into bf16 planes once and kept in LDS for all
+ * A-stationary (linear.hip k_rows_w): the 64 fp32 rows of a tile are split into bf16 planes once and kept in LDS for all
  * output columns.  `w_frag` = pm_split_planes_frag of the weight: kind 0 for W [Nout, K] (y = x W^T), kind 1 for
  * W [K, 32*w_tiles] (y = x W; only the first Nout columns are used). */
 int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
@@ -188,7 +188,7 @@ int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, cons
                          pm_stream_t stream);
 /* The same for a long inner dimension and d output columns: C[N, Nout] = X[N, K] @ W, K a multiple of 128, Nout in
  * {128, 256} (chord encoder forward model.py:384-390 without its bias; chord decoder input gradient): producer waves split
- * 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves contract them (gcl.hip k_rows_wk).  `w_frag`: kind 0
+ * 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves contract them (linear.hip k_rows_wk).  `w_frag`: kind 0
  * for W [Nout, 16*w_pitch] (y = x W[:, :K]^T), kind 1 for W [K, Nout] (y = x W). */
 int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
                                int32_t w_pitch, int32_t Nout, float* C, int32_t ldc, pm_stream_t stream);

@@ -23,13 +23,7 @@
 #include <stdlib.h>
 #include "prof.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define GCL_OOB ((int)0x80000000)
-#ifndef GCL_BDEPTH
-#define GCL_BDEPTH 2          // k-steps of weight fragments in flight per consumer wave
-#endif
+#include "gcl_tiles.h"
 #ifndef GCL_TRACE
 #define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
 #endif
@@ -41,8 +35,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 namespace {
-constexpr int BM = 64;        // rows (nodes) per workgroup
-constexpr int CH = 128;       // features of one relation block per chunk
 constexpr int EMAX = 3;       // edges per (node, relation) gathered in one go (beyond: a serial tail loop)
 #ifndef GCL_NPW
 #define GCL_NPW 8
@@ -51,9 +43,6 @@ constexpr int NPW = GCL_NPW;               // producer waves (waves 4 .. 4 + NPW
 constexpr int NTHR = (4 + NPW) * 64;       // threads per workgroup
 constexpr int RPP = NPW * 2;               // image rows per producer pass
 constexpr int NPS = BM / RPP;              // passes per chunk
-constexpr int ROWB = CH * 2;  // bytes of one image row (one plane)
-constexpr int PLANE = BM * ROWB;
-constexpr int IMG = 3 * PLANE;
 
 struct GclArgs {
   const float* x; const float* T; const float* bias;
@@ -805,335 +794,6 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
                        pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes);                                           \
   } while (0)
   if (d == 256) LAUNCH(256); else LAUNCH(128);
-#undef LAUNCH
-  pm_prof_close(st, pe);
-  return pm_check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The A-stationary shape for a PLAIN linear layer with a short inner dimension: C[N, Nout] = X[N, K] @ W (+ bias),
-// K = d in {128, 256}, Nout a multiple of K (chord decoder forward, model.py:555-559, and the chord encoder's input
-// gradient, autograd of model.py:384-390; Nout = S*d).  X is fp32: the 64 rows of a tile are split into the three
-// bf16 planes ONCE, in the prologue, into the LDS image the MFMA waves then read for every block of K output columns;
-// the weight comes as fragment-major planes (pm_split_planes_frag; kind 0: W [Nout, K] used as B[n][k], kind 1: W [K, ldw]
-// used as B[k][n]); store waves write finished blocks (+ bias) as whole rows.  The in-kernel split (x6) tile kernel
-// it replaces re-splits every operand element once per 128x128 tile that uses it.
-template <int D, int BKIND>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ wfrag, int wtiles, int nblk,
-         const float* __restrict__ bias, float* __restrict__ C, int ldc) {
-  constexpr int TN = D / 128, KS = D / 16, RB = D * 2, PL = BM * RB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
-  const int ntile = (N + BM - 1) / BM;
-  int t = blockIdx.x;
-  {
-    const int q = ntile >> 3, r = ntile & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = t * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  if (wave >= 4) {
-    // ---- store waves: block q of the stage (+ bias) -> C rows, 16 bytes per lane
-    constexpr int LPR = D / 4, RPW = 64 / LPR, NR = BM / (4 * RPW);
-    const int st = tid - 256, c4 = st % LPR, r0 = st / LPR;
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, GCL_OOB, 0x00020000);
-    __syncthreads();                                           // (image filled)
-#pragma unroll 1
-    for (int qb = 0; qb < nblk; ++qb) {
-      __syncthreads();                                         // consumers: stage free -> they fill it
-      __syncthreads();                                         // stage holds block qb
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) bv = *reinterpret_cast<const float4*>(bias + qb * D + c4 * 4);
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const int rr = r0 + k * 4 * RPW, row = m0 + rr;
-        float4 v = *reinterpret_cast<const float4*>(sC + rr * D + c4 * 4);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crs,
-            row < N ? (int)(((int64_t)row * ldc + qb * D + c4 * 4) * 4) : GCL_OOB, 0, 0);
-      }
-    }
-    return;
-  }
-  // ---- the tile's rows: fp32 -> three bf16 planes -> XOR-swizzled LDS image (16-byte chunk c of row r at c ^ (r & 15))
-  {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, GCL_OOB, 0x00020000);
-    constexpr int CPR = D / 8, NCHK = BM * CPR / 256;            // 8-value chunks per row, chunks per thread
-    u32x4 v[NCHK][2];
-#pragma unroll
-    for (int k = 0; k < NCHK; ++k) {
-      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR, row = m0 + rr;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        v[k][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, row < N ? (int)(((int64_t)row * ldx + ch * 8 + h * 4) * 4) : GCL_OOB, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < NCHK; ++k) {
-      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR;
-      unsigned p1[4], p2[4], p3[4];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        pm_split3_pair(__uint_as_float(v[k][h][0]), __uint_as_float(v[k][h][1]), p1[2 * h], p2[2 * h], p3[2 * h]);
-        pm_split3_pair(__uint_as_float(v[k][h][2]), __uint_as_float(v[k][h][3]), p1[2 * h + 1], p2[2 * h + 1], p3[2 * h + 1]);
-      }
-      char* dst = smem + rr * RB + ((ch ^ (rr & 15)) << 4);
-      *reinterpret_cast<u32x4*>(dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
-      *reinterpret_cast<u32x4*>(dst + PL) = u32x4{p2[0], p2[1], p2[2], p2[3]};
-      *reinterpret_cast<u32x4*>(dst + 2 * PL) = u32x4{p3[0], p3[1], p3[2], p3[3]};
-    }
-  }
-  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
-  auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global step gs = block index * KS + k-step
-    const int qb = min(gs / KS, nblk - 1), ks = gs % KS;
-    const int n0 = qb * D + wave * (D / 4);                      // first output column of this wave in block qb
-    // kind 0: blocks ordered [32-column tile of W rows][k-step]; kind 1: [k-step][32-column tile], wtiles tiles per k-step
-    const int soff = __builtin_amdgcn_readfirstlane(BKIND == 0 ? ((n0 >> 5) * KS + ks) * 3072 : (ks * wtiles + (n0 >> 5)) * 3072);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * (BKIND == 0 ? KS : 1) * 3072 + p * 1024, 0));
-  };
-  bf16x8 bq[GCL_BDEPTH][3][TN];
-#pragma unroll
-  for (int s2 = 0; s2 < GCL_BDEPTH; ++s2) bload(bq[s2], s2);
-  __syncthreads();
-  auto aload = [&](bf16x8 (&a)[3][2], int ks) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rr = i * 32 + li;
-        a[p][i] = *reinterpret_cast<const bf16x8*>(smem + p * PL + rr * RB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
-      }
-  };
-  bf16x8 af[2][3][2];
-  aload(af[0], 0);
-#pragma unroll 1
-  for (int qb = 0; qb < nblk; ++qb) {
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      aload(af[(ks + 1) & 1], (ks + 1) % KS);
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
-#pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
-      bload(bq[ks % GCL_BDEPTH], qb * KS + ks + GCL_BDEPTH);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();                                             // the store waves have read the previous block
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / 4) + j * 32 + li] = acc[i][j][r];
-    __syncthreads();
-  }
-}
-
-extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
-                                    int32_t w_tiles, int32_t Nout, const float* bias, float* C, int32_t ldc,
-                                    pm_stream_t stream) {
-  if (!X || !w_frag || !C || N <= 0 || (K != 128 && K != 256) || Nout <= 0 || (Nout % K) || (kind != 0 && kind != 1) ||
-      ldx < K || ldc < Nout || (ldx & 3) || (ldc & 3) || ((uintptr_t)X % 16) || ((uintptr_t)C % 16) ||
-      ((uintptr_t)w_frag % 16) || (bias && ((uintptr_t)bias % 16)) || (int64_t)N * ldx * 4 >= 0x7fffffffLL ||
-      (int64_t)N * ldc * 4 >= 0x7fffffffLL || (kind == 1 && w_tiles * 32 < Nout))
-    return PM_E_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
-  const size_t lds = (size_t)3 * BM * K * 2 + (size_t)BM * K * 4;
-  const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
-#define LAUNCH(DD, KD)                                                                                                 \
-  do {                                                                                                                 \
-    static bool once = false;                                                                                          \
-    if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_rows_w<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((k_rows_w<DD, KD>), grid, block, lds, st, X, ldx, N, reinterpret_cast<const char*>(w_frag),     \
-                       w_tiles, Nout / K, bias, C, ldc);                                                               \
-  } while (0)
-  if (K == 256) { if (kind == 0) LAUNCH(256, 0); else LAUNCH(256, 1); }
-  else { if (kind == 0) LAUNCH(128, 0); else LAUNCH(128, 1); }
-#undef LAUNCH
-  pm_prof_close(st, pe);
-  return pm_check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// ... and for a plain linear layer with a LONG inner dimension and d output columns: C[N, D] = X[N, K] @ W, K = S*d
-// (chord encoder forward, model.py:384-390, and the chord decoder's input gradient): the forward kernel's pipeline
-// without the gather — four producer waves split 64 x 128 fp32 chunks of the tile's rows into bf16 planes in a 2-image
-// LDS ring, four MFMA waves contract them with weight fragments straight from L2; output rows through LDS.
-template <int D, int BKIND>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __restrict__ wfrag, int wpitch,
-          float* __restrict__ C, int ldc) {
-  constexpr int TN = D / 128, HS = D + 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const sH = reinterpret_cast<float*>(smem);            // [BM][HS] output tile (epilogue; over the images)
-  const int ntile = (N + BM - 1) / BM, nchunk = K / CH;
-  int t = blockIdx.x;
-  {
-    const int q = ntile >> 3, r = ntile & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = t * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave >= 4) {
-    // ---- producers: chunk c (128 features of the 64 rows) -> planes image c & 1; 32 lanes per row, 8 rows per pass
-    const int pt = tid - 256, q = pt & 31, prow = pt >> 5;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, GCL_OOB, 0x00020000);
-    auto issue = [&](float4 (&xs)[8], int c) {
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = m0 + ps * 8 + prow;
-        xs[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-            xrs, (row < N && c < nchunk) ? (int)(((int64_t)row * ldx + c * CH + q * 4) * 4) : GCL_OOB, 0, 0));
-      }
-    };
-    auto put = [&](const float4 (&xs)[8], int c) {
-      char* img = smem + (c & 1) * IMG;
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int rr = ps * 8 + prow;
-        unsigned l1, l2, l3, u1, u2, u3;
-        pm_split3_pair(xs[ps].x, xs[ps].y, l1, l2, l3);
-        pm_split3_pair(xs[ps].z, xs[ps].w, u1, u2, u3);
-        const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
-        char* dst = img + rr * ROWB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
-        *reinterpret_cast<pm_u32x2*>(dst) = p1;
-        *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
-        *reinterpret_cast<pm_u32x2*>(dst + 2 * PLANE) = p3;
-      }
-    };
-    float4 xa[8], xb[8];                                         // two chunks in flight
-    issue(xa, 0);
-    issue(xb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    put(xa, 0);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nchunk; c += 2) {                        // (same barrier sequence as the MFMA waves: one per chunk)
-      issue(xa, c + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      put(xb, c + 1);
-      __syncthreads();
-      if (c + 1 >= nchunk) break;
-      issue(xb, c + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      put(xa, c + 2);
-      __syncthreads();
-    }
-  } else {
-    const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
-    const int n0 = wave * (D / 4);
-    auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {             // fragments of global k-step gs (16 rows of K)
-      const int kk = min(gs, nchunk * 8 - 1);
-      // kind 0: W [D, .] as B[n][k], wpitch = k-steps per 32-row tile of W; kind 1: W [K, D] as B[k][n], D/32 tiles per k-step
-      const int soff = __builtin_amdgcn_readfirstlane(BKIND == 0 ? ((n0 >> 5) * wpitch + kk) * 3072 : (kk * (D / 32) + (n0 >> 5)) * 3072);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * (BKIND == 0 ? wpitch : 1) * 3072 + p * 1024, 0));
-    };
-    bf16x8 bq[GCL_BDEPTH][3][TN];
-#pragma unroll
-    for (int s2 = 0; s2 < GCL_BDEPTH; ++s2) bload(bq[s2], s2);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
-      const char* img = smem + (c & 1) * IMG;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8 a[3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int rr = i * 32 + li;
-            a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
-          }
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
-#pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
-        bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-    }
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          sH[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * HS + n0 + j * 32 + li] = acc[i][j][r];
-  }
-  __syncthreads();
-  // ---- all waves: rows out, 4*D bytes per row and wave-instruction group
-  constexpr int NG = 512 / D, RG = BM / NG;
-  const int col = tid % D, rg = tid / D;
-  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, GCL_OOB, 0x00020000);
-#pragma unroll 8
-  for (int k = 0; k < RG; ++k) {
-    const int rr = rg * RG + k, row = m0 + rr;
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sH[rr * HS + col]), crs, row < N ? (int)(((int64_t)row * ldc + col) * 4) : GCL_OOB, 0, 0);
-  }
-}
-
-extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag,
-                                          int32_t kind, int32_t w_pitch, int32_t Nout, float* C, int32_t ldc,
-                                          pm_stream_t stream) {
-  if (!X || !w_frag || !C || N <= 0 || K <= 0 || (K % CH) || (Nout != 128 && Nout != 256) || (kind != 0 && kind != 1) ||
-      ldx < K || ldc < Nout || (ldx & 3) || ((uintptr_t)X % 16) || ((uintptr_t)w_frag % 16) ||
-      (int64_t)N * ldx * 4 >= 0x7fffffffLL || (int64_t)N * ldc * 4 >= 0x7fffffffLL || (kind == 0 && w_pitch * 16 < K))
-    return PM_E_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
-  const size_t lds = 2 * IMG;
-  const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
-#define LAUNCH(DD, KD)                                                                                                 \
-  do {                                                                                                                 \
-    static bool once = false;                                                                                          \
-    if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_rows_wk<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((k_rows_wk<DD, KD>), grid, block, lds, st, X, ldx, N, K, reinterpret_cast<const char*>(w_frag), \
-                       w_pitch, C, ldc);                                                                               \
-  } while (0)
-  if (Nout == 256) { if (kind == 0) LAUNCH(256, 0); else LAUNCH(256, 1); }
-  else { if (kind == 0) LAUNCH(128, 0); else LAUNCH(128, 1); }
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();

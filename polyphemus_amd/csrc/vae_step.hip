@@ -357,7 +357,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
     if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
     else {             // x0 = relu(X[:, :S] @ Wc[:, :S*d]^T + (bias + all-PAD tail slots, one vector per node group))
-      if (wf_enc) {                // long-K kernel of gcl.hip: Wc [d, 15d] as fragment-major planes (kind 0), columns [0, S*d)
+      if (wf_enc) {                // long-K kernel of linear.hip: Wc [d, 15d] as fragment-major planes (kind 0), columns [0, S*d)
         RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 0, 1, (int64_t)PM_N_SLOTS * d * d,
                                    (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));
         RUN(pm_rows_times_weight_longk(s.X, S * d, N, S * d, wf_enc, 0, PM_N_SLOTS * d / 16, d, s.x0, d, c.st));
@@ -409,7 +409,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
-  // chord decoder (K = d, S*d output columns): A-stationary kernel of gcl.hip, its weight rows as fragment-major planes
+  // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
   const bool rows_w = (d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W");
   uint16_t* wf_dec = rows_w ? (uint16_t*)ar.take((size_t)S * d * d * 6) : nullptr;
   if (run) {
@@ -472,7 +472,7 @@ void backward_decoder(Ctx& c) {
   }
   float* dxL = ar.f((size_t)N * d);
   if ((d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W")) {
-    // dxL = dH @ W[:S*d, :] by the long-K kernel of gcl.hip (weight rows as fragment-major planes, kind 1)
+    // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
     uint16_t* wf = (uint16_t*)ar.take((size_t)S * d * d * 6);
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);    // weight and bias gradients
     RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, 1, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3, wf, c.st));

@@ -36,6 +36,8 @@ def klass(kernel_name):
     for k in ("gcl_fwd", "gcl_dagg", "gcl_dw"):
         if s.startswith("k_" + k):
             return k
+    if s.startswith("k_rows_w"):
+        return "gemm_NN_rows_w"
     return None
 
 

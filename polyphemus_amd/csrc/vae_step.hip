@@ -125,6 +125,11 @@ static bool gcl_fused_on() {
   static const bool on = !(getenv("PM_GCL_FUSED") && atoi(getenv("PM_GCL_FUSED")) == 0);
   return on;
 }
+// the kernels of gcl.hip / linear.hip address their operands with 32-bit byte offsets: batches beyond these sizes
+// (N > ~349 k nodes at d = 256) take the round-1 kernels
+static bool gcl_fits(int N, int d, int S) {
+  return (int64_t)N * 4 * d * 6 < 0x7fffffffLL && (int64_t)N * 4 * d * 4 < 0x7fffffffLL && (int64_t)N * S * d * 4 < 0x7fffffffLL;
+}
 // descriptor skeleton of the compact GCL contractions: four track-relation groups, rows of group t listed in
 // plan.trk_list[t*N ..], live count plan.trk_cnt[t]
 PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
@@ -192,7 +197,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     const float* W = c.P + g.weight[i];
     double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
     // one kernel for aggregate + product (gcl.hip) where it applies: compact planes path, fragment-major weights
-    const bool fused = c.planes && c.compact && sv.Wfn && (d == 128 || d == 256) && gcl_fused_on();
+    const bool fused = c.planes && c.compact && sv.Wfn && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1);
     if (fused)
       RUN(pm_gcl_forward_fused(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                  sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], getenv("PM_GCL_NO_CLASSES") ? 0 : 1,
@@ -264,7 +269,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
         if (sv.Wft) q.b_frag = sv.Wft + (int64_t)i * sv.wf_stride;
       }
-      if (c.planes && sv.Wft && (d == 128 || d == 256) && gcl_fused_on())      // A-stationary kernel (gcl.hip)
+      if (c.planes && sv.Wft && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip)
         RUN(pm_gcl_input_grad_fused(dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                       getenv("PM_GCL_NO_CLASSES") ? 0 : 1, dA, c.st));
       else
@@ -277,7 +282,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
         w.B = (const float*)dhp; w.b_plane_stride = dps;
       }
-      if (c.planes && (d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_GCL_NO_DW"))      // 128x128 tiles (gcl.hip)
+      if (c.planes && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1) && !getenv("PM_GCL_NO_DW"))      // 128x128 tiles (gcl.hip)
         RUN(pm_gcl_weight_grad_fused(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d,
                                        getenv("PM_GCL_NO_CLASSES") ? 0 : 1, dW, c.st));
       else
@@ -345,7 +350,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
-  uint16_t* wf_enc = ((d == 128 || d == 256) && S < PM_N_SLOTS && gcl_fused_on() && !getenv("PM_NO_ROWS_W"))
+  uint16_t* wf_enc = ((d == 128 || d == 256) && S < PM_N_SLOTS && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W"))
                          ? (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6) : nullptr;
   if (run) {
     RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
@@ -410,7 +415,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
-  const bool rows_w = (d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W");
+  const bool rows_w = (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W");
   uint16_t* wf_dec = rows_w ? (uint16_t*)ar.take((size_t)S * d * d * 6) : nullptr;
   if (run) {
     if (rows_w) {
@@ -471,7 +476,7 @@ void backward_decoder(Ctx& c) {
                       PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
-  if ((d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W")) {
+  if ((d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W")) {
     // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
     uint16_t* wf = (uint16_t*)ar.take((size_t)S * d * d * 6);
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);    // weight and bias gradients
@@ -548,7 +553,7 @@ void backward_encoder_tail(Ctx& c) {
     RUN(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
                       nullptr, 0, nullptr, c.st));
     RUN(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
-    if ((d == 128 || d == 256) && gcl_fused_on() && !getenv("PM_NO_ROWS_W")) {      // dX = dx0 @ Wc[:, :S*d], A-stationary
+    if ((d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W")) {      // dX = dx0 @ Wc[:, :S*d], A-stationary
       uint16_t* wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
       RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 1, 1, (int64_t)PM_N_SLOTS * d * d,
                                  (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));

@@ -433,6 +433,10 @@ def main():
                                  "achieved_TFLOP/s_per_gpu": round(value * fpb / 1e12 / world, 2),
                                  "frac_of_fp32_mfma_peak": round(value * fpb / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4)},
             "losses": {k: round(v, 5) for k, v in losses.items()},
+            "losses_note": ("last of warmup+steps Adam steps on ONE fixed synthetic batch; kld is reported unweighted and is "
+                            "unconstrained at beta = 0 (the reference's schedule starts there, training.json): it spikes "
+                            "to 1e3-1e5 around steps 3-5 with every kernel set and usually, not always, is back at ~33 "
+                            "by step 25 (DESIGN.md section 5)"),
             "roofline": roof, "roofline_segreduce": roof_seg,
         }
         if dp is not None:

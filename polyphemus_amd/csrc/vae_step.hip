@@ -166,7 +166,6 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     for (int i = 0; i < c.L; ++i)
       if (g.weight[i] < sv.wp_base || ((g.weight[i] - sv.wp_base) & 7)) RUN(PM_E_INVALID);
     sv.Wp = (uint16_t*)ar.take((size_t)sv.wp_stride * 6);
-    if (ar.base) RUN(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
     // fragment-major copies for the B-direct mode (d a multiple of 32, the layers' matrices equally spaced)
     sv.Wfn = sv.Wft = nullptr; sv.wf_stride = 7 * dd * 3;
     // (layer 0 is followed by the shared edge_nn parameters, so it is converted on its own; layers 1.. are equally
@@ -188,6 +187,11 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       }
     }
   }
+  // plain (row-major) planes of the weights: operand of the grouped planes products only — the kernels of gcl.hip take
+  // the fragment-major copies (forward, input gradient) or no weight at all (weight gradient)
+  const bool gcl_kernels = c.planes && c.compact && sv.Wfn && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1);
+  if (c.planes && !gcl_kernels && ar.base)
+    RUN(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
   for (int i = 0; i < c.L; ++i) {
     if (c.planes) { sv.Ap[i] = (uint16_t*)ar.take((size_t)aps * 6); sv.A[i] = nullptr; }
     else sv.A[i] = ar.f((size_t)N * nb * d);
@@ -197,7 +201,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     const float* W = c.P + g.weight[i];
     double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
     // one kernel for aggregate + product (gcl.hip) where it applies: compact planes path, fragment-major weights
-    const bool fused = c.planes && c.compact && sv.Wfn && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1);
+    const bool fused = gcl_kernels;
     if (fused)
       RUN(pm_gcl_forward_fused(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                  sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], getenv("PM_GCL_NO_CLASSES") ? 0 : 1,

@@ -859,7 +859,8 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false, bool
   // default: the large UNGROUPED NN / NT products (chord encoder / decoder and their input gradients) run in split
   // mode (78-90 us against 99-112 us in the step); weight gradients stay on the fp32 tiles (split mode: 132 against 106 us)
   static const bool split_ungrouped = !(getenv("PM_GEMM_SPLIT_UNGROUPED") && atoi(getenv("PM_GEMM_SPLIT_UNGROUPED")) == 0);
-  if ((split_on || (split_ungrouped && ungrouped && !transA)) && x6_ok && (double)M * N * K >= 1.0e9) {
+  // (N < 128: the 128-wide split tiles would be partly empty — the duration un-embedding, N = 99: 60 us against 46 us on the fp32 tiles)
+  if ((split_on || (split_ungrouped && ungrouped && !transA && N >= 128)) && x6_ok && (double)M * N * K >= 1.0e9) {
     if (transA) return 5;
     return K >= 1024 ? 7 : 4;
   }

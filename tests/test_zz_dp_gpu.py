@@ -69,7 +69,9 @@ def test_two_rank_step_matches_mean_gradient_step():
         tr.train_step(_rank_batch(rank).to("cuda"), eps)
         grads.append(tr.grads.detach().clone())
     gsum = grads[0] + grads[1]
-    assert float((gsum.cpu() - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    # (the two runs add their float atomics — split-K slices, embedding sums — in different orders: 1-2e-5 of the largest
+    #  element has been observed; a wrong or missing reduction is an O(1) error)
+    assert float((gsum.cpu() - g0).abs().max()) <= 5e-5 * float(g0.abs().max())
     p = init.clone()
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     ops.adam_step(p, gsum, m, v, 1e-3, 0.9, 0.98, 1e-9, 1, grad_scale=0.5)

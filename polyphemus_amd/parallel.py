@@ -28,6 +28,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     if (world > 1 or os.environ.get("PM_DP_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL / tensor sharing across processes)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

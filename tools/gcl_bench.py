@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Development micro-benchmark: the fused GCL forward kernel (gcl.hip) against the unfused pair it replaces, on the
-bench batch (B = 256, d = 256).  `PM_LIB_PATH` selects a library variant (tools/build_variants.py)."""
+"""Development micro-benchmark of the three GCL kernels of csrc/gcl.hip against the kernels they replace, on the bench
+batch (B = 256, d = 256).  WHICH selects what runs (u unfused forward pair, f fused forward, p fused forward without the A'
+output, n input gradient, w weight gradient); PM_LIB_PATH selects a library variant (tools/build_variants.py); TRACE=1 / n / w
+prints the in-kernel timeline of one workgroup from a -DGCL_TRACE=<block + 1> build."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -38,7 +38,12 @@ enum {
 
 enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR = 99, PM_N_TOK = 230 };
 
-/* Library / device identification (host only, no GPU needed). */
+/* Library / device identification (host only, no GPU needed).  pm_abi_version() returns the PM_ABI_VERSION the library
+ * was built with; a host must refuse a library whose version differs from the header it was compiled against (struct
+ * layouts — PmBatch, PmGemmDesc, PmVaeLayout —, argument lists and the dropout stream are part of the version).
+ *   1: round 1.  2: round 2 (PmBatch.ce_scale, pm_attnpool_bwd +2 arguments, one hash per four channels in the dropout
+ *   stream).  3: round 3 (d = 512 in the gcl / linear entry points, pm_gcl_forward_from_planes). */
+#define PM_ABI_VERSION 3
 int pm_abi_version(void);
 const char* pm_build_info(void);
 
@@ -156,7 +161,9 @@ int pm_segreduce_fwd_planes(const float* x, const float* T, const int32_t* plan,
  * weight).  h[n] = A'[n] @ W + bias, bit-identical to pm_segreduce_fwd_planes followed by the grouped planes product;
  * `col_stats` as PmGemmDesc.col_stats; `planes` (optional) receives the A' planes the weight gradient of the backward
  * pass contracts (blocks of row tiles without onset / next receivers are not written when use_classes != 0: the
- * backward never reads them).  d in {128, 256}; the batch must satisfy the compact-GCL premise (track_unique). */
+ * backward never reads them).  d in {128, 256, 512}; the batch must satisfy the compact-GCL premise (track_unique).
+ * d = 512 (training.json's width) runs the ring pipeline of wide.hip: eight MFMA waves x 64 of the 512 output columns,
+ * the aggregate streamed through the same 2-image LDS ring, the distance table in per-chunk slices. */
 int pm_gcl_forward_fused(const float* x /* [N,d] */, const float* T /* [32,d] */, const int32_t* plan, int32_t N,
                          int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid,
                          const uint16_t* w_frag, const float* bias /* [d] or NULL */, int32_t use_classes,
@@ -166,28 +173,38 @@ int pm_gcl_forward_fused(const float* x /* [N,d] */, const float* T /* [32,d] */
  * A-stationary (gcl.hip): a workgroup keeps the dh planes of 64 rows of a track group in LDS and walks all 4d output
  * columns; `w_frag_t` = pm_split_planes_frag kind 0 of the layer's [7d, d] weight.  Same result as the grouped planes
  * product with transB (blocks of row tiles without onset / next receivers are not written when use_classes != 0: the
- * segment-reduce backward never reads them).  d in {128, 256}, compact graphs. */
+ * segment-reduce backward never reads them).  d in {128, 256, 512}, compact graphs (d = 512: the dh planes stream through
+ * the LDS ring of wide.hip once per live 512-column output block instead of staying resident: 192 KB would not fit). */
 int pm_gcl_input_grad_fused(const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t plane_stride, const int32_t* plan,
                             int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
                             float* dA /* [N,4d] */, pm_stream_t stream);
 /* Weight gradient of that product, d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t] (gcl.hip): 128x128 output tiles,
  * one workgroup per (tile, track group, K slice), operands streamed by loader waves through an LDS ring, K slices added
  * with float atomics; `dW` is the layer's [7d, d] gradient (+=).  Same result as the grouped planes product with transA
- * up to the order of the atomic adds.  d in {128, 256}, compact graphs. */
+ * up to the order of the atomic adds.  d in {128, 256, 512}, compact graphs. */
 int pm_gcl_weight_grad_fused(const uint16_t* a_planes /* 3 planes [N,4d] */, int64_t a_plane_stride,
                              const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t dh_plane_stride, const int32_t* plan,
                              int32_t N, int32_t E, int32_t G, int32_t d, int32_t use_classes, float* dW /* [7d,d] += */,
                              pm_stream_t stream);
-/* C[N, Nout] = X[N, K] @ W (+ bias) for a plain linear layer with a short inner dimension, K in {128, 256}, Nout a
+/* The weight products of GCL.forward (model.py:112-119) with the aggregate READ from A' planes (written by
+ * pm_segreduce_fwd_planes) instead of built in the kernel: h[n] = A'[n] @ [W_t; W_4; W_5; root] + bias, `col_stats` as
+ * above.  The path of dense graphs (BASELINE configs[4]: hundreds of edges per node — the fused kernel's producers keep
+ * at most three edges per (node, relation) in flight).  d = 512 (wide.hip). */
+int pm_gcl_forward_from_planes(const uint16_t* a_planes /* 3 planes [N,4d] */, int64_t plane_stride, const int32_t* plan,
+                               int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag,
+                               const float* bias /* [d] or NULL */, int32_t use_classes, float* h /* [N,d] */,
+                               double* col_stats /* [PM_BN_REPL][2][d] += or NULL */, pm_stream_t stream);
+/* C[N, Nout] = X[N, K] @ W (+ bias) for a plain linear layer with a short inner dimension, K in {128, 256, 512}, Nout a
  * multiple of K (chord decoder forward model.py:555-559; chord encoder input gradient, autograd of model.py:384-390),
  * A-stationary (linear.hip k_rows_w): the 64 fp32 rows of a tile are split into bf16 planes once and kept in LDS for all
  * output columns.  `w_frag` = pm_split_planes_frag of the weight: kind 0 for W [Nout, K] (y = x W^T), kind 1 for
- * W [K, 32*w_tiles] (y = x W; only the first Nout columns are used). */
+ * W [K, 32*w_tiles] (y = x W; only the first Nout columns are used).  K = 512: wide.hip (X re-split per 512-column
+ * output block, streamed through the LDS ring). */
 int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
                          int32_t w_tiles, int32_t Nout, const float* bias /* [Nout] or NULL */, float* C, int32_t ldc,
                          pm_stream_t stream);
 /* The same for a long inner dimension and d output columns: C[N, Nout] = X[N, K] @ W, K a multiple of 128, Nout in
- * {128, 256} (chord encoder forward model.py:384-390 without its bias; chord decoder input gradient): producer waves split
+ * {128, 256, 512} (chord encoder forward model.py:384-390 without its bias; chord decoder input gradient): producer waves split
  * 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves contract them (linear.hip k_rows_wk).  `w_frag`: kind 0
  * for W [Nout, 16*w_pitch] (y = x W[:, :K]^T), kind 1 for W [K, Nout] (y = x W). */
 int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,

@@ -36,6 +36,7 @@ _SIGS = {
     "pm_gcl_forward_fused": "pppiiiifuuppipppls",
     "pm_gcl_input_grad_fused": "plpiiiipips",
     "pm_gcl_weight_grad_fused": "plplpiiiiips",
+    "pm_gcl_forward_from_planes": "plpiiiippipps",
     "pm_rows_times_weight": "piiipiiippis",
     "pm_rows_times_weight_longk": "piiipiiipis",
     "pm_segreduce_bwd": "pppppiiiifuuipps",
@@ -110,6 +111,7 @@ _SIGS = {
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes"}
+ABI_VERSION = 3          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])
 
@@ -136,6 +138,9 @@ def lib() -> C.CDLL:
         L.pm_vae_layout_bytes.restype = C.c_int64
         L.pm_vae_step_state_bytes.restype = C.c_int64
         L.pm_abi_version.restype = C.c_int
+        if L.pm_abi_version() != ABI_VERSION:      # struct layouts and argument lists below are those of ONE header version
+            raise HipExtensionError(f"{LIB_PATH} has ABI version {L.pm_abi_version()}, this binding expects {ABI_VERSION}: "
+                                    "rebuild it (`python -m polyphemus_amd.build --force`)")
         L.pm_build_info.restype = C.c_char_p
         L.pm_dropout_hash.argtypes = [C.c_uint32] * 4
         L.pm_dropout_hash.restype = C.c_uint32

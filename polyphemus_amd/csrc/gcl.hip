@@ -24,6 +24,7 @@
 #include "prof.h"
 
 #include "gcl_tiles.h"
+#include "wide.h"
 #ifndef GCL_TRACE
 #define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
 #endif
@@ -566,10 +567,12 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
 extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
                                        int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
                                        float* dA, pm_stream_t stream) {
-  if (!dh_planes || !plan || !w_frag_t || !dA || N <= 0 || (d != 128 && d != 256) || plane_stride < (int64_t)N * d ||
+  if (!dh_planes || !plan || !w_frag_t || !dA || N <= 0 || (d != 128 && d != 256 && d != 512) || plane_stride < (int64_t)N * d ||
       (plane_stride & 7) || ((uintptr_t)dh_planes % 16) || ((uintptr_t)w_frag_t % 16) || ((uintptr_t)dA % 16) ||
       plane_stride * 6 >= 0x7fffffffLL || (int64_t)N * 4 * d * 4 >= 0x7fffffffLL)
     return PM_E_INVALID;
+  if (d == 512)                 // 512-wide layers: the ring pipeline of wide.hip
+    return pm_wide_gcl_input_grad(dh_planes, plane_stride, plan, N, E, G, w_frag_t, use_classes, dA, (hipStream_t)stream);
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(pm_cdiv(N, BM) + 4)), block(512);
@@ -659,64 +662,17 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
   const int kper = (((K + nsplit - 1) / nsplit + DW_KT - 1) / DW_KT) * DW_KT;
   const int kbeg = zs * kper, kend = min(kbeg + kper, K);
   if (kbeg >= kend) return;
-  const int nt = (kend - kbeg + DW_KT - 1) / DW_KT;
-  const int* list = trk_list + (int64_t)grp * N + lo + kbeg;
+  const int* list = trk_list + (int64_t)grp * N + lo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int nst = 0;
   STAMP2();
-  for (int i = tid; i < nt * DW_KT; i += 512) sMap[i] = i < kend - kbeg ? list[i] : -1;
-  __syncthreads();
-  STAMP2();
-
-  if (wave >= 4) {
-    // ---- loaders: thread -> 16-byte chunk ch of rows r0 and r0 + 16 of each tile, three planes, both operands
-    const int lt = tid - 256, ch = lt & 15, r0 = lt >> 4;
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ap), 0, GCL_OOB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
-    const int acol = (ft * DW_T + ch * 8) * 2, dcol = (ct * DW_T + ch * 8) * 2;
-    const int aps_b = (int)(aps * 2), dps_b = (int)(dps * 2);
-    auto issue = [&](u32x4 (&v)[2][2][3], int t) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = t < nt ? sMap[t * DW_KT + r0 + j * 16] : -1;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          v[j][0][p] = __builtin_amdgcn_raw_buffer_load_b128(ars, n >= 0 ? n * (4 * D * 2) + acol + p * aps_b : GCL_OOB, 0, 0);
-          v[j][1][p] = __builtin_amdgcn_raw_buffer_load_b128(drs, n >= 0 ? n * (D * 2) + dcol + p * dps_b : GCL_OOB, 0, 0);
-        }
-      }
-    };
-    auto put = [&](const u32x4 (&v)[2][2][3], int t) {
-      char* st = smem + (t & 1) * DW_STAGE;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<u32x4*>(st + (o * 3 + p) * DW_PLANE + (r0 + j * 16) * DW_PITCH + ch * 16) = v[j][o][p];
-    };
-    u32x4 va[2][2][3], vb[2][2][3];
-    issue(va, 0);
-    issue(vb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    put(va, 0);
-    __syncthreads();
-#pragma unroll 1
-    for (int t = 0; t < nt; t += 2) {
-      issue(va, t + 2);                                          // (past the end: out-of-range offsets, zeros, no traffic)
-      __builtin_amdgcn_sched_barrier(0);
-      put(vb, t + 1);                                            // waits for tile t+1 only: tile t+2 stays in flight
-      __syncthreads();
-      if (t + 1 >= nt) break;
-      issue(vb, t + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      put(va, t + 2);
-      __syncthreads();
-    }
-    return;
-  }
-  // ---- MFMA waves: 64x64 quarter (wr, wc) of the tile
+  // loaders: thread -> 16-byte chunk ch of rows r0 and r0 + 16 of each tile, three planes, both operands
+  const int lt = tid - 256, ch = lt & 15, r0 = lt >> 4;
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ap), 0, GCL_OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
+  const int acol = (ft * DW_T + ch * 8) * 2, dcol = (ct * DW_T + ch * 8) * 2;
+  const int aps_b = (int)(aps * 2), dps_b = (int)(dps * 2);
+  // MFMA waves: 64x64 quarter (wr, wc) of the tile
   const int li = lane & 31, lh = lane >> 5, wr = wave >> 1, wc = wave & 1;
   f32x16 acc[2][2];
 #pragma unroll
@@ -725,33 +681,86 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  __syncthreads();                                               // tile 0 staged
-  STAMP2();
+  // The slice's row list goes through LDS in segments of DW_MAP entries (one segment at the bench sizes); the tile ring
+  // restarts with every segment.
 #pragma unroll 1
-  for (int t = 0; t < nt; ++t) {
-    if ((t & 7) == 0) STAMP2();
-    const char* st = smem + (t & 1) * DW_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < DW_KT / 16; ++ks) {
-      bf16x8 a[3][2], b[3][2];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
-          b[p][i] = dw_frag(st + (3 + p) * DW_PLANE, wc * 64 + i * 32, ks, lane);
-        }
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
-#pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
-    }
+  for (int s0 = kbeg; s0 < kend; s0 += DW_MAP) {
+    const int slen = min(DW_MAP, kend - s0), nt = (slen + DW_KT - 1) / DW_KT;
+    if (s0 > kbeg) __syncthreads();                              // the previous segment's list and tiles are done with
+    for (int i = tid; i < nt * DW_KT; i += 512) sMap[i] = i < slen ? list[s0 + i] : -1;
     __syncthreads();
+    STAMP2();
+    if (wave >= 4) {
+      auto issue = [&](u32x4 (&v)[2][2][3], int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = t < nt ? sMap[t * DW_KT + r0 + j * 16] : -1;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            v[j][0][p] = __builtin_amdgcn_raw_buffer_load_b128(ars, n >= 0 ? n * (4 * D * 2) + acol + p * aps_b : GCL_OOB, 0, 0);
+            v[j][1][p] = __builtin_amdgcn_raw_buffer_load_b128(drs, n >= 0 ? n * (D * 2) + dcol + p * dps_b : GCL_OOB, 0, 0);
+          }
+        }
+      };
+      auto put = [&](const u32x4 (&v)[2][2][3], int t) {
+        char* st = smem + (t & 1) * DW_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              *reinterpret_cast<u32x4*>(st + (o * 3 + p) * DW_PLANE + (r0 + j * 16) * DW_PITCH + ch * 16) = v[j][o][p];
+      };
+      u32x4 va[2][2][3], vb[2][2][3];
+      issue(va, 0);
+      issue(vb, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      put(va, 0);
+      __syncthreads();
+#pragma unroll 1
+      for (int t = 0; t < nt; t += 2) {
+        issue(va, t + 2);                                          // (past the end: out-of-range offsets, zeros, no traffic)
+        __builtin_amdgcn_sched_barrier(0);
+        put(vb, t + 1);                                            // waits for tile t+1 only: tile t+2 stays in flight
+        __syncthreads();
+        if (t + 1 >= nt) break;
+        issue(vb, t + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        put(va, t + 2);
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();                                             // tile 0 staged
+      STAMP2();
+#pragma unroll 1
+      for (int t = 0; t < nt; ++t) {
+        if ((t & 7) == 0) STAMP2();
+        const char* st = smem + (t & 1) * DW_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < DW_KT / 16; ++ks) {
+          bf16x8 a[3][2], b[3][2];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
+              b[p][i] = dw_frag(st + (3 + p) * DW_PLANE, wc * 64 + i * 32, ks, lane);
+            }
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+          for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    }
   }
+  if (wave >= 4) return;
   STAMP2();
   // ---- epilogue: the tile is one K slice's (and, for the shared blocks, one group's) term: float atomics
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -770,15 +779,21 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
 extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
                                         int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                                         int32_t d, int32_t use_classes, float* dW, pm_stream_t stream) {
-  if (!a_planes || !dh_planes || !plan || !dW || N <= 0 || (d != 128 && d != 256) || a_plane_stride < (int64_t)N * 4 * d ||
+  if (!a_planes || !dh_planes || !plan || !dW || N <= 0 || (d != 128 && d != 256 && d != 512) || a_plane_stride < (int64_t)N * 4 * d ||
       dh_plane_stride < (int64_t)N * d || (a_plane_stride & 7) || (dh_plane_stride & 7) || ((uintptr_t)a_planes % 16) ||
       ((uintptr_t)dh_planes % 16) || a_plane_stride * 6 >= 0x7fffffffLL)
     return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
-  // K slices: four (256 workgroups at d = 256), more when a slice's row list would not fit its LDS copy
+  // K slices: d = 256: four (256 workgroups), more while a slice's row list would not fit one LDS segment (the historic
+  // rule, kept: 8 slices at the bench size); d = 512: 64 output tiles per track group already make 256 workgroups per
+  // slice — two slices (A/B: PM_GCL_DW_SPLIT), longer row lists go through LDS in segments
   int nsplit = d == 256 ? 4 : 16;
-  while ((int64_t)nsplit * (DW_MAP - DW_KT) < N) nsplit *= 2;
+  if (d == 512) {
+    static const int env_split = getenv("PM_GCL_DW_SPLIT") ? atoi(getenv("PM_GCL_DW_SPLIT")) : 0;
+    nsplit = env_split > 0 && env_split <= 64 ? env_split : 2;
+  } else
+    while ((int64_t)nsplit * (DW_MAP - DW_KT) < N) nsplit *= 2;
   const int per = (4 * d / DW_T) * (d / DW_T);
   const dim3 grid((unsigned)(per * 4 * nsplit)), block(512);
   const size_t lds = 2 * DW_STAGE + DW_MAP * 4;
@@ -793,7 +808,7 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
     hipLaunchKernelGGL((k_gcl_dw<DD>), grid, block, lds, st, a_planes, a_plane_stride, dh_planes, dh_plane_stride,     \
                        pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes);                                           \
   } while (0)
-  if (d == 256) LAUNCH(256); else LAUNCH(128);
+  if (d == 512) LAUNCH(512); else if (d == 256) LAUNCH(256); else LAUNCH(128);
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();
@@ -807,12 +822,15 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
                                     int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag,
                                     const float* bias, int32_t use_classes, float* h, double* col_stats, uint16_t* planes,
                                     int64_t plane_stride, pm_stream_t stream) {
-  if (!x || !T || !plan || !w_frag || !h || N <= 0 || (d != 128 && d != 256) || dropout_p < 0.f || dropout_p >= 1.f ||
+  if (!x || !T || !plan || !w_frag || !h || N <= 0 || (d != 128 && d != 256 && d != 512) || dropout_p < 0.f || dropout_p >= 1.f ||
       ((uintptr_t)w_frag % 16) || ((uintptr_t)x % 16) || ((uintptr_t)T % 16) || (int64_t)N * d * 4 >= 0x7fffffffLL || N >= (1 << 27))
     return PM_E_INVALID;
   if (planes && (plane_stride < (int64_t)N * 4 * d || (plane_stride & 7) || ((uintptr_t)planes % 16) ||
                  plane_stride * 6 >= 0x7fffffffLL))
     return PM_E_INVALID;
+  if (d == 512)                 // 512-wide layers: the ring pipeline of wide.hip
+    return pm_wide_gcl_forward(x, T, plan, N, E, G, dropout_p, seed, layer_uid, w_frag, bias, use_classes, h, col_stats,
+                               planes, plane_stride, nullptr, (hipStream_t)stream);
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   GclArgs a;
   a.x = x; a.T = T; a.bias = bias; a.rowptr = pv.rowptr; a.csr_src = pv.csr_src; a.csr_dist = pv.csr_dist;
@@ -842,4 +860,18 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();
+}
+
+// The same product with the aggregate READ from A' planes instead of built in the kernel: dense graphs (hundreds of edges
+// per node, BASELINE configs[4]) keep the stand-alone segment-reduce forward (pm_segreduce_fwd_planes) — the fused
+// kernel's producers gather at most three edges per (node, relation) in flight — and contract its planes here.
+// Reference: the weight products of GCL.forward (model.py:112-119).  d = 512.
+extern "C" int pm_gcl_forward_from_planes(const uint16_t* a_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
+                                          int32_t E, int32_t G, int32_t d, const uint16_t* w_frag, const float* bias,
+                                          int32_t use_classes, float* h, double* col_stats, pm_stream_t stream) {
+  if (!a_planes || !plan || !w_frag || !h || N <= 0 || d != 512 || ((uintptr_t)a_planes % 16) || ((uintptr_t)w_frag % 16) ||
+      ((uintptr_t)h % 16))
+    return PM_E_INVALID;
+  return pm_wide_gcl_forward(nullptr, nullptr, plan, N, E, G, 0.f, 0, 0, w_frag, bias, use_classes, h, col_stats, nullptr,
+                             plane_stride, a_planes, (hipStream_t)stream);
 }

@@ -9,6 +9,7 @@
 #include "gcl_tiles.h"
 #include <stdlib.h>
 #include "prof.h"
+#include "wide.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Short inner dimension: C[N, Nout] = X[N, K] @ W (+ bias),
@@ -148,11 +149,13 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
 extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
                                     int32_t w_tiles, int32_t Nout, const float* bias, float* C, int32_t ldc,
                                     pm_stream_t stream) {
-  if (!X || !w_frag || !C || N <= 0 || (K != 128 && K != 256) || Nout <= 0 || (Nout % K) || (kind != 0 && kind != 1) ||
+  if (!X || !w_frag || !C || N <= 0 || (K != 128 && K != 256 && K != 512) || Nout <= 0 || (Nout % K) || (kind != 0 && kind != 1) ||
       ldx < K || ldc < Nout || (ldx & 3) || (ldc & 3) || ((uintptr_t)X % 16) || ((uintptr_t)C % 16) ||
       ((uintptr_t)w_frag % 16) || (bias && ((uintptr_t)bias % 16)) || (int64_t)N * ldx * 4 >= 0x7fffffffLL ||
       (int64_t)N * ldc * 4 >= 0x7fffffffLL || (kind == 1 && w_tiles * 32 < Nout))
     return PM_E_INVALID;
+  if (K == 512)                 // 512-wide layers: the ring pipeline of wide.hip
+    return pm_wide_rows_times_weight(X, ldx, N, w_frag, kind, w_tiles, Nout, bias, C, ldc, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
   const size_t lds = (size_t)3 * BM * K * 2 + (size_t)BM * K * 4;
@@ -314,10 +317,12 @@ k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __rest
 extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag,
                                           int32_t kind, int32_t w_pitch, int32_t Nout, float* C, int32_t ldc,
                                           pm_stream_t stream) {
-  if (!X || !w_frag || !C || N <= 0 || K <= 0 || (K % CH) || (Nout != 128 && Nout != 256) || (kind != 0 && kind != 1) ||
+  if (!X || !w_frag || !C || N <= 0 || K <= 0 || (K % CH) || (Nout != 128 && Nout != 256 && Nout != 512) || (kind != 0 && kind != 1) ||
       ldx < K || ldc < Nout || (ldx & 3) || ((uintptr_t)X % 16) || ((uintptr_t)w_frag % 16) ||
       (int64_t)N * ldx * 4 >= 0x7fffffffLL || (int64_t)N * ldc * 4 >= 0x7fffffffLL || (kind == 0 && w_pitch * 16 < K))
     return PM_E_INVALID;
+  if (Nout == 512)              // 512-wide layers: the ring pipeline of wide.hip
+    return pm_wide_rows_times_weight_longk(X, ldx, N, K, w_frag, kind, w_pitch, C, ldc, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
   const size_t lds = 2 * IMG;

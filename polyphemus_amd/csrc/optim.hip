@@ -79,5 +79,5 @@ extern "C" int pm_adam_step(float* params, const float* grads, float* exp_avg, f
   return pm_check_launch();
 }
 
-extern "C" int pm_abi_version(void) { return 1; }
+extern "C" int pm_abi_version(void) { return PM_ABI_VERSION; }
 extern "C" const char* pm_build_info(void) { return "polyphemus_hip gfx950 (CDNA4) fp32-MFMA build " __DATE__; }

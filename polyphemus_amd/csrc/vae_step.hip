@@ -14,6 +14,35 @@
 
 namespace {
 
+// A/B switches of the step, read ONCE (first use): which kernel set the measured path takes never changes inside a run.
+//   PM_GCL_FUSED=0      the round-1 kernels (segment-reduce forward + grouped planes products, tile kernels for the chord
+//                       products) instead of gcl.hip / linear.hip / wide.hip
+//   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products
+//   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
+//   PM_FUSED_CE=0       un-embedding products + loss kernel instead of the fused un-embedding / cross-entropy kernel
+//   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
+//                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
+struct StepCfg {
+  bool gcl_fused, no_dw, no_rows_w, no_classes, no_bfrag, fused_ce, debug;
+  int dense_deg;
+};
+static const StepCfg& cfg() {
+  static const StepCfg c = [] {
+    auto flag = [](const char* n, bool dflt) { const char* v = getenv(n); return v ? atoi(v) != 0 : dflt; };
+    StepCfg k;
+    k.gcl_fused = flag("PM_GCL_FUSED", true);
+    k.no_dw = flag("PM_GCL_NO_DW", false);
+    k.no_rows_w = flag("PM_NO_ROWS_W", false);
+    k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
+    k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
+    k.fused_ce = flag("PM_FUSED_CE", false);
+    k.debug = getenv("PM_DEBUG") != nullptr;
+    k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
+    return k;
+  }();
+  return c;
+}
+
 // Bump allocator over the caller's workspace.  The first `zcap` bytes are the ZERO REGION: every small buffer that must
 // start the step cleared (accumulators, split-K outputs of the head products, atomics targets) is carved from it with
 // z() / zf() / zdbl() and the whole region is cleared by ONE memset at the start of pm_vae_step_forward — the step
@@ -84,7 +113,7 @@ struct Ctx {
   void chk(int r, int line = __builtin_LINE()) {       // first failure wins; PM_DEBUG=1 names the call site
     if (r != PM_OK && rc == PM_OK) {
       rc = r;
-      if (getenv("PM_DEBUG")) fprintf(stderr, "[polyphemus_hip] vae_step.hip:%d returned %d\n", line, r);
+      if (cfg().debug) fprintf(stderr, "[polyphemus_hip] vae_step.hip:%d returned %d\n", line, r);
     }
   }
 };
@@ -120,11 +149,9 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
                   dbias_pre, dx, c.s->bn_scratch, c.st));
 }
 
-// A/B switch: PM_GCL_FUSED=0 restores the unfused pair (segment-reduce forward, then the grouped planes product)
-static bool gcl_fused_on() {
-  static const bool on = !(getenv("PM_GCL_FUSED") && atoi(getenv("PM_GCL_FUSED")) == 0);
-  return on;
-}
+static bool gcl_fused_on() { return cfg().gcl_fused; }
+// widths the kernels of gcl.hip / linear.hip (128, 256) and wide.hip (512) cover
+static bool gcl_width(int d) { return d == 128 || d == 256 || d == 512; }
 // the kernels of gcl.hip / linear.hip address their operands with 32-bit byte offsets: batches beyond these sizes
 // (N > ~349 k nodes at d = 256) take the round-1 kernels
 static bool gcl_fits(int N, int d, int S) {
@@ -136,7 +163,7 @@ PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
   PmGemmDesc q;
   memset(&q, 0, sizeof(q));
   q.flags = PM_GEMM_PARTITION; q.split_k = 1; q.rowmap = pv.trk_list; q.rows_per_entry = 1; q.dyn_entries = pv.trk_cnt;
-  if (!getenv("PM_GCL_NO_CLASSES")) { q.class_ptr = pv.trk_cnt + 8; q.class_block = d; }   // skip all-zero onset / next blocks
+  if (!cfg().no_classes) { q.class_ptr = pv.trk_cnt + 8; q.class_block = d; }   // skip all-zero onset / next blocks
   q.n_groups = 4; q.map_group_stride = N; q.dyn_group_stride = 1;
   return q;
 }
@@ -171,7 +198,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     // (layer 0 is followed by the shared edge_nn parameters, so it is converted on its own; layers 1.. are equally
     //  spaced and go in one batched launch per kind)
     const int64_t lstride = c.L > 2 ? g.weight[2] - g.weight[1] : 7 * dd;
-    bool even = (d % 32) == 0 && c.compact && (lstride % 4) == 0 && !getenv("PM_GCL_NO_BFRAG");
+    bool even = (d % 32) == 0 && c.compact && (lstride % 4) == 0 && !cfg().no_bfrag;
     for (int i = 2; i < c.L; ++i) even = even && (g.weight[i] - g.weight[i - 1] == lstride);
     if (even) {
       sv.Wfn = (uint16_t*)ar.take((size_t)sv.wf_stride * 2 * c.L);
@@ -189,8 +216,11 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
   }
   // plain (row-major) planes of the weights: operand of the grouped planes products only — the kernels of gcl.hip take
   // the fragment-major copies (forward, input gradient) or no weight at all (weight gradient)
-  const bool gcl_kernels = c.planes && c.compact && sv.Wfn && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1);
-  if (c.planes && !gcl_kernels && ar.base)
+  const bool gcl_kernels = c.planes && c.compact && sv.Wfn && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1);
+  // dense graphs (mean in-degree >= cfg().dense_deg; the fused kernel's producers keep three edges per (node, relation)
+  // in flight and redo longer lists serially): stand-alone segment-reduce, then — at d = 512 — the product from its planes
+  const bool dense = (int64_t)c.E >= (int64_t)cfg().dense_deg * N;
+  if (c.planes && (!gcl_kernels || (dense && d != 512)) && ar.base)
     RUN(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
   for (int i = 0; i < c.L; ++i) {
     if (c.planes) { sv.Ap[i] = (uint16_t*)ar.take((size_t)aps * 6); sv.A[i] = nullptr; }
@@ -201,16 +231,20 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     const float* W = c.P + g.weight[i];
     double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
     // one kernel for aggregate + product (gcl.hip) where it applies: compact planes path, fragment-major weights
-    const bool fused = gcl_kernels;
+    const bool fused = gcl_kernels && !dense;
+    const bool from_planes = gcl_kernels && dense && d == 512;
     if (fused)
       RUN(pm_gcl_forward_fused(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
-                                 sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], getenv("PM_GCL_NO_CLASSES") ? 0 : 1,
+                                 sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
                                  sv.h[i], sums, sv.Ap[i], aps, c.st));
     else if (c.planes)
       RUN(pm_segreduce_fwd_planes(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
     else
       RUN(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
     if (fused) {
+    } else if (from_planes) {
+      RUN(pm_gcl_forward_from_planes(sv.Ap[i], aps, c.s->plan, N, c.E, c.Gn, d, sv.Wfn + (int64_t)i * sv.wf_stride,
+                                       c.P + g.bias[i], cfg().no_classes ? 0 : 1, sv.h[i], sums, c.st));
     } else if (!c.compact) {
       PmGemmDesc q;
       memset(&q, 0, sizeof(q));
@@ -273,9 +307,9 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
         if (sv.Wft) q.b_frag = sv.Wft + (int64_t)i * sv.wf_stride;
       }
-      if (c.planes && sv.Wft && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip)
+      if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
         RUN(pm_gcl_input_grad_fused(dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
-                                      getenv("PM_GCL_NO_CLASSES") ? 0 : 1, dA, c.st));
+                                      cfg().no_classes ? 0 : 1, dA, c.st));
       else
         RUN(pm_gemm_f32_desc(&q, c.st));
       PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
@@ -286,9 +320,9 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
         w.B = (const float*)dhp; w.b_plane_stride = dps;
       }
-      if (c.planes && (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, 1) && !getenv("PM_GCL_NO_DW"))      // 128x128 tiles (gcl.hip)
+      if (c.planes && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1) && !cfg().no_dw)      // 128x128 tiles (gcl.hip)
         RUN(pm_gcl_weight_grad_fused(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d,
-                                       getenv("PM_GCL_NO_CLASSES") ? 0 : 1, dW, c.st));
+                                       cfg().no_classes ? 0 : 1, dW, c.st));
       else
         RUN(pm_gemm_f32_desc(&w, c.st));
     }
@@ -354,7 +388,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
-  uint16_t* wf_enc = ((d == 128 || d == 256) && S < PM_N_SLOTS && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W"))
+  uint16_t* wf_enc = (gcl_width(d) && S < PM_N_SLOTS && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w)
                          ? (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6) : nullptr;
   if (run) {
     RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
@@ -419,7 +453,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
-  const bool rows_w = (d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W");
+  const bool rows_w = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
   uint16_t* wf_dec = rows_w ? (uint16_t*)ar.take((size_t)S * d * d * 6) : nullptr;
   if (run) {
     if (rows_w) {
@@ -431,7 +465,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits stay in the MFMA
     // accumulators, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
     // (opt-in, PM_FUSED_CE=1: measured 195-220 us against 159 us for the three products + the loss kernel, csrc/unembed.hip)
-    static const bool fused_ce = getenv("PM_FUSED_CE") && atoi(getenv("PM_FUSED_CE")) != 0;
+    const bool fused_ce = cfg().fused_ce;
     if (fused_ce) {
       RUN(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
                           c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
@@ -480,7 +514,7 @@ void backward_decoder(Ctx& c) {
                       PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
-  if ((d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W")) {
+  if (gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w) {
     // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
     uint16_t* wf = (uint16_t*)ar.take((size_t)S * d * d * 6);
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);    // weight and bias gradients
@@ -557,7 +591,7 @@ void backward_encoder_tail(Ctx& c) {
     RUN(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
                       nullptr, 0, nullptr, c.st));
     RUN(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
-    if ((d == 128 || d == 256) && gcl_fused_on() && gcl_fits(N, d, S) && !getenv("PM_NO_ROWS_W")) {      // dX = dx0 @ Wc[:, :S*d], A-stationary
+    if (gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w) {      // dX = dx0 @ Wc[:, :S*d], A-stationary
       uint16_t* wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
       RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 1, 1, (int64_t)PM_N_SLOTS * d * d,
                                  (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));
@@ -690,7 +724,7 @@ extern "C" int pm_vae_step_outputs(const void* state, float* s_logits, float* c_
   const size_t N = s->bt.N, S = s->bt.n_slots, G = s->bt.G, B = s->bt.B, d = s->lay.d;
   hipError_t e = hipSuccess;
   if (s_logits && e == hipSuccess) e = hipMemcpyAsync(s_logits, s->s_logits, sizeof(float) * G * 128, hipMemcpyDeviceToDevice, st);
-  static const bool fused_ce = getenv("PM_FUSED_CE") && atoi(getenv("PM_FUSED_CE")) != 0;
+  const bool fused_ce = cfg().fused_ce;
   if (c_logits && fused_ce && !(s->bt.flags & 4)) return PM_E_INVALID;      // the step was told not to keep the logits
   if (c_logits && e == hipSuccess) e = hipMemcpyAsync(c_logits, s->c_logits, sizeof(float) * N * S * PM_N_TOK, hipMemcpyDeviceToDevice, st);
   if (mu && e == hipSuccess) e = hipMemcpyAsync(mu, s->mu, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);

@@ -202,13 +202,23 @@ def mtp_from_logits(c_logits: torch.Tensor, s_tensor: torch.Tensor, check: bool 
 def gcl_forward_fused(x, T, plan: Plan, dropout_p: float, seed: int, layer_uid: int, w_frag, bias, col_stats=None,
                       planes=None, use_classes: bool = True):
     """`pm_gcl_forward_fused`: h = A'(x) @ [W_t; W_4; W_5; root] + bias of one GCL layer in one kernel (compact graphs,
-    d in {128, 256}); `w_frag` = `split_planes_frag(W, 1)`; `planes` (int16 [3, N*4d], optional) receives the A' planes."""
+    d in {128, 256, 512}); `w_frag` = `split_planes_frag(W, 1)`; `planes` (int16 [3, N*4d], optional) receives the A' planes."""
     _chk(x, F32, "x"); _chk(T, F32, "T")
     N, d = x.shape
     h = torch.empty(N, d, dtype=F32, device=x.device)
     call("pm_gcl_forward_fused", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, float(dropout_p),
          seed & 0xFFFFFFFF, layer_uid, ptr(w_frag), ptr(bias), 1 if use_classes else 0, ptr(h), ptr(col_stats),
          ptr(planes), 0 if planes is None else planes.shape[1], stream())
+    return h
+
+
+def gcl_forward_from_planes(a_planes, plan: Plan, d: int, w_frag, bias, col_stats=None, use_classes: bool = True):
+    """`pm_gcl_forward_from_planes`: h = A' @ [W_t; W_4; W_5; root] + bias with the aggregate read from the planes
+    `pm_segreduce_fwd_planes` wrote (int16 [3, N*4d]); the dense-graph path at d = 512."""
+    N = plan.N
+    h = torch.empty(N, d, dtype=F32, device=a_planes.device)
+    call("pm_gcl_forward_from_planes", ptr(a_planes), a_planes.shape[1], ptr(plan.buf), N, plan.E, plan.G, d, ptr(w_frag),
+         ptr(bias), 1 if use_classes else 0, ptr(h), ptr(col_stats), stream())
     return h
 
 

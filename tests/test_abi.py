@@ -49,7 +49,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(protos) >= 35
     for name in protos:
         assert hasattr(L, name), f"{name} declared in the header but not exported"
-    assert L.pm_abi_version() == 1
+    assert L.pm_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define PM_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
     assert b"gfx950" in L.pm_build_info()
 
 

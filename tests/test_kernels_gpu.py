@@ -734,7 +734,8 @@ def _masked_contractions(plan, N, on, nx, d, bfrag):
 
 
 @pytest.mark.parametrize("d,p,dense", [(128, 0.0, False), (256, 0.0, False), (256, 0.15, False), (128, 0.1, True),
-                                       (256, 0.0, True), (128, 0.1, "tiny"), (256, 0.0, "tiny")])
+                                       (256, 0.0, True), (128, 0.1, "tiny"), (256, 0.0, "tiny"),
+                                       (512, 0.0, False), (512, 0.1, False), (512, 0.1, True), (512, 0.0, "tiny")])
 def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     """`pm_gcl_forward_fused` (aggregate built in LDS, contracted in the same kernel) against the unfused pair it
     replaces — `pm_segreduce_fwd_planes` then the grouped planes product with row classes: same edge order and message
@@ -791,9 +792,14 @@ def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     # without the planes output and without row classes: same h
     h2 = ops.gcl_forward_fused(x, T, plan, p, 5, 2, Wf, bias, use_classes=False)
     assert torch.equal(h2, h1)
+    if d == 512:          # the product with the aggregate read from the pair's planes (the dense-graph path): same chain
+        s3 = torch.zeros(8, 2, d, dtype=torch.float64, device=DEV)
+        h3 = ops.gcl_forward_from_planes(P0, plan, d, Wf, bias, col_stats=s3)
+        assert torch.equal(h3, h1)
+        assert rel_err(s3.sum(0)[0], h1.double().sum(0)) < 1e-12
 
 
-@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 1)])
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 1), (512, 40), (512, 1)])
 def test_gcl_input_grad_fused_equals_grouped_product(d, B):
     """`pm_gcl_input_grad_fused` (dh rows resident in LDS, all 4d output columns per workgroup) against the grouped planes
     product with transB it replaces: same six products in the same k order -> BIT-identical wherever the segment-reduce
@@ -829,7 +835,7 @@ def test_gcl_input_grad_fused_equals_grouped_product(d, B):
     assert torch.equal(dA2[keep], dA1[keep]) and bool(torch.isfinite(dA2).all())
 
 
-@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 3), (128, 1)])
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 3), (128, 1), (512, 40), (512, 1)])
 def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
     """`pm_gcl_weight_grad_fused` (128x128 tiles, loader waves + LDS ring, K slices by atomics) against the grouped planes
     product with transA it replaces and against an fp64 contraction of the exact planes; accumulates into dW (+=)."""
@@ -867,7 +873,8 @@ def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
     assert float((dW2.double() - want).abs().max()) < 2e-6 * scale
 
 
-@pytest.mark.parametrize("K,Nout,N,kind", [(256, 1280, 16271, 0), (256, 1280, 5000, 1), (128, 384, 77, 0), (128, 256, 64, 1)])
+@pytest.mark.parametrize("K,Nout,N,kind", [(256, 1280, 16271, 0), (256, 1280, 5000, 1), (128, 384, 77, 0), (128, 256, 64, 1),
+                                           (512, 2560, 16271, 0), (512, 1536, 777, 1), (512, 512, 64, 0)])
 def test_rows_times_weight_matches_fp64(K, Nout, N, kind):
     """`pm_rows_times_weight` (A-stationary: the fp32 rows of a 64-row tile split into bf16 planes once, all output columns
     from that LDS image) for both weight orientations: y = x W^T + b (kind 0, W [Nout, K]) and y = x W[:, :Nout] (kind 1,
@@ -892,7 +899,8 @@ def test_rows_times_weight_matches_fp64(K, Nout, N, kind):
     assert bool((C[:, Nout:] == 7.0).all())
 
 
-@pytest.mark.parametrize("K,Nout,N,kind", [(1280, 256, 16271, 0), (1280, 256, 5000, 1), (384, 128, 77, 0), (128, 128, 64, 1)])
+@pytest.mark.parametrize("K,Nout,N,kind", [(1280, 256, 16271, 0), (1280, 256, 5000, 1), (384, 128, 77, 0), (128, 128, 64, 1),
+                                           (2560, 512, 16271, 0), (1536, 512, 777, 1), (128, 512, 64, 1)])
 def test_rows_times_weight_longk_matches_fp64(K, Nout, N, kind):
     """`pm_rows_times_weight_longk` (producer waves split 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves
     contract them): y = x W[:, :K]^T (kind 0, W [Nout, ldw]) and y = x W (kind 1, W [K, Nout]) against an fp64 product."""

@@ -38,7 +38,7 @@ PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 def kernel_source_digest():
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "gcl_tiles.h", "common.h"):
+    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "wide.hip", "gcl_tiles.h", "common.h"):
         h.update(open(os.path.join(ROOT, "polyphemus_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -60,6 +60,61 @@ def flops_per_bar(n_nodes, n_bars_total, d, L):
     """Algorithmic flops per bar-graph, forward+backward:
     3 * mean_nodes_per_bar * [(60 + 28 L) d^2 + 6900 d]."""
     return 3.0 * (n_nodes / n_bars_total) * ((60 + 28 * L) * d * d + 6900 * d)
+
+
+def executed_block_fraction(trainer, n_nodes, n_edges, G):
+    """Fraction of the compact GCL contraction [N, 4d] x [4d, d] the kernels of gcl.hip / wide.hip EXECUTE: a 64-row
+    tile of a track group skips the onset / next block when none of its rows receives such an edge (row classes,
+    plan.trk_cnt[8 + 5 * group ..]: class boundaries of the group's node list).  One host read of 28 integers, outside
+    the timed region."""
+    from polyphemus_amd._lib import PLAN_FIELDS, plan_layout
+    off = plan_layout(n_nodes, n_edges, G)
+    j = PLAN_FIELDS.index("trk_cnt")
+    tc = trainer._plan_buf[off[j]:off[j] + 28].tolist()
+    live = total = 0
+    for g in range(4):
+        cnt, cb = tc[g], tc[8 + 5 * g: 13 + 5 * g]
+        for m0 in range(0, cnt, 64):
+            on = m0 < cb[3] and m0 + 64 > cb[1]
+            nx = m0 < cb[4] and m0 + 64 > cb[2]
+            live += 2 + int(on) + int(nx)
+            total += 4
+    return live / total if total else 1.0
+
+
+def standalone_segreduce_fwd(batch, d, p=0.1, reps=20):
+    """"when the layer is fused the aggregates never reach HBM; keep the standalone kernel for this
+    measurement" — one in-process series of `pm_segreduce_fwd_planes` launches (compact [N, 4d] aggregate written as three
+    bf16 planes, the form the unfused step uses) on the bench batch, HIP events on the launch stream, untimed part of
+    the run.  Algorithmic bytes: x read 4dN + planes written 6 * 4dN + 12 E."""
+    from polyphemus_amd import ops
+    from polyphemus_amd._lib import call, ptr, stream
+    plan = ops.plan_build(batch.edge_index, batch.edge_type, batch.edge_dist, batch.bars, batch.batch, batch.is_drum,
+                          batch.tokens, batch.n_bars, batch.s_tensor.shape[0])
+    N, E = batch.num_nodes, batch.edge_index.shape[1]
+    dev = batch.edge_index.device
+    x = torch.randn(N, d, device=dev)
+    T = ops.edge_table(torch.randn(d, 32, device=dev) * 0.5, torch.randn(d, device=dev) * 0.1)
+    P = torch.empty(3, N * 4 * d, dtype=torch.int16, device=dev)
+
+    def run():
+        call("pm_segreduce_fwd_planes", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, 1, ptr(P), N * 4 * d, stream())
+
+    for _ in range(3):
+        run()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / reps * 1e3
+    nbytes = 4.0 * d * N + 6.0 * 4 * d * N + 12.0 * E
+    return {"kernel": "k_segreduce_fwd (stand-alone, compact aggregate as three bf16 planes)", "avg_launch_us": round(us, 2),
+            "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4),
+            "from": f"{reps} back-to-back launches on the bench batch after the warm-up, events on torch's current stream (the launch stream)"}
 
 
 def host_cores() -> int:
@@ -319,14 +374,19 @@ def main():
 
     SURVEY = 2
     EVENT_STRIDE = int(os.environ.get("PM_BENCH_EVENT_STRIDE", "5" if args.steps >= 5 else "1"))
-    for _ in range(max(args.warmup - SURVEY, 0)):
-        trainer.train_step(batch)
+    losses_first = None
+    for i in range(max(args.warmup - SURVEY, 0)):
+        o = trainer.train_step(batch)
+        if i == 0 and dp is None:
+            losses_first = trainer.losses_dict(o)                  # step 1 of the run: default init, reproducible to 1e-9
     L.pm_prof_configure(-1, 1)
     L.pm_prof_begin(SURVEY * 200)
     for _ in range(SURVEY):
         trainer.train_step(batch)
     sync()
     survey = prof_collect()
+    exec_frac = executed_block_fraction(trainer, n_nodes, n_edges, G) if trainer.step_info()["compact"] else 1.0
+    seg_alone = standalone_segreduce_fwd(batch, args.d) if rank == 0 else None
     mfma_classes = [k for k in survey if k.startswith(("gemm", "gcl"))]       # every kernel class that runs on the matrix cores
     dom = max(mfma_classes, key=lambda k: survey[k]["total_ms"])
     # the aggregation kernel of the forward: the fused layer kernel (gcl.hip) where it runs, else the segment-reduce
@@ -366,8 +426,14 @@ def main():
         workload_key = f"B{args.batch}_d{args.d}_nb{args.n_bars}_L{args.layers}" + ("_dense" if args.dense else "")
         sampling = (f"HIP events around every {EVENT_STRIDE}-th launch of this kernel inside the timed region "
                     f"({ds['launches']} launches sampled)")
-        gcl_names = {"gcl_fwd": "k_gcl_fwd: GCL forward, aggregate built in LDS + weight product in one kernel",
-                     "gcl_dagg": "k_gcl_dagg: GCL input gradient, A-stationary", "gcl_dw": "k_gcl_dw: GCL weight gradient, 128x128 tiles"}
+        if args.d == 512:
+            gcl_names = {"gcl_fwd": ("k_wide<V_FWDP>: GCL forward product from the segment-reduce's A' planes (wide.hip)" if args.dense else
+                                     "k_wide<V_FWD>: GCL forward, aggregate built in LDS + weight product in one kernel (wide.hip)"),
+                         "gcl_dagg": "k_wide<V_DAGG>: GCL input gradient, dh streamed through the LDS ring (wide.hip)",
+                         "gcl_dw": "k_gcl_dw<512>: GCL weight gradient, 128x128 tiles"}
+        else:
+            gcl_names = {"gcl_fwd": "k_gcl_fwd: GCL forward, aggregate built in LDS + weight product in one kernel",
+                         "gcl_dagg": "k_gcl_dagg: GCL input gradient, A-stationary", "gcl_dw": "k_gcl_dw: GCL weight gradient, 128x128 tiles"}
         kname = f"{gcl_names[dom]} ({insn})" if dom in gcl_names else f"k_gemm<{dom[8:]},{dom[5:7]}> ({insn})"
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -376,6 +442,12 @@ def main():
                              + f"; {round(tf / PEAK_FP32_MFMA_TFLOPS, 3)} of the 157.3 TFLOP/s fp32 MFMA peak",
                 "launches_per_step": survey[dom]["launches"] / SURVEY, "avg_launch_us": round(ds["avg_us"], 2),
                 "algorithmic_gflop_per_launch": round(ds["work"] / ds["launches"] / 1e9, 3), "sampling": sampling,
+                # `achieved` prices the full [N, 4d] x [4d, d] contraction; the GCL kernels skip the onset / next blocks no row
+                # of a 64-row tile receives (row classes): what they EXECUTE, and the rate on that
+                "executed": ({"fraction_of_algorithmic": round(exec_frac, 4),
+                              "gflop_per_launch": round(exec_frac * ds["work"] / ds["launches"] / 1e9, 3),
+                              "TFLOP/s": round(exec_frac * tf, 2), "frac": round(exec_frac * tf / peak, 4)}
+                             if dom.startswith("gcl") else None),
                 "survey_note": f"all_gemm / other_gemm_classes: every launch bracketed in the last {SURVEY} untimed warm-up steps",
                 "all_gemm": {"TFLOP/s": round(gemm_tf, 2), "ms_per_step": round(gemm_ms / SURVEY, 3)},
                 "other_gemm_classes": {k: {"TFLOP/s": round(survey[k]["work"] / (survey[k]["total_ms"] * 1e-3) / 1e12, 2),
@@ -415,6 +487,8 @@ def main():
                                     "algorithmic_bytes_per_launch": sb["work"] / sb["launches"],
                                     "traffic": pmc_traffic("segreduce_bwd", workload_key),
                                     "from": "survey steps (every launch bracketed)"}
+        if seg_alone is not None:
+            roof_seg["standalone_fwd"] = seg_alone
         bars_total = float(tot_nodes[1].item())
         value = bars_total * args.steps / elapsed
         fpb = flops_per_bar(float(tot_nodes[0].item()), bars_total, args.d, args.layers)
@@ -423,21 +497,30 @@ def main():
             "value": round(value, 1), "unit": "bar-graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("dense-graph stress (BASELINE configs[4])" if args.dense else
+            "config": {"workload": ("dense-graph stress, one GPU's shard (BASELINE configs[4])" if args.dense else
                                     "LMD2 2-bar, 4 tracks, 32 ts, batch=256 per GPU, d_hidden=256 (BASELINE configs[1]; "
-                                    "configs[3] when n_gpus=8)"),
+                                    "configs[3] when n_gpus=8)" if (args.d, args.batch, args.n_bars) == (256, 256, 2) else
+                                    "LMD16 16-bar, batch=64, d_hidden=256 (BASELINE configs[2])" if (args.d, args.batch, args.n_bars) == (256, 64, 16) else
+                                    "LMD2 2-bar, batch=256, d_hidden=512 (the reference's training.json)" if (args.d, args.batch, args.n_bars) == (512, 256, 2) else
+                                    f"LMD {args.n_bars}-bar, batch={args.batch} per GPU, d_hidden={args.d}"),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "n_bars": args.n_bars,
                        "d": args.d, "gnn_n_layers": args.layers, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
                        "message_dropout": 0.1, "parallelism": f"dp{world}", "weights": "default init, manual_seed(0)",
                        "step": "plan+fwd+loss+bwd+allreduce+Adam"},
+            # SURVEY 8(d)'s operation count (7 products of N d^2 per GCL) and what the step executes: the compact GCL
+            # contracts K = 4d (one track block per node) and skips all-zero onset / next blocks tile by tile
             "step_flops_model": {"algorithmic_gflop_per_bar": round(fpb / 1e9, 3),
-                                 "achieved_TFLOP/s_per_gpu": round(value * fpb / 1e12 / world, 2),
-                                 "frac_of_fp32_mfma_peak": round(value * fpb / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4)},
+                                 "algorithmic_TFLOP/s_per_gpu": round(value * fpb / 1e12 / world, 2),
+                                 "executed_gflop_per_bar": round(3.0 * (float(tot_nodes[0].item()) / bars_total) * (
+                                     (60 + 16 * args.layers * exec_frac) * args.d ** 2 + 6900 * args.d) / 1e9, 3),
+                                 "note": "algorithmic = SURVEY 8(d) (14 N d^2 per GCL); executed = compact GCL (8 N d^2) "
+                                         "x the fraction of (tile, block) pairs that are not all-zero"},
+            "losses_first_step": ({k: round(v, 5) for k, v in losses_first.items()} if losses_first else None),
             "losses": {k: round(v, 5) for k, v in losses.items()},
-            "losses_note": ("last of warmup+steps Adam steps on ONE fixed synthetic batch; kld is reported unweighted and is "
-                            "unconstrained at beta = 0 (the reference's schedule starts there, training.json): it spikes "
-                            "to 1e3-1e5 around steps 3-5 with every kernel set and usually, not always, is back at ~33 "
-                            "by step 25 (DESIGN.md section 5)"),
+            "losses_note": ("`losses_first_step`: step 1 from the default init (reproducible; pinned against the oracle in "
+                            "tests/test_fullsize_gpu.py).  `losses`: last of warmup + steps Adam steps on ONE fixed batch; "
+                            "the unweighted kld goes through a transient at beta = 0 that the fp64 oracle shows as well "
+                            "(tests/test_native_step_gpu.py::test_loss_trajectory_follows_the_fp64_oracle)"),
             "roofline": roof, "roofline_segreduce": roof_seg,
         }
         if dp is not None:

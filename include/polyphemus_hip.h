@@ -611,6 +611,10 @@ typedef struct PmBatch {                                    /* device pointers o
   const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
+/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_GCL_NO_CLASSES,
+ * PM_GCL_NO_BFRAG, PM_FUSED_CE, PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_DEBUG) are read once, when the library is loaded;
+ * this re-reads them (host only) so that one process can run one batch through two kernel sets. */
+int pm_vae_step_reload_switches(void);
 int64_t pm_vae_layout_bytes(void);
 int64_t pm_vae_step_state_bytes(void);
 int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B,

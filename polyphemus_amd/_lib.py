@@ -108,6 +108,7 @@ _SIGS = {
     "pm_vae_step_backward_decoder": "ps",
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",
+    "pm_vae_step_reload_switches": "",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes"}

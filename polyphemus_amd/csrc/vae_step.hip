@@ -25,23 +25,24 @@ namespace {
 struct StepCfg {
   bool gcl_fused, no_dw, no_rows_w, no_classes, no_bfrag, fused_ce, debug;
   int dense_deg;
+  int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
 };
-static const StepCfg& cfg() {
-  static const StepCfg c = [] {
-    auto flag = [](const char* n, bool dflt) { const char* v = getenv(n); return v ? atoi(v) != 0 : dflt; };
-    StepCfg k;
-    k.gcl_fused = flag("PM_GCL_FUSED", true);
-    k.no_dw = flag("PM_GCL_NO_DW", false);
-    k.no_rows_w = flag("PM_NO_ROWS_W", false);
-    k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
-    k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
-    k.fused_ce = flag("PM_FUSED_CE", false);
-    k.debug = getenv("PM_DEBUG") != nullptr;
-    k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
-    return k;
-  }();
-  return c;
+static StepCfg read_cfg() {
+  auto flag = [](const char* n, bool dflt) { const char* v = getenv(n); return v ? atoi(v) != 0 : dflt; };
+  StepCfg k;
+  k.gcl_fused = flag("PM_GCL_FUSED", true);
+  k.no_dw = flag("PM_GCL_NO_DW", false);
+  k.no_rows_w = flag("PM_NO_ROWS_W", false);
+  k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
+  k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
+  k.fused_ce = flag("PM_FUSED_CE", false);
+  k.debug = getenv("PM_DEBUG") != nullptr;
+  k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
+  k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
+  return k;
 }
+static StepCfg g_cfg = read_cfg();          // read once, at library load (pm_vae_step_reload_switches re-reads: tests)
+static const StepCfg& cfg() { return g_cfg; }
 
 // Bump allocator over the caller's workspace.  The first `zcap` bytes are the ZERO REGION: every small buffer that must
 // start the step cleared (accumulators, split-K outputs of the head products, atomics targets) is carved from it with
@@ -155,7 +156,8 @@ static bool gcl_width(int d) { return d == 128 || d == 256 || d == 512; }
 // the kernels of gcl.hip / linear.hip address their operands with 32-bit byte offsets: batches beyond these sizes
 // (N > ~349 k nodes at d = 256) take the round-1 kernels
 static bool gcl_fits(int N, int d, int S) {
-  return (int64_t)N * 4 * d * 6 < 0x7fffffffLL && (int64_t)N * 4 * d * 4 < 0x7fffffffLL && (int64_t)N * S * d * 4 < 0x7fffffffLL;
+  const int64_t lim = cfg().offset_limit;
+  return (int64_t)N * 4 * d * 6 < lim && (int64_t)N * 4 * d * 4 < lim && (int64_t)N * S * d * 4 < lim;
 }
 // descriptor skeleton of the compact GCL contractions: four track-relation groups, rows of group t listed in
 // plan.trk_list[t*N ..], live count plan.trk_cnt[t]
@@ -636,6 +638,14 @@ void measure_backward(Ctx& c) {
 }  // namespace
 
 extern "C" int64_t pm_vae_layout_bytes(void) { return (int64_t)sizeof(PmVaeLayout); }
+// The A/B switches of the step (PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_GCL_NO_CLASSES, PM_GCL_NO_BFRAG, PM_FUSED_CE,
+// PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_DEBUG) are read from the environment once, when the library is loaded; this
+// re-reads them (host only; the next pm_vae_step_forward sees the new values) so that one process can run the same
+// batch through two kernel sets.
+extern "C" int pm_vae_step_reload_switches(void) {
+  g_cfg = read_cfg();
+  return PM_OK;
+}
 extern "C" int64_t pm_vae_step_state_bytes(void) { return (int64_t)sizeof(StepState); }
 
 // Arena requirement of a step, by a launch-free pass over the carve-outs: bytes of the zero region (rounded to 4 KiB)

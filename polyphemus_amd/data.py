@@ -128,7 +128,9 @@ class DeviceLoader:
         order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
         if self.world > 1:
             total = self._shard_len() * self.world
-            order = np.concatenate([order, order[:total - n]])[self.rank::self.world]   # DistributedSampler's rule
+            # DistributedSampler's rule: wrap around — repeatedly when the dataset is smaller than the world (np.resize
+            # tiles) — so that every rank gets the same number of samples and batches: the all-reduce needs lock step
+            order = np.resize(order, total)[self.rank::self.world]
             n = order.shape[0]
         out = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
         if self.drop_last and out and len(out[-1]) < self.batch_size:

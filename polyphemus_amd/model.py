@@ -353,8 +353,9 @@ class VAE(nn.Module):
         self.encoder.__dict__["_vae"] = weakref.ref(self)
         self.decoder.__dict__["_vae"] = weakref.ref(self)
         self.msg_dropout = 0.1                # GCL message dropout, hard-wired in the reference (SURVEY B-2)
-        self.seed = 0x5EED
-        self._step = 0
+        self.seed = 0x5EED                    # BASE seed of the counter-based dropout streams (checkpointed as is)
+        self.rank_salt = 0                    # data parallel: mixed into every derived seed, so ranks draw different masks;
+        self._step = 0                        # set by the trainer from the rank, never stored in a checkpoint
         self._flatten()
 
     # ---- flat parameter / buffer storage ---------------------------------------------------
@@ -439,7 +440,7 @@ class VAE(nn.Module):
 
     def _next_seed(self) -> int:
         self._step += 1
-        return (self.seed * 0x9E3779B1 + self._step * 0x85EBCA77) & 0xFFFFFFFF
+        return (((self.seed ^ self.rank_salt) & 0xFFFFFFFF) * 0x9E3779B1 + self._step * 0x85EBCA77) & 0xFFFFFFFF
 
     def _prepare(self, graph) -> ops.Plan:
         self._check_flat()

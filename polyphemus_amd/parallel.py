@@ -19,7 +19,12 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
-    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).
+
+    Call it BEFORE anything initialises HIP in this process (`torch.cuda.is_available()`, any tensor on the GPU): the
+    dmabuf-IPC switch below is read by the runtime when it starts and has no effect afterwards — RCCL then fails with
+    `hipIpcGetMemHandle: invalid argument`.  Launchers that start the ranks (bench.py, tests/util.run_ranks) put the
+    variable into the child environment themselves; this default only covers a bare `torchrun`."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

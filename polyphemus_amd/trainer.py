@@ -71,12 +71,15 @@ class HipTrainer:
         # the C++ step covers the configuration of training.json (batch_norm = True, dropout = 0: what bench.py measures);
         # the two non-default constructor switches of the model (model.py:176,188,218,278) run the same kernels through
         # the Python orchestration (engine.py)
-        self.native = bool(native and vae.cfg["batch_norm"] and not vae.cfg["dropout"] and not sync_bn)
+        self.sync_bn = bool(sync_bn)
+        import torch.distributed as _dist
+        _world = _dist.get_world_size(process_group) if (_dist.is_available() and _dist.is_initialized()) else 1
         # Synchronised BatchNorm: every training-mode norm takes its statistics over the GLOBAL batch, so that
         # — together with global_token_mean — a data-parallel step equals the single-device step on the concatenated
         # batch.  Runs through the Python orchestration (one small all-reduce per norm and direction, one host read per
-        # step); an option for parity checks, not for throughput runs.
-        self.sync_bn = bool(sync_bn)
+        # step); an option for parity checks, not for throughput runs.  With ONE rank the statistics are global anyway:
+        # the native step stays on.
+        self.native = bool(native and vae.cfg["batch_norm"] and not vae.cfg["dropout"] and not (self.sync_bn and _world > 1))
         if iters_to_accumulate < 1:
             raise ValueError("iters_to_accumulate must be >= 1")
         self.iters_to_accumulate = int(iters_to_accumulate)            # training.py:83,149,158
@@ -114,9 +117,14 @@ class HipTrainer:
         self._accum_bucket = GradBuckets(self.grad_accum, [], process_group) if self.grad_accum is not None else None
         broadcast_([vae.flat_params, vae.flat_buffers], 0, process_group)
         vae.engine.set_sync_bn(process_group, self.sync_bn and self.world > 1)
-        if self.world > 1:                      # every rank its own message-dropout stream (same seed = same masks)
+        # every rank its own message-dropout stream (same seed = same masks on every replica): the model keeps its BASE
+        # seed — what checkpoints store — and the rank only salts the seeds derived from it (VAE._next_seed), so building a
+        # second trainer on the same model, resuming from a rank-0 checkpoint or resuming with another world size all give
+        # each rank a stream of its own
+        vae.rank_salt = 0
+        if self.world > 1:
             import torch.distributed as dist
-            vae.seed = (vae.seed ^ (0x9E3779B9 * (dist.get_rank(process_group) + 1))) & 0xFFFFFFFF
+            vae.rank_salt = (0x9E3779B9 * (dist.get_rank(process_group) + 1)) & 0xFFFFFFFF
         # native step plumbing
         self._layout = build_layout(vae) if self.native else None
         self._flat_ptr = flat.data_ptr()

@@ -66,3 +66,21 @@ def test_binary_from_logits_and_structure_from_binary():
     assert b[0, 0].sum() == 1 and b[0, 0, 1, 5] and b[1, 1, 0, 0] and b[1, 1].sum() == 1
     g = vae.decoder._structure_from_binary(b)
     assert g.num_nodes == 4 and g.edge_index.shape[1] == 4 and int(g.bars.max()) == 1
+
+
+def test_dropout_seed_keeps_a_base_seed_and_salts_it_per_rank():
+    """the model keeps its BASE seed (what a checkpoint stores); the rank only salts the seeds derived from it.
+    Two ranks draw different streams, re-applying the salt is idempotent (a second trainer on the same model), and a
+    base seed restored from a rank-0 checkpoint still gives every rank its own stream."""
+    from polyphemus_amd.model import VAE
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=32, n_bars=2, resolution=8)
+    vae = VAE(**cfg, device=torch.device("cpu"))
+    base = vae.seed
+    salts = [(0x9E3779B9 * (r + 1)) & 0xFFFFFFFF for r in range(2)]
+    seen = []
+    for salt in salts + [salts[0]]:
+        vae.rank_salt, vae._step = salt, 0
+        seen.append([vae._next_seed() for _ in range(3)])
+        assert vae.seed == base                                   # never rewritten
+    assert seen[0] != seen[1] and seen[0] == seen[2]
+    assert len(set(seen[0] + seen[1])) == 6

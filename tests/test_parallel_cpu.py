@@ -143,3 +143,34 @@ def test_device_loader_shards_are_disjoint_and_in_lock_step():
     assert len(set(a) & set(b)) <= 1 and set(a) | set(b) == set(range(11))
     order = np.random.default_rng(5 + 3).permutation(11)
     assert list(a) == list(np.concatenate([order, order[:1]])[0::2])
+
+
+@pytest.mark.parametrize("n,world,bs", [(2051, 8, 256), (5, 8, 2), (8, 8, 1), (17, 8, 4)])
+def test_device_loader_world8_shards(n, world, bs):
+    """World-8 index plan (BASELINE configs[3]: 2048 samples over 8 ranks), including a dataset SMALLER than the world
+    (the wrap-around used to pad by at most one copy of the permutation, leaving ranks with unequal batch
+    counts and the gradient all-reduce waiting for a rank that had no batch): every rank the same number of samples
+    and batches, shards disjoint up to the wrapped tail, every sample covered."""
+    import numpy as np
+    from polyphemus_amd.data import DeviceLoader
+
+    class DS:
+        n_bars = 2
+
+        def __len__(self):
+            return n
+
+    plans = []
+    for rank in range(world):
+        ld = DeviceLoader.__new__(DeviceLoader)
+        ld.dataset, ld.batch_size, ld.shuffle, ld.seed, ld.drop_last, ld.epoch = DS(), bs, True, 11, False, 0
+        ld.rank, ld.world = rank, world
+        plans.append(ld._index_batches())
+        assert len(plans[-1]) == len(ld)
+    counts = [sum(len(b) for b in p) for p in plans]
+    assert len(set(counts)) == 1 and len({len(p) for p in plans}) == 1            # lock step
+    per_rank = -(-n // world)
+    assert counts[0] == per_rank
+    seen = np.concatenate([np.concatenate(p) for p in plans])
+    assert set(seen.tolist()) == set(range(n))
+    assert len(seen) - n == per_rank * world - n                                   # only the wrapped tail repeats

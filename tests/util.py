@@ -200,7 +200,12 @@ FULLSIZE = {
     "configs1_lmd2_b256_d256": dict(B=256, nb=2, d=256, L=8, p=0.25, dense=False, msg_p=0.1, seed=1234),
     "configs2_lmd16_b64_d256": dict(B=64, nb=16, d=256, L=8, p=0.25, dense=False, msg_p=0.1, seed=1234),
     "configs4_dense_shard_b8_d512": dict(B=8, nb=2, d=512, L=8, p=1.0, dense=True, msg_p=0.0, seed=1234),
+    # the reference's own training configuration (training.json:2-9: batch 256, d = 512, 8 layers, 2 bars)
+    "training_json_b256_d512": dict(B=256, nb=2, d=512, L=8, p=0.25, dense=False, msg_p=0.1, seed=1234),
 }
+# one GPU's shard of configs[4] at its real size (B = 64: N = 16,384 nodes, 2.08 M edges): too large for the oracle's
+# per-edge fp64 tensors — property checks only (tests/test_fullsize_gpu.py)
+DENSE_SHARD_B64 = dict(B=64, nb=2, d=512, L=8, p=1.0, dense=True, msg_p=0.1, seed=1234)
 
 
 def _as_dtype(batch, dtype):
@@ -212,19 +217,14 @@ def _as_dtype(batch, dtype):
     return out
 
 
-def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
-    """One native HIP training step (the measured variant) and the same step through oracle/vae_cpu.py in fp32 and in
-    fp64 (same weights, eps and — replayed from the counter hash — the same message-dropout mask).  Returns the
-    relative errors (max|a-b| / max|b|) of every model output, loss and of the gradient against the fp64 oracle, for
-    both the HIP path and the fp32 oracle: the fp32 reference arithmetic is itself only defined up to its distance
-    from fp64, which is what the tolerances of the full-size tests are measured against."""
+def hip_fullsize_step(spec, dev="cuda", lr=5e-6, keep=None):
+    """One native HIP training step (the measured variant) on the synthetic batch of `spec`, default-init weights under
+    manual_seed(0) and a fixed eps: model outputs, losses, gradients, the step variant, and what the oracle needs to
+    replay it (batch, state dict, eps, the two dropout seeds)."""
     import time
-    from oracle import vae_cpu
     from polyphemus_amd.model import VAE
     from polyphemus_amd.synthetic import synthetic_batch
     from polyphemus_amd.trainer import HipTrainer
-    if threads:
-        torch.set_num_threads(threads)
     cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=spec["L"], d=spec["d"], n_bars=spec["nb"], resolution=8)
     cpu = synthetic_batch(spec["B"], spec["nb"], p=spec["p"], seed=spec["seed"], dense=spec["dense"])
     torch.manual_seed(0)
@@ -234,19 +234,44 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
     sd = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
     names = [n for n, _ in vae.named_parameters()]
     eps = torch.randn(spec["B"], spec["d"], generator=torch.Generator().manual_seed(99))
-    tr = HipTrainer(vae, lr=5e-6)
+    tr = HipTrainer(vae, lr=lr)
     tr.keep_logits = True
     step0 = vae._step
     t0 = time.time()
-    got_l = tr.losses_dict(tr.train_step(cpu.to(dev), eps.to(dev)))
+    # launch-class counters of the in-library profiler: WHICH kernels the step took (35 / 36 / 37 = the three GCL kernels of
+    # gcl.hip / wide.hip, 38 = the chord products of linear.hip / wide.hip, 27 / 28 / 26 = the grouped planes products)
+    import ctypes
+    from polyphemus_amd._lib import lib
+    L = lib()
+    L.pm_prof_configure(-1, 1)
+    L.pm_prof_begin(1024)
+    gpu_batch = cpu.to(dev)
+    got_l = tr.losses_dict(tr.train_step(gpu_batch, eps.to(dev)))
+    ms, work, cnt = (ctypes.c_double * 64)(), (ctypes.c_double * 64)(), (ctypes.c_int64 * 64)()
+    L.pm_prof_end(*(ctypes.cast(a, ctypes.c_void_p) for a in (ms, work, cnt)))
     (s_h, c_h), mu_h, lv_h = tr.step_outputs()
     info = tr.step_info()
-    S = info["n_slots"]
+    info["launches"] = {"gcl_fwd": int(cnt[35]), "gcl_dagg": int(cnt[36]), "gcl_dw": int(cnt[37]), "rows_w": int(cnt[38]),
+                        "planesB_nn": int(cnt[27]), "planesB_nt": int(cnt[28]), "planes_tn": int(cnt[26]),
+                        "segreduce_fwd": int(cnt[33]), "segreduce_bwd": int(cnt[34])}
     hip = dict(s_logits=s_h.cpu(), c_logits=c_h.cpu(), mu=mu_h.cpu(), log_var=lv_h.cpu())
     hip_g = {n: tr._G[n].detach().cpu() for n in names}
     t_hip = time.time() - t0
     vae._step = step0
     seeds = {"encoder": vae._next_seed(), "decoder": vae._next_seed()}
+    out = dict(cfg=cfg, cpu=cpu, sd=sd, names=names, eps=eps, losses=got_l, outputs=hip, grads=hip_g, info=info,
+               seconds=t_hip, seeds=seeds)
+    if keep is not None:                      # the live objects, for tests that take further steps on the same model
+        keep.update(vae=vae, trainer=tr, batch=gpu_batch, eps=eps.to(dev), step0=step0)
+    return out
+
+
+def oracle_fullsize(spec, run, dtypes=(("o64", torch.float64), ("o32", torch.float32))):
+    """oracle/vae_cpu.py on what `hip_fullsize_step` ran (same weights, eps and — replayed from the counter hash — the
+    same message-dropout mask), per dtype: (outputs, losses, gradients), and the seconds each took."""
+    import time
+    from oracle import vae_cpu
+    cfg, cpu, sd, names, eps, seeds = (run[k] for k in ("cfg", "cpu", "sd", "names", "eps", "seeds"))
     masks = {}
 
     def keep(key, eids, dd):
@@ -255,9 +280,8 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
             masks[k] = torch.from_numpy(dropout_keep_np(seeds[key.split(".")[0]], layer_uid_of(key), eids.numpy(), dd, spec["msg_p"]))
         return masks[k]
 
-    res = {}
-    times = {}
-    for tag, dt in (("o64", torch.float64), ("o32", torch.float32)):
+    res, times = {}, {}
+    for tag, dt in dtypes:
         t0 = time.time()
         P, _ = vae_cpu.split_state({k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}, names)
         opt = torch.optim.SGD([P[n] for n in names], lr=0.0)
@@ -266,27 +290,27 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
         res[tag] = (dict(zip(("s_logits", "c_logits", "mu", "log_var"), (o.detach() for o in outs))),
                     {k: float(v.detach()) for k, v in parts.items()}, grads)
         times[tag] = time.time() - t0
-    o64, l64, g64 = res["o64"]
-    o32, l32, g32 = res["o32"]
-    rep = {"info": info, "N": cpu.num_nodes, "E": int(cpu.edge_index.shape[1]), "seconds": {"hip_first_step": t_hip, **times},
-           "outputs": {}, "losses": {}, "grad": {}}
-    for k in ("s_logits", "c_logits", "mu", "log_var"):
-        ref64 = o64[k][:, :S] if k == "c_logits" else o64[k]
-        ref32 = o32[k][:, :S] if k == "c_logits" else o32[k]
-        rep["outputs"][k] = {"hip_vs_o64": rel_err(hip[k], ref64), "o32_vs_o64": rel_err(ref32, ref64), "hip_vs_o32": rel_err(hip[k], ref32)}
-    for k in ("pitch", "dur", "structure", "kld"):
-        den = max(1.0, abs(l64[k]))
-        rep["losses"][k] = {"hip_vs_o64": abs(got_l[k] - l64[k]) / den, "o32_vs_o64": abs(l32[k] - l64[k]) / den}
+    return res, times
+
+
+def grad_errors(names, hip_g, g64, g32=None):
+    """Per-tensor and whole-vector gradient errors against the fp64 oracle: per tensor max|a-b| over
+    max(max|ref|, 1 % of the largest gradient) (the metric of tests/test_model_gpu._grad_err), and the relative L2 error
+    of the concatenated gradient."""
     live = [n for n in names if g64[n] is not None]
     gmax = max(float(g64[n].abs().max()) for n in live)
-    worst = {"hip_vs_o64": (0.0, ""), "o32_vs_o64": (0.0, ""), "hip_vs_o32": (0.0, "")}
-    per_tensor = []
-    num = {"hip_vs_o64": 0.0, "o32_vs_o64": 0.0, "hip_vs_o32": 0.0}
-    den2 = 0.0
+    pairs = {"hip_vs_o64": (hip_g, g64)}
+    if g32 is not None:
+        pairs["o32_vs_o64"] = (g32, g64)
+        pairs["hip_vs_o32"] = (hip_g, g32)
+    worst = {t: (0.0, "") for t in pairs}
+    num = {t: 0.0 for t in pairs}
+    per_tensor, den2 = [], 0.0
     for n in live:
-        a, b, c = hip_g[n].double(), g32[n].double(), g64[n].double()
-        den = max(float(c.abs().max()), 1e-2 * gmax)        # the metric of tests/test_model_gpu._grad_err
-        for tag, (x, y) in (("hip_vs_o64", (a, c)), ("o32_vs_o64", (b, c)), ("hip_vs_o32", (a, b))):
+        c = g64[n].double()
+        den = max(float(c.abs().max()), 1e-2 * gmax)
+        for tag, (xa, ya) in pairs.items():
+            x, y = xa[n].double(), ya[n].double()
             e = float((x - y).abs().max()) / den
             if e > worst[tag][0]:
                 worst[tag] = (e, n)
@@ -295,10 +319,39 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
             num[tag] += float(((x - y) ** 2).sum())
         den2 += float((c ** 2).sum())
     for n in names:
-        if g64[n] is None:
+        if g64[n] is None and hip_g[n] is not None:
             assert float(hip_g[n].abs().max()) == 0.0, n
-    rep["grad"] = {tag: {"worst_tensor_err": worst[tag][0], "worst_tensor": worst[tag][1], "rel_l2": (num[tag] / den2) ** 0.5}
-                   for tag in worst}
-    rep["grad"]["gmax"] = gmax
-    rep["grad"]["hip_worst_tensors"] = [{"err": round(e, 6), "tensor": n, "scale_vs_gmax": round(sc, 5)} for e, n, sc in sorted(per_tensor, reverse=True)[:10]]
+    out = {tag: {"worst_tensor_err": worst[tag][0], "worst_tensor": worst[tag][1], "rel_l2": (num[tag] / den2) ** 0.5}
+           for tag in pairs}
+    out["gmax"] = gmax
+    out["hip_worst_tensors"] = [{"err": round(e, 6), "tensor": n, "scale_vs_gmax": round(sc, 5)} for e, n, sc in sorted(per_tensor, reverse=True)[:10]]
+    out["per_tensor"] = {n: e for e, n, _ in per_tensor}
+    return out
+
+
+def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
+    """One native HIP training step (the measured variant) and the same step through oracle/vae_cpu.py in fp32 and in
+    fp64 (same weights, eps and — replayed from the counter hash — the same message-dropout mask).  Returns the
+    relative errors (max|a-b| / max|b|) of every model output, loss and of the gradient against the fp64 oracle, for
+    both the HIP path and the fp32 oracle: the fp32 reference arithmetic is itself only defined up to its distance
+    from fp64, which is what the tolerances of the full-size tests are measured against."""
+    if threads:
+        torch.set_num_threads(threads)
+    run = hip_fullsize_step(spec, dev)
+    cpu, names, got_l, hip, hip_g, info = (run[k] for k in ("cpu", "names", "losses", "outputs", "grads", "info"))
+    S = info["n_slots"]
+    res, times = oracle_fullsize(spec, run)
+    o64, l64, g64 = res["o64"]
+    o32, l32, g32 = res["o32"]
+    rep = {"info": info, "N": cpu.num_nodes, "E": int(cpu.edge_index.shape[1]), "seconds": {"hip_first_step": run["seconds"], **times},
+           "outputs": {}, "losses": {}, "grad": {}}
+    for k in ("s_logits", "c_logits", "mu", "log_var"):
+        ref64 = o64[k][:, :S] if k == "c_logits" else o64[k]
+        ref32 = o32[k][:, :S] if k == "c_logits" else o32[k]
+        rep["outputs"][k] = {"hip_vs_o64": rel_err(hip[k], ref64), "o32_vs_o64": rel_err(ref32, ref64), "hip_vs_o32": rel_err(hip[k], ref32)}
+    for k in ("pitch", "dur", "structure", "kld"):
+        den = max(1.0, abs(l64[k]))
+        rep["losses"][k] = {"hip_vs_o64": abs(got_l[k] - l64[k]) / den, "o32_vs_o64": abs(l32[k] - l64[k]) / den}
+    rep["grad"] = grad_errors(names, hip_g, g64, g32)
+    rep["grad"].pop("per_tensor")
     return rep

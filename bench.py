@@ -238,6 +238,10 @@ def stub_main(args):
 
     for _ in range(args.warmup):
         step()
+    gb.trace = True
+    step()
+    timeline = gb.timeline()
+    gb.trace = False
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -254,7 +258,8 @@ def stub_main(args):
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": args.steps / float(t), "unit": "steps/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t) / args.steps,
-                          "dp": {"ranks_seen": world, "backend": "gloo", "allreduce_checksum_ok": ok}}))
+                          "dp": {"ranks_seen": world, "backend": "gloo", "allreduce_checksum_ok": ok,
+                                 "buckets_timeline": timeline}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -353,6 +358,11 @@ def main():
             trainer.train_step(batch)
         sync()
         t_dp = (time.perf_counter() - t0) / reps
+        trainer.buckets.trace = True                            # one more step with every bucket launch / completion stamped
+        trainer.train_step(batch)
+        sync()
+        timeline = trainer.buckets.timeline()
+        trainer.buckets.trace = False
         trainer.buckets.disabled = True                         # same step without the exchange (ranks drift apart ...)
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -370,6 +380,9 @@ def main():
               "allreduce_alone_ms": round(1e3 * t_alone, 3), "step_ms_with_exchange": round(1e3 * t_dp, 3),
               "step_ms_without_exchange": round(1e3 * t_nodp, 3), "allreduce_exposed_ms": round(1e3 * exposed, 3),
               "overlapped_fraction": round(1.0 - min(exposed / t_alone, 1.0), 3) if t_alone > 0 else None,
+              # rank 0's compute-stream clock, one traced step: per bucket the compute that ran between its launch and the
+              # point where Adam needs the gradients (window) and how long the step then stood waiting for it (exposed)
+              "buckets_timeline": timeline,
               "note": f"max over ranks, {reps} repetitions each, measured before the timed region"}
 
     SURVEY = 2

@@ -66,17 +66,60 @@ class GradBuckets:
         self._work = []
         self.hold = False        # True: launches are skipped (micro-batches of a gradient accumulation)
         self.disabled = False    # True: no exchange at all (bench.py: cost of the step without the all-reduce)
+        # trace = True: every launch / completion of the next exchange is stamped (bench.py's `dp` block; off in timed
+        # regions: a stamp on a GPU stream is an event record, i.e. a barrier packet)
+        self.trace = False
+        self._marks: List[dict] = []
+        self._wait0 = None
+
+    def _stamp(self):
+        """a point in the order of the COMPUTE stream (HIP event) for GPU buffers, the host clock otherwise"""
+        if self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
 
     def launch(self, i: int) -> None:
         if self.active and not self.hold and not self.disabled:
+            if self.trace:
+                if not self._work:
+                    self._marks = []
+                self._marks.append({"bucket": i, "bytes": int(self.views[i].numel() * self.views[i].element_size()),
+                                    "launch": self._stamp()})
             self._work.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> float:
         """Wait for every launched bucket; returns the factor that turns the sum into the mean."""
-        for w in self._work:
-            w.wait()
+        tr = self.trace and len(self._marks) == len(self._work)
+        if tr:
+            self._wait0 = self._stamp()
+        for k, w in enumerate(self._work):
+            w.wait()                      # (RCCL: the compute stream waits for the bucket; gloo: the host does)
+            if tr:
+                self._marks[k]["done"] = self._stamp()
         self._work = []
         return 1.0 / self.world
+
+    def timeline(self) -> List[dict]:
+        """Per bucket of the last traced exchange, in milliseconds on the compute stream's clock: when it was launched
+        (relative to the first launch), the `window` of compute that ran between its launch and the point where the
+        step needs the gradients (wait), and the time the step then stood `exposed`, waiting for this bucket after the
+        previous one had arrived.  window >> 0 and exposed ~ 0 is what "overlapped with the backward" means."""
+        if not self._marks or self._wait0 is None or "done" not in self._marks[-1]:
+            return []
+        if self.flat.is_cuda:
+            torch.cuda.synchronize()
+            dt = lambda a, b: a.elapsed_time(b)
+        else:
+            dt = lambda a, b: 1e3 * (b - a)
+        out, prev = [], self._wait0
+        for m in self._marks:
+            out.append({"bucket": m["bucket"], "bytes": m["bytes"], "launched_at_ms": round(dt(self._marks[0]["launch"], m["launch"]), 3),
+                        "window_ms": round(dt(m["launch"], self._wait0), 3), "exposed_ms": round(max(dt(prev, m["done"]), 0.0), 3)})
+            prev = m["done"]
+        return out
 
 
 def broadcast_(tensors: Sequence[torch.Tensor], src: int = 0, group=None) -> None:

@@ -90,14 +90,14 @@ def test_harness_reports_a_failing_rank_and_kills_the_others():
     assert not multiprocessing.active_children()
 
 
-def _bench(*extra, env=None):
+def _bench(*extra, env=None, gpus=2):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step", "--steps", "3",
-                        "--warmup", "1", *extra], capture_output=True, text=True, timeout=120,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--stub-step", "--steps", "3",
+                        "--warmup", "1", *extra], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, **(env or {})))
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     return r.returncode, lines, r.stderr
@@ -111,7 +111,21 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, lines                                  # ONE line, from rank 0
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    tl = line["dp"].pop("buckets_timeline")
     assert line["dp"] == {"ranks_seen": 2, "backend": "gloo", "allreduce_checksum_ok": True}
+    # one traced exchange: the three buckets in launch order (decoder first), every one launched before the wait
+    assert [b["bucket"] for b in tl] == [2, 1, 0] and [b["bytes"] for b in tl] == [1200, 1600, 1200]
+    assert all(b["window_ms"] >= 0 and b["exposed_ms"] >= 0 for b in tl) and tl[0]["launched_at_ms"] == 0
+
+
+def test_bench_launcher_with_eight_ranks():
+    """configs[3]'s world size through the self-launcher (stub step on CPU / gloo): eight ranks rendezvous, the bucketed
+    exchange adds up over all of them, ONE line comes back."""
+    rc, lines, err = _bench(gpus=8)
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8
+    assert lines[0]["dp"]["ranks_seen"] == 8 and lines[0]["dp"]["allreduce_checksum_ok"] is True
+    assert [b["bucket"] for b in lines[0]["dp"]["buckets_timeline"]] == [2, 1, 0]
 
 
 def test_bench_fails_when_a_rank_dies():

@@ -509,12 +509,17 @@ int pm_content_ce_scaled(const float* c_logits, const int32_t* tokens, const int
  * two CrossEntropyLoss(ignore_index = PAD) terms of `_losses` (training.py:316-323) in one launch: the logits of a
  * 64-row tile stay in the MFMA accumulators, only d_logits [N,S,230] is written (and `logits` when not NULL).
  * H [N,S,d] is the chord decoder's output; out[0] / out[1] receive the pitch / duration loss (zeroed by the call);
- * db_* (all or none) += the bias gradients; dev_scale as in pm_content_ce_scaled. */
+ * db_* (all or none) += the bias gradients; dev_scale as in pm_content_ce_scaled.
+ * `w_planes`: scratch of pm_unembed_scratch_bytes(d) bytes (bf16 planes of the three weights + accumulator replicas);
+ * with it and d/2 in {64, 128, 256} the products run on the bf16 matrix pipe (six products of exact three-way splits,
+ * k_unembed_ce_planes); NULL or another width: the fp32-MFMA kernel of round 2. */
+int64_t pm_unembed_scratch_bytes(int32_t d);
 int pm_unembed_ce(const float* H, const float* w_pitch_drum /* [131,d/2] */, const float* b_pitch_drum,
                   const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur /* [99,d/2] */, const float* b_dur,
                   const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
                   float grad_scale, const float* dev_scale, float* logits /* or NULL */, float* d_logits,
-                  float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream);
+                  float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes /* or NULL */,
+                  pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
            float* dlog_var, double* out, pm_stream_t stream);
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,

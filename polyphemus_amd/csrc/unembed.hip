@@ -11,13 +11,15 @@
 // pitch products (drum rows | non-drum rows, row lists of the plan) and the duration product (all rows) are independent
 // jobs of one launch (blockIdx.y).  Persistent workgroups: bias gradients and loss partial sums stay in registers across
 // a workgroup's tiles and reach memory once.
-// Measured (configs[1], round 2): 195-220 us per launch against 97 us (three products) + 62 us (k_content_ce) of the
-// unfused path — the fusion removes 150 MB of logit traffic but its single 64-row-tile pipeline (fp32 MFMA at three
-// waves per SIMD, 153 VGPRs) is slower than the two streaming kernels it replaces, so the native step uses it only
-// with PM_FUSED_CE=1; both paths are parity-tested.
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Two kernels.  k_unembed_ce_planes (d/2 in {64, 128, 256}, round 3, the step's default): the products run on the bf16
+// matrix pipe as six products of exact three-way bf16 splits (the scheme of the GCL kernels): the 64 fp32 rows of a tile
+// are split into planes once, into an LDS image; FIVE MFMA waves take one 32-column block of the vocabulary each (131 ->
+// 5 blocks, 99 -> 4) for all 64 rows, weight fragments straight from fragment-major planes (zero-padded to 32 columns,
+// prepared once per step by k_unembed_wplanes: 176 KB, cache resident); the logits tile then replaces the image in LDS
+// and the row-wise soft-max runs one wave per row.  k_unembed_ce (any width, round 2): the same on the fp32 MFMA —
+// 195-220 us per launch at configs[1] against 97 us (three products) + 62 us (k_content_ce) of the unfused path, which
+// is why round 2 left the fusion off by default.
+#include "gcl_tiles.h"
 
 namespace {
 constexpr int UBM = 64, UBK = 32, UNB = 5;             // rows per tile, k per stage, 32-column blocks of the widest job
@@ -211,13 +213,299 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_UNE
     if (t != 0) atomicAdd(&a.out[jb.kind], t / nval);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fragment-major bf16 planes of the three un-embedding weights (pm_split_planes_frag kind 0 layout: per 32-row tile of
+// W and 16-wide k-step one 3 x 1 KiB block), rows zero-padded to a multiple of 32: job j at plane offset woff[j].
+constexpr int UREP = 16;                                // replicas of the bias-gradient / loss accumulators
+constexpr int UREP_F = 3 * 160;                         // floats per replica: [3 jobs][160 columns]
+__global__ void __launch_bounds__(256) k_unembed_wplanes(UnembedArgs a, uint16_t* __restrict__ out, int o1, int o2,
+                                                         float* __restrict__ dbrep, double* __restrict__ lossrep) {
+  const int j = blockIdx.y;
+  if (j == 0)                                           // (the accumulators the tile kernel adds into)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < UREP * UREP_F + UREP * 2; i += gridDim.x * blockDim.x) {
+      if (i < UREP * UREP_F) dbrep[i] = 0.f;
+      else lossrep[i - UREP * UREP_F] = 0.0;
+    }
+  const UnembedJob jb = a.job[j];
+  uint16_t* dst = out + (j == 0 ? 0 : (j == 1 ? o1 : o2));
+  const int vpad = ((jb.V + 31) >> 5) << 5, ks_n = a.dh >> 4;
+  const int chunks = vpad * (a.dh >> 3);                          // 8 consecutive k of one row
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
+    const int n = c / (a.dh >> 3), k0 = (c % (a.dh >> 3)) * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = n < jb.V ? jb.W[(int64_t)n * a.dh + k0 + e] : 0.f;
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
+    const int blk = (n >> 5) * ks_n + (k0 >> 4), lane = ((k0 >> 3) & 1) * 32 + (n & 31);
+    uint16_t* o = dst + (int64_t)blk * 1536 + lane * 8;
+    *reinterpret_cast<u32x4*>(o) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(o + 512) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    *reinterpret_cast<u32x4*>(o + 1024) = u32x4{p3[0], p3[1], p3[2], p3[3]};
+  }
+}
+
+constexpr int UBD = 2;                                  // k-steps of weight fragments in flight per MFMA wave
+constexpr int PNW = 5;                                  // MFMA waves = 32-column blocks of the widest vocabulary (131 -> 160)
+constexpr int PLDL = PNW * 32 + 4;                      // row pitch of the logits tile
+template <int DH>
+__global__ void __launch_bounds__(PNW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_unembed_ce_planes(UnembedArgs a, const char* __restrict__ wplanes, int o1, int o2,
+                                                                float* __restrict__ dbrep, double* __restrict__ lossrep) {
+  constexpr int RB = DH * 2, PL = UBM * RB, KS = DH / 16, SWZ = (DH / 8 - 1) < 15 ? (DH / 8 - 1) : 15;
+  constexpr int NTHR = PNW * 64;
+  constexpr int IMGB = 3 * PL, TILEB = UBM * PLDL * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];    // max(operand image, logits tile) + row ids + targets
+  float* const sL = reinterpret_cast<float*>(smem);
+  int* const s_row = reinterpret_cast<int*>(smem + (IMGB > TILEB ? IMGB : TILEB));
+  int* const s_tgt = s_row + UBM;
+  double* const s_loss = reinterpret_cast<double*>(s_tgt + UBM);     // [PNW] (all of it dynamic: the image may take 96 KB)
+  float* const s_red = reinterpret_cast<float*>(s_loss + PNW);       // [UBM][PNW][2]: per (row, 32-column segment) max and sum
+  const UnembedJob jb = a.job[blockIdx.y];
+  const char* const wf = wplanes + 2 * (int64_t)(blockIdx.y == 0 ? 0 : (blockIdx.y == 1 ? o1 : o2));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int M = jb.dyn_rows ? *jb.dyn_rows : a.R;
+  const int nblk = (jb.V + 31) >> 5;                              // live MFMA waves of this job
+  const double rows15 = (double)(a.R / a.S) * PM_N_SLOTS;
+  const double nval = rows15 - (double)(jb.kind == 0 ? a.hist[0 * PM_N_PITCH + 130] + a.hist[1 * PM_N_PITCH + 130]
+                                                     : a.hist[2 * PM_N_PITCH + 98] + a.hist[3 * PM_N_PITCH + 98]);
+  const float gk = a.grad_scale * (float)(1.0 / nval) * (a.dev_scale ? a.dev_scale[jb.kind] : 1.f);
+  const int mycol = wave * 32 + li;
+  const float bcol = (wave < nblk && mycol < jb.V) ? jb.bias[mycol] : 0.f;
+  float dbacc[3] = {0.f, 0.f, 0.f};                              // bias gradient of columns lane + 64 q (store phase)
+  double lacc = 0;
+  float lloss = 0.f;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.H), 0, GCL_OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wf), 0, GCL_OOB, 0x00020000);
+  for (int m0 = blockIdx.x * UBM; m0 < M; m0 += gridDim.x * UBM) {
+    if (tid < UBM) {                                   // row ids and target tokens of the tile
+      const int r = m0 + tid;
+      int rg = -1, tg = jb.pad;
+      if (r < M) {
+        rg = jb.rowmap ? jb.rowmap[r] : r;
+        const int n = rg / a.S, s = rg - n * a.S + 1;
+        tg = a.tok[((int64_t)n * 16 + s) * 2 + jb.kind];
+      }
+      s_row[tid] = rg; s_tgt[tid] = tg;
+    }
+    __syncthreads();
+    // ---- the tile's rows of H (this job's half of the d columns): fp32 -> three bf16 planes -> swizzled LDS image
+    {
+      constexpr int QPR = DH / 4, NP = UBM * QPR;                // float4 pieces per row / per tile
+      constexpr int PPT = (NP + NTHR - 1) / NTHR;
+      float4 v[PPT];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int pi = tid + k * NTHR, rr = pi / QPR, q = pi % QPR;
+        const int rg = pi < NP ? s_row[rr] : -1;
+        v[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+            hrs, rg >= 0 ? (int)(((int64_t)rg * a.d + jb.koff + q * 4) * 4) : GCL_OOB, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int pi = tid + k * NTHR, rr = pi / QPR, q = pi % QPR;
+        if (pi >= NP) continue;
+        unsigned l1, l2, l3, u1, u2, u3;
+        pm_split3_pair(v[k].x, v[k].y, l1, l2, l3);
+        pm_split3_pair(v[k].z, v[k].w, u1, u2, u3);
+        const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+        char* dst = smem + rr * RB + (((q >> 1) ^ (rr & SWZ)) << 4) + ((q & 1) << 3);
+        *reinterpret_cast<pm_u32x2*>(dst) = p1;
+        *reinterpret_cast<pm_u32x2*>(dst + PL) = p2;
+        *reinterpret_cast<pm_u32x2*>(dst + 2 * PL) = p3;
+      }
+    }
+    __syncthreads();
+    // ---- products: wave w < nblk owns vocabulary columns [32 w, 32 w + 32) for all 64 rows
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    if (wave < nblk) {
+      auto bload = [&](bf16x8 (&dst)[3], int ks) {
+        const int soff = __builtin_amdgcn_readfirstlane((wave * KS + (ks < KS ? ks : KS - 1)) * 3072);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          dst[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + p * 1024, 0));
+      };
+      // weight fragments UBD k-steps ahead (2 / 4 / 8 measured: 126.7 / 126.3 / 154 us per launch at configs[1])
+      bf16x8 bq[UBD][3];
+#pragma unroll
+      for (int s2 = 0; s2 < UBD; ++s2) bload(bq[s2], s2);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 av[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int rr = i * 32 + li;
+            av[p][i] = *reinterpret_cast<const bf16x8*>(smem + p * PL + rr * RB + (((ks * 2 + lh) ^ (rr & SWZ)) << 4));
+          }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[t6]][i], bq[ks % UBD][PB[t6]], acc[i], 0, 0, 0);
+        bload(bq[ks % UBD], ks + UBD);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                              // every wave has read the image: the logits tile replaces it
+    if (wave < nblk) {
+      // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sL[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PLDL + mycol] = acc[i][r] + bcol;
+    }
+    __syncthreads();
+    // ---- soft-max, loss, d_logits.  Thread (row = lane, segment = wave) owns 32 consecutive columns of one row: no
+    // cross-lane reduction anywhere (round 2 and the first version of this kernel ran one wave per row with two chains of
+    // six dependent cross-lane steps per row: 91 of the kernel's 146 us at one or two waves per SIMD).  The five
+    // segments of a row meet through LDS (max, sum); d_logits goes back into the tile and leaves it row by row, whole
+    // 524- / 396-byte segments per wave-instruction.
+    constexpr float LOG2E = 1.4426950408889634f;
+    if (a.logits) {                                               // (evaluation / tests: the logits themselves, before the tile is overwritten)
+      for (int r = wave; r < UBM; r += PNW) {
+        const int rg = s_row[r];
+        if (rg < 0) continue;
+        float* lg = a.logits + (int64_t)rg * PM_N_TOK + jb.coff;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int c = lane + 64 * q;
+          if (c < jb.V) lg[c] = sL[r * PLDL + c];
+        }
+      }
+      __syncthreads();
+    }
+    {
+      const int r = lane, c0 = wave * 32;
+      const int rg = s_row[r], tg = s_tgt[r];
+      float* const lrow = sL + r * PLDL + c0;
+      float e[32];
+      float cmax = -INFINITY, vt = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(lrow + 4 * i);
+        e[4 * i] = t.x; e[4 * i + 1] = t.y; e[4 * i + 2] = t.z; e[4 * i + 3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (c0 + j >= jb.V) e[j] = -INFINITY;                     // (columns past the vocabulary; never-written blocks)
+        cmax = fmaxf(cmax, e[j]);
+        vt = (c0 + j == tg) ? e[j] : vt;                          // the target's logit, if it lies in this segment
+      }
+      float csum = 0.f;
+      if (c0 < jb.V) {
+        const float m2 = cmax * LOG2E;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { e[j] = __builtin_amdgcn_exp2f(e[j] * LOG2E - m2); csum += e[j]; }   // exp2(-inf) = 0
+      }
+      s_red[(r * PNW + wave) * 2] = cmax;
+      s_red[(r * PNW + wave) * 2 + 1] = csum;
+      __syncthreads();
+      float mx = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < PNW; ++w) mx = fmaxf(mx, s_red[(r * PNW + w) * 2]);
+      float ssum = 0.f;
+#pragma unroll
+      for (int w = 0; w < PNW; ++w) {
+        const float mw = s_red[(r * PNW + w) * 2];
+        ssum += mw == -INFINITY ? 0.f : s_red[(r * PNW + w) * 2 + 1] * __builtin_amdgcn_exp2f((mw - mx) * LOG2E);
+      }
+      const bool vrow = rg >= 0 && tg != jb.pad;                  // ignore_index = PAD (training.py:101-102); rows past the end
+      const float k = vrow ? gk : 0.f;
+      const float sc = c0 < jb.V ? __builtin_amdgcn_exp2f((cmax - mx) * LOG2E) * (k / ssum) : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 t;
+        t.x = e[4 * i] * sc - (c0 + 4 * i == tg ? k : 0.f);
+        t.y = e[4 * i + 1] * sc - (c0 + 4 * i + 1 == tg ? k : 0.f);
+        t.z = e[4 * i + 2] * sc - (c0 + 4 * i + 2 == tg ? k : 0.f);
+        t.w = e[4 * i + 3] * sc - (c0 + 4 * i + 3 == tg ? k : 0.f);
+        *reinterpret_cast<float4*>(lrow + 4 * i) = t;
+      }
+      if (vrow && tg >= c0 && tg < c0 + 32) lloss += __logf(ssum) + mx - vt;
+    }
+    __syncthreads();
+    for (int r = wave; r < UBM; r += PNW) {
+      const int rg = s_row[r];
+      if (rg < 0) continue;                                       // (rows past the end of the row list)
+      float* gl = a.dlogits + (int64_t)rg * PM_N_TOK + jb.coff;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = lane + 64 * q;
+        if (c < jb.V) {
+          const float g = sL[r * PLDL + c];
+          gl[c] = g;
+          dbacc[q] += g;
+        }
+      }
+    }
+    lacc += (double)lloss;
+    lloss = 0.f;
+    __syncthreads();                                              // the tile and the row ids are rewritten by the next trip
+  }
+  // Bias gradients and loss: the workgroup's five partial sums are combined in LDS and added to ONE of UREP replicas
+  // (k_unembed_fold sums them): 1536 workgroups x 5 waves adding to the same 361 addresses serialise at the memory side —
+  // that, not the products, was what made the round-2 kernel slow (195-220 us for 4.8 GFLOP).
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; ++q) sL[wave * 192 + q * 64 + lane] = dbacc[q];
+  lacc = pm_wave_sum_d(lacc);
+  if (lane == 0) s_loss[wave] = lacc;
+  __syncthreads();
+  const int rep = blockIdx.x % UREP;
+  if (tid < 192 && tid < jb.V) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < PNW; ++w) t += sL[w * 192 + tid];
+    if (t != 0.f) atomicAdd(dbrep + rep * UREP_F + blockIdx.y * 160 + tid, t);
+  }
+  if (tid == 0) {
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < PNW; ++w) t += s_loss[w];
+    if (t != 0) atomicAdd(lossrep + rep * 2 + jb.kind, t / nval);
+  }
+}
+// replicas -> bias gradients (+=) and the two losses
+__global__ void __launch_bounds__(512) k_unembed_fold(UnembedArgs a, const float* __restrict__ dbrep, const double* __restrict__ lossrep) {
+  const int t = threadIdx.x;
+  if (t < UREP_F) {
+    const int j = t / 160, c = t % 160;
+    const UnembedJob jb = a.job[j];
+    if (jb.dbias && c < jb.V) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < UREP; ++r) v += dbrep[r * UREP_F + t];
+      jb.dbias[c] += v;
+    }
+  } else if (t < UREP_F + 2) {
+    double v = 0;
+#pragma unroll
+    for (int r = 0; r < UREP; ++r) v += lossrep[r * 2 + (t - UREP_F)];
+    a.out[t - UREP_F] = v;
+  }
+}
 }  // namespace
+
+// bytes of the `w_planes` scratch of pm_unembed_ce at width d: the weight planes + the accumulator replicas
+extern "C" int64_t pm_unembed_scratch_bytes(int32_t d) {
+  return (int64_t)448 * (d / 2) * 3 * 2 + (int64_t)UREP * UREP_F * 4 + UREP * 2 * 8;
+}
 
 extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
                              const float* b_pitch_nd, const float* w_dur, const float* b_dur, const int32_t* tokens,
                              const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
                              float grad_scale, const float* dev_scale, float* logits, float* d_logits,
-                             float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, pm_stream_t stream) {
+                             float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes,
+                             pm_stream_t stream) {
   if (!H || !w_pitch_drum || !b_pitch_drum || !w_pitch_nd || !b_pitch_nd || !w_dur || !b_dur || !tokens || !plan ||
       !d_logits || !out || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
     return PM_E_INVALID;
@@ -234,8 +522,33 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
   a.job[2] = {w_dur, b_dur, db_dur, nullptr, nullptr, PM_N_DUR, dh, PM_N_PITCH, 1, 98};
   a.H = H; a.tok = tokens; a.hist = pv.tok_hist; a.dev_scale = dev_scale; a.logits = logits; a.dlogits = d_logits; a.out = out;
   a.R = (int)R; a.S = n_slots; a.d = d; a.dh = dh; a.grad_scale = grad_scale;
-  hipMemsetAsync(out, 0, 2 * sizeof(double), st);
   int nb = (int)pm_cdiv(R, UBM);
+  if (w_planes && (dh == 64 || dh == 128 || dh == 256) && !((uintptr_t)w_planes % 16) && !((uintptr_t)H % 16) &&
+      R * (int64_t)d * 4 < 0x7fffffffLL) {
+    // planes kernel: weight planes first (zero-padded to 160 / 160 / 128 rows), then the persistent tile loop
+    const int o1 = 160 * dh * 3, o2 = 2 * o1;
+    float* dbrep = reinterpret_cast<float*>(w_planes + (size_t)448 * dh * 3);
+    double* lossrep = reinterpret_cast<double*>(dbrep + UREP * UREP_F);
+    hipLaunchKernelGGL(k_unembed_wplanes, dim3(16, 3), dim3(256), 0, st, a, w_planes, o1, o2, dbrep, lossrep);
+    if (nb > 512) nb = 512;
+    const size_t img = (size_t)3 * UBM * dh * 2, tile = (size_t)UBM * PLDL * 4;
+    const size_t lds = (img > tile ? img : tile) + 2 * UBM * sizeof(int) + PNW * sizeof(double) + (size_t)UBM * PNW * 2 * sizeof(float);
+#define LAUNCH(DHV)                                                                                                    \
+  do {                                                                                                                 \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      hipFuncSetAttribute((const void*)k_unembed_ce_planes<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_unembed_ce_planes<DHV>), dim3(nb, 3), dim3(PNW * 64), lds, st, a,                            \
+                       reinterpret_cast<const char*>(w_planes), o1, o2, dbrep, lossrep);                               \
+  } while (0)
+    if (dh == 256) LAUNCH(256); else if (dh == 128) LAUNCH(128); else LAUNCH(64);
+#undef LAUNCH
+    hipLaunchKernelGGL(k_unembed_fold, dim3(1), dim3(512), 0, st, a, dbrep, lossrep);
+    return pm_check_launch();
+  }
+  hipMemsetAsync(out, 0, 2 * sizeof(double), st);
   if (nb > 768) nb = 768;                              // persistent: ~3 resident workgroups per CU and job
   hipLaunchKernelGGL(k_unembed_ce, dim3(nb, 3), dim3(256), 0, st, a);
   return pm_check_launch();

@@ -19,7 +19,7 @@ namespace {
 //                       products) instead of gcl.hip / linear.hip / wide.hip
 //   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products
 //   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
-//   PM_FUSED_CE=0       un-embedding products + loss kernel instead of the fused un-embedding / cross-entropy kernel
+//   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
 //   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
 //                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
 struct StepCfg {
@@ -35,7 +35,7 @@ static StepCfg read_cfg() {
   k.no_rows_w = flag("PM_NO_ROWS_W", false);
   k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
   k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
-  k.fused_ce = flag("PM_FUSED_CE", false);
+  k.fused_ce = flag("PM_FUSED_CE", true);
   k.debug = getenv("PM_DEBUG") != nullptr;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
@@ -457,6 +457,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
   const bool rows_w = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
   uint16_t* wf_dec = rows_w ? (uint16_t*)ar.take((size_t)S * d * d * 6) : nullptr;
+  const bool fused_ce = cfg().fused_ce;
+  uint16_t* w_unembed = fused_ce ? (uint16_t*)ar.take((size_t)pm_unembed_scratch_bytes(d)) : nullptr;   // planes of the three un-embedding weights + accumulator replicas
   if (run) {
     if (rows_w) {
       RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, 0, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3, wf_dec, c.st));
@@ -464,15 +466,14 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     } else
       lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);          // rows [0, S*d) of chord_decoder.weight
     // un-embedding (model.py:561-576: duration logits for every (node, slot) row, pitch logits per drum / non-drum row
-    // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits stay in the MFMA
-    // accumulators, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
-    // (opt-in, PM_FUSED_CE=1: measured 195-220 us against 159 us for the three products + the loss kernel, csrc/unembed.hip)
-    const bool fused_ce = cfg().fused_ce;
+    // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits of a 64-row tile never
+    // leave the CU, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
+    // (csrc/unembed.hip; PM_FUSED_CE=0: three products + the loss kernel)
     if (fused_ce) {
       RUN(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
                           c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
                           (s.bt.flags & 4) ? s.c_logits : nullptr, s.dc_logits, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b,
-                          c.G + Y.dec_dur.b, s.losses, c.st));
+                          c.G + Y.dec_dur.b, s.losses, w_unembed, c.st));
     } else {
     RUN(pm_gemm_f32(0, 1, (int)R, PM_N_DUR, dh, s.H + dh, d, c.P + Y.dec_dur.w, dh, s.c_logits + PM_N_PITCH, PM_N_TOK,
                       c.P + Y.dec_dur.b, 0, 1, nullptr, 0, nullptr, c.st));

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import constants as C
-from ._lib import PLAN_FIELDS, HipExtensionError, call, plan_layout, ptr, stream
+from ._lib import PLAN_FIELDS, HipExtensionError, call, lib, plan_layout, ptr, stream
 
 F32, I32, I64, U8, F64 = torch.float32, torch.int32, torch.int64, torch.uint8, torch.float64
 
@@ -120,7 +120,8 @@ def tokens_from_onehot(c_tensor: torch.Tensor) -> torch.Tensor:
     return tok
 
 
-def plan_build(edge_index, edge_type, edge_dist, bars, batch, is_drum, tokens, n_bars: int, G: int) -> Plan:
+def plan_build(edge_index, edge_type, edge_dist, bars, batch, is_drum, tokens, n_bars: int, G: int,
+               n_slots: int = C.N_SLOTS) -> Plan:
     _chk(edge_index, I64, "edge_index"); _chk(edge_type, I32, "edge_type"); _chk(edge_dist, I32, "edge_dist")
     _chk(bars, I64, "bars"); _chk(batch, I64, "batch"); _chk(tokens, I32, "tokens")
     if is_drum.dtype == torch.bool:
@@ -130,7 +131,7 @@ def plan_build(edge_index, edge_type, edge_dist, bars, batch, is_drum, tokens, n
     off = plan_layout(N, E, G)
     buf = torch.empty(off[-1], dtype=I32, device=bars.device)
     call("pm_plan_build", ptr(edge_index), ptr(edge_type), ptr(edge_dist), ptr(bars), ptr(batch), ptr(is_drum),
-         ptr(tokens), n_bars, C.N_SLOTS, N, E, G, ptr(buf), stream())
+         ptr(tokens), n_bars, n_slots, N, E, G, ptr(buf), stream())
     return Plan(buf, N, E, G, n_bars, tokens, is_drum)
 
 
@@ -562,16 +563,17 @@ def content_ce(c_logits, plan: Plan, grad_scale=1.0, want_grad=True, out=None, d
 
 
 def unembed_ce(H, w_pd, b_pd, w_pnd, b_pnd, w_dur, b_dur, plan: Plan, grad_scale=1.0, want_logits=False, out=None,
-               dbias=None, dev_scale=None):
+               dbias=None, dev_scale=None, planes=True):
     """Fused un-embedding + cross-entropy (`pm_unembed_ce`): H [N,15,d] -> (out, d_logits [N,15,230], logits or None)."""
     N, S, d = H.shape
     out = out if out is not None else torch.empty(4, dtype=F64, device=H.device)
     dl = torch.empty(N, S, C.D_TOKEN_PAIR, dtype=F32, device=H.device)
     lg = torch.empty_like(dl) if want_logits else None
     b = dbias if dbias is not None else (None, None, None)
+    wpl = torch.empty(int(lib().pm_unembed_scratch_bytes(d)), dtype=torch.uint8, device=H.device) if planes else None
     call("pm_unembed_ce", ptr(H), ptr(w_pd), ptr(b_pd), ptr(w_pnd), ptr(b_pnd), ptr(w_dur), ptr(b_dur), ptr(plan.tokens),
          ptr(plan.buf), N, plan.E, plan.G, d, S, grad_scale, ptr(dev_scale), ptr(lg), ptr(dl), ptr(b[0]), ptr(b[1]), ptr(b[2]),
-         ptr(out), stream())
+         ptr(out), ptr(wpl), stream())
     return out, dl, lg
 
 

@@ -243,7 +243,7 @@ class HipTrainer:
         """`((s_logits, c_logits), mu, log_var)` of the last native `train_step` — what `VAE.forward` returns
         (model.py:676-678) — copied out of the workspace arena.  c_logits holds the active slots only: [N, S, 230]
         (the remaining slots are PAD in every node of the batch; the fused step never computes them)."""
-        if not self.keep_logits and os.environ.get("PM_FUSED_CE", "0") not in ("", "0"):
+        if not self.keep_logits and os.environ.get("PM_FUSED_CE", "1") not in ("", "0"):
             raise RuntimeError("step_outputs needs trainer.keep_logits = True before the step (the fused un-embedding + "
                                "cross-entropy does not store the logits otherwise)")
         i = self.step_info()

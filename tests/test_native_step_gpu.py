@@ -371,10 +371,11 @@ def test_evaluate_loop_and_checkpoint_round_trip(tmp_path):
     assert float(diff.max()) <= 2.5e-4 and float(diff.mean()) < 2e-6
 
 
-def _fused_ce_worker(rank, world, case):
-    """Fresh process (the switch is read once): the native step with the fused un-embedding + cross-entropy kernel."""
+def _unfused_ce_worker(rank, world, case):
+    """Fresh process (the switch is read when the library loads): the native step with the three un-embedding products +
+    the loss kernel instead of the fused un-embedding + cross-entropy kernel."""
     import os
-    os.environ["PM_FUSED_CE"] = "1"
+    os.environ["PM_FUSED_CE"] = "0"
     z, cfg = load_case(case)
     vae = VAE(**cfg, device=DEV).to(DEV)
     vae.load_state_dict(state_dict_from_golden(z))
@@ -389,10 +390,11 @@ def _fused_ce_worker(rank, world, case):
 
 @pytest.mark.parametrize("case", ["lmd2_tiny", "d128_l2"])
 def test_native_step_with_fused_unembed_ce_matches_the_unfused_step(case):
-    """PM_FUSED_CE=1 (csrc/unembed.hip) against the default step — three un-embedding products + the
-    loss kernel — on a reference-captured batch: same losses (and the goldens'), logits, and gradients."""
+    """The default step (fused un-embedding + cross-entropy, csrc/unembed.hip, SURVEY 8(f).2: at d = 128 the bf16-planes
+    kernel, at d = 32 the fp32-MFMA one) against PM_FUSED_CE=0 — three un-embedding products + the loss kernel — on a
+    reference-captured batch: same losses (and the goldens'), logits, and gradients.  (lf / gf / cf: the unfused run.)"""
     from util import run_ranks
-    (lf, gf, cf), = run_ranks(_fused_ce_worker, 1, (case,), timeout=120.0)
+    (lf, gf, cf), = run_ranks(_unfused_ce_worker, 1, (case,), timeout=120.0)
     z, cfg = load_case(case)
     vae = VAE(**cfg, device=DEV).to(DEV)
     vae.load_state_dict(state_dict_from_golden(z))

@@ -785,15 +785,13 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
     return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
-  // K slices: d = 256: four (256 workgroups), more while a slice's row list would not fit one LDS segment (the historic
-  // rule, kept: 8 slices at the bench size); d = 512: 64 output tiles per track group already make 256 workgroups per
-  // slice — two slices (A/B: PM_GCL_DW_SPLIT), longer row lists go through LDS in segments
-  int nsplit = d == 256 ? 4 : 16;
-  if (d == 512) {
-    static const int env_split = getenv("PM_GCL_DW_SPLIT") ? atoi(getenv("PM_GCL_DW_SPLIT")) : 0;
-    nsplit = env_split > 0 && env_split <= 64 ? env_split : 2;
-  } else
-    while ((int64_t)nsplit * (DW_MAP - DW_KT) < N) nsplit *= 2;
+  // K slices (one workgroup per output tile, track group and slice; slices add with float atomics): d = 512 two (64 output
+  // tiles per track group already make 256 workgroups per slice), d = 256 four (256 workgroups: measured 47.9 us against
+  // 54.1 with eight, 70.4 with two, 74.5 with sixteen — round 2 ran eight because a slice's row list had to fit one LDS
+  // segment; longer lists now go through LDS in segments), d = 128 sixteen.  A/B: PM_GCL_DW_SPLIT.
+  static const int env_split = getenv("PM_GCL_DW_SPLIT") ? atoi(getenv("PM_GCL_DW_SPLIT")) : 0;
+  int nsplit = d == 512 ? 2 : (d == 256 ? 4 : 16);
+  if (env_split > 0 && env_split <= 64) nsplit = env_split;
   const int per = (4 * d / DW_T) * (d / DW_T);
   const dim3 grid((unsigned)(per * 4 * nsplit)), block(512);
   const size_t lds = 2 * DW_STAGE + DW_MAP * 4;

@@ -44,13 +44,15 @@ def kernel_source_digest():
 
 
 def pmc_traffic(kernel_class, workload):
-    try:
-        rec = json.load(open(PMC_TRAFFIC_JSON))
-    except (OSError, ValueError):
-        return None
-    if rec.get("source_digest") != kernel_source_digest() or rec.get("workload") != workload:
-        return None
-    return rec.get("bytes_per_launch", {}).get(kernel_class)
+    """profiles/pmc_traffic_<workload>.json if there is one, else profiles/pmc_traffic.json (the bench's default workload)"""
+    for path in (PMC_TRAFFIC_JSON.replace(".json", f"_{workload}.json"), PMC_TRAFFIC_JSON):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("source_digest") == kernel_source_digest() and rec.get("workload") == workload:
+            return rec.get("bytes_per_launch", {}).get(kernel_class)
+    return None
 
 
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; ~6.3 TB/s achievable

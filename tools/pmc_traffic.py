@@ -38,6 +38,9 @@ def klass(kernel_name):
             return k
     if s.startswith("k_rows_w"):
         return "gemm_NN_rows_w"
+    if s.startswith("k_wide<"):                    # wide.hip: k_wide<VAR, DROP, NPW, BKIND>, VAR 0/1 forward, 2 input gradient, 3/4 chord products
+        var = int(s[len("k_wide<"):].split(",")[0])
+        return {0: "gcl_fwd", 1: "gcl_fwd", 2: "gcl_dagg", 3: "gemm_NN_rows_w", 4: "gemm_NN_rows_w"}.get(var)
     return None
 
 

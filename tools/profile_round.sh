@@ -1,22 +1,39 @@
 #!/bin/bash
 # One gpurun call that produces everything profiles/ keeps for a state of the code (run from the repo root on the GPU box):
 #   tools/profile_round.sh <out-dir under gpurun_out>
-# full GPU suite, smoke, bench line, rocprofv3 kernel trace summary, PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately).
+# full GPU suite, smoke, bench lines (configs[1]; d = 512 = training.json; dense shard of configs[4]; LMD16 = configs[2]),
+# rocprofv3 kernel-trace summaries (d = 256, d = 512, dense), PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately; d = 256
+# and d = 512).
 set -u
 O=gpurun_out/$1
 mkdir -p "$O"
 python -m pytest tests -m gpu -q --durations=15 > "$O/pytest_gpu.log" 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 python bench.py > "$O/bench.json" 2> "$O/bench.err"
+python bench.py --d 512 --steps 10 --warmup 4 --no-cpu-baseline > "$O/bench_d512.json" 2> "$O/bench_d512.err"
+python bench.py --dense --d 512 --batch 64 --steps 5 --warmup 3 --no-cpu-baseline > "$O/bench_dense.json" 2> "$O/bench_dense.err"
+python bench.py --batch 64 --n-bars 16 --steps 10 --warmup 4 --no-cpu-baseline > "$O/bench_lmd16.json" 2> "$O/bench_lmd16.err"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$O/trace.log" 2>&1
-KT=$(find "$O/trace" -name "*kernel_trace.csv" | head -1)
-python tools/trace_summary.py "$KT" --steps 13 --md > "$O/kernel_stats.md" 2>> "$O/trace.log"
-cp "$(find "$O/trace" -name "*kernel_stats.csv" | head -1)" "$O/kernel_stats.csv"
-rm -rf "$O/trace"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$O/pmc_$c.log" 2>&1
-done
-python tools/pmc_traffic.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" --workload B256_d256_nb2_L8 > "$O/pmc_traffic.json" 2>> "$O/trace.log"
-find "$O" -name "*kernel_trace.csv" -delete
-tail -3 "$O/pytest_gpu.log"; tail -2 "$O/smoke.log"; python tools/benchline.py final < "$O/bench.json"
+trace() {   # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_$name" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > "$O/trace_$name.log" 2>&1
+  KT=$(find "$O/trace_$name" -name "*kernel_trace.csv" | head -1)
+  python tools/trace_summary.py "$KT" --steps 13 --md > "$O/kernel_stats_$name.md" 2>> "$O/trace_$name.log"
+  cp "$(find "$O/trace_$name" -name "*kernel_stats.csv" | head -1)" "$O/kernel_stats_$name.csv"
+  rm -rf "$O/trace_$name"
+}
+trace d256
+trace d512 --d 512
+trace dense --dense --d 512 --batch 64
+pmc() {     # name, workload key, bench args...
+  local name=$1 key=$2; shift 2
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_${name}_$c" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$O/pmc_${name}_$c.log" 2>&1
+  done
+  python tools/pmc_traffic.py "$O/pmc_${name}_FETCH_SIZE" "$O/pmc_${name}_WRITE_SIZE" --workload "$key" > "$O/pmc_traffic_$name.json" 2>> "$O/trace_d256.log"
+  find "$O" -name "*kernel_trace.csv" -delete
+  rm -rf "$O/pmc_${name}_FETCH_SIZE" "$O/pmc_${name}_WRITE_SIZE"
+}
+pmc d256 B256_d256_nb2_L8
+pmc d512 B256_d512_nb2_L8 --d 512
+tail -3 "$O/pytest_gpu.log"; tail -2 "$O/smoke.log"; python tools/benchline.py final < "$O/bench.json"; python tools/benchline.py d512 < "$O/bench_d512.json"; python tools/benchline.py dense < "$O/bench_dense.json"; python tools/benchline.py lmd16 < "$O/bench_lmd16.json"

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"k_gemm<(\d+), (\d+), (\d+), \d+, \d+, (\w+), (\w+), (\w+), (\w+)(?:, (\w+))?>", name)
     if m:
         bm, bn, bk, ta, tb, va, vb, x6 = m.groups()

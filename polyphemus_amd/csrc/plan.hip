@@ -160,14 +160,80 @@ __global__ void k_finish_csc(const int64_t* __restrict__ ei, const int32_t* __re
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int beg = colptr[n], end = colptr[n + 1];
+  // Out-edges of a source ordered by (distance, edge id): the backward (k_segreduce_bwd) adds the table-gradient terms of a
+  // RUN of equal distances in registers and touches the LDS table once per run — on dense graphs (127 out-edges per node
+  // over 32 distances) that is a quarter of the LDS float atomics, which bound that kernel.  The order is a pure function
+  // of the edge list (deterministic sums).  (Edge ids beyond 2^26 keep the plain edge-id order.)
+  const bool by_dist = E < (1 << 26);
+  if (by_dist)
+    for (int p = beg; p < end; ++p) csc_eid[p] |= ed[csc_eid[p]] << 26;
   sort_segment(csc_eid, beg, end);
   for (int p = beg; p < end; ++p) {
-    const int e = csc_eid[p];
+    const int e = by_dist ? (csc_eid[p] & ((1 << 26) - 1)) : csc_eid[p];
+    csc_eid[p] = e;
     const int d = (int)ei[(int64_t)E + e], r = et[e];
     const int cnt = rowptr[d * PM_N_REL + r + 1] - rowptr[d * PM_N_REL + r];
     csc_dst[p] = d;
     csc_reldist[p] = r | (ed[e] << 8);
     csc_invcnt[p] = 1.0f / (float)(cnt > 1 ? cnt : 1);                      // scatter 'mean': sum / clamp(count, 1)
+  }
+}
+// Dense graphs (mean degree >= 16: hundreds of edges per segment): one WAVE per segment instead of one thread — the
+// per-thread insertion sort is quadratic in global memory (k_finish_csc took 1.9 ms at 127 edges per node).  The keys of a
+// segment go to LDS, every lane ranks its own keys against all of them (keys are unique: the rank is the position), lanes
+// then fill the per-edge arrays.  Segments longer than SEGW_MAX keys fall back to the serial sort by one lane.
+constexpr int SEGW_MAX = 512;
+__device__ static inline void sort_segment_wave(int* a, int beg, int end, int* sk, int lane) {
+  const int n = end - beg;
+  if (n <= 1) return;
+  if (n > SEGW_MAX) {
+    if (lane == 0) sort_segment(a, beg, end);
+    return;
+  }
+  for (int i = lane; i < n; i += 64) sk[i] = a[beg + i];
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < n; i += 64) {
+    const int v = sk[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += sk[j] < v ? 1 : 0;
+    a[beg + rank] = v;
+  }
+}
+__global__ void __launch_bounds__(256) k_finish_csr_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed,
+                                                         int E, int nseg, const int* __restrict__ rowptr, int* csr_eid,
+                                                         int* csr_src, int* csr_dist) {
+  __shared__ int sk[4][SEGW_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= nseg) return;
+  const int beg = rowptr[k], end = rowptr[k + 1];
+  sort_segment_wave(csr_eid, beg, end, sk[wave], lane);
+  __threadfence_block();
+  for (int p = beg + lane; p < end; p += 64) { const int e = csr_eid[p]; csr_src[p] = (int)ei[e]; csr_dist[p] = ed[e]; }
+}
+__global__ void __launch_bounds__(256) k_finish_csc_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
+                                                         const int32_t* __restrict__ ed, int E, int N,
+                                                         const int* __restrict__ rowptr, const int* __restrict__ colptr,
+                                                         int* csc_eid, int* csc_dst, int* csc_reldist, float* csc_invcnt) {
+  __shared__ int sk[4][SEGW_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const int beg = colptr[n], end = colptr[n + 1];
+  const bool by_dist = E < (1 << 26);                          // (as k_finish_csc: out-edges ordered by (distance, edge id))
+  if (by_dist)
+    for (int p = beg + lane; p < end; p += 64) csc_eid[p] |= ed[csc_eid[p]] << 26;
+  __threadfence_block();
+  sort_segment_wave(csc_eid, beg, end, sk[wave], lane);
+  __threadfence_block();
+  for (int p = beg + lane; p < end; p += 64) {
+    const int e = by_dist ? (csc_eid[p] & ((1 << 26) - 1)) : csc_eid[p];
+    csc_eid[p] = e;
+    const int d = (int)ei[(int64_t)E + e], r = et[e];
+    const int cnt = rowptr[d * PM_N_REL + r + 1] - rowptr[d * PM_N_REL + r];
+    csc_dst[p] = d;
+    csc_reldist[p] = r | (ed[e] << 8);
+    csc_invcnt[p] = 1.0f / (float)(cnt > 1 ? cnt : 1);
   }
 }
 __global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int S, int* list,
@@ -328,12 +394,21 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   exclusive_scan(drumpos, (int64_t)N + 1, sums, st);
   hipLaunchKernelGGL(k_fill, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr, cur_in,
                      cur_out, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSC_EID]);
-  hipLaunchKernelGGL(k_finish_csr, dim3(pm_cdiv((int64_t)N * PM_N_REL, T)), dim3(T), 0, st, edge_index, edge_dist, E,
-                     N * PM_N_REL, rowptr, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSR_SRC],
-                     plan + o[PM_PLAN_CSR_DIST]);
-  hipLaunchKernelGGL(k_finish_csc, dim3(pm_cdiv(N, T)), dim3(T), 0, st, edge_index, edge_type, edge_dist, E, N, rowptr,
-                     colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
-                     reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
+  if ((int64_t)E >= 16 * (int64_t)N) {       // dense graphs: one wave per segment (long segments)
+    hipLaunchKernelGGL(k_finish_csr_wave, dim3(pm_cdiv((int64_t)N * PM_N_REL, 4)), dim3(256), 0, st, edge_index, edge_dist,
+                       E, N * PM_N_REL, rowptr, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSR_SRC],
+                       plan + o[PM_PLAN_CSR_DIST]);
+    hipLaunchKernelGGL(k_finish_csc_wave, dim3(pm_cdiv(N, 4)), dim3(256), 0, st, edge_index, edge_type, edge_dist, E, N,
+                       rowptr, colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
+                       reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
+  } else {
+    hipLaunchKernelGGL(k_finish_csr, dim3(pm_cdiv((int64_t)N * PM_N_REL, T)), dim3(T), 0, st, edge_index, edge_dist, E,
+                       N * PM_N_REL, rowptr, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSR_SRC],
+                       plan + o[PM_PLAN_CSR_DIST]);
+    hipLaunchKernelGGL(k_finish_csc, dim3(pm_cdiv(N, T)), dim3(T), 0, st, edge_index, edge_type, edge_dist, E, N, rowptr,
+                       colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
+                       reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
+  }
   {
     int* cls = sums + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;     // [N] node class, then [nblk][16] histograms
     const int nblk = (int)pm_cdiv(N, CLS_T);

@@ -188,7 +188,12 @@ extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int
 // FUSE: dx is the output gradient of the BatchNorm of the layer below (x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206);
 // the three column sums its backward needs (sum du, sum du*xhat, sum xhat; du = dx * [BN(h) > 0]) are accumulated here,
 // while the dx row is still in registers, instead of by a separate pass over dx and h (pm_bn_bwd_fused, sums_ready).
-template <int NV, bool DROP, bool FUSE>
+// RL: the table-gradient terms of a RUN of equal distances (the CSC row is ordered by distance, plan.hip) add up in
+// registers and reach the LDS table once per run.  Dense graphs (127 out-edges per node over 32 distances): a quarter of
+// the LDS float atomics, which bound the kernel there — 2.01 -> 0.74 ms per launch at d = 512, 2.08 M edges.  At d = 256 it
+// costs nothing; the d = 512 kernel with the norm sums is at its 128-VGPR budget (12 spilled registers, 85 -> 92 us on
+// sparse graphs), so sparse batches keep the per-edge form there.
+template <int NV, bool DROP, bool FUSE, bool RL>
 __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict__ x, const float* __restrict__ T,
                                                        const float* __restrict__ dA, const float* __restrict__ dres,
                                                        const int* __restrict__ colptr, const int* __restrict__ csc_dst,
@@ -249,6 +254,34 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     n_hi = min(N, ((int)(blockIdx.x & 7) + 1) * xcd_nodes);
     n_step = (gridDim.x >> 3) * nwv;
   }
+  // table-gradient terms of the current run of equal distances of the node's CSC row
+  float run[NV][4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) run[v][j] = 0.f;
+  int cur = -1;
+  auto flush_run = [&](int v, int dist_r) {
+    if (dist_r < 0) return;
+    {
+      if (dist_r == 0) {                                       // onset edges (a third of all): row 0 stays in registers
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z0[v][j] += run[v][j];
+      } else if (dist_r <= pr) {                               // private row: no atomics
+        float4* pp = reinterpret_cast<float4*>(sP + (dist_r - 1) * d + c[v]);
+        float4 t = *pp;
+        t.x += run[v][0]; t.y += run[v][1]; t.z += run[v][2]; t.w += run[v][3];
+        *pp = t;
+      } else {                                                 // one uniform branch per run, not per element
+        float* row = sT + dist_r * d + (c[v] >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (run[v][j] != 0.f) atomicAdd(row + j * dq, run[v][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) run[v][j] = 0.f;
+    }
+  };
   for (int n0 = n_lo; n0 < n_hi; n0 += n_step) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
     if (n >= n_hi) continue;
@@ -280,6 +313,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         w[u] = live ? csc_invcnt[q] * scale : 0.f;
         key[u] = DROP ? pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[q]) : 0u;
       }
+      // run boundaries of the table-gradient accumulation (dist is wave-uniform: scalar branches)
+      const int prev[2] = {cur, dist[0]};
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if (!ok[v]) continue;
@@ -305,23 +340,26 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
             ap[j] += gg * ts[j];
             gt[j] = gg * xs[j];
           }
-          if (dist[u] == 0) {                                // onset edges (a third of all): row 0 stays in registers
+          if (RL) {
+            // table gradient: the terms of a run of equal distances add up in registers and reach the table once per run
+            if (dist[u] != prev[u]) flush_run(v, prev[u]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z0[v][j] += gt[j];
-          } else if (dist[u] <= pr) {                        // private row: no atomics
-            float4* pp = reinterpret_cast<float4*>(sP + (dist[u] - 1) * d + c[v]);
-            float4 t = *pp;
-            t.x += gt[0]; t.y += gt[1]; t.z += gt[2]; t.w += gt[3];
-            *pp = t;
-          } else {                                           // one uniform branch per edge, not per element
-            float* row = sT + dist[u] * d + (c[v] >> 2);
+            for (int j = 0; j < 4; ++j) run[v][j] += gt[j];
+          } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (gt[j] != 0.f) atomicAdd(row + j * dq, gt[j]);
+            for (int j = 0; j < 4; ++j) run[v][j] = gt[j];
+            flush_run(v, dist[u]);
           }
         }
       }
+      cur = dist[1];
     }
+    if (RL) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (ok[v]) flush_run(v, cur);
+    }
+    cur = -1;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
@@ -404,11 +442,11 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
 }
 
 // > 64 KiB of dynamic LDS needs the attribute: set once per instantiation and size
-template <int NV, bool DR, bool FU>
+template <int NV, bool DR, bool FU, bool RL>
 static void seg_bwd_lds_attr(size_t lds) {
   static size_t granted = 64 * 1024;
   if (lds > granted) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segreduce_bwd<NV, DR, FU>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segreduce_bwd<NV, DR, FU, RL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     granted = lds;
   }
@@ -444,11 +482,14 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   PmNormSums none;
   memset(&none, 0, sizeof(none));
   const PmNormSums nv_ = nn ? *nn : none;
-#define LAUNCH(NV, DR, FU)                                                                                           \
-  do { seg_bwd_lds_attr<NV, DR, FU>(lds);                                                                         \
-  hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,      \
+#define LAUNCH(NV, DR, FU, RL)                                                                                       \
+  do { seg_bwd_lds_attr<NV, DR, FU, RL>(lds);                                                                     \
+  hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU, RL>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,  \
                      pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes, pr); } while (0)
-#define LAUNCH2(NV, DR) do { if (nn) LAUNCH(NV, DR, true); else LAUNCH(NV, DR, false); } while (0)
+  // run-length form: always at d <= 256 (free), on dense graphs (mean out-degree >= 16) at any width
+  const bool rl = d <= 256 || (int64_t)E >= 16 * (int64_t)N;
+#define LAUNCH2(NV, DR) do { if (nn) { if (rl) LAUNCH(NV, DR, true, true); else LAUNCH(NV, DR, true, false); }       \
+                             else { if (rl) LAUNCH(NV, DR, false, true); else LAUNCH(NV, DR, false, false); } } while (0)
   const int nv = (int)pm_cdiv(d, 256);
   // algorithmic bytes: read dA (all stored blocks, the root block included) and the residual gradient,
   // write dx, + the pre-norm activations when the next norm's sums ride along, edge records, table gradient; the

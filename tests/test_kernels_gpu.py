@@ -46,7 +46,7 @@ def test_plan_matches_numpy(dense):
     np.testing.assert_array_equal(f("csr_eid")[:E], order)
     np.testing.assert_array_equal(f("csr_src")[:E], src[order])
     np.testing.assert_array_equal(f("csr_dist")[:E], ed[order])
-    order2 = np.lexsort((np.arange(E), src))
+    order2 = np.lexsort((np.arange(E), ed, src))             # by source, then distance, ties by edge id (runs of equal distance)
     colptr = np.zeros(N + 1, np.int64)
     np.add.at(colptr, src + 1, 1)
     np.testing.assert_array_equal(f("colptr")[:N + 1], np.cumsum(colptr))

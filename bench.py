@@ -38,7 +38,7 @@ PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 def kernel_source_digest():
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "wide.hip", "gcl_tiles.h", "common.h"):
+    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "wide.hip", "gcl_tiles.h", "tile_order.h", "common.h"):
         h.update(open(os.path.join(ROOT, "polyphemus_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -64,6 +64,9 @@ def flops_per_bar(n_nodes, n_bars_total, d, L):
     return 3.0 * (n_nodes / n_bars_total) * ((60 + 28 * L) * d * d + 6900 * d)
 
 
+ROW_TILES = 0          # 64-row tiles of the batch's four track groups (set by executed_block_fraction)
+
+
 def executed_block_fraction(trainer, n_nodes, n_edges, G):
     """Fraction of the compact GCL contraction [N, 4d] x [4d, d] the kernels of gcl.hip / wide.hip EXECUTE: a 64-row
     tile of a track group skips the onset / next block when none of its rows receives such an edge (row classes,
@@ -74,6 +77,8 @@ def executed_block_fraction(trainer, n_nodes, n_edges, G):
     j = PLAN_FIELDS.index("trk_cnt")
     tc = trainer._plan_buf[off[j]:off[j] + 28].tolist()
     live = total = 0
+    global ROW_TILES
+    ROW_TILES = sum((tc[g] + 63) // 64 for g in range(4))
     for g in range(4):
         cnt, cb = tc[g], tc[8 + 5 * g: 13 + 5 * g]
         for m0 in range(0, cnt, 64):
@@ -276,6 +281,7 @@ def main():
     ap.add_argument("--n-bars", type=int, default=2)
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[4] dense-graph stress")
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic batch (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
@@ -309,7 +315,7 @@ def main():
     vae.train()
     tj = dict(peak_lr=1e-4, final_lr_scale=0.01, warmup_steps=8000, decay_steps=800000)      # training.json:19-24
     trainer = HipTrainer(vae, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler=tj)        # training.json:11-18
-    batch = synthetic_batch(args.batch, args.n_bars, p=0.25, seed=1234 + rank, dense=args.dense).to(dev)
+    batch = synthetic_batch(args.batch, args.n_bars, p=0.25, seed=args.seed + rank, dense=args.dense).to(dev)
     n_nodes, n_edges, G = batch.num_nodes, batch.edge_index.shape[1], batch.s_tensor.shape[0]
 
     def sync():
@@ -417,9 +423,12 @@ def main():
     gst = prof_collect()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot_nodes = torch.tensor([float(n_nodes), float(G)], dtype=torch.float64, device=dev)
+    tiles_all = torch.zeros(world, dtype=torch.float64, device=dev)
+    tiles_all[rank] = float(ROW_TILES)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(tot_nodes)
+        torch.distributed.all_reduce(tiles_all)
     elapsed = float(t.item())
     losses = trainer.losses_dict(out)
     if world > 1:                                                # every rank must hold the same parameters after the run
@@ -520,6 +529,10 @@ def main():
                                     f"LMD {args.n_bars}-bar, batch={args.batch} per GPU, d_hidden={args.d}"),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "n_bars": args.n_bars,
                        "d": args.d, "gnn_n_layers": args.layers, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
+                       "batch_seed": args.seed, "row_tiles_per_rank": [int(v) for v in tiles_all.tolist()],
+                       "row_tiles_note": "64-row tiles of the rank's batch (seed + rank); the row-tile kernels hold one "
+                                         "workgroup per CU (256): a batch with more tiles than CUs pays a second, short "
+                                         "round in 36 launches (+11 % step time at 257-261 tiles; DESIGN.md section 5)",
                        "message_dropout": 0.1, "parallelism": f"dp{world}", "weights": "default init, manual_seed(0)",
                        "step": "plan+fwd+loss+bwd+allreduce+Adam"},
             # SURVEY 8(d)'s operation count (7 products of N d^2 per GCL) and what the step executes: the compact GCL

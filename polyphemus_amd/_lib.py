@@ -22,6 +22,7 @@ PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", 
 # argument codes: p = device pointer, i = int32, l = int64, f = float, u = uint32, s = stream
 _SIGS = {
     "pm_plan_layout": "iiip",
+    "pm_gcl_tile_order": "piipi",
     "pm_plan_build": "pppppppiiiiips",
     "pm_edge_attrs_to_ids": "pipps",
     "pm_tokens_from_onehot": "pips",
@@ -175,3 +176,15 @@ def plan_layout(N: int, E: int, G: int):
     if rc != 0:
         raise HipExtensionError(f"pm_plan_layout({N},{E},{G}) failed: {_ERR.get(rc, rc)}")
     return list(off)
+
+
+def gcl_tile_order(trk_cnt, use_classes: bool, N: int):
+    """Host-only: [(track group, tile)] in workgroup order of the GCL products (csrc/tile_order.h); (-1, -1) for
+    workgroups that exit.  `trk_cnt`: the 32 ints of the plan's trk_cnt field."""
+    tc = (C.c_int32 * 32)(*[int(v) for v in trk_cnt])
+    grid = lib().pm_gcl_tile_order(C.cast(tc, C.c_void_p), int(bool(use_classes)), int(N), None, 0)
+    if grid < 0:
+        raise HipExtensionError(f"pm_gcl_tile_order failed: {_ERR.get(grid, grid)}")
+    out = (C.c_int32 * (2 * grid))()
+    lib().pm_gcl_tile_order(C.cast(tc, C.c_void_p), int(bool(use_classes)), int(N), C.cast(out, C.c_void_p), grid)
+    return [(out[2 * b], out[2 * b + 1]) for b in range(grid)]

@@ -73,20 +73,9 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   float* const sH = reinterpret_cast<float*>(smem);          // [BM][HS] output tile (epilogue; over the images)
 
   // ---- tile -> (track group, first row): the packed tile list of the grouped GEMM, XCD-contiguous
-  int cnt[4], nt[4], nwg = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { cnt[q] = g.trk_cnt[q]; nt[q] = (cnt[q] + BM - 1) / BM; nwg += nt[q]; }
-  int t = blockIdx.x;
-  if (t >= nwg) return;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int grp = 0;
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-    if (grp == q && t >= nt[q]) { t -= nt[q]; grp = q + 1; }
-  const int M = grp == 0 ? cnt[0] : grp == 1 ? cnt[1] : grp == 2 ? cnt[2] : cnt[3];
+  int grp = 0, t = 0;
+  if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, grp, t)) return;
+  const int M = g.trk_cnt[grp];
   const int m0 = t * BM;
   const int* list = g.trk_list + (int64_t)grp * g.N;
   bool use_on = true, use_nx = true;
@@ -418,20 +407,9 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
   int* const sNode = reinterpret_cast<int*>(sC);               // the rows' nodes (until the first block is staged)
 
-  int cnt[4], nt[4], nwg = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { cnt[q] = trk_cnt[q]; nt[q] = (cnt[q] + BM - 1) / BM; nwg += nt[q]; }
-  int t = blockIdx.x;
-  if (t >= nwg) return;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int grp = 0;
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-    if (grp == q && t >= nt[q]) { t -= nt[q]; grp = q + 1; }
-  const int M = grp == 0 ? cnt[0] : grp == 1 ? cnt[1] : grp == 2 ? cnt[2] : cnt[3];
+  int grp = 0, t = 0;
+  if (!pm_gcl_tile(trk_cnt, use_classes, blockIdx.x, grp, t)) return;
+  const int M = trk_cnt[grp];
   const int m0 = t * BM;
   const int* list = trk_list + (int64_t)grp * N;
   bool use_on = true, use_nx = true;
@@ -575,7 +553,7 @@ extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_
     return pm_wide_gcl_input_grad(dh_planes, plane_stride, plan, N, E, G, w_frag_t, use_classes, dA, (hipStream_t)stream);
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(pm_cdiv(N, BM) + 4)), block(512);
+  const dim3 grid(pm_gcl_grid(N)), block(512);
   const size_t lds = (size_t)3 * BM * d * 2 + (size_t)BM * d * 4;
   const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD)                                                                                                     \
@@ -839,7 +817,7 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
   a.seed = seed; a.layer_uid = layer_uid; a.thresh = pm_keep_threshold(dropout_p);
   a.scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(pm_cdiv(N, BM) + 4)), block(NTHR);
+  const dim3 grid(pm_gcl_grid(N)), block(NTHR);
   const size_t lds = gcl_lds_bytes(d, drop);
   // profiler work: the product's flops (as the GEMM classes); the kernel's algorithmic HBM bytes are x read + h written
   // + A' planes written (when kept) + edges + the weight planes once = 8dN (+ 24dN) + 12E + 42d^2 (bench.py)

@@ -2,6 +2,7 @@
 // layer) and linear.hip (plain linear layers on the same pipelines).
 #pragma once
 #include "common.h"
+#include "tile_order.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -12,9 +13,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 namespace {
-constexpr int BM = 64;        // rows per workgroup
+constexpr int BM = PM_TILE_ROWS;   // rows per workgroup
 constexpr int CH = 128;       // features per chunk of the chunked pipelines
 constexpr int ROWB = CH * 2;  // bytes of one row of a chunk image (one plane)
 constexpr int PLANE = BM * ROWB;
 constexpr int IMG = 3 * PLANE;
+
 }  // namespace

@@ -5,6 +5,7 @@
 // 2 x 6 x 16 times per forward (model.py:104-105); torch.unique(return_counts)
 // (model.py:543); the boolean-mask drum / non-drum splits (model.py:352-353,552-553).
 #include "common.h"
+#include "tile_order.h"
 
 void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   int64_t sz[PM_PLAN_NFIELDS];
@@ -27,6 +28,19 @@ extern "C" int pm_plan_layout(int32_t N, int32_t E, int32_t G, int64_t* offsets)
   if (N < 0 || E < 0 || G < 0 || !offsets) return PM_E_INVALID;
   pm_plan_offsets(N, E, G, offsets);
   return PM_OK;
+}
+
+// Host-side view of the tile schedule of the GCL products (tile_order.h): out[2b], out[2b+1] = (track group, tile) of
+// workgroup b, or (-1, -1) for a workgroup that exits; returns the number of workgroups launched for N nodes.
+extern "C" int pm_gcl_tile_order(const int32_t* trk_cnt_host, int32_t use_classes, int32_t N, int32_t* out, int32_t cap) {
+  if (!trk_cnt_host || N < 0) return PM_E_INVALID;
+  const int grid = (int)pm_gcl_grid(N);
+  for (int b = 0; out && b < grid && b < cap; ++b) {
+    int grp = -1, t = -1;
+    if (!pm_gcl_tile(trk_cnt_host, use_classes, b, grp, t)) grp = t = -1;
+    out[2 * b] = grp; out[2 * b + 1] = t;
+  }
+  return grid;
 }
 
 // ---------------------------------------------------------------- exclusive scan (int32, in place)

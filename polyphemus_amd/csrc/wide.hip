@@ -75,19 +75,9 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
   const int* list = nullptr;
   bool use_on = true, use_nx = true;
   if constexpr (GCL) {
-    int cnt[4], nt[4], nwg = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { cnt[q] = g.trk_cnt[q]; nt[q] = (cnt[q] + BM - 1) / BM; nwg += nt[q]; }
-    int t = blockIdx.x;
-    if (t >= nwg) return;
-    {
-      const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
-      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (grp == q && t >= nt[q]) { t -= nt[q]; grp = q + 1; }
-    M = grp == 0 ? cnt[0] : grp == 1 ? cnt[1] : grp == 2 ? cnt[2] : cnt[3];
+    int t = 0;
+    if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, grp, t)) return;
+    M = g.trk_cnt[grp];
     m0 = t * BM;
     list = g.trk_list + (int64_t)grp * g.N;
     if (g.use_classes) {
@@ -576,7 +566,7 @@ int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int
   a.scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
   a.wfrag = reinterpret_cast<const char*>(w_frag); a.wp = d / 32;
   a.bias = bias; a.out = h; a.ldo = d; a.colstats = col_stats;
-  const unsigned grid = (unsigned)(pm_cdiv(N, BM) + 4);
+  const unsigned grid = pm_gcl_grid(N);
   const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, 2.0 * N * 4.0 * d * d);
   if (a_planes_in) {
     a.pin = a_planes_in; a.pin_stride = plane_stride;
@@ -602,7 +592,7 @@ int pm_wide_gcl_input_grad(const uint16_t* dh_planes, int64_t plane_stride, cons
   a.pin = dh_planes; a.pin_stride = plane_stride;
   a.wfrag = reinterpret_cast<const char*>(w_frag_t); a.wp = d / 16;
   a.out = dA; a.ldo = 4 * d;
-  const unsigned grid = (unsigned)(pm_cdiv(N, BM) + 4);
+  const unsigned grid = pm_gcl_grid(N);
   const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
   if (wide_npw(4) == 8) launch_wide<V_DAGG, false, 8, 0>(a, grid, wide_lds(V_DAGG), st);
   else launch_wide<V_DAGG, false, 4, 0>(a, grid, wide_lds(V_DAGG), st);

@@ -102,3 +102,44 @@ def test_dropout_stream_statistics_and_numpy_replica():
     assert abs((drop[:-1] & drop[1:]).mean() - p * p) < sig2                      # same channel, next edge
     other = dropout_keep_np(77, 4, eids, d, p).astype(bool)                       # next layer: another stream
     assert abs((drop & ~other).mean() - p * p) < sig2
+
+
+def _tile_weight(tc, grp, t, use_classes):
+    if not use_classes:
+        return 4
+    cb = tc[8 + 5 * grp: 13 + 5 * grp]
+    m0 = t * 64
+    return 2 + int(m0 < cb[3] and m0 + 64 > cb[1]) + int(m0 < cb[4] and m0 + 64 > cb[2])
+
+
+@pytest.mark.parametrize("use_classes", [False, True])
+def test_gcl_tile_schedule_covers_every_tile_once_heaviest_first(use_classes):
+    """csrc/tile_order.h (host copy of the function the GCL kernels run): every (track group, tile) exactly once, every
+    XCD (workgroup index mod 8) the same number of tiles within one, its heavy tiles (4 blocks of K) before its light
+    ones — the workgroups beyond one per CU are the cheapest tiles."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        tc = [0] * 32
+        scale = (40, 300, 3000, 20000)[trial % 4]
+        for g in range(4):
+            c = [0 if rng.random() < 0.2 else int(rng.integers(0, scale)) for _ in range(4)]
+            tc[g] = sum(c)
+            tc[8 + 5 * g: 13 + 5 * g] = [0, c[0], c[0] + c[1], c[0] + c[1] + c[2], sum(c)]
+        N = sum(tc[:4])
+        order = _lib.gcl_tile_order(tc, use_classes, N)
+        assert len(order) % 8 == 0
+        live = [(b, g, t) for b, (g, t) in enumerate(order) if g >= 0]
+        want = {(g, t) for g in range(4) for t in range((tc[g] + 63) // 64)}
+        assert len(live) == len(want) and {(g, t) for _, g, t in live} == want
+        per_xcd = [[_tile_weight(tc, g, t, use_classes) for b, g, t in live if b % 8 == x] for x in range(8)]
+        assert max(map(len, per_xcd)) - min(map(len, per_xcd)) <= 1
+        for w in per_xcd:
+            assert w == sorted(w, reverse=True)
+        # a workgroup that exits is never followed by a live one of the same XCD (the hardware deals them in order)
+        for x in range(8):
+            seq = [g >= 0 for g, _ in order[x::8]]
+            assert seq == sorted(seq, reverse=True)
+        # blocks of K per XCD: balanced to within one heavy tile
+        tot = [sum(w) for w in per_xcd]
+        assert max(tot) - min(tot) <= 4 + 2

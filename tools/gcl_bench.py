@@ -12,7 +12,7 @@ from polyphemus_amd.synthetic import synthetic_batch
 
 def main():
     B = int(os.environ.get("B", 256)); d = int(os.environ.get("D", 256)); p = float(os.environ.get("P", 0.1))
-    cpu = synthetic_batch(B, 2, p=0.25, seed=1234)
+    cpu = synthetic_batch(B, 2, p=0.25, seed=int(os.environ.get("SEED", 1234)))
     b = cpu.to("cuda")
     plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars, b.s_tensor.shape[0])
     N, dd = cpu.num_nodes, d * d
@@ -62,7 +62,8 @@ def main():
     def tn_fused(): ops.gcl_weight_grad_fused(Ap, dhp, plan, d, dWb)
     tag = os.path.basename(os.environ.get("PM_LIB_PATH", "default"))
     which = os.environ.get("WHICH", "ufpnw")
-    out = [tag, f"N={N}"]
+    tiles = int(sum((int(c) + 63) // 64 for c in tc[:4].tolist()))
+    out = [tag, f"N={N} tiles={tiles}"]
     if "u" in which: out.append(f"unfused {timeit(unfused):.1f} us")
     if "f" in which: out.append(f"fused {timeit(fused):.1f} us")
     if "p" in which: out.append(f"fused(no A' out) {timeit(fused_np):.1f} us")

@@ -43,7 +43,7 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  * layouts — PmBatch, PmGemmDesc, PmVaeLayout —, argument lists and the dropout stream are part of the version).
  *   1: round 1.  2: round 2 (PmBatch.ce_scale, pm_attnpool_bwd +2 arguments, one hash per four channels in the dropout
  *   stream).  3: round 3 (d = 512 in the gcl / linear entry points, pm_gcl_forward_from_planes). */
-#define PM_ABI_VERSION 3
+#define PM_ABI_VERSION 4
 int pm_abi_version(void);
 const char* pm_build_info(void);
 
@@ -312,6 +312,9 @@ typedef struct PmGemmDesc {
                                otherwise, over the whole stored matrix with `ldb` columns).  The kernel then takes its B
                                operands straight from memory into registers (no LDS image of B); used when the shape
                                is aligned with the fragment grid (N % 128 == 0, K % 32 == 0), ignored otherwise. */
+  float* a_colsum;          /* optional, transA (weight gradient dW = dy^T x of a linear layer, A = dy stored [K, M]):
+                               a_colsum[m] += sum_k A[k, m] — the layer's bias gradient, computed by the same launch
+                               (no row map, one group, fp32 operands) */
 } PmGemmDesc;
 /* Fragment-major bf16 planes of weight matrices W [rows, cols] (fp32; rows, cols multiples of 32) for PmGemmDesc.b_frag:
  * per (32-wide n tile, 16-wide k-step) three contiguous 1 KiB blocks (planes) in MFMA operand order.  kind 0: n = row,

@@ -114,7 +114,7 @@ _SIGS = {
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes"}
-ABI_VERSION = 3          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
+ABI_VERSION = 4          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])
 

@@ -56,6 +56,7 @@ struct GemmArgs {
   double* colstats;                          // optional [2][N]: += column sums of the stored values and of their squares
   // MODE 3: B (a weight matrix) as fragment-major planes (pm_split_planes_frag); bf_n = K/16 (transB) or N/32 tiles
   const char* bfrag; int bf_n;
+  float* colsum_a;                           // optional (transA, fp32 tiles): += sum over K of A[k, m]  (bias gradient)
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -695,6 +696,13 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     }
   } else {
   __syncthreads();
+  // bias gradient riding along with a weight gradient dW = dy^T x (PmGemmDesc.a_colsum): the waves of the first column
+  // of the first column tile add up the A fragments they feed to the matrix core anyway (lane (li, lh) holds
+  // A[k + lh, m + li]); one atomic per output row and workgroup in the epilogue
+  const bool do_cs = TA && MODE == 0 && g.colsum_a != nullptr && n0 == 0 && wc == 0;
+  float csa[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) csa[i] = 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
@@ -724,6 +732,12 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      if constexpr (TA && MODE == 0) {
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) csa[i] += a[cur][i];
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
@@ -732,6 +746,16 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     }
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (TA && MODE == 0) {
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float v = csa[i] + __shfl_xor(csa[i], 32);
+        const int row = m0 + wr * WM + i * 32 + li;
+        if (lh == 0 && row < M) atomicAdd(g.colsum_a + row, v);
+      }
+    }
   }
   }
 
@@ -892,6 +916,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   g.bias_boff = q->bias_group_stride; g.map_boff = q->map_group_stride; g.dyn_boff = q->dyn_group_stride;
   g.b_split = q->b_split_rows; g.b_hi = q->b_shared_off; g.c_split = q->c_split_rows; g.c_hi = q->c_shared_off;
   g.colstats = q->col_stats;
+  g.colsum_a = nullptr;
   if (q->col_stats && (transA || (q->flags & PM_GEMM_ACCUM))) return PM_E_INVALID;   // stats of plainly stored tiles only
   // float4 staging needs 16-byte aligned rows and a contiguous extent that is a multiple of 4
   const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
@@ -922,6 +947,16 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
     if (transA) { if (M == 4 * blk && blk % BM == 0) g.cls_dim = 3; }
     else if (transB) { if (N == 4 * blk && blk % BN == 0) g.cls_dim = 2; }
     else if (planes && K == 4 * blk && blk % BK == 0 && q->split_k == 1) g.cls_dim = 1;
+  }
+  // bias gradient with the weight gradient: the fp32 tile kernels fold it into the product, any other route takes the
+  // column-sum kernel (same result, one more launch)
+  if (q->a_colsum) {
+    if (!transA || q->rowmap || q->dyn_entries || n_groups != 1 || planes) return PM_E_INVALID;
+    if (cfg <= 3) g.colsum_a = q->a_colsum;
+    else {
+      const int rc = pm_colsum_acc(q->A, K, M, q->lda, q->a_colsum, stream);
+      if (rc != PM_OK) return rc;
+    }
   }
   g.ntm = (int)pm_cdiv(M, BM); g.ntn = (int)pm_cdiv(N, BN);
   const int64_t tiles = (int64_t)g.ntm * g.ntn;
@@ -997,7 +1032,7 @@ extern "C" int pm_gemm_f32_grouped(int transA, int transB, int32_t M, int32_t N,
   q.a_group_stride = a_group_stride; q.b_group_stride = b_group_stride; q.c_group_stride = c_group_stride;
   q.bias_group_stride = bias_group_stride; q.map_group_stride = map_group_stride; q.dyn_group_stride = dyn_group_stride;
   q.b_split_rows = 0; q.b_shared_off = 0; q.c_split_rows = 0; q.c_shared_off = 0; q.col_stats = nullptr;
-  q.operand_planes = 0; q.a_plane_stride = 0; q.b_plane_stride = 0;
+  q.operand_planes = 0; q.a_plane_stride = 0; q.b_plane_stride = 0; q.a_colsum = nullptr;
   q.class_ptr = nullptr; q.class_block = 0; q.b_frag = nullptr;
   return pm_gemm_f32_desc(&q, stream);
 }

@@ -11,6 +11,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -20,10 +21,13 @@ namespace {
 //   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products
 //   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
+//   PM_SIDE_STREAM=m    bit mask of the structure-branch sites issued on the library's second stream (default 15 = all;
+//                       0: everything on the caller's stream)
 //   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
 //                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
 struct StepCfg {
   bool gcl_fused, no_dw, no_rows_w, no_classes, no_bfrag, fused_ce, debug;
+  int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
 };
@@ -37,6 +41,7 @@ static StepCfg read_cfg() {
   k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
   k.fused_ce = flag("PM_FUSED_CE", true);
   k.debug = getenv("PM_DEBUG") != nullptr;
+  k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 15;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
@@ -90,7 +95,7 @@ struct StepState {
   const float* P; float* Bf; float* G;
   PmBatch bt; const int32_t* plan; const float* eps;
   Arena ar;
-  double* bn_scratch; double* losses;
+  double* bn_scratch; double* bn_scratch_side; double* losses;
   float beta; int fix_structure;
   // encoder
   float *c0, *a0, *m0, *v0, *p0, *c1, *a1, *m1, *v1, *h1, *h2, *zcat;
@@ -100,13 +105,16 @@ struct StepState {
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
+  uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
   float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
   int rc;
+  unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
 };
 constexpr uint64_t kMagic = 0x504d5354455031ULL;
 
 struct Ctx {
   StepState* s; hipStream_t st; int rc;
+  double* bn_scratch;                    // reduction scratch of the norms issued on `st` (the second stream has its own)
   int N, E, Gn, B, d, nb, L, S;          // S = active token slots (1..15)
   int compact;                           // 1: one track relation per node -> [N,4d] aggregates, K = 4d
   int planes;                            // 1 (needs compact): GCL GEMM operands as pre-split bf16 planes
@@ -123,6 +131,74 @@ struct Ctx {
 // only walks the carve-outs: the workspace requirement is measured by the code that uses it, forward AND backward.
 #define RUN(expr) do { if (c.s->ar.base) c.chk(expr); } while (0)
 
+// ---- the structure branch on a second stream -------------------------------------------------------------------------
+// The structure encoder / decoder (model.py:211-299, 434-445, 500-505) are chains of ~12-20 launches with 1-64
+// workgroups each that share nothing with the content path between the points where the two meet (the merge layer, the
+// decoder's first layer): on one stream they cost 140 + 150 + 190 us of a 5.6 ms step with the chip all but idle.  The
+// library therefore owns ONE non-blocking stream per device; a branch is issued there between an event recorded on the
+// caller's stream (fork) and an event the caller's stream waits for (join) — plain stream order for the caller, and
+// capturable.  Norms on the branch use their own reduction scratch.
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_SITES };
+struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES]; bool ok; };
+static Branch* branch_of_device() {
+  static Branch br[16];
+  static bool tried[16];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Branch& b = br[dev];
+  if (!tried[dev]) {
+    tried[dev] = true;
+    // lowest priority: the branch's workgroups take what the content path's kernels leave free (those hold one large
+    // workgroup per CU and must not queue behind a 2048-workgroup convolution)
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (getenv("PM_SIDE_PRIO")) lo = atoi(getenv("PM_SIDE_PRIO"));
+    b.ok = hipStreamCreateWithPriority(&b.st, hipStreamNonBlocking, lo) == hipSuccess;
+    for (int i = 0; i < BR_SITES && b.ok; ++i)
+      b.ok = hipEventCreateWithFlags(&b.fork[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming) == hipSuccess;
+  }
+  return b.ok ? &b : nullptr;
+}
+// Launches between the constructor and end() go to the second stream (when there is one; else they stay where they are)
+struct BranchScope {
+  Ctx& c; hipStream_t main; double* scratch_main; Branch* b; int site;
+  BranchScope(Ctx& c_, int site_) : c(c_), main(c_.st), scratch_main(c_.bn_scratch), b(nullptr), site(site_) {
+    if (!c.s->ar.base || !(cfg().side_stream & (1 << site_))) return;
+    b = branch_of_device();
+    if (!b) return;
+    if (hipEventRecord(b->fork[site], main) != hipSuccess || hipStreamWaitEvent(b->st, b->fork[site], 0) != hipSuccess) {
+      c.chk(PM_E_LAUNCH);
+      b = nullptr;
+      return;
+    }
+    c.st = b->st; c.bn_scratch = c.s->bn_scratch_side;
+  }
+  // an intermediate join point: what has been issued on the branch so far is what branch_join(c, at) waits for
+  void mark(int at) {
+    if (!b) return;
+    if (hipEventRecord(b->join[at], b->st) != hipSuccess) c.chk(PM_E_LAUNCH);
+    c.s->br_open |= 1u << at;
+  }
+  void end() {
+    if (!b) return;
+    if (hipEventRecord(b->join[site], b->st) != hipSuccess) c.chk(PM_E_LAUNCH);
+    c.st = main; c.bn_scratch = scratch_main;
+    c.s->br_open |= 1u << site;
+    b = nullptr;
+  }
+  ~BranchScope() { end(); }
+};
+// the caller's stream waits for the branch issued at `site` (no-op when it ran on the caller's stream)
+void branch_join(Ctx& c, int site) {
+  if (!c.s->ar.base || !(c.s->br_open & (1u << site))) return;
+  Branch* b = branch_of_device();
+  if (!b || hipStreamWaitEvent(c.st, b->join[site], 0) != hipSuccess) c.chk(PM_E_LAUNCH);
+  c.s->br_open &= ~(1u << site);
+}
+
 // y[M, Nout] = x @ W^T + b      (x: leading dim lda, y: leading dim ldc)
 void lin(Ctx& c, const float* x, PmLin l, int M, int Nout, int Kin, float* y, bool relu, int lda = 0, int ldc = 0) {
   RUN(pm_gemm_f32(0, 1, M, Nout, Kin, x, lda ? lda : Kin, c.P + l.w, Kin, y, ldc ? ldc : Nout, c.P + l.b,
@@ -132,22 +208,25 @@ void lin(Ctx& c, const float* x, PmLin l, int M, int Nout, int Kin, float* y, bo
 void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, int Kin, float* dx, int lddy = 0,
              int ldx = 0, int lddx = 0, bool want_bias = true) {
   lddy = lddy ? lddy : Nout;
-  RUN(pm_gemm_f32(1, 0, Nout, Kin, M, dy, lddy, x, ldx ? ldx : Kin, c.G + l.w, Kin, nullptr, PM_GEMM_ACCUM, 0,
-                    nullptr, 0, nullptr, c.st));
-  if (want_bias) RUN(pm_colsum_acc(dy, M, Nout, lddy, c.G + l.b, c.st));
+  PmGemmDesc w;                              // dW += dy^T x, the bias gradient (column sums of dy) in the same launch
+  memset(&w, 0, sizeof(w));
+  w.transA = 1; w.M = Nout; w.N = Kin; w.K = M; w.A = dy; w.lda = lddy; w.B = x; w.ldb = ldx ? ldx : Kin;
+  w.C = c.G + l.w; w.ldc = Kin; w.flags = PM_GEMM_ACCUM; w.split_k = 0; w.n_groups = 1;
+  w.a_colsum = want_bias ? c.G + l.b : nullptr;
+  RUN(pm_gemm_f32_desc(&w, c.st));
   if (dx) RUN(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
                             c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
 }
 // training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
 void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
             float* var) {
-  RUN(pm_bn_stats(x, O, C, I, mean, var, c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.s->bn_scratch, c.st));
+  RUN(pm_bn_stats(x, O, C, I, mean, var, c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.bn_scratch, c.st));
   RUN(pm_bn_apply(x, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, res, relu ? 1 : 0, y, c.st));
 }
 void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn bn, const float* mean, const float* var,
             bool relu, float* dx, float* dbias_pre = nullptr) {
   RUN(pm_bn_bwd(x, dy, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, relu ? 1 : 0, c.G + bn.w, c.G + bn.b,
-                  dbias_pre, dx, c.s->bn_scratch, c.st));
+                  dbias_pre, dx, c.bn_scratch, c.st));
 }
 
 static bool gcl_fused_on() { return cfg().gcl_fused; }
@@ -175,20 +254,26 @@ PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
 //   h[rows_t] = A[rows_t, 0:4d] @ [W_t; W_4; W_5; root] + b   (t = 0..3)
 // one grouped launch over the four track relations whose B operand is "stacked" (group rows + shared rows),
 // i.e. 8 N d^2 flops instead of 14 N d^2 (the other three track blocks of every row are identically zero).
-float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t seed, uint32_t uid0, float p) {
+// which kernel set a GCN stack of this batch takes (host-known: shapes and switches)
+struct GcnRoute { bool gcl_kernels, dense; };
+GcnRoute gcn_route(const Ctx& c, const GcnSaved& sv) {
+  GcnRoute r;
+  // the kernels of gcl.hip take the fragment-major weight copies (forward, input gradient) or no weight at all (weight gradient)
+  r.gcl_kernels = c.planes && c.compact && sv.Wfn && gcl_width(c.d) && gcl_fused_on() && gcl_fits(c.N, c.d, 1);
+  // dense graphs (mean in-degree >= cfg().dense_deg; the fused kernel's producers keep three edges per (node, relation)
+  // in flight and redo longer lists serially): stand-alone segment-reduce, then — at d = 512 — the product from its planes
+  r.dense = (int64_t)c.E >= (int64_t)cfg().dense_deg * c.N;
+  return r;
+}
+// The part of a GCN stack's forward that depends on the parameters only: the distance table of the shared edge_nn and
+// the bf16 planes of the layers' weights.  Issued at the start of the step, on the second stream.
+void gcn_prepare(Ctx& c, const PmGcn& g, GcnSaved& sv) {
   Arena& ar = c.s->ar;
-  const int N = c.N, d = c.d, nb = c.compact ? 4 : 7;
+  const int N = c.N, d = c.d;
   const int64_t dd = (int64_t)d * d;
   sv.T = ar.f((size_t)PM_N_DIST * d);
-  sv.seed = seed; sv.uid0 = uid0; sv.p = p;
-  PmPlanView pv;
-  if (ar.base) {
-    RUN(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
-    pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
-  }
-  sv.x[0] = x0;
+  if (ar.base) RUN(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
   sv.pool = ar.zdbl((size_t)c.L * 5 * d * PM_BN_REPL);
-  const int64_t aps = (int64_t)N * nb * d;                // plane stride of the aggregates (elements)
   if (c.planes) {                                         // the GCL weights of this stack, split once per step
     sv.wp_base = g.weight[0];
     sv.wp_stride = (g.weight[c.L - 1] + 7 * dd - g.weight[0] + 7) & ~(int64_t)7;
@@ -216,14 +301,24 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       }
     }
   }
-  // plain (row-major) planes of the weights: operand of the grouped planes products only — the kernels of gcl.hip take
-  // the fragment-major copies (forward, input gradient) or no weight at all (weight gradient)
-  const bool gcl_kernels = c.planes && c.compact && sv.Wfn && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1);
-  // dense graphs (mean in-degree >= cfg().dense_deg; the fused kernel's producers keep three edges per (node, relation)
-  // in flight and redo longer lists serially): stand-alone segment-reduce, then — at d = 512 — the product from its planes
-  const bool dense = (int64_t)c.E >= (int64_t)cfg().dense_deg * N;
-  if (c.planes && (!gcl_kernels || (dense && d != 512)) && ar.base)
+  // plain (row-major) planes of the weights: operand of the grouped planes products only
+  const GcnRoute r = gcn_route(c, sv);
+  if (c.planes && (!r.gcl_kernels || (r.dense && d != 512)) && ar.base)
     RUN(pm_split_planes(c.P + sv.wp_base, sv.wp_stride & ~(int64_t)3, sv.Wp, sv.wp_stride, c.st));
+  (void)N;
+}
+
+float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t seed, uint32_t uid0, float p) {
+  Arena& ar = c.s->ar;
+  const int N = c.N, d = c.d, nb = c.compact ? 4 : 7;
+  const int64_t dd = (int64_t)d * d;
+  sv.seed = seed; sv.uid0 = uid0; sv.p = p;
+  PmPlanView pv;
+  if (ar.base) pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
+  sv.x[0] = x0;
+  const int64_t aps = (int64_t)N * nb * d;                // plane stride of the aggregates (elements)
+  const GcnRoute r = gcn_route(c, sv);
+  const bool gcl_kernels = r.gcl_kernels, dense = r.dense;
   for (int i = 0; i < c.L; ++i) {
     if (c.planes) { sv.Ap[i] = (uint16_t*)ar.take((size_t)aps * 6); sv.A[i] = nullptr; }
     else sv.A[i] = ar.f((size_t)N * nb * d);
@@ -348,7 +443,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
 
 Ctx make_ctx(StepState* s, hipStream_t st) {
   Ctx c;
-  c.s = s; c.st = st; c.rc = PM_OK;
+  c.s = s; c.st = st; c.rc = PM_OK; c.bn_scratch = s->bn_scratch;
   c.N = s->bt.N; c.E = s->bt.E; c.Gn = s->bt.G; c.B = s->bt.B;
   c.d = s->lay.d; c.nb = s->lay.n_bars; c.L = s->lay.n_layers;
   c.S = s->bt.n_slots;
@@ -368,12 +463,40 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   PmPlanView pv;
   if (run) pv = pm_plan_view(s.plan, N, c.E, Gn);
   s.bn_scratch = ar.dbl((size_t)PM_BN_SCRATCH(2 * d > 16 ? 2 * d : 16));
+  s.bn_scratch_side = ar.dbl((size_t)PM_BN_SCRATCH(2 * d > 16 ? 2 * d : 16));
+  c.bn_scratch = s.bn_scratch;
   // ---------------- structure encoder (model.py:211-256,434-445)
   s.zcat = ar.f((size_t)B * 2 * d);
   s.c0 = ar.f((size_t)Gn * 8 * 128); s.a0 = ar.f((size_t)Gn * 8 * 128); s.m0 = ar.f(8); s.v0 = ar.f(8);
   s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
   s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.zf((size_t)Gn * d);
-  if (run) {
+  {
+    // second stream: first everything that depends on the parameters only (joined before the chord encoder), then the
+    // structure encoder (joined before the merge layer); the caller's stream meanwhile builds the plan
+    BranchScope br(c, BR_ENC_FWD);
+    const int S = c.S;
+    const bool rows_w = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
+    gcn_prepare(c, Y.enc_gcn, s.eg);
+    gcn_prepare(c, Y.dec_gcn, s.dg);
+    // chord encoder Wc [d, 15d]: kind 0 for the forward (long-K kernel, columns [0, S*d)), kind 1 for its input gradient
+    s.wf_enc = s.wf_enc_t = s.wf_dec = s.wf_dec_t = nullptr;
+    if (rows_w && S < PM_N_SLOTS) {
+      s.wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
+      s.wf_enc_t = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
+      for (int kind = 0; kind < 2; ++kind)
+        RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, kind, 1, (int64_t)PM_N_SLOTS * d * d,
+                                   (int64_t)PM_N_SLOTS * d * d * 3, kind ? s.wf_enc_t : s.wf_enc, c.st));
+    }
+    // chord decoder, rows [0, S*d) of its weight [15d, d]: kind 0 for the forward, kind 1 for the input gradient
+    if (rows_w) {
+      s.wf_dec = (uint16_t*)ar.take((size_t)S * d * d * 6);
+      s.wf_dec_t = (uint16_t*)ar.take((size_t)S * d * d * 6);
+      for (int kind = 0; kind < 2; ++kind)
+        RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, kind, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3,
+                                   kind ? s.wf_dec_t : s.wf_dec, c.st));
+    }
+    br.mark(BR_WPREP);
+    if (run) {
     RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
     bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
     RUN(pm_maxpool4_fwd(s.a0, (int64_t)Gn * 8 * 32, s.p0, c.st));
@@ -382,7 +505,12 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.a1, Y.enc_lin1, Gn, d, 512, s.h1, true);
     lin(c, s.h1, Y.enc_lin4, Gn, d, d, s.h2, false);
     lin(c, s.h2, Y.enc_s_bars, B, d, nb * d, s.zcat + d, false, nb * d, 2 * d);           // z_s = zcat[:, d:]
+    }
   }
+  // ---------------- the batch's plan (CSR / CSC, row lists, histograms: plan.hip), while the structure encoder runs
+  if (run)
+    RUN(pm_plan_build(s.bt.edge_index, s.bt.edge_type, s.bt.edge_dist, s.bt.bars, s.bt.batch, s.bt.is_drum, s.bt.tokens,
+                        nb, s.bt.n_slots, N, c.E, Gn, const_cast<int32_t*>(s.plan), c.st));
   // ---------------- content encoder (model.py:344-417)
   float* tables = ar.f((size_t)4 * PM_N_PITCH * dh);
   s.emb_stats = ar.f((size_t)4 * 2 * dh);
@@ -390,8 +518,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
-  uint16_t* wf_enc = (gcl_width(d) && S < PM_N_SLOTS && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w)
-                         ? (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6) : nullptr;
+  uint16_t* const wf_enc = s.wf_enc;
   if (run) {
     RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                           c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_d.b,
@@ -400,11 +527,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                           c.Bf + Y.enc_bn_dur.rm, c.Bf + Y.enc_bn_dur.rv, pv.tok_hist, d, 1, 1e-5f, 0.1f, tables,
                           s.emb_stats, c.st));
     RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
+    branch_join(c, BR_WPREP);                          // weight planes and distance tables are ready
     if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
     else {             // x0 = relu(X[:, :S] @ Wc[:, :S*d]^T + (bias + all-PAD tail slots, one vector per node group))
       if (wf_enc) {                // long-K kernel of linear.hip: Wc [d, 15d] as fragment-major planes (kind 0), columns [0, S*d)
-        RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 0, 1, (int64_t)PM_N_SLOTS * d * d,
-                                   (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));
         RUN(pm_rows_times_weight_longk(s.X, S * d, N, S * d, wf_enc, 0, PM_N_SLOTS * d / 16, d, s.x0, d, c.st));
       } else
         RUN(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
@@ -416,7 +542,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);
   if (run) {
     RUN(pm_gate_fwd(xL, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
-    RUN(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, s.bn_scratch, c.st));
+    RUN(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, c.bn_scratch, c.st));
     RUN(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
                           s.alpha, s.pooled, c.st));
     lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);            // z_c = zcat[:, :d]
@@ -425,6 +551,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.m = ar.zf((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
   s.mu = ar.zf((size_t)B * d); s.lv = ar.zf((size_t)B * d); s.z = ar.f((size_t)B * d);
   if (run) {
+    branch_join(c, BR_ENC_FWD);
     lin(c, s.zcat, Y.enc_merge, B, d, 2 * d, s.m, false);
     bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
     lin(c, s.zg, Y.enc_mu, B, d, d, s.mu, false);
@@ -440,12 +567,15 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   if (run) {
     lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
     bn_fwd(c, s.zd, B, 2 * d, 1, Y.dec_bn, true, nullptr, s.zr, s.dm, s.dv);
-    lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                      // A = zr[:, :d]
-    lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
-    lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
-    RUN(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
-    bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
-    RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
+    {
+      BranchScope br(c, BR_DEC_FWD);                   // joined before the losses
+      lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                    // A = zr[:, :d]
+      lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
+      lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
+      RUN(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
+      bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
+      RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
+    }
     lin(c, s.zr + d, Y.dec_c_bars, B, nb * d, d, s.cb, false, 2 * d, 0);                  // A = zr[:, d:]
     RUN(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
   }
@@ -455,13 +585,12 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
-  const bool rows_w = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
-  uint16_t* wf_dec = rows_w ? (uint16_t*)ar.take((size_t)S * d * d * 6) : nullptr;
+  uint16_t* const wf_dec = s.wf_dec;
+  const bool rows_w = wf_dec != nullptr;
   const bool fused_ce = cfg().fused_ce;
   uint16_t* w_unembed = fused_ce ? (uint16_t*)ar.take((size_t)pm_unembed_scratch_bytes(d)) : nullptr;   // planes of the three un-embedding weights + accumulator replicas
   if (run) {
     if (rows_w) {
-      RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, 0, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3, wf_dec, c.st));
       RUN(pm_rows_times_weight(xdL, d, N, d, wf_dec, 0, 0, S * d, c.P + Y.dec_chord.b, s.H, S * d, c.st));
     } else
       lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);          // rows [0, S*d) of chord_decoder.weight
@@ -485,6 +614,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                                c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     }
     RUN(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
+    branch_join(c, BR_DEC_FWD);
     if (s.fix_structure)
       RUN(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
     else      // training.py:307 evaluates the BCE on the target itself: a constant, no gradient (SURVEY B-1)
@@ -501,6 +631,22 @@ void backward_decoder(Ctx& c) {
   const int S = c.S;
   const int64_t R = (int64_t)N * S;
   float* dzr = ar.zf((size_t)B * 2 * d);
+  // ---- structure decoder (only when the structure loss reaches the logits)
+  if (s.fix_structure) {
+    BranchScope br(c, BR_DEC_BWD);                     // joined before the norm of the decoder's first layer
+    float* da2 = ar.f((size_t)Gn * 8 * 128); float* dc2 = ar.f((size_t)Gn * 8 * 128);
+    float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.zf((size_t)Gn * d); float* dsb = ar.zf((size_t)Gn * d);
+    RUN(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
+    RUN(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
+    bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
+    RUN(pm_conv3x3_bwd_weight(s.u2, dc2, Gn, 16, 8, 4, 32, 1, c.G + Y.dec_conv1.w, c.G + Y.dec_conv1.b, c.st));
+    RUN(pm_conv3x3_bwd_data(dc2, c.P + Y.dec_conv1.w, Gn, 16, 8, 4, 32, 1, du2, c.st));
+    RUN(pm_relu_bwd(du2, s.u2, (int64_t)Gn * 512, du2, c.st));
+    lin_bwd(c, du2, s.u1, Y.dec_s_lin4, Gn, 512, d, du1);
+    RUN(pm_relu_bwd(du1, s.u1, (int64_t)Gn * d, du1, c.st));
+    lin_bwd(c, du1, s.sb, Y.dec_s_lin1, Gn, d, d, dsb);
+    lin_bwd(c, dsb, s.zr, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
+  }
   // ---- content decoder
   float* dH = ar.f((size_t)R * d);
   RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
@@ -517,33 +663,17 @@ void backward_decoder(Ctx& c) {
                       PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
-  if (gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w) {
+  if (s.wf_dec_t) {
     // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
-    uint16_t* wf = (uint16_t*)ar.take((size_t)S * d * d * 6);
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);    // weight and bias gradients
-    RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, 1, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3, wf, c.st));
-    RUN(pm_rows_times_weight_longk(dH, S * d, N, S * d, wf, 1, 0, d, dxL, d, c.st));
+    RUN(pm_rows_times_weight_longk(dH, S * d, N, S * d, s.wf_dec_t, 1, 0, d, dxL, d, c.st));
   } else
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);        // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
   float* dcb = ar.f((size_t)Gn * d);
   RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
   lin_bwd(c, dcb, s.zr + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d);
-  // ---- structure decoder (only when the structure loss reaches the logits)
-  if (s.fix_structure) {
-    float* da2 = ar.f((size_t)Gn * 8 * 128); float* dc2 = ar.f((size_t)Gn * 8 * 128);
-    float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.zf((size_t)Gn * d); float* dsb = ar.zf((size_t)Gn * d);
-    RUN(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
-    RUN(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
-    bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
-    RUN(pm_conv3x3_bwd_weight(s.u2, dc2, Gn, 16, 8, 4, 32, 1, c.G + Y.dec_conv1.w, c.G + Y.dec_conv1.b, c.st));
-    RUN(pm_conv3x3_bwd_data(dc2, c.P + Y.dec_conv1.w, Gn, 16, 8, 4, 32, 1, du2, c.st));
-    RUN(pm_relu_bwd(du2, s.u2, (int64_t)Gn * 512, du2, c.st));
-    lin_bwd(c, du2, s.u1, Y.dec_s_lin4, Gn, 512, d, du1);
-    RUN(pm_relu_bwd(du1, s.u1, (int64_t)Gn * d, du1, c.st));
-    lin_bwd(c, du1, s.sb, Y.dec_s_lin1, Gn, d, d, dsb);
-    lin_bwd(c, dsb, s.zr, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
-  }
+  branch_join(c, BR_DEC_BWD);
   float* dzd = ar.f((size_t)B * 2 * d);
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
   s.dz = ar.zf((size_t)B * d);
@@ -564,6 +694,24 @@ void backward_encoder(Ctx& c) {
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
   float* dzcat = ar.zf((size_t)B * 2 * d);
   lin_bwd(c, dm, s.zcat, Y.enc_merge, B, d, 2 * d, dzcat);
+  // ---- structure branch (z_s = zcat[:, d:]): on the second stream, under the whole content-encoder backward; joined at
+  // the end of backward_encoder_tail
+  {
+    BranchScope br(c, BR_ENC_BWD);
+    float* dh2 = ar.zf((size_t)Gn * d); float* dh1 = ar.zf((size_t)Gn * d); float* da1 = ar.zf((size_t)Gn * 512);
+    float* dc1 = ar.f((size_t)Gn * 512); float* dp0 = ar.f((size_t)Gn * 8 * 32); float* da0 = ar.f((size_t)Gn * 8 * 128);
+    float* dc0 = ar.f((size_t)Gn * 8 * 128);
+    lin_bwd(c, dzcat + d, s.h2, Y.enc_s_bars, B, d, nb * d, dh2, 2 * d, nb * d, nb * d);
+    lin_bwd(c, dh2, s.h1, Y.enc_lin4, Gn, d, d, dh1);
+    RUN(pm_relu_bwd(dh1, s.h1, (int64_t)Gn * d, dh1, c.st));
+    lin_bwd(c, dh1, s.a1, Y.enc_lin1, Gn, d, 512, da1);
+    bn_bwd(c, s.c1, da1, Gn, 16, 32, Y.enc_bn5, s.m1, s.v1, true, dc1);
+    RUN(pm_conv3x3_bwd_weight(s.p0, dc1, Gn, 8, 16, 4, 8, 0, c.G + Y.enc_conv4.w, c.G + Y.enc_conv4.b, c.st));
+    RUN(pm_conv3x3_bwd_data(dc1, c.P + Y.enc_conv4.w, Gn, 8, 16, 4, 8, 0, dp0, c.st));
+    RUN(pm_maxpool4_bwd(s.a0, dp0, (int64_t)Gn * 8 * 32, da0, c.st));
+    bn_bwd(c, s.c0, da0, Gn, 8, 128, Y.enc_bn1, s.m0, s.v0, true, dc0);
+    RUN(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
+  }
   // ---- content branch (z_c = zcat[:, :d])
   float* dpooled = ar.zf((size_t)Gn * d);
   lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d);
@@ -591,14 +739,16 @@ void backward_encoder_tail(Ctx& c) {
   float* gsum = ar.f((size_t)2 * d);
   if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
-    RUN(pm_gemm_f32(1, 0, d, S * d, N, dx0, d, s.X, S * d, c.G + Y.enc_chord.w, PM_N_SLOTS * d, nullptr, PM_GEMM_ACCUM, 0,
-                      nullptr, 0, nullptr, c.st));
-    RUN(pm_colsum_acc(dx0, N, d, d, c.G + Y.enc_chord.b, c.st));
-    if (gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w) {      // dX = dx0 @ Wc[:, :S*d], A-stationary
-      uint16_t* wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
-      RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, 1, 1, (int64_t)PM_N_SLOTS * d * d,
-                                 (int64_t)PM_N_SLOTS * d * d * 3, wf_enc, c.st));
-      RUN(pm_rows_times_weight(dx0, d, N, d, wf_enc, 1, PM_N_SLOTS * d / 32, S * d, nullptr, dX, S * d, c.st));
+    {
+      PmGemmDesc w;                          // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0
+      memset(&w, 0, sizeof(w));
+      w.transA = 1; w.M = d; w.N = S * d; w.K = N; w.A = dx0; w.lda = d; w.B = s.X; w.ldb = S * d;
+      w.C = c.G + Y.enc_chord.w; w.ldc = PM_N_SLOTS * d; w.flags = PM_GEMM_ACCUM; w.split_k = 0; w.n_groups = 1;
+      w.a_colsum = c.G + Y.enc_chord.b;
+      RUN(pm_gemm_f32_desc(&w, c.st));
+    }
+    if (s.wf_enc_t) {                                     // dX = dx0 @ Wc[:, :S*d], A-stationary
+      RUN(pm_rows_times_weight(dx0, d, N, d, s.wf_enc_t, 1, PM_N_SLOTS * d / 32, S * d, nullptr, dX, S * d, c.st));
     } else
       RUN(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
                         nullptr, c.st));
@@ -612,20 +762,7 @@ void backward_encoder_tail(Ctx& c) {
                             c.G + Y.enc_pitch_d.b, c.G + Y.enc_pitch_nd.w, c.G + Y.enc_pitch_nd.b, c.G + Y.enc_dur.w,
                             c.G + Y.enc_dur.b, c.G + Y.enc_bn_d.w, c.G + Y.enc_bn_d.b, c.G + Y.enc_bn_nd.w,
                             c.G + Y.enc_bn_nd.b, c.G + Y.enc_bn_dur.w, c.G + Y.enc_bn_dur.b, c.st));
-  // ---- structure branch (z_s = zcat[:, d:])
-  float* dh2 = ar.zf((size_t)Gn * d); float* dh1 = ar.zf((size_t)Gn * d); float* da1 = ar.zf((size_t)Gn * 512);
-  float* dc1 = ar.f((size_t)Gn * 512); float* dp0 = ar.f((size_t)Gn * 8 * 32); float* da0 = ar.f((size_t)Gn * 8 * 128);
-  float* dc0 = ar.f((size_t)Gn * 8 * 128);
-  lin_bwd(c, dzcat + d, s.h2, Y.enc_s_bars, B, d, nb * d, dh2, 2 * d, nb * d, nb * d);
-  lin_bwd(c, dh2, s.h1, Y.enc_lin4, Gn, d, d, dh1);
-  RUN(pm_relu_bwd(dh1, s.h1, (int64_t)Gn * d, dh1, c.st));
-  lin_bwd(c, dh1, s.a1, Y.enc_lin1, Gn, d, 512, da1);
-  bn_bwd(c, s.c1, da1, Gn, 16, 32, Y.enc_bn5, s.m1, s.v1, true, dc1);
-  RUN(pm_conv3x3_bwd_weight(s.p0, dc1, Gn, 8, 16, 4, 8, 0, c.G + Y.enc_conv4.w, c.G + Y.enc_conv4.b, c.st));
-  RUN(pm_conv3x3_bwd_data(dc1, c.P + Y.enc_conv4.w, Gn, 8, 16, 4, 8, 0, dp0, c.st));
-  RUN(pm_maxpool4_bwd(s.a0, dp0, (int64_t)Gn * 8 * 32, da0, c.st));
-  bn_bwd(c, s.c0, da0, Gn, 8, 128, Y.enc_bn1, s.m0, s.v0, true, dc0);
-  RUN(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
+  branch_join(c, BR_ENC_BWD);                        // the structure branch issued by backward_encoder
 }
 
 // arena use of the backward passes: the real carve-out code, launches skipped (RUN)
@@ -705,9 +842,7 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
   s->ar.zcap = zb; s->ar.zused = 0;
   if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess) return PM_E_LAUNCH;
   Ctx c = make_ctx(s, st);
-  RUN(pm_plan_build(batch->edge_index, batch->edge_type, batch->edge_dist, batch->bars, batch->batch, batch->is_drum,
-                      batch->tokens, lay->n_bars, batch->n_slots, batch->N, batch->E, batch->G, plan, stream));
-  forward(c, msg_dropout, seed_enc, seed_dec);
+  forward(c, msg_dropout, seed_enc, seed_dec);         // (builds the plan: after the structure branch has been forked)
   if (s->ar.overflow) return PM_E_INVALID;
   s->rc = c.rc;
   return c.rc;

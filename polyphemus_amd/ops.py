@@ -302,21 +302,21 @@ class _GemmDesc(ctypes.Structure):
                 ("c_split_rows", ctypes.c_int32), ("c_shared_off", ctypes.c_int64), ("col_stats", ctypes.c_void_p),
                 ("operand_planes", ctypes.c_int32), ("a_plane_stride", ctypes.c_int64),
                 ("b_plane_stride", ctypes.c_int64), ("class_ptr", ctypes.c_void_p), ("class_block", ctypes.c_int32),
-                ("b_frag", ctypes.c_void_p)]
+                ("b_frag", ctypes.c_void_p), ("a_colsum", ctypes.c_void_p)]
 
 
 def gemm_desc(A, B, out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, relu=False, accum=False,
               split_k=1, rowmap=None, rows_per_entry=0, dyn_entries=None, n_groups=1, a_group_stride=0,
               b_group_stride=0, c_group_stride=0, bias_group_stride=0, map_group_stride=0, dyn_group_stride=0,
               b_split_rows=0, b_shared_off=0, c_split_rows=0, c_shared_off=0, partition=False, col_stats=None, planes=False, a_plane_stride=0,
-              b_plane_stride=0, class_ptr=None, class_block=0, b_frag=None):
+              b_plane_stride=0, class_ptr=None, class_block=0, b_frag=None, a_colsum=None):
     """Grouped / stacked-operand GEMM (`pm_gemm_f32_desc`): see PmGemmDesc in the header."""
     q = _GemmDesc(int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, ptr(bias),
                   (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_PARTITION if partition else 0),
                   split_k, ptr(rowmap), rows_per_entry,
                   ptr(dyn_entries), n_groups, a_group_stride, b_group_stride, c_group_stride, bias_group_stride,
                   map_group_stride, dyn_group_stride, b_split_rows, b_shared_off, c_split_rows, c_shared_off, ptr(col_stats), int(planes), a_plane_stride, b_plane_stride, ptr(class_ptr), class_block,
-                  ptr(b_frag))
+                  ptr(b_frag), ptr(a_colsum))
     call("pm_gemm_f32_desc", ctypes.addressof(q), stream())
     return out
 

@@ -129,6 +129,24 @@ def _same_step_up_to_relu_kinks(spec, env):
     return a, b
 
 
+@pytest.mark.parametrize("fix_structure", [False, True])
+def test_structure_branch_on_the_second_stream_changes_nothing(fix_structure):
+    """The step issues the structure encoder / decoder chains on the library's second stream (vae_step.hip: fork / join
+    events around them; forward of both, backward of the encoder's, and — when the structure loss reaches the logits —
+    backward of the decoder's).  Against PM_SIDE_STREAM=0 (everything on the caller's stream), at configs[1] where the
+    branches really run beside the content path: same losses, outputs and gradients (to what two fp32 runs can agree on).
+    The structure branch's own parameters all receive their gradient."""
+    spec = dict(FULLSIZE["configs1_lmd2_b256_d256"], fix_structure=fix_structure)
+    a, b = _same_step_up_to_relu_kinks(spec, {"PM_SIDE_STREAM": 0})
+    for k in ("pitch", "dur", "structure", "kld"):
+        assert abs(a["losses"][k] - b["losses"][k]) <= 1e-6 * max(1.0, abs(b["losses"][k])), k
+    branch = [k for k in a["names"] if k.startswith(("encoder.s_encoder.",) + (("decoder.s_decoder.",) if fix_structure else ()))]
+    assert len(branch) == (26 if fix_structure else 14)
+    for k in branch:
+        assert float(a["grads"][k].abs().max()) > 0, k
+    assert _rel_l2(a["grads"], b["grads"], branch) < 3e-3
+
+
 def test_dense_shard_at_its_real_size_properties():
     """configs[4], one GPU's shard (B = 64, d = 512, every cell active: N = 16,384, E = 2.08 M), without the oracle:
     (1) the step takes the dense route of the d = 512 kernels — stand-alone segment-reduce, then the product from its A'

@@ -184,6 +184,22 @@ def test_gemm_strided_views_and_rowmap():
     assert rel_err(dW, want) < 5e-6
 
 
+@pytest.mark.parametrize("Kr,M,N,ldx", [(512, 256, 512, 0), (16271, 256, 1280, 0), (300, 99, 68, 0), (256, 512, 256, 1024),
+                                         (77, 1, 256, 0), (4100, 1280, 256, 0)])
+def test_gemm_weight_gradient_carries_the_bias_gradient(Kr, M, N, ldx):
+    """PmGemmDesc.a_colsum: the weight-gradient product dW += dy^T x also leaves db += column sums of dy (what
+    `lin_bwd` of the native step issues for every plain linear layer: one launch instead of two).  Both accumulate."""
+    torch.manual_seed(Kr + M + N)
+    dy = torch.randn(Kr, M, device=DEV)
+    xs = torch.randn(Kr, ldx or N, device=DEV)
+    x = xs[:, :N]
+    dW0, db0 = torch.randn(M, N, device=DEV), torch.randn(M, device=DEV)
+    dW, db = dW0.clone(), db0.clone()
+    ops.gemm_desc(dy, xs, dW, M, N, Kr, M, xs.stride(0), N, transA=True, accum=True, split_k=0, a_colsum=db)
+    assert rel_err(dW, dW0.double() + dy.double().t() @ x.double()) < 5e-6
+    assert rel_err(db, db0.double() + dy.double().sum(0)) < 5e-6
+
+
 @pytest.mark.parametrize("cfg", [4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K,ta,tb", [
     (1000, 256, 1024, False, False), (333, 1024, 256, False, True), (1024, 256, 3001 * 4, True, False),

@@ -234,7 +234,7 @@ def hip_fullsize_step(spec, dev="cuda", lr=5e-6, keep=None):
     sd = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
     names = [n for n, _ in vae.named_parameters()]
     eps = torch.randn(spec["B"], spec["d"], generator=torch.Generator().manual_seed(99))
-    tr = HipTrainer(vae, lr=lr)
+    tr = HipTrainer(vae, lr=lr, structure_loss_on_logits=bool(spec.get("fix_structure", False)))
     tr.keep_logits = True
     step0 = vae._step
     t0 = time.time()

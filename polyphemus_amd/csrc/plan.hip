@@ -45,9 +45,12 @@ extern "C" int pm_gcl_tile_order(const int32_t* trk_cnt_host, int32_t use_classe
 
 // ---------------------------------------------------------------- exclusive scan (int32, in place)
 #define SCAN_ITEMS 8
+// The four offset arrays of the plan are scanned together: three launches (tile scans of all arrays, their tile sums,
+// the carry-in) instead of three per array.  (One workgroup per array walking it in 8192-element chunks measured 91 us
+// for the 1e5-element rowptr: each chunk is a dependent load - scan - store round trip.)
 #define SCAN_THREADS 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_THREADS)
-
+struct ScanArrays { int* p[4]; int64_t n[4]; int tile0[5]; };    // tile0[a]: first workgroup (= slot of `sums`) of array a
 __device__ static inline int block_exclusive_scan(int v, int* total) {
   // 256 threads = 4 waves; wave scan by shuffles, then 4 wave totals through LDS.
   __shared__ int wsum[SCAN_THREADS / PM_WAVE];
@@ -67,9 +70,14 @@ __device__ static inline int block_exclusive_scan(int v, int* total) {
   *total = tot;
   return base + inc - v;
 }
-
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(int* data, int64_t n, int* sums) {
-  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+__device__ static inline int scan_array_of(const ScanArrays& a, int b) {
+  return b >= a.tile0[3] ? 3 : (b >= a.tile0[2] ? 2 : (b >= a.tile0[1] ? 1 : 0));
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(ScanArrays a, int* sums) {
+  const int q = scan_array_of(a, blockIdx.x);
+  int* const data = a.p[q];
+  const int64_t n = a.n[q];
+  const int64_t base = (int64_t)(blockIdx.x - a.tile0[q]) * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int v[SCAN_ITEMS], s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? data[base + i] : 0; s += v[i]; }
@@ -79,57 +87,55 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_tile(int* data, int64_t n
   for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) data[base + i] = ex; ex += v[i]; }
   if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(int* sums, int nb) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(ScanArrays a, int* sums) {      // one workgroup per array
+  int* const sm = sums + a.tile0[blockIdx.x];
+  const int nb = a.tile0[blockIdx.x + 1] - a.tile0[blockIdx.x];
   int carry = 0;
-  for (int c0 = 0; c0 < nb; c0 += SCAN_THREADS) {      // sequential chunks, one block
+  for (int c0 = 0; c0 < nb; c0 += SCAN_THREADS) {      // sequential chunks
     int i = c0 + threadIdx.x;
-    int v = i < nb ? sums[i] : 0, tot;
+    int v = i < nb ? sm[i] : 0, tot;
     int ex = block_exclusive_scan(v, &tot);
-    if (i < nb) sums[i] = ex + carry;
+    if (i < nb) sm[i] = ex + carry;
     carry += tot;
   }
 }
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(int* data, int64_t n, const int* sums) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(ScanArrays a, const int* sums) {
+  const int q = scan_array_of(a, blockIdx.x);
+  if (blockIdx.x == a.tile0[q]) return;                  // first tile of an array: carry-in 0
+  int* const data = a.p[q];
+  const int64_t n = a.n[q];
   const int add = sums[blockIdx.x];
-  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  const int64_t base = (int64_t)(blockIdx.x - a.tile0[q]) * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) data[base + i] += add;
 }
-static void exclusive_scan(int* data, int64_t n, int* sums, hipStream_t st) {
-  const int nb = (int)pm_cdiv(n, SCAN_TILE);
-  hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(SCAN_THREADS), 0, st, data, n, sums);
-  if (nb > 1) {
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, st, data, n, sums);
-  }
-}
 
 // ---------------------------------------------------------------- counting
-__global__ void k_count_edges(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E, int* rowcnt,
-                              int* colcnt) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ static inline void d_count_edges(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E, int* rowcnt,
+                              int* colcnt, int bid) {
+  const int e = bid * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int s = (int)ei[e], d = (int)ei[(int64_t)E + e];
   atomicAdd(&rowcnt[d * PM_N_REL + et[e]], 1);
   atomicAdd(&colcnt[s], 1);
 }
-__global__ void k_count_nodes(const int64_t* __restrict__ bars, const int64_t* __restrict__ batch,
+__device__ static inline void d_count_nodes(const int64_t* __restrict__ bars, const int64_t* __restrict__ batch,
                               const uint8_t* __restrict__ is_drum, int n_bars, int N, int* node_bar, int* barcnt,
-                              int* drumflag) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+                              int* drumflag, int bid) {
+  const int n = bid * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int b = (int)(bars[n] + (int64_t)n_bars * batch[n]);                  // model.py:403
   node_bar[n] = b;
   atomicAdd(&barcnt[b], 1);
   drumflag[n] = is_drum[n] ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) k_tok_hist(const int32_t* __restrict__ tok, const uint8_t* __restrict__ is_drum,
-                                                  int N, int* hist) {
+__device__ static inline void d_tok_hist(const int32_t* __restrict__ tok, const uint8_t* __restrict__ is_drum,
+                                                  int N, int* hist, int bid, int nblk) {
   __shared__ int sh[4 * PM_N_PITCH];
   for (int i = threadIdx.x; i < 4 * PM_N_PITCH; i += blockDim.x) sh[i] = 0;
   __syncthreads();
   const int64_t total = (int64_t)N * PM_N_SLOTS;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
     const int n = (int)(i / PM_N_SLOTS), s = (int)(i % PM_N_SLOTS) + 1;       // slot 0 = SOS is dropped (model.py:349)
     const int g = is_drum[n] ? 0 : 1;
     const int p = tok[((int64_t)n * 16 + s) * 2 + 0], du = tok[((int64_t)n * 16 + s) * 2 + 1];
@@ -141,10 +147,10 @@ __global__ void __launch_bounds__(256) k_tok_hist(const int32_t* __restrict__ to
 }
 
 // ---------------------------------------------------------------- fill + per-segment order
-__global__ void k_fill(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E,
+__device__ static inline void d_fill(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E,
                        const int* __restrict__ rowptr, const int* __restrict__ colptr, int* cur_in, int* cur_out,
-                       int* csr_eid, int* csc_eid) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+                       int* csr_eid, int* csc_eid, int bid) {
+  const int e = bid * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int s = (int)ei[e], d = (int)ei[(int64_t)E + e];
   const int key = d * PM_N_REL + et[e];
@@ -159,19 +165,19 @@ __device__ static inline void sort_segment(int* a, int beg, int end) {       // 
     a[j + 1] = v;
   }
 }
-__global__ void k_finish_csr(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed, int E, int nseg,
-                             const int* __restrict__ rowptr, int* csr_eid, int* csr_src, int* csr_dist) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ static inline void d_finish_csr(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed, int E, int nseg,
+                             const int* __restrict__ rowptr, int* csr_eid, int* csr_src, int* csr_dist, int bid) {
+  const int k = bid * blockDim.x + threadIdx.x;
   if (k >= nseg) return;
   const int beg = rowptr[k], end = rowptr[k + 1];
   sort_segment(csr_eid, beg, end);
   for (int p = beg; p < end; ++p) { const int e = csr_eid[p]; csr_src[p] = (int)ei[e]; csr_dist[p] = ed[e]; }
 }
-__global__ void k_finish_csc(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
+__device__ static inline void d_finish_csc(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
                              const int32_t* __restrict__ ed, int E, int N, const int* __restrict__ rowptr,
                              const int* __restrict__ colptr, int* csc_eid, int* csc_dst, int* csc_reldist,
-                             float* csc_invcnt) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+                             float* csc_invcnt, int bid) {
+  const int n = bid * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int beg = colptr[n], end = colptr[n + 1];
   // Out-edges of a source ordered by (distance, edge id): the backward (k_segreduce_bwd) adds the table-gradient terms of a
@@ -213,25 +219,25 @@ __device__ static inline void sort_segment_wave(int* a, int beg, int end, int* s
     a[beg + rank] = v;
   }
 }
-__global__ void __launch_bounds__(256) k_finish_csr_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed,
+__device__ static inline void d_finish_csr_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed,
                                                          int E, int nseg, const int* __restrict__ rowptr, int* csr_eid,
-                                                         int* csr_src, int* csr_dist) {
+                                                         int* csr_src, int* csr_dist, int bid) {
   __shared__ int sk[4][SEGW_MAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = blockIdx.x * 4 + wave;
+  const int k = bid * 4 + wave;
   if (k >= nseg) return;
   const int beg = rowptr[k], end = rowptr[k + 1];
   sort_segment_wave(csr_eid, beg, end, sk[wave], lane);
   __threadfence_block();
   for (int p = beg + lane; p < end; p += 64) { const int e = csr_eid[p]; csr_src[p] = (int)ei[e]; csr_dist[p] = ed[e]; }
 }
-__global__ void __launch_bounds__(256) k_finish_csc_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
+__device__ static inline void d_finish_csc_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
                                                          const int32_t* __restrict__ ed, int E, int N,
                                                          const int* __restrict__ rowptr, const int* __restrict__ colptr,
-                                                         int* csc_eid, int* csc_dst, int* csc_reldist, float* csc_invcnt) {
+                                                         int* csc_eid, int* csc_dst, int* csc_reldist, float* csc_invcnt, int bid) {
   __shared__ int sk[4][SEGW_MAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * 4 + wave;
+  const int n = bid * 4 + wave;
   if (n >= N) return;
   const int beg = colptr[n], end = colptr[n + 1];
   const bool by_dist = E < (1 << 26);                          // (as k_finish_csc: out-edges ordered by (distance, edge id))
@@ -250,9 +256,9 @@ __global__ void __launch_bounds__(256) k_finish_csc_wave(const int64_t* __restri
     csc_invcnt[p] = 1.0f / (float)(cnt > 1 ? cnt : 1);
   }
 }
-__global__ void k_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int S, int* list,
-                             int* rows, int* cnt) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ static inline void d_group_list(const int* __restrict__ pos, const uint8_t* __restrict__ is_drum, int N, int S, int* list,
+                             int* rows, int* cnt, int bid) {
+  const int n = bid * blockDim.x + threadIdx.x;
   if (n == 0) {
     cnt[0] = pos[N]; cnt[1] = N - pos[N];
     cnt[2] = S * pos[N]; cnt[3] = S * (N - pos[N]);
@@ -287,12 +293,12 @@ __device__ static inline int node_class(const int* __restrict__ rowptr, int n, i
   *nrel_out = nrel;
   return t * 4 + (on ? (nx ? 2 : 1) : (nx ? 3 : 0));
 }
-__global__ void __launch_bounds__(CLS_T) k_node_class(const int* __restrict__ rowptr, int N, int* __restrict__ trel,
-                                                     int* __restrict__ cls, int* __restrict__ bh, int* __restrict__ cnt) {
+__device__ static inline void d_node_class(const int* __restrict__ rowptr, int N, int* __restrict__ trel,
+                                                     int* __restrict__ cls, int* __restrict__ bh, int* __restrict__ cnt, int bid) {
   __shared__ int h[16];
   if (threadIdx.x < 16) h[threadIdx.x] = 0;
   __syncthreads();
-  const int n = blockIdx.x * CLS_T + threadIdx.x;
+  const int n = bid * CLS_T + threadIdx.x;
   if (n < N) {
     int nrel;
     const int c = node_class(rowptr, n, &nrel);
@@ -302,38 +308,43 @@ __global__ void __launch_bounds__(CLS_T) k_node_class(const int* __restrict__ ro
     atomicAdd(&h[c], 1);
   }
   __syncthreads();
-  if (threadIdx.x < 16) bh[blockIdx.x * 16 + threadIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < 16) bh[bid * 16 + threadIdx.x] = h[threadIdx.x];
 }
 // bh[b][c] -> first list position of class c in workgroup b; cnt[0..3] = track sizes; cnt[8 + 5t + k] = boundaries b_k.
-// One wave per class (16 waves): column sums, then an exclusive scan down the column 64 workgroups at a time.
-__global__ void __launch_bounds__(1024) k_class_scan(int* __restrict__ bh, int nblk, int N, int* __restrict__ cnt) {
+// One 256-thread workgroup, a wave per class (four classes per wave): column sums, then an exclusive scan down the
+// column 64 workgroups at a time.
+__device__ static inline void d_class_scan(int* __restrict__ bh, int nblk, int N, int* __restrict__ cnt) {
   __shared__ int tot[16];
-  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int sum = 0;
-  for (int b = lane; b < nblk; b += 64) sum += bh[b * 16 + c];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = w; c < 16; c += 4) {
+    int sum = 0;
+    for (int b = lane; b < nblk; b += 64) sum += bh[b * 16 + c];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-  if (lane == 0) tot[c] = sum;
-  __syncthreads();
-  const int t = c >> 2;
-  int off = 0;
-  for (int k = t * 4; k < c; ++k) off += tot[k];
-  int run = t * N + off;
-  for (int base = 0; base < nblk; base += 64) {
-    const int b = base + lane;
-    const int v = b < nblk ? bh[b * 16 + c] : 0;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
-    if (b < nblk) bh[b * 16 + c] = run + x - v;
-    run += __shfl(x, 63, 64);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) tot[c] = sum;
   }
-  if (lane == 0) {
-    cnt[8 + t * 5 + (c & 3)] = off;
-    if ((c & 3) == 3) { cnt[8 + t * 5 + 4] = off + tot[c]; cnt[t] = off + tot[c]; }
+  __syncthreads();
+  for (int c = w; c < 16; c += 4) {
+    const int t = c >> 2;
+    int off = 0;
+    for (int k = t * 4; k < c; ++k) off += tot[k];
+    int run = t * N + off;
+    for (int base = 0; base < nblk; base += 64) {
+      const int b = base + lane;
+      const int v = b < nblk ? bh[b * 16 + c] : 0;
+      int x = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (b < nblk) bh[b * 16 + c] = run + x - v;
+      run += __shfl(x, 63, 64);
+    }
+    if (lane == 0) {
+      cnt[8 + t * 5 + (c & 3)] = off;
+      if ((c & 3) == 3) { cnt[8 + t * 5 + 4] = off + tot[c]; cnt[t] = off + tot[c]; }
+    }
   }
 }
 __global__ void __launch_bounds__(CLS_T) k_class_scatter(const int* __restrict__ cls, const int* __restrict__ bh, int N,
@@ -362,6 +373,53 @@ __global__ void __launch_bounds__(256) k_zero_regions(ZeroRegions z) {
     for (int64_t i = tid; i < z.n[r]; i += step) z.p[r][i] = 0;
 }
 
+// The plan is built by EIGHT launches (21 before: every launch of these few-microsecond kernels is ~5 us of the step's
+// critical path and ~10 us of host time): stages that only depend on the previous stage share a launch, each taking its
+// own range of workgroups (256 threads everywhere):
+//   1 clear the counters | 2 count edges, nodes, tokens | 3 scan the four offset arrays (three launches) | 4 fill the CSR / CSC edge
+//   ids, classify the nodes, list the drum / non-drum rows | 5 order and expand the CSR and CSC segments, scan the class
+//   histograms | 6 scatter the nodes into the class-sorted track lists
+struct PlanArgs {
+  const int64_t* ei; const int32_t* et; const int32_t* ed; const int64_t* bars; const int64_t* batch; const uint8_t* is_drum;
+  const int32_t* tokens;
+  int n_bars, n_slots, N, E;
+  int *rowptr, *colptr, *barptr, *cur_in, *cur_out, *drumpos, *node_bar, *tok_hist;
+  int *csr_eid, *csr_src, *csr_dist, *csc_eid, *csc_dst, *csc_reldist; float* csc_invcnt;
+  int *group_list, *row_list, *group_cnt, *node_trel, *trk_list, *trk_cnt, *cls, *bh;
+  int nb_e, nb_n, nb_tok, nb_cls, nb_seg, nb_csc, wave_sort;
+};
+__global__ void __launch_bounds__(256) k_plan_count(PlanArgs a) {
+  int b = blockIdx.x;
+  if (b < a.nb_e) { d_count_edges(a.ei, a.et, a.E, a.rowptr, a.colptr, b); return; }
+  b -= a.nb_e;
+  if (b < a.nb_n) { d_count_nodes(a.bars, a.batch, a.is_drum, a.n_bars, a.N, a.node_bar, a.barptr, a.drumpos, b); return; }
+  b -= a.nb_n;
+  d_tok_hist(a.tokens, a.is_drum, a.N, a.tok_hist, b, a.nb_tok);
+}
+__global__ void __launch_bounds__(256) k_plan_fill(PlanArgs a) {
+  int b = blockIdx.x;
+  if (b < a.nb_e) { d_fill(a.ei, a.et, a.E, a.rowptr, a.colptr, a.cur_in, a.cur_out, a.csr_eid, a.csc_eid, b); return; }
+  b -= a.nb_e;
+  if (b < a.nb_cls) { d_node_class(a.rowptr, a.N, a.node_trel, a.cls, a.bh, a.trk_cnt, b); return; }
+  b -= a.nb_cls;
+  d_group_list(a.drumpos, a.is_drum, a.N, a.n_slots, a.group_list, a.row_list, a.group_cnt, b);
+}
+__global__ void __launch_bounds__(256) k_plan_finish(PlanArgs a) {
+  int b = blockIdx.x;
+  if (b < a.nb_seg) {
+    if (a.wave_sort) d_finish_csr_wave(a.ei, a.ed, a.E, a.N * PM_N_REL, a.rowptr, a.csr_eid, a.csr_src, a.csr_dist, b);
+    else d_finish_csr(a.ei, a.ed, a.E, a.N * PM_N_REL, a.rowptr, a.csr_eid, a.csr_src, a.csr_dist, b);
+    return;
+  }
+  b -= a.nb_seg;
+  if (b < a.nb_csc) {
+    if (a.wave_sort) d_finish_csc_wave(a.ei, a.et, a.ed, a.E, a.N, a.rowptr, a.colptr, a.csc_eid, a.csc_dst, a.csc_reldist, a.csc_invcnt, b);
+    else d_finish_csc(a.ei, a.et, a.ed, a.E, a.N, a.rowptr, a.colptr, a.csc_eid, a.csc_dst, a.csc_reldist, a.csc_invcnt, b);
+    return;
+  }
+  d_class_scan(a.bh, a.nb_cls, a.N, a.trk_cnt);
+}
+
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
                              const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
                              const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
@@ -372,68 +430,64 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   hipStream_t st = (hipStream_t)stream;
   int64_t o[PM_PLAN_NFIELDS + 1];
   pm_plan_offsets(N, E, G, o);
-  int* rowptr = plan + o[PM_PLAN_ROWPTR];
-  int* colptr = plan + o[PM_PLAN_COLPTR];
-  int* barptr = plan + o[PM_PLAN_BAR_PTR];
-  int* cur_in = plan + o[PM_PLAN_SCRATCH];
-  int* cur_out = cur_in + (int64_t)N * PM_N_REL;
-  int* drumpos = cur_out + N;
-  int* sums = drumpos + N + 1;
-  {                                          // every counter array of the plan in ONE launch (six memsets before)
+  PlanArgs a;
+  a.ei = edge_index; a.et = edge_type; a.ed = edge_dist; a.bars = bars; a.batch = batch; a.is_drum = is_drum; a.tokens = tokens;
+  a.n_bars = n_bars; a.n_slots = n_slots; a.N = N; a.E = E;
+  a.rowptr = plan + o[PM_PLAN_ROWPTR]; a.colptr = plan + o[PM_PLAN_COLPTR]; a.barptr = plan + o[PM_PLAN_BAR_PTR];
+  a.cur_in = plan + o[PM_PLAN_SCRATCH];
+  a.cur_out = a.cur_in + (int64_t)N * PM_N_REL;
+  a.drumpos = a.cur_out + N;
+  int* const sums = a.drumpos + N + 1;
+  // (behind the tile sums of the four scans — the layout reserves cdiv(6N + 1, 2048) + 64 + 4 (N + 1) ints from `sums` on)
+  const int64_t scan_tiles = pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 2 * pm_cdiv((int64_t)N + 1, 2048) + pm_cdiv((int64_t)G + 1, 2048);
+  a.cls = sums + scan_tiles + 64;                                         // [N] node class, then [nb_cls][16] histograms
+  a.bh = a.cls + N;
+  a.node_bar = plan + o[PM_PLAN_NODE_BAR]; a.tok_hist = plan + o[PM_PLAN_TOK_HIST];
+  a.csr_eid = plan + o[PM_PLAN_CSR_EID]; a.csr_src = plan + o[PM_PLAN_CSR_SRC]; a.csr_dist = plan + o[PM_PLAN_CSR_DIST];
+  a.csc_eid = plan + o[PM_PLAN_CSC_EID]; a.csc_dst = plan + o[PM_PLAN_CSC_DST]; a.csc_reldist = plan + o[PM_PLAN_CSC_RELDIST];
+  a.csc_invcnt = reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]);
+  a.group_list = plan + o[PM_PLAN_GROUP_LIST]; a.row_list = plan + o[PM_PLAN_ROW_LIST]; a.group_cnt = plan + o[PM_PLAN_GROUP_CNT];
+  a.node_trel = plan + o[PM_PLAN_NODE_TREL]; a.trk_list = plan + o[PM_PLAN_TRK_LIST]; a.trk_cnt = plan + o[PM_PLAN_TRK_CNT];
+  const int T = 256;
+  a.nb_e = (int)pm_cdiv(E, T); a.nb_n = (int)pm_cdiv(N, T); a.nb_cls = (int)pm_cdiv(N, CLS_T);
+  a.nb_tok = 0;
+  if (tokens) {
+    a.nb_tok = (int)pm_cdiv((int64_t)N * PM_N_SLOTS, 4096);
+    if (a.nb_tok > 1024) a.nb_tok = 1024;
+  }
+  a.wave_sort = (int64_t)E >= 16 * (int64_t)N ? 1 : 0;                   // dense graphs: one wave per segment (long segments)
+  a.nb_seg = (int)pm_cdiv((int64_t)N * PM_N_REL, a.wave_sort ? 4 : T);
+  a.nb_csc = (int)pm_cdiv(N, a.wave_sort ? 4 : T);
+  {                                          // 1: every counter array of the plan in ONE launch
     ZeroRegions z;
-    z.p[0] = rowptr; z.n[0] = (int64_t)N * PM_N_REL + 1;
-    z.p[1] = colptr; z.n[1] = (int64_t)N + 1;
-    z.p[2] = barptr; z.n[2] = (int64_t)G + 1;
-    z.p[3] = plan + o[PM_PLAN_GROUP_CNT]; z.n[3] = o[PM_PLAN_ROW_LIST] - o[PM_PLAN_GROUP_CNT];
-    z.p[4] = cur_in; z.n[4] = (int64_t)N * PM_N_REL + N + N + 1;
-    z.p[5] = plan + o[PM_PLAN_TRK_CNT]; z.n[5] = 32;
+    z.p[0] = a.rowptr; z.n[0] = (int64_t)N * PM_N_REL + 1;
+    z.p[1] = a.colptr; z.n[1] = (int64_t)N + 1;
+    z.p[2] = a.barptr; z.n[2] = (int64_t)G + 1;
+    z.p[3] = a.group_cnt; z.n[3] = o[PM_PLAN_ROW_LIST] - o[PM_PLAN_GROUP_CNT];
+    z.p[4] = a.cur_in; z.n[4] = (int64_t)N * PM_N_REL + N + N + 1;
+    z.p[5] = a.trk_cnt; z.n[5] = 32;
     int64_t tot = 0;
     for (int r = 0; r < 6; ++r) tot += z.n[r];
     int nb = (int)pm_cdiv(tot, 1024);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_zero_regions, dim3(nb), dim3(256), 0, st, z);
   }
-  const int T = 256;
-  hipLaunchKernelGGL(k_count_edges, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr);
-  hipLaunchKernelGGL(k_count_nodes, dim3(pm_cdiv(N, T)), dim3(T), 0, st, bars, batch, is_drum, n_bars, N,
-                     plan + o[PM_PLAN_NODE_BAR], barptr, drumpos);
-  if (tokens) {
-    int nb = (int)pm_cdiv((int64_t)N * PM_N_SLOTS, 4096);
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(k_tok_hist, dim3(nb), dim3(256), 0, st, tokens, is_drum, N, plan + o[PM_PLAN_TOK_HIST]);
+  hipLaunchKernelGGL(k_plan_count, dim3(a.nb_e + a.nb_n + a.nb_tok), dim3(T), 0, st, a);                 // 2
+  {                                                                                                        // 3
+    ScanArrays sc;
+    sc.p[0] = a.rowptr; sc.n[0] = (int64_t)N * PM_N_REL + 1;
+    sc.p[1] = a.colptr; sc.n[1] = (int64_t)N + 1;
+    sc.p[2] = a.barptr; sc.n[2] = (int64_t)G + 1;
+    sc.p[3] = a.drumpos; sc.n[3] = (int64_t)N + 1;
+    sc.tile0[0] = 0;
+    for (int q = 0; q < 4; ++q) sc.tile0[q + 1] = sc.tile0[q] + (int)pm_cdiv(sc.n[q], SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_tile, dim3(sc.tile0[4]), dim3(SCAN_THREADS), 0, st, sc, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(4), dim3(SCAN_THREADS), 0, st, sc, sums);
+    hipLaunchKernelGGL(k_scan_add, dim3(sc.tile0[4]), dim3(SCAN_THREADS), 0, st, sc, sums);
   }
-  exclusive_scan(rowptr, (int64_t)N * PM_N_REL + 1, sums, st);
-  exclusive_scan(colptr, (int64_t)N + 1, sums, st);
-  exclusive_scan(barptr, (int64_t)G + 1, sums, st);
-  exclusive_scan(drumpos, (int64_t)N + 1, sums, st);
-  hipLaunchKernelGGL(k_fill, dim3(pm_cdiv(E, T)), dim3(T), 0, st, edge_index, edge_type, E, rowptr, colptr, cur_in,
-                     cur_out, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSC_EID]);
-  if ((int64_t)E >= 16 * (int64_t)N) {       // dense graphs: one wave per segment (long segments)
-    hipLaunchKernelGGL(k_finish_csr_wave, dim3(pm_cdiv((int64_t)N * PM_N_REL, 4)), dim3(256), 0, st, edge_index, edge_dist,
-                       E, N * PM_N_REL, rowptr, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSR_SRC],
-                       plan + o[PM_PLAN_CSR_DIST]);
-    hipLaunchKernelGGL(k_finish_csc_wave, dim3(pm_cdiv(N, 4)), dim3(256), 0, st, edge_index, edge_type, edge_dist, E, N,
-                       rowptr, colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
-                       reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
-  } else {
-    hipLaunchKernelGGL(k_finish_csr, dim3(pm_cdiv((int64_t)N * PM_N_REL, T)), dim3(T), 0, st, edge_index, edge_dist, E,
-                       N * PM_N_REL, rowptr, plan + o[PM_PLAN_CSR_EID], plan + o[PM_PLAN_CSR_SRC],
-                       plan + o[PM_PLAN_CSR_DIST]);
-    hipLaunchKernelGGL(k_finish_csc, dim3(pm_cdiv(N, T)), dim3(T), 0, st, edge_index, edge_type, edge_dist, E, N, rowptr,
-                       colptr, plan + o[PM_PLAN_CSC_EID], plan + o[PM_PLAN_CSC_DST], plan + o[PM_PLAN_CSC_RELDIST],
-                       reinterpret_cast<float*>(plan + o[PM_PLAN_CSC_INVCNT]));
-  }
-  {
-    int* cls = sums + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64;     // [N] node class, then [nblk][16] histograms
-    const int nblk = (int)pm_cdiv(N, CLS_T);
-    int* bh = cls + N;
-    int* tcnt = plan + o[PM_PLAN_TRK_CNT];
-    hipLaunchKernelGGL(k_node_class, dim3(nblk), dim3(CLS_T), 0, st, rowptr, N, plan + o[PM_PLAN_NODE_TREL], cls, bh, tcnt);
-    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(1024), 0, st, bh, nblk, N, tcnt);
-    hipLaunchKernelGGL(k_class_scatter, dim3(nblk), dim3(CLS_T), 0, st, cls, bh, N, plan + o[PM_PLAN_TRK_LIST]);
-  }
-  hipLaunchKernelGGL(k_group_list, dim3(pm_cdiv(N, T)), dim3(T), 0, st, drumpos, is_drum, N, n_slots,
-                     plan + o[PM_PLAN_GROUP_LIST], plan + o[PM_PLAN_ROW_LIST], plan + o[PM_PLAN_GROUP_CNT]);
+  hipLaunchKernelGGL(k_plan_fill, dim3(a.nb_e + a.nb_cls + a.nb_n), dim3(T), 0, st, a);                   // 4
+  hipLaunchKernelGGL(k_plan_finish, dim3(a.nb_seg + a.nb_csc + 1), dim3(T), 0, st, a);                     // 5
+  hipLaunchKernelGGL(k_class_scatter, dim3(a.nb_cls), dim3(CLS_T), 0, st, a.cls, a.bh, N, a.trk_list);    // 6
   return pm_check_launch();
 }
 

@@ -94,8 +94,10 @@ int pm_plan_build(const int64_t* edge_index /* [2,E] row0=src,row1=dst (data.py:
 /* HOST function (no GPU): the schedule of the GCL products over the plan's (track group, 64-row tile) list — the
  * kernels keep one workgroup per CU and a tile costs 2-4 blocks of K, so workgroup b of XCD b % 8 takes the XCD's
  * share of the 4-block tiles first, then of the 3-block, then of the 2-block tiles (csrc/tile_order.h).
- * trk_cnt_host: a host copy of the plan's PM_PLAN_TRK_CNT field [32]; out [2 * cap]: (group, tile) of workgroup b or
- * (-1, -1); returns the number of workgroups a launch for N nodes has. */
+ * With 257..264 tiles (one or a few more than the 256 CUs) an XCD that has a tile too many runs one of its cheapest
+ * tiles as two 32-row halves behind two others, which keeps the launch as long as its heaviest tile.
+ * trk_cnt_host: a host copy of the plan's PM_PLAN_TRK_CNT field [32]; out [3 * cap]: (group, first row of the group's
+ * list, rows = 64 | 32) of workgroup b or (-1, -1, 0); returns the number of workgroups a launch for N nodes has. */
 int pm_gcl_tile_order(const int32_t* trk_cnt_host, int32_t use_classes, int32_t N, int32_t* out, int32_t cap);
 /* Active slots: slot s >= S holds the PAD token in EVERY node of the batch (S = longest chord + EOS, known
  * to the host that built the batch).  PAD rows carry no loss (ignore_index) and an identical embedding, so the

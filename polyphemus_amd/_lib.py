@@ -179,12 +179,12 @@ def plan_layout(N: int, E: int, G: int):
 
 
 def gcl_tile_order(trk_cnt, use_classes: bool, N: int):
-    """Host-only: [(track group, tile)] in workgroup order of the GCL products (csrc/tile_order.h); (-1, -1) for
-    workgroups that exit.  `trk_cnt`: the 32 ints of the plan's trk_cnt field."""
+    """Host-only: [(track group, first row, rows)] in workgroup order of the GCL products (csrc/tile_order.h); rows is 64,
+    or 32 for half a tile; (-1, -1, 0) for workgroups that exit.  `trk_cnt`: the 32 ints of the plan's trk_cnt field."""
     tc = (C.c_int32 * 32)(*[int(v) for v in trk_cnt])
     grid = lib().pm_gcl_tile_order(C.cast(tc, C.c_void_p), int(bool(use_classes)), int(N), None, 0)
     if grid < 0:
         raise HipExtensionError(f"pm_gcl_tile_order failed: {_ERR.get(grid, grid)}")
-    out = (C.c_int32 * (2 * grid))()
+    out = (C.c_int32 * (3 * grid))()
     lib().pm_gcl_tile_order(C.cast(tc, C.c_void_p), int(bool(use_classes)), int(N), C.cast(out, C.c_void_p), grid)
-    return [(out[2 * b], out[2 * b + 1]) for b in range(grid)]
+    return [(out[3 * b], out[3 * b + 1], out[3 * b + 2]) for b in range(grid)]

@@ -24,6 +24,7 @@
 #include "prof.h"
 
 #include "gcl_tiles.h"
+#include <type_traits>
 #include "wide.h"
 #ifndef GCL_TRACE
 #define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
@@ -35,6 +36,14 @@
 #define STAMP() do {} while (0)
 #endif
 
+#ifdef GCL_BLOCKLOG
+// development builds (tools/build_variants.py gcl.hip log=-DGCL_BLOCKLOG): realtime ticks (100 MHz) at the start and end of
+// every workgroup of the last k_gcl_fwd launch, its XCC id and what it worked on
+__device__ long long g_blocklog[1024][4];
+extern "C" int pm_debug_read_blocklog(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blocklog), sizeof(long long) * 1024 * 4) == hipSuccess ? 0 : 1;
+}
+#endif
 namespace {
 constexpr int EMAX = 3;       // edges per (node, relation) gathered in one go (beyond: a serial tail loop)
 #ifndef GCL_NPW
@@ -73,16 +82,27 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   float* const sH = reinterpret_cast<float*>(smem);          // [BM][HS] output tile (epilogue; over the images)
 
   // ---- tile -> (track group, first row): the packed tile list of the grouped GEMM, XCD-contiguous
-  int grp = 0, t = 0;
-  if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, grp, t)) return;
+  PmTile tl;
+#ifdef GCL_BLOCKLOG
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_blocklog[blockIdx.x][0] = (long long)__builtin_amdgcn_s_memrealtime();
+    g_blocklog[blockIdx.x][1] = 0;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_blocklog[blockIdx.x][2] = (long long)(xcc & 0xf);
+    g_blocklog[blockIdx.x][3] = -1;
+  }
+#endif
+  if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+  const int grp = tl.grp, m0 = tl.m0, rows = tl.rows;        // rows = 64, or 32: half a tile (tile_order.h)
+  const bool full = rows > BM / 2;                           // half tiles: the second 32-row block is neither built nor multiplied
   const int M = g.trk_cnt[grp];
-  const int m0 = t * BM;
   const int* list = g.trk_list + (int64_t)grp * g.N;
   bool use_on = true, use_nx = true;
   if (g.use_classes) {
     const int* cb = g.trk_cnt + 8 + grp * 5;
-    use_on = m0 < cb[3] && m0 + BM > cb[1];
-    use_nx = m0 < cb[4] && m0 + BM > cb[2];
+    use_on = m0 < cb[3] && m0 + rows > cb[1];
+    use_nx = m0 < cb[4] && m0 + rows > cb[2];
   }
   // block sequence [self, track, onset?, next?]; chunk c -> (block, half).  The self block comes first: its gather needs
   // the node list only, so it runs while the consumer waves fetch the rows' CSR offsets and edge lists.
@@ -98,7 +118,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   // ---- prologue (all waves): the rows' nodes; the distance table
   if (tid < BM) {
     const int row = m0 + tid;
-    sNode[tid] = row < M ? list[row] : -1;
+    sNode[tid] = (row < M && tid < rows) ? list[row] : -1;
   }
   for (int i = tid; i < PM_N_DIST * D / 4; i += NTHR)
     reinterpret_cast<float4*>(sT)[i] = reinterpret_cast<const float4*>(g.T)[i];
@@ -299,33 +319,39 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   STAMP();
   __syncthreads();
   STAMP();
-  for (int c = 0; c < nchunk; ++c) {
-    const char* img = img0 + (c & 1) * IMG;
+  // (two copies of the loop, picked once: a half tile — tile_order.h — has no second 32-row block to multiply)
+  auto consume = [&](auto ni_tag) {
+    constexpr int NI = decltype(ni_tag)::value;
+    for (int c = 0; c < nchunk; ++c) {
+      const char* img = img0 + (c & 1) * IMG;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      bf16x8 a[3][2];
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 a[3][NI];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int rr = i * 32 + li;
-          a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
-        }
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+          for (int i = 0; i < NI; ++i) {
+            const int rr = i * 32 + li;
+            a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
+          }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
+        for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
-      bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
-      __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+        bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
+        __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
+      }
+      STAMP();
+      __syncthreads();
+      STAMP();
     }
-    STAMP();
-    __syncthreads();
-    STAMP();
-  }
+  };
+  if (full) consume(std::integral_constant<int, 2>{});
+  else consume(std::integral_constant<int, 1>{});
 
   // ---- h tile (+ bias) to LDS, over the images: C/D map of the 32x32 MFMA: col = lane & 31,
   // row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5); row stride HS = D + 8 floats (the two half-waves 32 banks apart)
@@ -371,6 +397,13 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
       atomicAdd(g.colstats + (int64_t)(blockIdx.x % PM_BN_REPL) * 2 * D + tid, v);
     }
   }
+#ifdef GCL_BLOCKLOG
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_blocklog[blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime();
+    g_blocklog[blockIdx.x][3] = (long long)(nblk * 100 + rows);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -407,16 +440,17 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
   int* const sNode = reinterpret_cast<int*>(sC);               // the rows' nodes (until the first block is staged)
 
-  int grp = 0, t = 0;
-  if (!pm_gcl_tile(trk_cnt, use_classes, blockIdx.x, grp, t)) return;
+  PmTile tl;
+  if (!pm_gcl_tile(trk_cnt, use_classes, blockIdx.x, tl)) return;
+  const int grp = tl.grp, m0 = tl.m0, rows = tl.rows;          // rows = 64, or 32: half a tile (tile_order.h)
+  const bool full = rows > BM / 2;
   const int M = trk_cnt[grp];
-  const int m0 = t * BM;
   const int* list = trk_list + (int64_t)grp * N;
   bool use_on = true, use_nx = true;
   if (use_classes) {
     const int* cb = trk_cnt + 8 + grp * 5;
-    use_on = m0 < cb[3] && m0 + BM > cb[1];
-    use_nx = m0 < cb[4] && m0 + BM > cb[2];
+    use_on = m0 < cb[3] && m0 + rows > cb[1];
+    use_nx = m0 < cb[4] && m0 + rows > cb[2];
   }
   const int nblk = 2 + (use_on ? 1 : 0) + (use_nx ? 1 : 0);
   auto blk_of = [&](int q) { return q == 0 ? 0 : (q == nblk - 1 ? 3 : (q == 1 ? (use_on ? 1 : 2) : 2)); };
@@ -424,7 +458,7 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   int nst = 0;
   STAMP2();
-  if (tid < BM) sNode[tid] = m0 + tid < M ? list[m0 + tid] : -1;
+  if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
   __syncthreads();
   STAMP2();
   if (wave >= 4) {
@@ -503,6 +537,9 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   };
   bf16x8 af[2][3][2];
   aload(af[0], 0);
+  // (two copies of the block loop, picked once: a half tile — tile_order.h — has no second 32-row block to multiply)
+  auto blocks = [&](auto ni_tag) {
+  constexpr int NI = decltype(ni_tag)::value;
 #pragma unroll 1
   for (int qb = 0; qb < nblk; ++qb) {
     f32x16 acc[2][TN];
@@ -519,7 +556,7 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
 #pragma unroll
       for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
@@ -540,6 +577,9 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
     STAMP2();
     __syncthreads();
   }
+  };
+  if (full) blocks(std::integral_constant<int, 2>{});
+  else blocks(std::integral_constant<int, 1>{});
 }
 
 extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,

@@ -30,15 +30,15 @@ extern "C" int pm_plan_layout(int32_t N, int32_t E, int32_t G, int64_t* offsets)
   return PM_OK;
 }
 
-// Host-side view of the tile schedule of the GCL products (tile_order.h): out[2b], out[2b+1] = (track group, tile) of
-// workgroup b, or (-1, -1) for a workgroup that exits; returns the number of workgroups launched for N nodes.
+// Host-side view of the tile schedule of the GCL products (tile_order.h): out[3b .. 3b+2] = (track group, first row, rows)
+// of workgroup b, or (-1, -1, 0) for a workgroup that exits; returns the number of workgroups launched for N nodes.
 extern "C" int pm_gcl_tile_order(const int32_t* trk_cnt_host, int32_t use_classes, int32_t N, int32_t* out, int32_t cap) {
   if (!trk_cnt_host || N < 0) return PM_E_INVALID;
   const int grid = (int)pm_gcl_grid(N);
   for (int b = 0; out && b < grid && b < cap; ++b) {
-    int grp = -1, t = -1;
-    if (!pm_gcl_tile(trk_cnt_host, use_classes, b, grp, t)) grp = t = -1;
-    out[2 * b] = grp; out[2 * b + 1] = t;
+    PmTile tl;
+    if (pm_gcl_tile(trk_cnt_host, use_classes, b, tl)) { out[3 * b] = tl.grp; out[3 * b + 1] = tl.m0; out[3 * b + 2] = tl.rows; }
+    else { out[3 * b] = -1; out[3 * b + 1] = -1; out[3 * b + 2] = 0; }
   }
   return grid;
 }

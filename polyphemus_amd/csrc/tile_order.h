@@ -11,20 +11,20 @@
 PM_HD inline int pm_imin(int a, int b) { return a < b ? a : b; }
 PM_HD inline int pm_imax(int a, int b) { return a > b ? a : b; }
 
-// Workgroups of a GCL product over the plan's (track group, 64-row tile) list: a multiple of 8 that leaves every XCD
-// room for its share (the groups' last tiles are partial: at most cdiv(N, PM_TILE_ROWS) + 3 tiles)
-inline unsigned pm_gcl_grid(int N) { return 8u * (unsigned)((((int64_t)N + PM_TILE_ROWS - 1) / PM_TILE_ROWS + 4 + 7) / 8); }
+#define PM_CUS_PER_XCD 32     /* MI355X: 256 CUs in 8 XCDs; the row-tile kernels hold one workgroup per CU */
 
-// Which tile workgroup `bid` takes.  The kernels hold ONE workgroup per CU and a tile costs 2, 3 or 4 blocks of K (its
-// rows' zero onset / next blocks are skipped), so the order of the tiles is the schedule: with N ~ 64 * 256 a batch has
-// a few tiles more or less than the chip has CUs, and in plain order the tiles of the second round started late and
-// were as likely heavy as light (+20 % per launch on 7 of 8 seeds of the bench batch).  Longest first: the hardware
-// deals workgroup b to XCD b % 8, so XCD x takes, in this order, its contiguous share of the 4-block tiles, of the
-// 3-block tiles, of the 2-block tiles (contiguous: neighbouring tiles gather neighbouring bars through one L2); the
-// shares' remainders rotate over the XCDs.  The tiles left for the second round are then the cheapest ones and start
-// when the cheapest of the first round end.  Everything here is wave-uniform (scalar unit).
-PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, int bid, int& grp, int& t) {
-  int len[4][5], wt[4][5], st[4][5];
+// Workgroups of a GCL product over the plan's (track group, 64-row tile) list: a multiple of 8 that leaves every XCD
+// room for its share (the groups' last tiles are partial: at most cdiv(N, PM_TILE_ROWS) + 3 tiles) and for the two
+// halves of a split tile
+inline unsigned pm_gcl_grid(int N) { return 8u * (unsigned)((((int64_t)N + PM_TILE_ROWS - 1) / PM_TILE_ROWS + 4 + 7) / 8 + 1); }
+
+// What a workgroup works on: rows [m0, m0 + rows) of track group grp's node list; rows = 64, or 32 for half a tile
+struct PmTile { int grp, m0, rows; };
+
+// The tiles of one weight class (a tile costs 2, 3 or 4 blocks of K: its rows' zero onset / next blocks are skipped), as
+// up to five runs per track group
+struct PmTileRuns { int len[4][5], wt[4][5], st[4][5]; };
+PM_HD inline void pm_tile_runs(const int* __restrict__ trk_cnt, int use_classes, PmTileRuns& R) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int nt = (trk_cnt[g] + PM_TILE_ROWS - 1) / PM_TILE_ROWS;
@@ -42,31 +42,103 @@ PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, 
 #pragma unroll
     for (int iv = 0; iv < 5; ++iv) {
       const int lo = iv == 0 ? 0 : s[iv - 1], hi = iv == 4 ? nt : s[iv];
-      st[g][iv] = lo; len[g][iv] = hi - lo;
-      wt[g][iv] = use_classes ? 2 + ((lo >= a1 && lo < b1) ? 1 : 0) + ((lo >= a2 && lo < b2) ? 1 : 0) : 4;
+      R.st[g][iv] = lo; R.len[g][iv] = hi - lo;
+      R.wt[g][iv] = use_classes ? 2 + ((lo >= a1 && lo < b1) ? 1 : 0) + ((lo >= a2 && lo < b2) ? 1 : 0) : 4;
     }
   }
-  int xr = bid & 7, k = bid >> 3;
+}
+PM_HD inline int pm_tile_count(const PmTileRuns& R, int W) {
+  int n = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int iv = 0; iv < 5; ++iv) n += R.wt[g][iv] == W ? R.len[g][iv] : 0;
+  return n;
+}
+// the j-th tile of weight W (groups in order, tiles in order)
+PM_HD inline bool pm_tile_at(const PmTileRuns& R, int W, int j, int& grp, int& t) {
+  bool found = false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int iv = 0; iv < 5; ++iv)
+      if (!found && R.wt[g][iv] == W) {
+        if (j < R.len[g][iv]) { grp = g; t = R.st[g][iv] + j; found = true; }
+        else j -= R.len[g][iv];
+      }
+  return found;
+}
+
+// Which tile workgroup `bid` takes.  The kernels hold ONE workgroup per CU, so the order of the tiles is the schedule —
+// and with N ~ 64 * 256 a batch has a few tiles more or fewer than the chip has CUs (seeds 1234..1241 of the bench
+// batch: 256, 258, 261, 257, 258, 257, 259, 257).
+//  * Longest first: the hardware deals workgroup b to XCD b % 8, so XCD x takes, in this order, its contiguous share of
+//    the 4-block tiles, of the 3-block tiles, of the 2-block tiles (contiguous: neighbouring tiles gather neighbouring
+//    bars through one L2).  Tiles beyond one per CU are then the cheapest ones.
+//  * 257 .. 264 tiles: E = tiles - 256 XCDs have one tile more than CUs.  A 2-block tile costs ~0.6 of a 4-block tile
+//    and HALF a 2-block tile (32 rows: half the gathers, half the MFMAs) ~0.4, so an XCD can run 33 tiles in the time of
+//    its 4-block tiles if it has three 2-block tiles: two run whole, the third as two halves that follow them on the same
+//    CUs.  Such an XCD therefore gets three of the 2-block tiles (as long as there are 3 E of them), ends its list with
+//    the two halves, and the rest of the classes is shared out as before.  (bench batch seeds 1235 / 1236 / 1237:
+//    82 / 84 / 83 us per forward launch in plain longest-first order, 66 / 67 / 66 us this way, 256 tiles: 62 us.)
+// Everything here is wave-uniform (scalar unit).
+PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, int bid, PmTile& out) {
+  PmTileRuns R;
+  pm_tile_runs(trk_cnt, use_classes, R);
+  const int n4 = pm_tile_count(R, 4), n3 = pm_tile_count(R, 3), n2 = pm_tile_count(R, 2), nwg = n4 + n3 + n2;
+  const int x = bid & 7;
+  int k = bid >> 3, grp = 0, t = 0;
+  out.rows = PM_TILE_ROWS;
+  const int E = nwg - 8 * PM_CUS_PER_XCD;
+  bool split = use_classes && E > 0 && E <= 8 && n2 >= 3 * E;
+  if (split) {
+    // shares of XCD y: c_y tiles in all; w2: three for an XCD with 33 tiles, the others dealt round starting behind them;
+    // w4: dealt round; w3: what is left
+    const int rem2 = n2 - 3 * E, q2 = rem2 >> 3, r2 = rem2 & 7, q4 = n4 >> 3, r4 = n4 & 7;
+    int s2 = 0, s3 = 0, s4 = 0, w2 = 0, w3 = 0, w4 = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const int cy = PM_CUS_PER_XCD + (y < E ? 1 : 0);
+      const int a2 = (y < E ? 3 : 0) + q2 + ((((y - E) & 7) < r2) ? 1 : 0);
+      const int a4 = q4 + ((((y - E - r2) & 7) < r4) ? 1 : 0);
+      const int a3 = cy - a2 - a4;
+      if (a3 < 0) split = false;
+      if (y < x) { s2 += a2; s3 += a3; s4 += a4; }
+      if (y == x) { w2 = a2; w3 = a3; w4 = a4; }
+    }
+    if (split) {
+      const int halves = x < E ? 1 : 0;                  // tiles of this XCD that run as two halves (its last 2-block tile)
+      // An XCD deals its workgroups to its four shader engines in turn (eight CUs each) and in order: workgroups 32 and 33
+      // — the two halves — wait for a CU of engines 0 and 1 (measured: per-workgroup clocks of a -DGCL_BLOCKLOG build,
+      // profiles/LOG.md).  So the 2-block tiles that run whole must sit at positions 28, 29 (engines 0, 1), not at the
+      // very end of the list: the last four positions are rotated.
+      if (halves && k >= PM_CUS_PER_XCD - 4 && k < PM_CUS_PER_XCD) {
+        const int whole2 = pm_imin(4, w2 - halves);
+        k = PM_CUS_PER_XCD - 4 + ((k - (PM_CUS_PER_XCD - 4)) + (4 - whole2)) % 4;
+      }
+      if (k < w4) { if (!pm_tile_at(R, 4, s4 + k, grp, t)) return false; }
+      else if ((k -= w4) < w3) { if (!pm_tile_at(R, 3, s3 + k, grp, t)) return false; }
+      else if ((k -= w3) < w2 - halves) { if (!pm_tile_at(R, 2, s2 + k, grp, t)) return false; }
+      else {
+        k -= w2 - halves;
+        if (k >= 2 * halves) return false;
+        if (!pm_tile_at(R, 2, s2 + w2 - halves + (k >> 1), grp, t)) return false;
+        out.grp = grp; out.m0 = t * PM_TILE_ROWS + (k & 1) * (PM_TILE_ROWS / 2); out.rows = PM_TILE_ROWS / 2;
+        return out.m0 < trk_cnt[grp];                     // (the second half of a group's last, partial tile may be empty)
+      }
+      out.grp = grp; out.m0 = t * PM_TILE_ROWS;
+      return true;
+    }
+  }
+  int xr = x;
 #pragma unroll
   for (int W = 4; W >= 2; --W) {
-    int nW = 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int iv = 0; iv < 5; ++iv) nW += wt[g][iv] == W ? len[g][iv] : 0;
+    const int nW = W == 4 ? n4 : (W == 3 ? n3 : n2);
     const int q = nW >> 3, r = nW & 7, c = q + (xr < r ? 1 : 0);
     if (k < c) {
-      int j = xr * q + pm_imin(xr, r) + k;
-      bool found = false;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int iv = 0; iv < 5; ++iv)
-          if (!found && wt[g][iv] == W) {
-            if (j < len[g][iv]) { grp = g; t = st[g][iv] + j; found = true; }
-            else j -= len[g][iv];
-          }
-      return found;
+      if (!pm_tile_at(R, W, xr * q + pm_imin(xr, r) + k, grp, t)) return false;
+      out.grp = grp; out.m0 = t * PM_TILE_ROWS;
+      return true;
     }
     k -= c;
     xr = (xr - r) & 7;

@@ -26,6 +26,7 @@
 // Arithmetic (edge order of the mean, split, k order, product order of the six-term chain) is that of gcl.hip /
 // linear.hip / the grouped planes products, so results are bit-identical to the round-1 kernels they replace.
 #include "gcl_tiles.h"
+#include <type_traits>
 #include <stdlib.h>
 #include "prof.h"
 #include "wide.h"
@@ -71,19 +72,19 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
   char* const stage0 = MULTI ? reinterpret_cast<char*>(sNode + BM) : smem;   // single-pass variants: over the ring, after the last chunk
 
   // ---- tile
-  int grp = 0, m0 = 0, M = 0;
+  int grp = 0, m0 = 0, M = 0, rows = BM;
   const int* list = nullptr;
   bool use_on = true, use_nx = true;
   if constexpr (GCL) {
-    int t = 0;
-    if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, grp, t)) return;
+    PmTile tl;
+    if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+    grp = tl.grp; m0 = tl.m0; rows = tl.rows;                  // rows = 64, or 32: half a tile (tile_order.h)
     M = g.trk_cnt[grp];
-    m0 = t * BM;
     list = g.trk_list + (int64_t)grp * g.N;
     if (g.use_classes) {
       const int* cb = g.trk_cnt + 8 + grp * 5;
-      use_on = m0 < cb[3] && m0 + BM > cb[1];
-      use_nx = m0 < cb[4] && m0 + BM > cb[2];
+      use_on = m0 < cb[3] && m0 + rows > cb[1];
+      use_nx = m0 < cb[4] && m0 + rows > cb[2];
     }
   } else {
     const int ntile = (g.M + BM - 1) / BM;
@@ -95,7 +96,8 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
     }
     m0 = t * BM; M = g.M;
   }
-  const int nvalid = min(BM, M - m0);
+  const int nvalid = min(rows, M - m0);
+  const bool full = rows > BM / 2;                             // half tiles: the second 32-row block is not multiplied
   const int nblk = 2 + (use_on ? 1 : 0) + (use_nx ? 1 : 0);
   // forward: chunk c -> block [self, track, onset?, next?] (the self block first: its gather needs the node list only)
   auto chunk_blk = [&](int c) { const int q = c / NCHW; return q == 0 ? 3 : (q == 1 ? 0 : (q == 2 ? (use_on ? 1 : 2) : 2)); };
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if constexpr (GCL) {
-    if (tid < BM) sNode[tid] = m0 + tid < M ? list[m0 + tid] : -1;
+    if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
     __syncthreads();
   }
 
@@ -476,6 +478,9 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
   };
 
   __syncthreads();                                               // image 0 (and the row metadata) ready
+  // (two copies of the chunk loop, picked once: a half tile — tile_order.h — has no second 32-row block to multiply)
+  auto chunks = [&](auto ni_tag) {
+  constexpr int NI = decltype(ni_tag)::value;
   int pass = 0, cc = 0;
 #pragma unroll 1
   for (int gc = 0; gc < total; ++gc) {
@@ -485,11 +490,11 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
     const char* img = img0 + (gc & 1) * IMG;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      bf16x8 a[3][2];
+      bf16x8 a[3][NI];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
           const int rr = i * 32 + li;
           a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
         }
@@ -500,7 +505,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
 #pragma unroll
       for (int t6 = 0; t6 < 6; ++t6) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % BD][PB[t6]][j], acc[i][j], 0, 0, 0);
@@ -521,6 +526,12 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
       if (nc == 0) { epilogue(pass); zero_acc(); }
     }
     pass = np; cc = nc; base_cur = base_next;
+  }
+  };
+  if constexpr (MULTI) chunks(std::integral_constant<int, 2>{});   // (two copies with the epilogue inside the loop: the accumulators leave the registers)
+  else {
+    if (full) chunks(std::integral_constant<int, 2>{});
+    else chunks(std::integral_constant<int, 1>{});
   }
   if constexpr (!MULTI) epilogue(0);
 }

@@ -751,7 +751,8 @@ def _masked_contractions(plan, N, on, nx, d, bfrag):
 
 @pytest.mark.parametrize("d,p,dense", [(128, 0.0, False), (256, 0.0, False), (256, 0.15, False), (128, 0.1, True),
                                        (256, 0.0, True), (128, 0.1, "tiny"), (256, 0.0, "tiny"),
-                                       (512, 0.0, False), (512, 0.1, False), (512, 0.1, True), (512, 0.0, "tiny")])
+                                       (512, 0.0, False), (512, 0.1, False), (512, 0.1, True), (512, 0.0, "tiny"),
+                                       (256, 0.1, "split"), (512, 0.1, "split")])
 def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     """`pm_gcl_forward_fused` (aggregate built in LDS, contracted in the same kernel) against the unfused pair it
     replaces — `pm_segreduce_fwd_planes` then the grouped planes product with row classes: same edge order and message
@@ -761,6 +762,8 @@ def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
     lists overflow the LDS cache and the in-flight gather: the serial tail paths)."""
     if dense == "tiny":                # one sparse sample: a few dozen nodes, tiles far from full, class ranges partly empty
         cpu = synthetic_batch(1, 2, p=0.12, seed=41)
+    elif dense == "split":             # 258 row tiles for 256 CUs: two tiles run as 32-row halves (csrc/tile_order.h)
+        cpu, dense = synthetic_batch(256, 2, p=0.25, seed=1235), False
     else:
         cpu = synthetic_batch(3 if dense else 40, 2, p=0.3, seed=17, dense=dense)
     assert cpu.track_unique
@@ -815,12 +818,15 @@ def test_gcl_forward_fused_equals_segreduce_plus_product(d, p, dense):
         assert rel_err(s3.sum(0)[0], h1.double().sum(0)) < 1e-12
 
 
-@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 1), (512, 40), (512, 1)])
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 1), (512, 40), (512, 1), (256, "split"), (512, "split")])
 def test_gcl_input_grad_fused_equals_grouped_product(d, B):
     """`pm_gcl_input_grad_fused` (dh rows resident in LDS, all 4d output columns per workgroup) against the grouped planes
     product with transB it replaces: same six products in the same k order -> BIT-identical wherever the segment-reduce
     backward reads dA' (track and self blocks of every row, onset / next blocks of the rows that receive such edges)."""
-    cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=19)
+    if B == "split":                   # 258 row tiles for 256 CUs: two tiles run as 32-row halves (csrc/tile_order.h)
+        cpu = synthetic_batch(256, 2, p=0.25, seed=1235)
+    else:
+        cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=19)
     b, plan = make_plan(cpu)
     N, dd = cpu.num_nodes, d * d
     torch.manual_seed(4)

@@ -18,8 +18,9 @@ trace() {   # name, bench args...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_$name" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > "$O/trace_$name.log" 2>&1
   KT=$(find "$O/trace_$name" -name "*kernel_trace.csv" | head -1)
-  python tools/trace_summary.py "$KT" --steps 13 --md > "$O/kernel_stats_$name.md" 2>> "$O/trace_$name.log"
+  python tools/trace_summary.py "$KT" --steps 0 --md > "$O/kernel_stats_$name.md" 2>> "$O/trace_$name.log"
   cp "$(find "$O/trace_$name" -name "*kernel_stats.csv" | head -1)" "$O/kernel_stats_$name.csv"
+  python tools/step_sequence.py "$KT" > "$O/step_sequence_$name.txt" 2>> "$O/trace_$name.log"
   rm -rf "$O/trace_$name"
 }
 trace d256
@@ -34,6 +35,9 @@ pmc() {     # name, workload key, bench args...
   find "$O" -name "*kernel_trace.csv" -delete
   rm -rf "$O/pmc_${name}_FETCH_SIZE" "$O/pmc_${name}_WRITE_SIZE"
 }
+# the bench batch has 256 row tiles = one per CU; seven of the eight seeds 1234..1241 have 257-261
+for sd in 1234 1235 1236 1237; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --seed $sd 2>/dev/null | python tools/benchline.py "seed $sd"; done > "$O/bench_seeds.txt" 2>&1
+for m in 0 15; do PM_SIDE_STREAM=$m python tools/phase_times.py; done > "$O/phase_times.txt" 2>&1
 pmc d256 B256_d256_nb2_L8
 pmc d512 B256_d512_nb2_L8 --d 512
 tail -3 "$O/pytest_gpu.log"; tail -2 "$O/smoke.log"; python tools/benchline.py final < "$O/bench.json"; python tools/benchline.py d512 < "$O/bench_d512.json"; python tools/benchline.py dense < "$O/bench_dense.json"; python tools/benchline.py lmd16 < "$O/bench_lmd16.json"

@@ -2,7 +2,9 @@
 
     python tools/trace_summary.py gpurun_out/prof/<pid>_kernel_trace.csv|<name>_results.db [--steps K] [--skip-frac F] [--md]
 
-`--skip-frac` drops the leading fraction of the trace (warm-up steps); `--steps` divides totals into per-step figures.
+`--skip-frac` drops the leading fraction of the trace (warm-up steps); `--steps` divides totals into per-step figures;
+`--steps 0` takes the training steps from the trace itself: the launches between the first and the last Adam launch
+(model set-up, the batch's host-to-device copies and whatever follows the last step are then not counted).
 """
 import argparse
 import csv
@@ -41,6 +43,12 @@ def main():
         rows = list(csv.DictReader(open(a.csv)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[int(len(rows) * a.skip_frac):]
+    if a.steps == 0:
+        adam = [i for i, r in enumerate(rows) if "k_adam" in r["Kernel_Name"]]
+        if len(adam) < 2:
+            raise SystemExit("--steps 0 needs at least two Adam launches in the trace")
+        rows = rows[adam[0] + 1: adam[-1] + 1]
+        a.steps = len(adam) - 1
     agg = defaultdict(lambda: [0, 0.0])
     for r in rows:
         grid = (int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))

@@ -99,6 +99,9 @@ int pm_plan_build(const int64_t* edge_index /* [2,E] row0=src,row1=dst (data.py:
  * trk_cnt_host: a host copy of the plan's PM_PLAN_TRK_CNT field [32]; out [3 * cap]: (group, first row of the group's
  * list, rows = 64 | 32) of workgroup b or (-1, -1, 0); returns the number of workgroups a launch for N nodes has. */
 int pm_gcl_tile_order(const int32_t* trk_cnt_host, int32_t use_classes, int32_t N, int32_t* out, int32_t cap);
+/* ... and of the uniform 64-row tiles of the chord products (pm_rows_times_weight*): out [2 * cap]: (first row, rows =
+ * 64 | 32) of workgroup b or (-1, 0); returns the number of workgroups a launch over M rows has. */
+int pm_row_tile_order(int32_t M, int32_t* out, int32_t cap);
 /* Active slots: slot s >= S holds the PAD token in EVERY node of the batch (S = longest chord + EOS, known
  * to the host that built the batch).  PAD rows carry no loss (ignore_index) and an identical embedding, so the
  * token-level tensors of the fused step are [N, S, .] instead of [N, 15, .]; results are unchanged. */

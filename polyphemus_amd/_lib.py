@@ -23,6 +23,7 @@ PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", 
 _SIGS = {
     "pm_plan_layout": "iiip",
     "pm_gcl_tile_order": "piipi",
+    "pm_row_tile_order": "ipi",
     "pm_plan_build": "pppppppiiiiips",
     "pm_edge_attrs_to_ids": "pipps",
     "pm_tokens_from_onehot": "pips",

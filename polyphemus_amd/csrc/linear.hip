@@ -7,6 +7,7 @@
 // output columns), chunk by chunk by producer waves when it is S*d (k_rows_wk).  Weights come as fragment-major bf16
 // planes (pm_split_planes_frag), straight from L2 into the MFMA waves' registers.  51-55 us per product.
 #include "gcl_tiles.h"
+#include <type_traits>
 #include <stdlib.h>
 #include "prof.h"
 #include "wide.h"
@@ -26,13 +27,10 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
   constexpr int TN = D / 128, KS = D / 16, RB = D * 2, PL = BM * RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
-  const int ntile = (N + BM - 1) / BM;
-  int t = blockIdx.x;
-  {
-    const int q = ntile >> 3, r = ntile & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = t * BM;
+  int m0 = 0, rows = BM;
+  if (!pm_row_tile(N, blockIdx.x, m0, rows)) return;             // rows = 64, or 32: half a tile (tile_order.h)
+  const bool full = rows > BM / 2;
+  N = min(N, m0 + rows);                                         // (rows past a half tile: out of range like rows past the end)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   if (wave >= 4) {
     // ---- store waves: block q of the stage (+ bias) -> C rows, 16 bytes per lane
@@ -111,6 +109,9 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
   };
   bf16x8 af[2][3][2];
   aload(af[0], 0);
+  // (two copies of the block loop, picked once: a half tile has no second 32-row block to multiply)
+  auto blocks = [&](auto ni_tag) {
+  constexpr int NI = decltype(ni_tag)::value;
 #pragma unroll 1
   for (int qb = 0; qb < nblk; ++qb) {
     f32x16 acc[2][TN];
@@ -127,7 +128,7 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
 #pragma unroll
       for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
@@ -144,6 +145,9 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
           sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / 4) + j * 32 + li] = acc[i][j][r];
     __syncthreads();
   }
+  };
+  if (full) blocks(std::integral_constant<int, 2>{});
+  else blocks(std::integral_constant<int, 1>{});
 }
 
 extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
@@ -157,7 +161,7 @@ extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int3
   if (K == 512)                 // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_rows_times_weight(X, ldx, N, w_frag, kind, w_tiles, Nout, bias, C, ldc, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
+  const dim3 grid(pm_row_grid(N)), block(512);
   const size_t lds = (size_t)3 * BM * K * 2 + (size_t)BM * K * 4;
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
 #define LAUNCH(DD, KD)                                                                                                 \
@@ -189,13 +193,11 @@ k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __rest
   constexpr int TN = D / 128, HS = D + 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const sH = reinterpret_cast<float*>(smem);            // [BM][HS] output tile (epilogue; over the images)
-  const int ntile = (N + BM - 1) / BM, nchunk = K / CH;
-  int t = blockIdx.x;
-  {
-    const int q = ntile >> 3, r = ntile & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = t * BM;
+  const int nchunk = K / CH;
+  int m0 = 0, rows = BM;
+  if (!pm_row_tile(N, blockIdx.x, m0, rows)) return;             // rows = 64, or 32: half a tile (tile_order.h)
+  const bool full = rows > BM / 2;
+  N = min(N, m0 + rows);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave >= 4) {
     // ---- producers: chunk c (128 features of the 64 rows) -> planes image c & 1; 32 lanes per row, 8 rows per pass
@@ -267,32 +269,38 @@ k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __rest
 #pragma unroll
     for (int s2 = 0; s2 < GCL_BDEPTH; ++s2) bload(bq[s2], s2);
     __syncthreads();
+    // (two copies of the chunk loop, picked once: a half tile has no second 32-row block to multiply)
+    auto chunks = [&](auto ni_tag) {
+      constexpr int NI = decltype(ni_tag)::value;
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
-      const char* img = smem + (c & 1) * IMG;
+      for (int c = 0; c < nchunk; ++c) {
+        const char* img = smem + (c & 1) * IMG;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8 a[3][2];
+        for (int ks = 0; ks < 8; ++ks) {
+          bf16x8 a[3][NI];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int rr = i * 32 + li;
-            a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
-          }
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+            for (int i = 0; i < NI; ++i) {
+              const int rr = i * 32 + li;
+              a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
+            }
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
+          for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
-        bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
-        __builtin_amdgcn_sched_barrier(0);
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+          bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
       }
-      __syncthreads();
-    }
+    };
+    if (full) chunks(std::integral_constant<int, 2>{});
+    else chunks(std::integral_constant<int, 1>{});
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -324,7 +332,7 @@ extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N
   if (Nout == 512)              // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_rows_times_weight_longk(X, ldx, N, K, w_frag, kind, w_pitch, C, ldc, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)pm_cdiv(N, BM)), block(512);
+  const dim3 grid(pm_row_grid(N)), block(512);
   const size_t lds = 2 * IMG;
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
 #define LAUNCH(DD, KD)                                                                                                 \

@@ -43,6 +43,18 @@ extern "C" int pm_gcl_tile_order(const int32_t* trk_cnt_host, int32_t use_classe
   return grid;
 }
 
+// ... and of the uniform row tiles of the chord products: out[2b], out[2b+1] = (first row, rows) of workgroup b, (-1, 0) for one that exits
+extern "C" int pm_row_tile_order(int32_t M, int32_t* out, int32_t cap) {
+  if (M <= 0) return PM_E_INVALID;
+  const int grid = (int)pm_row_grid(M);
+  for (int b = 0; out && b < grid && b < cap; ++b) {
+    int m0 = -1, rows = 0;
+    if (!pm_row_tile(M, b, m0, rows)) { m0 = -1; rows = 0; }
+    out[2 * b] = m0; out[2 * b + 1] = rows;
+  }
+  return grid;
+}
+
 // ---------------------------------------------------------------- exclusive scan (int32, in place)
 #define SCAN_ITEMS 8
 // The four offset arrays of the plan are scanned together: three launches (tile scans of all arrays, their tile sums,

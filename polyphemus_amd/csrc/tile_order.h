@@ -145,3 +145,25 @@ PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, 
   }
   return false;
 }
+
+// Uniform row tiles (the chord products of linear.hip / wide.hip: every 64-row tile costs the same): XCD x takes a
+// contiguous run of tiles.  With 257 .. 264 tiles an XCD that has 33 runs its last tile as two 32-row halves (workgroups
+// 32 and 33 of the XCD: shader engines 0 and 1), which ends the launch after ~1.5 tile times instead of 2.
+inline unsigned pm_row_grid(int M) { return 8u * (unsigned)((((int64_t)M + PM_TILE_ROWS - 1) / PM_TILE_ROWS + 7) / 8 + 1); }
+PM_HD inline bool pm_row_tile(int M, int bid, int& m0, int& rows) {
+  const int ntile = (M + PM_TILE_ROWS - 1) / PM_TILE_ROWS;
+  const int q = ntile >> 3, r = ntile & 7, x = bid & 7, k = bid >> 3;
+  const int c = q + (x < r ? 1 : 0), first = x * q + pm_imin(x, r);
+  const int E = ntile - 8 * PM_CUS_PER_XCD;
+  rows = PM_TILE_ROWS;
+  if (E > 0 && E <= 8 && x < E) {                        // (then q = 32 and c = 33)
+    if (k < c - 1) { m0 = (first + k) * PM_TILE_ROWS; return true; }
+    if (k >= c + 1) return false;
+    rows = PM_TILE_ROWS / 2;
+    m0 = (first + c - 1) * PM_TILE_ROWS + (k - (c - 1)) * (PM_TILE_ROWS / 2);
+    return m0 < M;
+  }
+  if (k >= c) return false;
+  m0 = (first + k) * PM_TILE_ROWS;
+  return true;
+}

@@ -87,14 +87,8 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
       use_nx = m0 < cb[4] && m0 + rows > cb[2];
     }
   } else {
-    const int ntile = (g.M + BM - 1) / BM;
-    int t = blockIdx.x;
-    if (t >= ntile) return;
-    {
-      const int q = ntile >> 3, r = ntile & 7, xcd = t & 7, idx = t >> 3;
-      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    m0 = t * BM; M = g.M;
+    if (!pm_row_tile(g.M, blockIdx.x, m0, rows)) return;       // rows = 64, or 32: half a tile (tile_order.h)
+    M = min(g.M, m0 + rows);
   }
   const int nvalid = min(rows, M - m0);
   const bool full = rows > BM / 2;                             // half tiles: the second 32-row block is not multiplied
@@ -618,7 +612,7 @@ int pm_wide_rows_times_weight(const float* X, int32_t ldx, int32_t N, const uint
   a.M = N; a.x = X; a.ldx = ldx;
   a.wfrag = reinterpret_cast<const char*>(w_frag); a.wp = kind ? w_tiles : d / 16;
   a.npass = Nout / d; a.bias = bias; a.out = C; a.ldo = ldc;
-  const unsigned grid = (unsigned)pm_cdiv(N, BM);
+  const unsigned grid = pm_row_grid(N);
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)d * Nout);
   const size_t lds = wide_lds(V_ROWSW);
   if (wide_npw(4) == 8) { if (kind) launch_wide<V_ROWSW, false, 8, 1>(a, grid, lds, st); else launch_wide<V_ROWSW, false, 8, 0>(a, grid, lds, st); }
@@ -634,7 +628,7 @@ int pm_wide_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int3
   a.M = N; a.x = X; a.ldx = ldx; a.K = K;
   a.wfrag = reinterpret_cast<const char*>(w_frag); a.wp = kind ? d / 32 : w_pitch;
   a.out = C; a.ldo = ldc;
-  const unsigned grid = (unsigned)pm_cdiv(N, BM);
+  const unsigned grid = pm_row_grid(N);
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * d);
   const size_t lds = wide_lds(V_ROWSWK);
   if (wide_npw(4) == 8) { if (kind) launch_wide<V_ROWSWK, false, 8, 1>(a, grid, lds, st); else launch_wide<V_ROWSWK, false, 8, 0>(a, grid, lds, st); }

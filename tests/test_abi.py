@@ -212,3 +212,29 @@ def test_gcl_tile_schedule_absorbs_a_few_tiles_more_than_cus():
             assert not any(rows == 32 for _, _, _, rows in live)
             assert span <= 68.0 + 1e-9
     assert seen_split >= 40
+
+
+def test_uniform_row_tiles_cover_every_row_once():
+    """`pm_row_tile` (chord products: uniform 64-row tiles): every row in exactly one workgroup; with 257..264 tiles an XCD
+    that has 33 runs its last tile as two halves at positions 32 and 33 of its list."""
+    import ctypes
+    L = _lib.lib()
+    for M in (1, 63, 64, 65, 5000, 16271, 16384, 16385, 16417, 16550, 16896, 16897, 20000, 40000):
+        grid = L.pm_row_tile_order(M, None, 0)
+        out = (ctypes.c_int32 * (2 * grid))()
+        assert L.pm_row_tile_order(M, ctypes.cast(out, ctypes.c_void_p), grid) == grid and grid % 8 == 0
+        seen = [0] * M
+        ntile = (M + 63) // 64
+        halves = 0
+        for b in range(grid):
+            m0, rows = out[2 * b], out[2 * b + 1]
+            if rows == 0:
+                continue
+            assert rows in (32, 64) and 0 <= m0 < M
+            halves += rows == 32
+            if rows == 32:
+                assert b // 8 in (32, 33)
+            for r in range(m0, min(M, m0 + rows)):
+                seen[r] += 1
+        assert all(v == 1 for v in seen), M
+        assert (halves > 0) == (256 < ntile <= 264), (M, halves)

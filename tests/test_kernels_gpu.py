@@ -896,7 +896,9 @@ def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
 
 
 @pytest.mark.parametrize("K,Nout,N,kind", [(256, 1280, 16271, 0), (256, 1280, 5000, 1), (128, 384, 77, 0), (128, 256, 64, 1),
-                                           (512, 2560, 16271, 0), (512, 1536, 777, 1), (512, 512, 64, 0)])
+                                           (512, 2560, 16271, 0), (512, 1536, 777, 1), (512, 512, 64, 0),
+                                           # 257 / 259 tiles for 256 CUs: one / three tiles run as 32-row halves (tile_order.h)
+                                           (256, 1280, 16417, 1), (256, 512, 16550, 0), (512, 1024, 16417, 0)])
 def test_rows_times_weight_matches_fp64(K, Nout, N, kind):
     """`pm_rows_times_weight` (A-stationary: the fp32 rows of a 64-row tile split into bf16 planes once, all output columns
     from that LDS image) for both weight orientations: y = x W^T + b (kind 0, W [Nout, K]) and y = x W[:, :Nout] (kind 1,
@@ -922,7 +924,8 @@ def test_rows_times_weight_matches_fp64(K, Nout, N, kind):
 
 
 @pytest.mark.parametrize("K,Nout,N,kind", [(1280, 256, 16271, 0), (1280, 256, 5000, 1), (384, 128, 77, 0), (128, 128, 64, 1),
-                                           (2560, 512, 16271, 0), (1536, 512, 777, 1), (128, 512, 64, 1)])
+                                           (2560, 512, 16271, 0), (1536, 512, 777, 1), (128, 512, 64, 1),
+                                           (1280, 256, 16417, 1), (512, 256, 16550, 0), (1024, 512, 16417, 0)])
 def test_rows_times_weight_longk_matches_fp64(K, Nout, N, kind):
     """`pm_rows_times_weight_longk` (producer waves split 64 x 128 fp32 chunks into bf16 planes in an LDS ring, MFMA waves
     contract them): y = x W[:, :K]^T (kind 0, W [Nout, ldw]) and y = x W (kind 1, W [K, Nout]) against an fp64 product."""

@@ -78,9 +78,11 @@ enum {
   PM_PLAN_NODE_TREL,    /* [N] the track relation (0..3) that has in-edges at the node (see pm_segreduce_fwd) */
   PM_PLAN_TRK_LIST,     /* [4N] nodes grouped by that relation (group t at offset t*N), inside a group sorted by
                            class (receives onset edges, receives next edges) in the order (0,0) (1,0) (1,1) (0,1) */
-  PM_PLAN_TRK_CNT,      /* [32] {4 group sizes, #nodes with in-edges of more than one track relation, 0,0,0,
+  PM_PLAN_TRK_CNT,      /* [32 + 4 W] {4 group sizes, #nodes with in-edges of more than one track relation, 0,0,0,
                            then 5 class boundaries b0..b4 per group at [8 + 5t + k]: rows [b1,b3) of the list
-                           receive onset edges, rows [b2,b4) receive next edges} */
+                           receive onset edges, rows [b2,b4) receive next edges}; from [32] on the tile schedule of
+                           the GCL products, (group, first row, rows, 0) for each of the W workgroups of a launch
+                           (pm_gcl_tile_order gives the same from a host copy of the first 32 ints) */
   PM_PLAN_SCRATCH,      /* cursors + scan partials                                */
   PM_PLAN_NFIELDS
 };

@@ -182,7 +182,7 @@ def plan_layout(N: int, E: int, G: int):
 def gcl_tile_order(trk_cnt, use_classes: bool, N: int):
     """Host-only: [(track group, first row, rows)] in workgroup order of the GCL products (csrc/tile_order.h); rows is 64,
     or 32 for half a tile; (-1, -1, 0) for workgroups that exit.  `trk_cnt`: the 32 ints of the plan's trk_cnt field."""
-    tc = (C.c_int32 * 32)(*[int(v) for v in trk_cnt])
+    tc = (C.c_int32 * 32)(*[int(v) for v in list(trk_cnt)[:32]])
     grid = lib().pm_gcl_tile_order(C.cast(tc, C.c_void_p), int(bool(use_classes)), int(N), None, 0)
     if grid < 0:
         raise HipExtensionError(f"pm_gcl_tile_order failed: {_ERR.get(grid, grid)}")

@@ -93,7 +93,10 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
     g_blocklog[blockIdx.x][3] = -1;
   }
 #endif
-  if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+  if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+#ifdef GCL_BLOCKLOG
+  const long long t_sched = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   const int grp = tl.grp, m0 = tl.m0, rows = tl.rows;        // rows = 64, or 32: half a tile (tile_order.h)
   const bool full = rows > BM / 2;                           // half tiles: the second 32-row block is neither built nor multiplied
   const int M = g.trk_cnt[grp];
@@ -401,7 +404,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     g_blocklog[blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime();
-    g_blocklog[blockIdx.x][3] = (long long)(nblk * 100 + rows);
+    g_blocklog[blockIdx.x][3] = (long long)(nblk * 100 + rows) + 100000 * (t_sched - g_blocklog[blockIdx.x][0]);   // + ticks spent finding the tile
   }
 #endif
 }
@@ -441,7 +444,7 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   int* const sNode = reinterpret_cast<int*>(sC);               // the rows' nodes (until the first block is staged)
 
   PmTile tl;
-  if (!pm_gcl_tile(trk_cnt, use_classes, blockIdx.x, tl)) return;
+  if (!pm_gcl_tile_lookup(trk_cnt, use_classes, blockIdx.x, tl)) return;
   const int grp = tl.grp, m0 = tl.m0, rows = tl.rows;          // rows = 64, or 32: half a tile (tile_order.h)
   const bool full = rows > BM / 2;
   const int M = trk_cnt[grp];

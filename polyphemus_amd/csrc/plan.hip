@@ -15,7 +15,8 @@ void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   sz[PM_PLAN_CSC_DST] = E; sz[PM_PLAN_CSC_RELDIST] = E; sz[PM_PLAN_CSC_EID] = E; sz[PM_PLAN_CSC_INVCNT] = E;
   sz[PM_PLAN_NODE_BAR] = N; sz[PM_PLAN_BAR_PTR] = (int64_t)G + 1; sz[PM_PLAN_GROUP_LIST] = 2 * (int64_t)N;
   sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH; sz[PM_PLAN_ROW_LIST] = 2 * (int64_t)N * PM_N_SLOTS;
-  sz[PM_PLAN_NODE_TREL] = N; sz[PM_PLAN_TRK_LIST] = 4 * (int64_t)N; sz[PM_PLAN_TRK_CNT] = 32;
+  sz[PM_PLAN_NODE_TREL] = N; sz[PM_PLAN_TRK_LIST] = 4 * (int64_t)N;
+  sz[PM_PLAN_TRK_CNT] = 32 + 4 * (int64_t)pm_gcl_grid(N);      // counts and class boundaries, then the tile schedule of the GCL products
   // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums | track flags/positions 4 x [N+1]
   sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64 +
                         4 * ((int64_t)N + 1);
@@ -359,10 +360,10 @@ __device__ static inline void d_class_scan(int* __restrict__ bh, int nblk, int N
     }
   }
 }
-__global__ void __launch_bounds__(CLS_T) k_class_scatter(const int* __restrict__ cls, const int* __restrict__ bh, int N,
-                                                        int* __restrict__ list) {
+__device__ static inline void d_class_scatter(const int* __restrict__ cls, const int* __restrict__ bh, int N,
+                                                        int* __restrict__ list, int bid) {
   __shared__ int wcnt[CLS_T / 64][16];
-  const int n = blockIdx.x * CLS_T + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = bid * CLS_T + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = n < N ? cls[n] : -1;
   int rank = 0;
   for (int k = 0; k < 16; ++k) {                                   // stable rank inside the wave, class by class
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(CLS_T) k_class_scatter(const int* __restrict__
   __syncthreads();
   if (c >= 0) {
     for (int q = 0; q < w; ++q) rank += wcnt[q][c];
-    list[bh[blockIdx.x * 16 + c] + rank] = n;
+    list[bh[bid * 16 + c] + rank] = n;
   }
 }
 
@@ -415,6 +416,18 @@ __global__ void __launch_bounds__(256) k_plan_fill(PlanArgs a) {
   if (b < a.nb_cls) { d_node_class(a.rowptr, a.N, a.node_trel, a.cls, a.bh, a.trk_cnt, b); return; }
   b -= a.nb_cls;
   d_group_list(a.drumpos, a.is_drum, a.N, a.n_slots, a.group_list, a.row_list, a.group_cnt, b);
+}
+// stage 6: the class-sorted track lists, and — the counts and class boundaries are final — the tile schedule of the GCL
+// products (tile_order.h; the kernels look their tile up instead of deriving it: 3 us of scalar code per workgroup)
+__global__ void __launch_bounds__(256) k_plan_scatter(PlanArgs a, int grid_tiles) {
+  int b = blockIdx.x;
+  if (b < a.nb_cls) { d_class_scatter(a.cls, a.bh, a.N, a.trk_list, b); return; }
+  b = (b - a.nb_cls) * 256 + threadIdx.x;
+  if (b >= grid_tiles) return;
+  PmTile tl;
+  int4 e = make_int4(-1, -1, 0, 0);
+  if (pm_gcl_tile(a.trk_cnt, 1, b, tl)) e = make_int4(tl.grp, tl.m0, tl.rows, 0);
+  reinterpret_cast<int4*>(a.trk_cnt + 32)[b] = e;
 }
 __global__ void __launch_bounds__(256) k_plan_finish(PlanArgs a) {
   int b = blockIdx.x;
@@ -499,7 +512,10 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   }
   hipLaunchKernelGGL(k_plan_fill, dim3(a.nb_e + a.nb_cls + a.nb_n), dim3(T), 0, st, a);                   // 4
   hipLaunchKernelGGL(k_plan_finish, dim3(a.nb_seg + a.nb_csc + 1), dim3(T), 0, st, a);                     // 5
-  hipLaunchKernelGGL(k_class_scatter, dim3(a.nb_cls), dim3(CLS_T), 0, st, a.cls, a.bh, N, a.trk_list);    // 6
+  {                                                                                                        // 6
+    const int gt = (int)pm_gcl_grid(N);
+    hipLaunchKernelGGL(k_plan_scatter, dim3(a.nb_cls + (int)pm_cdiv(gt, 256)), dim3(256), 0, st, a, gt);
+  }
   return pm_check_launch();
 }
 

@@ -167,3 +167,14 @@ PM_HD inline bool pm_row_tile(int M, int bid, int& m0, int& rows) {
   m0 = (first + k) * PM_TILE_ROWS;
   return true;
 }
+
+#ifdef __HIPCC__
+// Device side: the plan holds the schedule (plan.hip, stage 6) behind the 32 counters of its trk_cnt field, one
+// (group, first row, rows, 0) per workgroup; without row classes (an A/B switch) the tile is derived here.
+__device__ __forceinline__ bool pm_gcl_tile_lookup(const int* __restrict__ trk_cnt, int use_classes, int bid, PmTile& out) {
+  if (!use_classes) return pm_gcl_tile(trk_cnt, 0, bid, out);
+  const int4 e = reinterpret_cast<const int4*>(trk_cnt + 32)[bid];
+  out.grp = e.x; out.m0 = e.y; out.rows = e.z;
+  return e.x >= 0;
+}
+#endif

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
   bool use_on = true, use_nx = true;
   if constexpr (GCL) {
     PmTile tl;
-    if (!pm_gcl_tile(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+    if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
     grp = tl.grp; m0 = tl.m0; rows = tl.rows;                  // rows = 64, or 32: half a tile (tile_order.h)
     M = g.trk_cnt[grp];
     list = g.trk_list + (int64_t)grp * g.N;

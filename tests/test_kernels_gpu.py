@@ -703,6 +703,15 @@ def test_plan_track_lists_are_class_sorted_and_gemm_skips_zero_blocks():
         for k in range(4):
             want = np.nonzero((trel == t) & (cls == k))[0]
             np.testing.assert_array_equal(lists[t, bnd[k]:bnd[k + 1]], want)
+    # behind the counters: the tile schedule of the GCL products, as csrc/tile_order.h derives it from them (the host copy)
+    from polyphemus_amd._lib import gcl_tile_order
+    for cpu2 in (cpu, synthetic_batch(256, 2, p=0.25, seed=1235)):        # (the second one: 258 tiles, two of them split)
+        _, plan2 = make_plan(cpu2)
+        tc2 = plan2.field("trk_cnt").cpu().numpy()
+        want = gcl_tile_order(tc2[:32], True, cpu2.num_nodes)
+        got = tc2[32:32 + 4 * len(want)].reshape(-1, 4)
+        np.testing.assert_array_equal(got[:, :3], np.array(want))
+        assert len(tc2) == 32 + 4 * len(want)
     # masked contractions == unmasked ones (d = 64: one 64-wide tile per block column; d = 128 also with the weights
     # as fragment-major planes: the B-direct tiles are 128 wide)
     for d, bfrag in ((64, False), (128, False), (128, True)):

@@ -29,7 +29,9 @@ for _ in range(5): ops.gcl_forward_fused(x, T, plan, 0.1, 5, 2, Wf, bias, col_st
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 4096)()
 lib().pm_debug_read_blocklog(buf)
-rows = [(i, buf[4*i], buf[4*i+1], buf[4*i+2], buf[4*i+3]) for i in range(1024) if buf[4*i] and buf[4*i+3] >= 0]
+rows = [(i, buf[4*i], buf[4*i+1], buf[4*i+2], buf[4*i+3] % 100000) for i in range(1024) if buf[4*i] and buf[4*i+3] >= 0]
+sched = [buf[4*i+3] // 100000 for i in range(1024) if buf[4*i] and buf[4*i+3] >= 0]
+print("ticks (10 ns) between workgroup start and its tile being known: min / median / max", min(sched), sorted(sched)[len(sched)//2], max(sched))
 t0 = min(r[1] for r in rows)
 print("seed", seed, "live blocks", len(rows), "span us", (max(r[2] for r in rows) - t0) / 100.0)
 for x8 in range(8):

@@ -633,13 +633,19 @@ typedef struct PmBatch {                                    /* device pointers o
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
 /* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_GCL_NO_CLASSES,
- * PM_GCL_NO_BFRAG, PM_FUSED_CE, PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_DEBUG) are read once, when the library is loaded;
+ * PM_GCL_NO_BFRAG, PM_FUSED_CE, PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_SIDE_STREAM, PM_DEBUG) are read once, when the library is loaded;
  * this re-reads them (host only) so that one process can run one batch through two kernel sets. */
 int pm_vae_step_reload_switches(void);
 int64_t pm_vae_layout_bytes(void);
 int64_t pm_vae_step_state_bytes(void);
 int64_t pm_vae_step_workspace_bytes(const PmVaeLayout* lay, int32_t N, int32_t E, int32_t G, int32_t B,
                                     int32_t n_slots);
+/* Streams: the pm_vae_step_* calls are ordered on `stream` for the caller.  Internally the structure encoder / decoder
+ * (model.py:211-299,434-445,500-505) and the parameter-only preparation (weight planes, distance tables) are issued on one
+ * further non-blocking stream per device, created by the library on first use, between an event recorded on `stream` and an
+ * event `stream` waits for before it reads their results (the structure encoder's backward: forked by
+ * pm_vae_step_backward_encoder, joined by pm_vae_step_backward_encoder_tail).  No host synchronisation; capturable.
+ * PM_SIDE_STREAM=0 keeps every launch on `stream`.  pm_vae_step_forward builds the plan itself (pm_plan_build). */
 int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buffers, float* grads,
                         const PmBatch* batch, int32_t* plan, const float* eps /* [B,d] */, float msg_dropout,
                         uint32_t seed_enc, uint32_t seed_dec, float beta, int structure_loss_on_logits,

@@ -234,8 +234,7 @@ __device__ static inline void sort_segment_wave(int* a, int beg, int end, int* s
 }
 __device__ static inline void d_finish_csr_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ ed,
                                                          int E, int nseg, const int* __restrict__ rowptr, int* csr_eid,
-                                                         int* csr_src, int* csr_dist, int bid) {
-  __shared__ int sk[4][SEGW_MAX];
+                                                         int* csr_src, int* csr_dist, int bid, int (*sk)[SEGW_MAX]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = bid * 4 + wave;
   if (k >= nseg) return;
@@ -247,8 +246,8 @@ __device__ static inline void d_finish_csr_wave(const int64_t* __restrict__ ei, 
 __device__ static inline void d_finish_csc_wave(const int64_t* __restrict__ ei, const int32_t* __restrict__ et,
                                                          const int32_t* __restrict__ ed, int E, int N,
                                                          const int* __restrict__ rowptr, const int* __restrict__ colptr,
-                                                         int* csc_eid, int* csc_dst, int* csc_reldist, float* csc_invcnt, int bid) {
-  __shared__ int sk[4][SEGW_MAX];
+                                                         int* csc_eid, int* csc_dst, int* csc_reldist, float* csc_invcnt, int bid,
+                                                         int (*sk)[SEGW_MAX]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = bid * 4 + wave;
   if (n >= N) return;
@@ -430,15 +429,16 @@ __global__ void __launch_bounds__(256) k_plan_scatter(PlanArgs a, int grid_tiles
   reinterpret_cast<int4*>(a.trk_cnt + 32)[b] = e;
 }
 __global__ void __launch_bounds__(256) k_plan_finish(PlanArgs a) {
+  __shared__ int sk[4][SEGW_MAX];            // key buffer of the wave sorts (one allocation for both: a workgroup runs one of them)
   int b = blockIdx.x;
   if (b < a.nb_seg) {
-    if (a.wave_sort) d_finish_csr_wave(a.ei, a.ed, a.E, a.N * PM_N_REL, a.rowptr, a.csr_eid, a.csr_src, a.csr_dist, b);
+    if (a.wave_sort) d_finish_csr_wave(a.ei, a.ed, a.E, a.N * PM_N_REL, a.rowptr, a.csr_eid, a.csr_src, a.csr_dist, b, sk);
     else d_finish_csr(a.ei, a.ed, a.E, a.N * PM_N_REL, a.rowptr, a.csr_eid, a.csr_src, a.csr_dist, b);
     return;
   }
   b -= a.nb_seg;
   if (b < a.nb_csc) {
-    if (a.wave_sort) d_finish_csc_wave(a.ei, a.et, a.ed, a.E, a.N, a.rowptr, a.colptr, a.csc_eid, a.csc_dst, a.csc_reldist, a.csc_invcnt, b);
+    if (a.wave_sort) d_finish_csc_wave(a.ei, a.et, a.ed, a.E, a.N, a.rowptr, a.colptr, a.csc_eid, a.csc_dst, a.csc_reldist, a.csc_invcnt, b, sk);
     else d_finish_csc(a.ei, a.et, a.ed, a.E, a.N, a.rowptr, a.colptr, a.csc_eid, a.csc_dst, a.csc_reldist, a.csc_invcnt, b);
     return;
   }

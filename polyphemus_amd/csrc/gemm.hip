@@ -981,7 +981,8 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   // Latency-bound small products (the heads: a few dozen tiles, K of 256 or more): the K loop is the critical path, so
   // split it over the otherwise idle CUs.  C is cleared first and accumulated with atomics (bias by slice 0);
   // only for a plainly stored contiguous C (no ReLU / statistics / row map / accumulate).
-  if (!transA && q->split_k == 1 && n_groups == 1 && tiles <= 64 && K >= 256 && ldc_contig(q, N) &&
+  // (a C with a row pitch only when the caller vouches that it is already zero: the clear here is one contiguous memset)
+  if (!transA && q->split_k == 1 && n_groups == 1 && tiles <= 64 && K >= 256 && (ldc_contig(q, N) || (flags & PM_GEMM_ZEROED)) &&
       !(flags & (PM_GEMM_RELU | PM_GEMM_ACCUM | PM_GEMM_RELU_ADD)) && !q->col_stats && !q->rowmap && !planes) {
     split_k = K / 64 < 8 ? K / 64 : 8;
     if (split_k > 1) {

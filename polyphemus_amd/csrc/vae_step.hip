@@ -466,7 +466,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.bn_scratch_side = ar.dbl((size_t)PM_BN_SCRATCH(2 * d > 16 ? 2 * d : 16));
   c.bn_scratch = s.bn_scratch;
   // ---------------- structure encoder (model.py:211-256,434-445)
-  s.zcat = ar.f((size_t)B * 2 * d);
+  s.zcat = ar.zf((size_t)B * 2 * d);                   // (zero region: its two halves are written by split-K products)
   s.c0 = ar.f((size_t)Gn * 8 * 128); s.a0 = ar.f((size_t)Gn * 8 * 128); s.m0 = ar.f(8); s.v0 = ar.f(8);
   s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
   s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.zf((size_t)Gn * d);

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/q
-for m in 15 13 15 13; do PM_SIDE_STREAM=$m python tools/phase_times.py | head -2; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/q/mask13.txt
-for m in 15 13; do PM_SIDE_STREAM=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python tools/benchline.py "mask=$m"; done | tee -a gpurun_out/q/mask13.txt
+python -m pytest tests/test_native_step_gpu.py tests/test_model_gpu.py tests/test_kernels_gpu.py -q -x 2>&1 | tail -2
+for lib in polyphemus_amd/variants/libpm_oldgcl.so ""; do PM_LIB_PATH=$lib python tools/phase_times.py; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/q/ph_heads.txt

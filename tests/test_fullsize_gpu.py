@@ -47,6 +47,7 @@ GRAD_CAPS = {                                            # measured (profiles/r0
     "configs1_lmd2_b256_d256": (4e-2, 1.5e-3),           # 1.32e-2 / 5.1e-4   (fp32 oracle: 5.2e-2 / 3.6e-3)
     "configs2_lmd16_b64_d256": (8e-3, 7e-4),             # 2.6e-3  / 2.3e-4   (5.1e-2 / 2.8e-3)
     "training_json_b256_d512": (2e-2, 1e-3),             # 5.7e-3  / 3.4e-4   (4.3e-2 / 3.0e-3)
+    "configs1_seed1235_258_tiles": (3e-2, 1.7e-3),       # 9.1e-3  / 5.5e-4   (4.0e-2 / 3.0e-3)   [profiles/r03_fullsize_parity_final.jsonl]
     # the dense shard is chaotic at the 1e-3 level: every cell of every bar is active, all bars have the same graph, the
     # aggregates of a bar's nodes are nearly equal and the BatchNorms run over near-constant channels.  Repetitions of
     # the SAME step with the round-1 kernel set differ from each other by up to 1.1e-3 in relative L2 (atomics order);

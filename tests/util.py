@@ -202,6 +202,9 @@ FULLSIZE = {
     "configs4_dense_shard_b8_d512": dict(B=8, nb=2, d=512, L=8, p=1.0, dense=True, msg_p=0.0, seed=1234),
     # the reference's own training configuration (training.json:2-9: batch 256, d = 512, 8 layers, 2 bars)
     "training_json_b256_d512": dict(B=256, nb=2, d=512, L=8, p=0.25, dense=False, msg_p=0.1, seed=1234),
+    # configs[1] with the batch of seed 1235: 258 row tiles for 256 CUs — two tiles of every GCL launch and one of every
+    # chord product run as 32-row halves (csrc/tile_order.h); rank 1's batch of a multi-GPU bench run
+    "configs1_seed1235_258_tiles": dict(B=256, nb=2, d=256, L=8, p=0.25, dense=False, msg_p=0.1, seed=1235),
 }
 # one GPU's shard of configs[4] at its real size (B = 64: N = 16,384 nodes, 2.08 M edges): too large for the oracle's
 # per-edge fp64 tensors — property checks only (tests/test_fullsize_gpu.py)

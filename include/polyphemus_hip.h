@@ -346,6 +346,16 @@ int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, int32_t I, 
               float* dgamma /* += */, float* dbeta /* += */, float* dbias_pre /* NULL or += */, float* dx,
               double* scratch /* [PM_BN_SCRATCH(C)] */, pm_stream_t stream);
 #define PM_BN_SCRATCH(C) (256 * 3 * (C) + 4 * (C))
+/* The same two operations in ONE launch each for small batches (row-major [O, C], O <= PM_BN_SMALL_MAX_ROWS: the norms of
+ * the heads over B rows, model.py:475,638): statistics (+ running statistics) and apply; backward sums and dx.  No scratch. */
+#define PM_BN_SMALL_MAX_ROWS 2048
+int pm_bn_small_fwd(const float* x, int32_t O, int32_t C, float eps, const float* gamma, const float* beta,
+                    const float* residual /* or NULL */, int relu, float* y, float* mean /* [C] out */,
+                    float* var /* [C] biased, out */, float* running_mean /* NULL or [C], updated */, float* running_var,
+                    float momentum, pm_stream_t stream);
+int pm_bn_small_bwd(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var, float eps,
+                    const float* gamma, const float* beta, int relu, float* dgamma /* += */, float* dbeta /* += */,
+                    float* dbias_pre /* NULL or += */, float* dx, pm_stream_t stream);
 /* Split forms for synchronised BatchNorm under data parallelism (the reference is single-device, so its
  * BatchNorm statistics span what is here the GLOBAL batch): the column sums of one rank come out as `sums` [3][C] fp64 —
  * statistics mode (dy == NULL): {sum x, sum x^2, 0}; backward mode: {sum du, sum du*xhat, sum xhat} —, the host adds them

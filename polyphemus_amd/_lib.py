@@ -49,6 +49,8 @@ _SIGS = {
     "pm_gemm_config": "iiii",
     "pm_gemm_force_config": "i",
     "pm_bn_stats": "piiippppfps",
+    "pm_bn_small_fwd": "piifpppipppppfs",
+    "pm_bn_small_bwd": "ppiippfppipppps",
     "pm_bn_apply": "piiippfpppips",
     "pm_bn_partial_sums": "ppiiippfppipps",
     "pm_bn_stats_from_sums": "pDippppfs",

@@ -220,11 +220,21 @@ void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, 
 // training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
 void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
             float* var) {
+  if (I == 1 && O <= PM_BN_SMALL_MAX_ROWS) {            // the heads (O = B rows): one launch
+    RUN(pm_bn_small_fwd(x, O, C, 1e-5f, c.P + bn.w, c.P + bn.b, res, relu ? 1 : 0, y, mean, var, c.Bf + bn.rm, c.Bf + bn.rv,
+                          0.1f, c.st));
+    return;
+  }
   RUN(pm_bn_stats(x, O, C, I, mean, var, c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.bn_scratch, c.st));
   RUN(pm_bn_apply(x, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, res, relu ? 1 : 0, y, c.st));
 }
 void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn bn, const float* mean, const float* var,
             bool relu, float* dx, float* dbias_pre = nullptr) {
+  if (I == 1 && O <= PM_BN_SMALL_MAX_ROWS) {
+    RUN(pm_bn_small_bwd(x, dy, O, C, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, relu ? 1 : 0, c.G + bn.w, c.G + bn.b,
+                          dbias_pre, dx, c.st));
+    return;
+  }
   RUN(pm_bn_bwd(x, dy, O, C, I, mean, var, 1e-5f, c.P + bn.w, c.P + bn.b, relu ? 1 : 0, c.G + bn.w, c.G + bn.b,
                   dbias_pre, dx, c.bn_scratch, c.st));
 }

@@ -374,6 +374,45 @@ def _planes_value(p):
     return f(p[0]) + f(p[1]) + f(p[2])
 
 
+@pytest.mark.parametrize("O,C,relu,res", [(256, 256, True, False), (256, 512, True, True), (37, 24, False, True), (2048, 40, True, False),
+                                          (1, 8, False, False)])
+def test_bn_small_batch_one_launch_per_direction(O, C, relu, res):
+    """`pm_bn_small_fwd / _bwd` (the norms of the heads: statistics + running statistics + apply, and backward sums + dx, in
+    one launch each) against torch's training-mode batch_norm in fp64."""
+    torch.manual_seed(O + C)
+    x = torch.randn(O, C, device=DEV) * 2 + 0.5
+    g, be = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    r = torch.randn_like(x) if res else None
+    y, mean, var = torch.full_like(x, float("nan")), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("pm_bn_small_fwd", ptr(x), O, C, 1e-5, ptr(g), ptr(be), ptr(r), int(relu), ptr(y), ptr(mean), ptr(var), ptr(rm), ptr(rv),
+         0.1, stream())
+    xr = x.double().requires_grad_(True)
+    gr, ber = g.double().requires_grad_(True), be.double().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device=DEV, dtype=torch.float64), torch.ones(C, device=DEV, dtype=torch.float64)
+    if O > 1:
+        yr = F.batch_norm(xr, rm2, rv2, gr, ber, True, 0.1, 1e-5)
+    else:                                  # (torch refuses one row in training mode; the kernel gives var = 0)
+        yr = (xr - xr.mean(0)) * torch.rsqrt(torch.zeros(C, device=DEV, dtype=torch.float64) + 1e-5) * gr + ber
+    if relu:
+        yr = F.relu(yr)
+    if res:
+        yr = yr + r.double()
+    assert rel_err(y, yr.detach()) < 1e-5
+    assert rel_err(mean, x.double().mean(0)) < 1e-6
+    if O > 1:
+        assert rel_err(var, x.double().var(0, unbiased=False)) < 1e-5 and rel_err(rm, rm2) < 1e-5 and rel_err(rv, rv2) < 1e-5
+    dy = torch.randn(O, C, device=DEV)
+    yr.backward(dy.double())
+    dg, db, dbp = torch.ones(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = torch.full_like(x, float("nan"))
+    call("pm_bn_small_bwd", ptr(x), ptr(dy), O, C, ptr(mean), ptr(var), 1e-5, ptr(g), ptr(be), int(relu), ptr(dg), ptr(db),
+         ptr(dbp), ptr(dx), stream())
+    assert rel_err(dx, xr.grad) < 2e-5
+    assert rel_err(dg - 1, gr.grad) < 1e-5 and rel_err(db - 1, ber.grad) < 1e-5          # (+=)
+    assert float(dbp.abs().max()) < 1e-3 * max(1e-30, float(dy.abs().sum(0).max()))
+
+
 @pytest.mark.parametrize("M,K,C", [(1000, 64, 256), (333, 40, 32), (5000, 128, 128)])
 def test_gcl_norm_fused_with_gemm_epilogue(M, K, C):
     """The GCL norm of the native step: column statistics accumulated by the GEMM epilogue (col_stats, replicated

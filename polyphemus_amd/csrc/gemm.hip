@@ -90,6 +90,7 @@ struct TileStage {
   unsigned s[NS > 0 ? NS : 1];
   int base[NE];                                       // tile-invariant byte offset of each element, or PM_OOB
   int krow[NE];                                       // !KC + row map: physical row of the next tile's k (prefetched)
+  int tail[KC && VEC ? NE : 1];                        // KC + VEC: k values left from this float4 on (< 4: the K tail, zeroed in store)
   __amdgpu_buffer_rsrc_t rsrc;
   const int32_t* map;
   int rpe, ld, tid;                                   // tid: index of this thread among the THREADS staging threads
@@ -124,6 +125,7 @@ struct TileStage {
       if (KC) {
         const int k = k0 + (VEC ? (f % (BK / 4)) * 4 : f % BK);
         off = (k < kmax && base[j] >= 0) ? base[j] + k0 * 4 : PM_OOB;
+        if constexpr (VEC) tail[j] = kmax - k;
       } else {
         const int k = k0 + (VEC ? f / (R / 4) : f / R);
         // gathered K rows: the row-map entry of THIS tile was fetched while the previous tile was being
@@ -195,9 +197,10 @@ struct TileStage {
       for (int j = 0; j < NV; ++j) {
         const int f = tid + j * THREADS;
         if (KC) {
-          const int r = f / (BK / 4), k = (f % (BK / 4)) * 4;
-          S[(k + 0) * LD + r] = __uint_as_float(v[j].x); S[(k + 1) * LD + r] = __uint_as_float(v[j].y);
-          S[(k + 2) * LD + r] = __uint_as_float(v[j].z); S[(k + 3) * LD + r] = __uint_as_float(v[j].w);
+          // (K not a multiple of 4: the last float4 of a row reaches past K into the row's next columns — zeroed here)
+          const int r = f / (BK / 4), k = (f % (BK / 4)) * 4, tl = tail[j];
+          S[(k + 0) * LD + r] = __uint_as_float(v[j].x); S[(k + 1) * LD + r] = tl > 1 ? __uint_as_float(v[j].y) : 0.f;
+          S[(k + 2) * LD + r] = tl > 2 ? __uint_as_float(v[j].z) : 0.f; S[(k + 3) * LD + r] = tl > 3 ? __uint_as_float(v[j].w) : 0.f;
         } else {
           const int k = f / (R / 4), r = (f % (R / 4)) * 4;
           *reinterpret_cast<u32x4*>(S + k * LD + r) = v[j];
@@ -922,6 +925,11 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   const bool va = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (q->a_group_stride % 4 == 0);
   const bool vb = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) &&
                   (q->b_group_stride % 4 == 0) && (q->b_shared_off % 4 == 0);
+  // the fp32 tile kernels (configs 0-3) stage with 16-byte loads whenever the rows are 16-byte aligned: an extent that is
+  // not a multiple of 4 makes the last float4 of a row reach into the row's own padding / next columns (lda % 4 == 0: never
+  // past the row) — K tails are zeroed when staged, M / N tails only reach accumulator rows / columns that are not stored
+  const bool va_rows = ((uintptr_t)q->A % 16 == 0) && (q->lda % 4 == 0) && (q->a_group_stride % 4 == 0);
+  const bool vb_rows = ((uintptr_t)q->B % 16 == 0) && (q->ldb % 4 == 0) && (q->b_group_stride % 4 == 0) && (q->b_shared_off % 4 == 0);
   const bool planes = q->operand_planes != 0;
   if (planes) {                              // bf16 planes: 16-byte chunks = 8 elements along the contiguous extent
     if (((uintptr_t)q->A % 16) || ((uintptr_t)q->B % 16) || (q->lda % 8) || (q->ldb % 8) || ((transA ? M : K) % 8) ||
@@ -1001,10 +1009,10 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);
   switch (cfg) {
-    case 0: launch_t<64, 64, 16, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
-    case 1: launch_t<128, 128, 16, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
-    case 2: launch_t<64, 64, 32, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
-    case 3: launch_t<128, 128, 32, 2, 2, 0>(transA, transB, va, vb, grid, st, g); break;
+    case 0: launch_t<64, 64, 16, 2, 2, 0>(transA, transB, va_rows, vb_rows, grid, st, g); break;
+    case 1: launch_t<128, 128, 16, 2, 2, 0>(transA, transB, va_rows, vb_rows, grid, st, g); break;
+    case 2: launch_t<64, 64, 32, 2, 2, 0>(transA, transB, va_rows, vb_rows, grid, st, g); break;
+    case 3: launch_t<128, 128, 32, 2, 2, 0>(transA, transB, va_rows, vb_rows, grid, st, g); break;
     case 4: launch_t<128, 128, 16, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
     case 5: launch_t<128, 64, 16, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;
     case 6: launch_t<64, 64, 32, 2, 2, 1>(transA, transB, va, vb, grid, st, g); break;

@@ -184,6 +184,33 @@ def test_gemm_strided_views_and_rowmap():
     assert rel_err(dW, want) < 5e-6
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,lda,ldb", [
+    (5000, 128, 131, False, False, 232, 128),      # dH = d_logits[:, :131] @ W: K tail inside 16-byte aligned rows
+    (5000, 128, 99, False, False, 232, 128),
+    (131, 128, 5000, True, False, 232, 256),       # dW = d_logits^T H: M tail
+    (99, 128, 3001, True, False, 232, 256),
+    (300, 131, 67, False, True, 68, 68),           # x @ W^T with K = 67 (both operands k-contiguous, K tail in both)
+    (70, 131, 130, False, False, 132, 132),        # N tail of a [K, N] operand
+])
+def test_gemm_aligned_rows_with_ragged_extents(M, N, K, ta, tb, lda, ldb):
+    """fp32 tile kernels: 16-byte staging whenever the ROWS are aligned (leading dimensions multiples of 4), whatever the
+    extents — the float4 that straddles the end of an extent reads the row's next columns (here NaN): a K tail is zeroed
+    when staged, M / N tails reach accumulator rows / columns that are never stored."""
+    torch.manual_seed(M + N + K)
+    A = torch.full((K, lda) if ta else (M, lda), float("nan"), device=DEV)
+    B = torch.full((N, ldb) if tb else (K, ldb), float("nan"), device=DEV)
+    a = torch.randn((K, M) if ta else (M, K), device=DEV)
+    b = torch.randn((N, K) if tb else (K, N), device=DEV)
+    A[:, :a.shape[1]] = a
+    B[:, :b.shape[1]] = b
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    out = torch.full((M, N + 3), 7.0, device=DEV)
+    ops.gemm(A, B, out, M, N, K, lda, ldb, N + 3, transA=ta, transB=tb, **({"accum": True, "split_k": 0} if ta else {}))
+    want = ref + (7.0 if ta else 0.0)
+    assert rel_err(out[:, :N], want) < 5e-6
+    assert bool((out[:, N:] == 7.0).all())
+
+
 @pytest.mark.parametrize("Kr,M,N,ldx", [(512, 256, 512, 0), (16271, 256, 1280, 0), (300, 99, 68, 0), (256, 512, 256, 1024),
                                          (77, 1, 256, 0), (4100, 1280, 256, 0)])
 def test_gemm_weight_gradient_carries_the_bias_gradient(Kr, M, N, ldx):

@@ -222,6 +222,11 @@ int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int32_t K, cons
  * for W [Nout, 16*w_pitch] (y = x W[:, :K]^T), kind 1 for W [K, Nout] (y = x W). */
 int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N, int32_t K, const uint16_t* w_frag, int32_t kind,
                                int32_t w_pitch, int32_t Nout, float* C, int32_t ldc, pm_stream_t stream);
+/* ... and the layer's weight gradient over the same rows: C[M, Nn] += A[:, :M]^T B[:, :Nn] (K rows each; fp32, leading
+ * dimensions multiples of 4, M and Nn multiples of 128), colsum_a (optional) [M] += column sums of A — the bias gradient
+ * when A is the layer's output gradient.  Six-product bf16 chain as the products above; K slices add with float atomics. */
+int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t Nn, int32_t K,
+                           float* C /* += */, int32_t ldc, float* colsum_a /* NULL or += */, pm_stream_t stream);
 /* pm_segreduce_bwd_norm: as pm_segreduce_bwd, and additionally accumulates the three column sums that the backward of
  * the BatchNorm BELOW needs (dx is that norm's output gradient: x_i = x_{i-1} + relu(BN(h_{i-1})), model.py:203-206)
  * into acc3 [PM_BN_REPL][3][d] (caller-zeroed), so that pm_bn_bwd_fused can run with sums_ready = 1. */
@@ -642,7 +647,7 @@ typedef struct PmBatch {                                    /* device pointers o
   const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
-/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_GCL_NO_CLASSES,
+/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_NO_ROWS_TN, PM_GCL_NO_CLASSES,
  * PM_GCL_NO_BFRAG, PM_FUSED_CE, PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_SIDE_STREAM, PM_DEBUG) are read once, when the library is loaded;
  * this re-reads them (host only) so that one process can run one batch through two kernel sets. */
 int pm_vae_step_reload_switches(void);

@@ -41,6 +41,7 @@ _SIGS = {
     "pm_gcl_forward_from_planes": "plpiiiippipps",
     "pm_rows_times_weight": "piiipiiippis",
     "pm_rows_times_weight_longk": "piiipiiipis",
+    "pm_rows_tn_weight_grad": "piipiiipips",
     "pm_segreduce_bwd": "pppppiiiifuuipps",
     "pm_segreduce_bwd_norm": "pppppiiiifuuippps",
     "pm_gemm_f32": "iiiiipipipipiipips",

@@ -352,3 +352,160 @@ extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N
   return pm_check_launch();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of a plain linear layer over the node rows: C[M, Nn] += A[:, a0 : a0 + M]^T B[:, :Nn], K = N rows
+// (chord encoder: dWc = dx0^T X, chord decoder: dWd = dH^T x_L — autograd of model.py:384-390 / 555-559), plus the bias
+// gradient db[M] += column sums of A.  The weight-gradient pipeline of gcl.hip (k_gcl_dw: 128 x 128 output tiles, loader
+// waves + two-stage LDS ring, transposing fragment reads, K slices added with float atomics) with fp32 operands: the
+// loaders split the rows into the three bf16 planes on the way into LDS (every element once per tile that uses it: twice
+// for the long operand), so no planes copy of the [N, S*d] activations is written.  The fp32-MFMA tile kernel it
+// replaces ran at 0.58-0.61 of the fp32 matrix peak (157 TFLOP/s); this one runs the six-product chain on the bf16 pipe.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int K, int ntn, int nsplit,
+          float* __restrict__ C, int ldc, float* __restrict__ colsum_a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntile = gridDim.x / nsplit;
+  // XCD-aware order: the tiles of one K slice share its operand rows -> consecutive slabs on one XCD
+  int L = blockIdx.x;
+  {
+    const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int zs = L / ntile, within = L % ntile, ft = within / ntn, ct = within % ntn;
+  const int kper = (((K + nsplit - 1) / nsplit + DW_KT - 1) / DW_KT) * DW_KT;
+  const int kbeg = zs * kper, kend = min(kbeg + kper, K);
+  if (kbeg >= kend) return;
+  const int nt = (kend - kbeg + DW_KT - 1) / DW_KT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave >= 4) {
+    // ---- loaders: thread -> four consecutive columns (float4) of rows r0, r0 + 8, r0 + 16, r0 + 24 of each tile, both operands
+    const int lt = tid - 256, c4 = lt & 31, r0 = lt >> 5;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, GCL_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, GCL_OOB, 0x00020000);
+    const int acol = (ft * DW_T + c4 * 4) * 4, bcol = (ct * DW_T + c4 * 4) * 4;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);                   // bias gradient: this thread's column sums of A
+    const bool want_cs = colsum_a != nullptr && ct == 0;
+    auto issue = [&](float4 (&v)[4][2], int t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = kbeg + t * DW_KT + r0 + j * 8;
+        const bool ok = t < nt && row < kend;
+        v[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, ok ? (int)((int64_t)row * lda * 4) + acol : GCL_OOB, 0, 0));
+        v[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brs, ok ? (int)((int64_t)row * ldb * 4) + bcol : GCL_OOB, 0, 0));
+      }
+    };
+    auto put = [&](const float4 (&v)[4][2], int t) {
+      char* st = smem + (t & 1) * DW_STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (want_cs) { cs.x += v[j][0].x; cs.y += v[j][0].y; cs.z += v[j][0].z; cs.w += v[j][0].w; }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          unsigned l1, l2, l3, u1, u2, u3;
+          pm_split3_pair(v[j][o].x, v[j][o].y, l1, l2, l3);
+          pm_split3_pair(v[j][o].z, v[j][o].w, u1, u2, u3);
+          const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+          char* dst = st + o * 3 * DW_PLANE + (r0 + j * 8) * DW_PITCH + c4 * 8;
+          *reinterpret_cast<pm_u32x2*>(dst) = p1;
+          *reinterpret_cast<pm_u32x2*>(dst + DW_PLANE) = p2;
+          *reinterpret_cast<pm_u32x2*>(dst + 2 * DW_PLANE) = p3;
+        }
+      }
+    };
+    float4 va[4][2], vb[4][2];
+    issue(va, 0);
+    issue(vb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    put(va, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nt; t += 2) {
+      issue(va, t + 2);                                            // (past the end: out-of-range offsets, zeros, no traffic)
+      __builtin_amdgcn_sched_barrier(0);
+      put(vb, t + 1);                                              // waits for tile t+1 only: tile t+2 stays in flight
+      __syncthreads();
+      if (t + 1 >= nt) break;
+      issue(vb, t + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      put(va, t + 2);
+      __syncthreads();
+    }
+    if (want_cs) {
+      float* dst = colsum_a + ft * DW_T + c4 * 4;
+      atomicAdd(dst, cs.x); atomicAdd(dst + 1, cs.y); atomicAdd(dst + 2, cs.z); atomicAdd(dst + 3, cs.w);
+    }
+    return;
+  }
+  // ---- MFMA waves: 64x64 quarter (wr, wc) of the tile
+  const int li = lane & 31, lh = lane >> 5, wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();                                                 // tile 0 staged
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * DW_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < DW_KT / 16; ++ks) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
+          b[p][i] = dw_frag(st + (3 + p) * DW_PLANE, wc * 64 + i * 32, ks, lane);
+        }
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: one K slice's term of the tile: float atomics
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = ft * DW_T + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* crow = C + (int64_t)row * ldc + ct * DW_T + wc * 64 + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
+    }
+}
+
+extern "C" int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t Nn,
+                                      int32_t K, float* C, int32_t ldc, float* colsum_a, pm_stream_t stream) {
+  if (!A || !B || !C || K <= 0 || M <= 0 || Nn <= 0 || (M % DW_T) || (Nn % DW_T) || lda < M || ldb < Nn || ldc < Nn ||
+      (lda & 3) || (ldb & 3) || ((uintptr_t)A % 16) || ((uintptr_t)B % 16) || (int64_t)K * lda * 4 >= 0x7fffffffLL ||
+      (int64_t)K * ldb * 4 >= 0x7fffffffLL)
+    return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntm = M / DW_T, ntn = Nn / DW_T, ntile = ntm * ntn;
+  // K slices: about one workgroup per CU (the kernel holds one); at least 8 k-tiles per slice
+  static const int target = getenv("PM_ROWS_TN_BLOCKS") ? atoi(getenv("PM_ROWS_TN_BLOCKS")) : 256;
+  int nsplit = (target + ntile - 1) / ntile;
+  const int maxs = (int)pm_cdiv(K, 8 * DW_KT);
+  if (nsplit > maxs) nsplit = maxs;
+  if (nsplit < 1) nsplit = 1;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute((const void*)k_rows_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * K * (double)M * Nn);
+  hipLaunchKernelGGL(k_rows_tn, dim3(ntile * nsplit), dim3(512), 2 * DW_STAGE, st, A, lda, B, ldb, K, ntn, nsplit, C, ldc,
+                     colsum_a);
+  pm_prof_close(st, pe);
+  return pm_check_launch();
+}

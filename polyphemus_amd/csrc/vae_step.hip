@@ -18,7 +18,8 @@ namespace {
 // A/B switches of the step, read ONCE (first use): which kernel set the measured path takes never changes inside a run.
 //   PM_GCL_FUSED=0      the round-1 kernels (segment-reduce forward + grouped planes products, tile kernels for the chord
 //                       products) instead of gcl.hip / linear.hip / wide.hip
-//   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products
+//   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products;
+//                       PM_NO_ROWS_TN=1: only the chord weight gradients back on the fp32 tile GEMM
 //   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
 //   PM_SIDE_STREAM=m    bit mask of the structure-branch sites issued on the library's second stream (default 15 = all;
@@ -26,7 +27,7 @@ namespace {
 //   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
 //                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
 struct StepCfg {
-  bool gcl_fused, no_dw, no_rows_w, no_classes, no_bfrag, fused_ce, debug;
+  bool gcl_fused, no_dw, no_rows_w, no_rows_tn, no_classes, no_bfrag, fused_ce, debug;
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -37,6 +38,7 @@ static StepCfg read_cfg() {
   k.gcl_fused = flag("PM_GCL_FUSED", true);
   k.no_dw = flag("PM_GCL_NO_DW", false);
   k.no_rows_w = flag("PM_NO_ROWS_W", false);
+  k.no_rows_tn = flag("PM_NO_ROWS_TN", false);
   k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
   k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
   k.fused_ce = flag("PM_FUSED_CE", true);
@@ -240,6 +242,10 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
 }
 
 static bool gcl_fused_on() { return cfg().gcl_fused; }
+// chord weight gradients on the bf16 pipe (k_rows_tn of linear.hip: the loaders split fp32 rows on the fly): measured
+// 400 against 449 us per launch at d = 512, but 140 against 117 us at d = 256 — there the loaders' split arithmetic (5.5
+// vector instructions per element, on the SIMDs the MFMA waves run on) costs more than the fp32 matrix pipe loses
+static bool rows_tn_pays(int d) { return !cfg().no_rows_tn && d >= 512 && d % 128 == 0; }
 // widths the kernels of gcl.hip / linear.hip (128, 256) and wide.hip (512) cover
 static bool gcl_width(int d) { return d == 128 || d == 256 || d == 512; }
 // the kernels of gcl.hip / linear.hip address their operands with 32-bit byte offsets: batches beyond these sizes
@@ -675,7 +681,10 @@ void backward_decoder(Ctx& c) {
   float* dxL = ar.f((size_t)N * d);
   if (s.wf_dec_t) {
     // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
-    lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);    // weight and bias gradients
+    if (rows_tn_pays(d))                                            // weight and bias gradients: dW[:S*d] += dH^T x_L (linear.hip)
+      RUN(pm_rows_tn_weight_grad(dH, S * d, S * d, s.dg.x[c.L], d, d, N, c.G + Y.dec_chord.w, d, c.G + Y.dec_chord.b, c.st));
+    else
+      lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);
     RUN(pm_rows_times_weight_longk(dH, S * d, N, S * d, s.wf_dec_t, 1, 0, d, dxL, d, c.st));
   } else
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);        // slots >= S: zero gradient (all PAD)
@@ -749,7 +758,9 @@ void backward_encoder_tail(Ctx& c) {
   float* gsum = ar.f((size_t)2 * d);
   if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
-    {
+    if (s.wf_enc_t && rows_tn_pays(d))                        // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0 (linear.hip)
+      RUN(pm_rows_tn_weight_grad(dx0, d, d, s.X, S * d, S * d, N, c.G + Y.enc_chord.w, PM_N_SLOTS * d, c.G + Y.enc_chord.b, c.st));
+    else {
       PmGemmDesc w;                          // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0
       memset(&w, 0, sizeof(w));
       w.transA = 1; w.M = d; w.N = S * d; w.K = N; w.A = dx0; w.lda = d; w.B = s.X; w.ldb = S * d;

@@ -1023,6 +1023,28 @@ def test_rows_times_weight_longk_matches_fp64(K, Nout, N, kind):
     assert bool((C[:, Nout:] == 7.0).all())
 
 
+@pytest.mark.parametrize("K,M,Nn,lda,ldb,ldc", [(16271, 256, 1280, 256, 1280, 3840), (16271, 1280, 256, 1280, 256, 256),
+                                                (300, 128, 128, 132, 136, 128), (5, 128, 256, 128, 256, 260),
+                                                (16417, 512, 2560, 512, 2560, 7680)])
+def test_rows_tn_weight_grad_matches_fp64(K, M, Nn, lda, ldb, ldc):
+    """`pm_rows_tn_weight_grad` (chord encoder / decoder weight gradients: 128x128 tiles, fp32 rows split into bf16 planes
+    by the loader waves, K slices by atomics): C += A^T B and colsum_a += column sums of A, against fp64; both accumulate;
+    columns of C beyond Nn untouched."""
+    torch.manual_seed(K + M)
+    A = torch.randn(K, lda, device=DEV)
+    B = torch.randn(K, ldb, device=DEV)
+    C0, cs0 = torch.randn(M, ldc, device=DEV), torch.randn(M, device=DEV)
+    C, cs = C0.clone(), cs0.clone()
+    call("pm_rows_tn_weight_grad", ptr(A), lda, M, ptr(B), ldb, Nn, K, ptr(C), ldc, ptr(cs), stream())
+    want = C0[:, :Nn].double() + A[:, :M].double().t() @ B[:, :Nn].double()
+    assert rel_err(C[:, :Nn], want) < 2e-6
+    assert torch.equal(C[:, Nn:], C0[:, Nn:])
+    assert rel_err(cs, cs0.double() + A[:, :M].double().sum(0)) < 5e-6
+    C2 = C0.clone()
+    call("pm_rows_tn_weight_grad", ptr(A), lda, M, ptr(B), ldb, Nn, K, ptr(C2), ldc, None, stream())
+    assert rel_err(C2[:, :Nn], want) < 2e-6
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

@@ -330,7 +330,7 @@ def main():
     tiles = ("64x64x16", "128x128x16", "64x64x32", "128x128x32", "x6:128x128x16", "x6:128x64x16", "x6:64x64x32",
              "x6:128x128x32", "planes:64x64x32", "planesB:64x128x32", "planes:128x128x32")
     lay = ("NN", "NT", "TN")
-    names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(33)] + ["segreduce_fwd", "segreduce_bwd", "gcl_fwd", "gcl_dagg", "gcl_dw", "gemm_NN_rows_w"]
+    names = [f"gemm_{lay[c % 3]}_{tiles[c // 3]}" for c in range(33)] + ["segreduce_fwd", "segreduce_bwd", "gcl_fwd", "gcl_dagg", "gcl_dw", "gemm_NN_rows_w", "gemm_TN_rows_tn"]
     names[9 * 3] = "gemm_NN_planesB:64x128x64"            # (the B-direct forward product takes k-tiles of 64)
 
     def prof_collect():

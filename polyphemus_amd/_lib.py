@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PM_LIB_PATH: development only — load a differently built library (kernel A/B variants of tools/build_variants.py)
 LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "libpolyphemus_hip.so")
 
-PROF_NCLASS = 39        # prof.h: 33 GEMM classes, segreduce_fwd, segreduce_bwd, gcl_fwd, gcl_dagg, gcl_dw, rows_w
+PROF_NCLASS = 40        # prof.h: 33 GEMM classes, segreduce_fwd, segreduce_bwd, gcl_fwd, gcl_dagg, gcl_dw, rows_w, rows_tn
 PLAN_FIELDS = ["rowptr", "csr_src", "csr_dist", "csr_eid", "colptr", "csc_dst", "csc_reldist", "csc_eid",
                "csc_invcnt", "node_bar", "bar_ptr", "group_list", "group_cnt", "tok_hist", "row_list", "node_trel", "trk_list", "trk_cnt", "scratch"]
 

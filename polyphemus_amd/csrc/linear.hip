@@ -503,7 +503,7 @@ extern "C" int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, co
     hipFuncSetAttribute((const void*)k_rows_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * K * (double)M * Nn);
+  const int pe = pm_prof_open(st, PM_PROF_ROWS_TN, 2.0 * K * (double)M * Nn);
   hipLaunchKernelGGL(k_rows_tn, dim3(ntile * nsplit), dim3(512), 2 * DW_STAGE, st, A, lda, B, ldb, K, ntn, nsplit, C, ldc,
                      colsum_a);
   pm_prof_close(st, pe);

@@ -13,7 +13,8 @@ enum {
   PM_PROF_GCL_DAGG = 36,        // input gradient of a GCL layer's product, A-stationary (gcl.hip)
   PM_PROF_GCL_DW = 37,          // weight gradient of a GCL layer's product, 128x128 tiles (gcl.hip)
   PM_PROF_ROWS_W = 38,          // plain linear layer with a short inner dimension, A-stationary (linear.hip k_rows_w)
-  PM_PROF_NCLASS = 39
+  PM_PROF_ROWS_TN = 39,         // weight gradient of a plain linear layer over the node rows (linear.hip k_rows_tn)
+  PM_PROF_NCLASS = 40
 };
 struct PmProfEvent { hipEvent_t a, b; int cls; double work; };
 struct PmProfState {

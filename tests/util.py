@@ -254,7 +254,7 @@ def hip_fullsize_step(spec, dev="cuda", lr=5e-6, keep=None):
     L.pm_prof_end(*(ctypes.cast(a, ctypes.c_void_p) for a in (ms, work, cnt)))
     (s_h, c_h), mu_h, lv_h = tr.step_outputs()
     info = tr.step_info()
-    info["launches"] = {"gcl_fwd": int(cnt[35]), "gcl_dagg": int(cnt[36]), "gcl_dw": int(cnt[37]), "rows_w": int(cnt[38]),
+    info["launches"] = {"gcl_fwd": int(cnt[35]), "gcl_dagg": int(cnt[36]), "gcl_dw": int(cnt[37]), "rows_w": int(cnt[38]), "rows_tn": int(cnt[39]),
                         "planesB_nn": int(cnt[27]), "planesB_nt": int(cnt[28]), "planes_tn": int(cnt[26]),
                         "segreduce_fwd": int(cnt[33]), "segreduce_bwd": int(cnt[34])}
     hip = dict(s_logits=s_h.cpu(), c_logits=c_h.cpu(), mu=mu_h.cpu(), log_var=lv_h.cpu())

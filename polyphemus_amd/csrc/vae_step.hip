@@ -22,7 +22,7 @@ namespace {
 //                       PM_NO_ROWS_TN=1: only the chord weight gradients back on the fp32 tile GEMM
 //   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
-//   PM_SIDE_STREAM=m    bit mask of the structure-branch sites issued on the library's second stream (default 15 = all;
+//   PM_SIDE_STREAM=m    bit mask of the branch sites (BR_* below) issued on the library's second stream (default: all;
 //                       0: everything on the caller's stream)
 //   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
 //                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
@@ -43,7 +43,7 @@ static StepCfg read_cfg() {
   k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
   k.fused_ce = flag("PM_FUSED_CE", true);
   k.debug = getenv("PM_DEBUG") != nullptr;
-  k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 15;
+  k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
@@ -140,7 +140,9 @@ struct Ctx {
 // library therefore owns ONE non-blocking stream per device; a branch is issued there between an event recorded on the
 // caller's stream (fork) and an event the caller's stream waits for (join) — plain stream order for the caller, and
 // capturable.  Norms on the branch use their own reduction scratch.
-enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_SITES };
+// sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
+// structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_SITES };
 struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES]; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
@@ -665,28 +667,37 @@ void backward_decoder(Ctx& c) {
   }
   // ---- content decoder
   float* dH = ar.f((size_t)R * d);
+  // input gradients of the three un-embeddings first (the critical chain: dH -> dxL -> the decoder's layers) ...
+  const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
   RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
                     nullptr, 0, 1, nullptr, 0, nullptr, c.st));
-  RUN(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
-                    nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
-  const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
   for (int g = 0; g < 2; ++g) {
     const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);   // (node, slot) rows of the group
-    const int32_t* cnt = pv.group_cnt + 2 + g;
     RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
-                      1, cnt, c.st));
-    RUN(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
-                      PM_GEMM_ACCUM, 0, lst, 1, cnt, c.st));
+                      1, pv.group_cnt + 2 + g, c.st));
   }
   float* dxL = ar.f((size_t)N * d);
-  if (s.wf_dec_t) {
-    // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
-    if (rows_tn_pays(d))                                            // weight and bias gradients: dW[:S*d] += dH^T x_L (linear.hip)
-      RUN(pm_rows_tn_weight_grad(dH, S * d, S * d, s.dg.x[c.L], d, d, N, c.G + Y.dec_chord.w, d, c.G + Y.dec_chord.b, c.st));
-    else
-      lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);
+  const bool chord_tn = s.wf_dec_t != nullptr;
+  {
+    // ... their weight gradients and the chord decoder's (nobody in this call waits for them) on the second stream
+    BranchScope br(c, BR_DEC_WGRAD);
+    RUN(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
+                      nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
+    for (int g = 0; g < 2; ++g) {
+      const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);
+      RUN(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
+                        PM_GEMM_ACCUM, 0, lst, 1, pv.group_cnt + 2 + g, c.st));
+    }
+    if (chord_tn) {
+      if (rows_tn_pays(d))                                          // dW[:S*d] += dH^T x_L, bias gradient (linear.hip)
+        RUN(pm_rows_tn_weight_grad(dH, S * d, S * d, s.dg.x[c.L], d, d, N, c.G + Y.dec_chord.w, d, c.G + Y.dec_chord.b, c.st));
+      else
+        lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);
+    }
+  }
+  if (chord_tn)     // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
     RUN(pm_rows_times_weight_longk(dH, S * d, N, S * d, s.wf_dec_t, 1, 0, d, dxL, d, c.st));
-  } else
+  else
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);        // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
   float* dcb = ar.f((size_t)Gn * d);
@@ -698,6 +709,7 @@ void backward_decoder(Ctx& c) {
   s.dz = ar.zf((size_t)B * d);
   lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz);
   RUN(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
+  branch_join(c, BR_DEC_WGRAD);                       // (the decoder's gradient bucket is exchanged next)
 }
 
 void backward_encoder(Ctx& c) {
@@ -758,15 +770,18 @@ void backward_encoder_tail(Ctx& c) {
   float* gsum = ar.f((size_t)2 * d);
   if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
-    if (s.wf_enc_t && rows_tn_pays(d))                        // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0 (linear.hip)
-      RUN(pm_rows_tn_weight_grad(dx0, d, d, s.X, S * d, S * d, N, c.G + Y.enc_chord.w, PM_N_SLOTS * d, c.G + Y.enc_chord.b, c.st));
-    else {
-      PmGemmDesc w;                          // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0
-      memset(&w, 0, sizeof(w));
-      w.transA = 1; w.M = d; w.N = S * d; w.K = N; w.A = dx0; w.lda = d; w.B = s.X; w.ldb = S * d;
-      w.C = c.G + Y.enc_chord.w; w.ldc = PM_N_SLOTS * d; w.flags = PM_GEMM_ACCUM; w.split_k = 0; w.n_groups = 1;
-      w.a_colsum = c.G + Y.enc_chord.b;
-      RUN(pm_gemm_f32_desc(&w, c.st));
+    {                                        // (the weight gradient beside the input gradient: second stream, joined below)
+      BranchScope br(c, BR_ENC_WGRAD);
+      if (s.wf_enc_t && rows_tn_pays(d))                      // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0 (linear.hip)
+        RUN(pm_rows_tn_weight_grad(dx0, d, d, s.X, S * d, S * d, N, c.G + Y.enc_chord.w, PM_N_SLOTS * d, c.G + Y.enc_chord.b, c.st));
+      else {
+        PmGemmDesc w;                        // d Wc[:, :S*d] += dx0^T X, d bias += column sums of dx0
+        memset(&w, 0, sizeof(w));
+        w.transA = 1; w.M = d; w.N = S * d; w.K = N; w.A = dx0; w.lda = d; w.B = s.X; w.ldb = S * d;
+        w.C = c.G + Y.enc_chord.w; w.ldc = PM_N_SLOTS * d; w.flags = PM_GEMM_ACCUM; w.split_k = 0; w.n_groups = 1;
+        w.a_colsum = c.G + Y.enc_chord.b;
+        RUN(pm_gemm_f32_desc(&w, c.st));
+      }
     }
     if (s.wf_enc_t) {                                     // dX = dx0 @ Wc[:, :S*d], A-stationary
       RUN(pm_rows_times_weight(dx0, d, N, d, s.wf_enc_t, 1, PM_N_SLOTS * d / 32, S * d, nullptr, dX, S * d, c.st));
@@ -783,6 +798,7 @@ void backward_encoder_tail(Ctx& c) {
                             c.G + Y.enc_pitch_d.b, c.G + Y.enc_pitch_nd.w, c.G + Y.enc_pitch_nd.b, c.G + Y.enc_dur.w,
                             c.G + Y.enc_dur.b, c.G + Y.enc_bn_d.w, c.G + Y.enc_bn_d.b, c.G + Y.enc_bn_nd.w,
                             c.G + Y.enc_bn_nd.b, c.G + Y.enc_bn_dur.w, c.G + Y.enc_bn_dur.b, c.st));
+  branch_join(c, BR_ENC_WGRAD);
   branch_join(c, BR_ENC_BWD);                        // the structure branch issued by backward_encoder
 }
 

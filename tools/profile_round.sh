@@ -37,7 +37,7 @@ pmc() {     # name, workload key, bench args...
 }
 # the bench batch has 256 row tiles = one per CU; seven of the eight seeds 1234..1241 have 257-261
 for sd in 1234 1235 1236 1237; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --seed $sd 2>/dev/null | python tools/benchline.py "seed $sd"; done > "$O/bench_seeds.txt" 2>&1
-for m in 0 15; do PM_SIDE_STREAM=$m python tools/phase_times.py; done > "$O/phase_times.txt" 2>&1
+for m in 0 65535; do PM_SIDE_STREAM=$m python tools/phase_times.py; done > "$O/phase_times.txt" 2>&1
 pmc d256 B256_d256_nb2_L8
 pmc d512 B256_d512_nb2_L8 --d 512
 tail -3 "$O/pytest_gpu.log"; tail -2 "$O/smoke.log"; python tools/benchline.py final < "$O/bench.json"; python tools/benchline.py d512 < "$O/bench_d512.json"; python tools/benchline.py dense < "$O/bench_dense.json"; python tools/benchline.py lmd16 < "$O/bench_lmd16.json"

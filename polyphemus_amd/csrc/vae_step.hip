@@ -585,19 +585,22 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   if (run) {
     lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
     bn_fwd(c, s.zd, B, 2 * d, 1, Y.dec_bn, true, nullptr, s.zr, s.dm, s.dv);
-    {
-      BranchScope br(c, BR_DEC_FWD);                   // joined before the losses
-      lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                    // A = zr[:, :d]
-      lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
-      lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
-      RUN(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
-      bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
-      RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
-    }
     lin(c, s.zr + d, Y.dec_c_bars, B, nb * d, d, s.cb, false, 2 * d, 0);                  // A = zr[:, d:]
     RUN(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
   }
+  // structure decoder: second stream, beside the chord decoder and the un-embedding (beside the decoder's first GCL layers it
+  // cost one k_gcl_fwd launch 22 us for the same step time); joined before the losses
+  auto structure_decoder = [&]() {
+    BranchScope br(c, BR_DEC_FWD);
+    lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                      // A = zr[:, :d]
+    lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
+    lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
+    RUN(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
+    bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
+    RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
+  };
   float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
+  if (run) structure_decoder();
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
   s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);

@@ -3,11 +3,14 @@
 // Reference: one iteration of PolyphemusTrainer.train (training.py:137-166) = VAE.forward
 // (model.py:665-678) + _losses (training.py:298-347) + backward.  The kernel sequence is the one of
 // polyphemus_amd/engine.py (the Python orchestration used by the autograd drop-in path); this file
-// is its native twin for the fused trainer: ~330 launches per step cost ~1 ms of host time here
-// against ~17 ms through Python/ctypes, which was the step's bottleneck once the kernels were fast.
+// is its native twin for the fused trainer: ~230 launches per step cost 2.9 ms of host time here
+// (tools/phase_times.py: ~11 us per launch through the HIP runtime) against 12-13 ms through Python/ctypes,
+// which was the step's bottleneck once the kernels were fast; the GPU needs 5.2 ms.
 //
 // Activations are carved from a caller-provided arena (pure function of the shapes, so the same
-// arena is reused every step and the sequence is hipGraph-capturable).
+// arena is reused every step and the sequence is hipGraph-capturable).  Chains that share nothing with the
+// content path between two points (the structure encoder / decoder, weight preparation, weight gradients
+// nobody waits for) are issued on a second stream between fork / join events (BranchScope below).
 #include "common.h"
 #include <stdio.h>
 #include <string.h>

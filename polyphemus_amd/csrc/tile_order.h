@@ -75,12 +75,15 @@ PM_HD inline bool pm_tile_at(const PmTileRuns& R, int W, int j, int& grp, int& t
 //  * Longest first: the hardware deals workgroup b to XCD b % 8, so XCD x takes, in this order, its contiguous share of
 //    the 4-block tiles, of the 3-block tiles, of the 2-block tiles (contiguous: neighbouring tiles gather neighbouring
 //    bars through one L2).  Tiles beyond one per CU are then the cheapest ones.
-//  * 257 .. 264 tiles: E = tiles - 256 XCDs have one tile more than CUs.  A 2-block tile costs ~0.6 of a 4-block tile
-//    and HALF a 2-block tile (32 rows: half the gathers, half the MFMAs) ~0.4, so an XCD can run 33 tiles in the time of
-//    its 4-block tiles if it has three 2-block tiles: two run whole, the third as two halves that follow them on the same
-//    CUs.  Such an XCD therefore gets three of the 2-block tiles (as long as there are 3 E of them), ends its list with
-//    the two halves, and the rest of the classes is shared out as before.  (bench batch seeds 1235 / 1236 / 1237:
-//    82 / 84 / 83 us per forward launch in plain longest-first order, 66 / 67 / 66 us this way, 256 tiles: 62 us.)
+//  * One to eight tiles more than a whole number of rounds over the chip: E XCDs have a tile too many.
+//    ONE round (257 .. 264 tiles): a 2-block tile costs ~0.6 of a 4-block tile and HALF a 2-block tile (32 rows: half the
+//    gathers, half the MFMAs) ~0.4, so an XCD can run 33 tiles in the time of its 4-block tiles if it has three 2-block
+//    tiles: two run whole, the third as two halves that follow them on the same CUs.  Such an XCD therefore gets three of
+//    the 2-block tiles (as long as there are 3 E of them) and ends its list with the two halves.  (bench batch seeds 1235 /
+//    1236 / 1237: 82 / 84 / 83 us per forward launch in plain longest-first order, 66 / 67 / 66 us this way, 256 tiles: 62 us.)
+//    SEVERAL rounds (LMD16: 512 tiles at seed 1234, 513-516 at the next ones): the extra tile rides on one CU that runs
+//    rounds + 1 two-block tiles while the others run `rounds` tiles.
+//    In both cases the rest of the classes is shared out as before.
 // Everything here is wave-uniform (scalar unit).
 PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, int bid, PmTile& out) {
   PmTileRuns R;
@@ -89,17 +92,19 @@ PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, 
   const int x = bid & 7;
   int k = bid >> 3, grp = 0, t = 0;
   out.rows = PM_TILE_ROWS;
-  const int E = nwg - 8 * PM_CUS_PER_XCD;
-  bool split = use_classes && E > 0 && E <= 8 && n2 >= 3 * E;
+  // nwg = rounds full rounds over the chip + E tiles: E XCDs have one tile more than `rounds` per CU
+  const int rounds = nwg > 0 ? (nwg - 1) / (8 * PM_CUS_PER_XCD) : 0, E = nwg - rounds * 8 * PM_CUS_PER_XCD;
+  const int chain = rounds == 1 ? 3 : rounds + 1;       // 2-block tiles an XCD needs to absorb its extra tile (below)
+  bool split = use_classes && rounds >= 1 && E > 0 && E <= 8 && n2 >= chain * E;
   if (split) {
-    // shares of XCD y: c_y tiles in all; w2: three for an XCD with 33 tiles, the others dealt round starting behind them;
-    // w4: dealt round; w3: what is left
-    const int rem2 = n2 - 3 * E, q2 = rem2 >> 3, r2 = rem2 & 7, q4 = n4 >> 3, r4 = n4 & 7;
+    // shares of XCD y: c_y tiles in all; w2: `chain` for an XCD with a tile more, the others dealt round starting behind
+    // them; w4: dealt round; w3: what is left
+    const int rem2 = n2 - chain * E, q2 = rem2 >> 3, r2 = rem2 & 7, q4 = n4 >> 3, r4 = n4 & 7;
     int s2 = 0, s3 = 0, s4 = 0, w2 = 0, w3 = 0, w4 = 0;
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      const int cy = PM_CUS_PER_XCD + (y < E ? 1 : 0);
-      const int a2 = (y < E ? 3 : 0) + q2 + ((((y - E) & 7) < r2) ? 1 : 0);
+      const int cy = rounds * PM_CUS_PER_XCD + (y < E ? 1 : 0);
+      const int a2 = (y < E ? chain : 0) + q2 + ((((y - E) & 7) < r2) ? 1 : 0);
       const int a4 = q4 + ((((y - E - r2) & 7) < r4) ? 1 : 0);
       const int a3 = cy - a2 - a4;
       if (a3 < 0) split = false;
@@ -107,11 +112,28 @@ PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, 
       if (y == x) { w2 = a2; w3 = a3; w4 = a4; }
     }
     if (split) {
-      const int halves = x < E ? 1 : 0;                  // tiles of this XCD that run as two halves (its last 2-block tile)
-      // An XCD deals its workgroups to its four shader engines in turn (eight CUs each) and in order: workgroups 32 and 33
-      // — the two halves — wait for a CU of engines 0 and 1 (measured: per-workgroup clocks of a -DGCL_BLOCKLOG build,
-      // profiles/LOG.md).  So the 2-block tiles that run whole must sit at positions 28, 29 (engines 0, 1), not at the
-      // very end of the list: the last four positions are rotated.
+      // An XCD deals its workgroups to its four shader engines in turn (eight CUs each) and in order; one that finds its
+      // engine full holds back those behind it (measured: per-workgroup clocks of a -DGCL_BLOCKLOG build, profiles/LOG.md).
+      const int extra = x < E ? 1 : 0, nx = w4 + w3 + w2;
+      if (extra && rounds >= 2) {
+        // Several rounds: the extra tile rides on ONE CU of engine 0 that runs a chain of 2-block tiles — positions 28, 32,
+        // 64, .., 32 rounds of the list (28: engine 0 of round 1; 32 j: the first workgroup handed out in round j + 1, which
+        // waits for engine 0) — rounds + 1 of them cost less than `rounds` tiles of 3.4 blocks on average.  Everything
+        // else keeps the longest-first order.
+        int below = 0, ci = -1;                            // chain positions below k / index of k in the chain
+        if (k == PM_CUS_PER_XCD - 4) ci = 0;
+        if (k > PM_CUS_PER_XCD - 4) ++below;
+#pragma unroll 1
+        for (int j = 1; j <= rounds; ++j) {
+          if (k == j * PM_CUS_PER_XCD) ci = j;
+          if (k > j * PM_CUS_PER_XCD) ++below;
+        }
+        if (k >= nx) return false;
+        k = ci >= 0 ? nx - 1 - ci : k - below;             // the chain: the XCD's lightest tiles (the end of its list)
+      }
+      const int halves = extra && rounds == 1 ? 1 : 0;     // one round: its last 2-block tile runs as two 32-row halves ..
+      // .. behind the two whole 2-block tiles, which therefore sit at positions 28, 29 (engines 0, 1: workgroups 32 and
+      // 33 wait for those engines), not at the very end of the list: the last four positions are rotated
       if (halves && k >= PM_CUS_PER_XCD - 4 && k < PM_CUS_PER_XCD) {
         const int whole2 = pm_imin(4, w2 - halves);
         k = PM_CUS_PER_XCD - 4 + ((k - (PM_CUS_PER_XCD - 4)) + (4 - whole2)) % 4;
@@ -147,16 +169,17 @@ PM_HD inline bool pm_gcl_tile(const int* __restrict__ trk_cnt, int use_classes, 
 }
 
 // Uniform row tiles (the chord products of linear.hip / wide.hip: every 64-row tile costs the same): XCD x takes a
-// contiguous run of tiles.  With 257 .. 264 tiles an XCD that has 33 runs its last tile as two 32-row halves (workgroups
-// 32 and 33 of the XCD: shader engines 0 and 1), which ends the launch after ~1.5 tile times instead of 2.
+// contiguous run of tiles.  With one to eight tiles more than whole rounds over the chip an XCD that has a tile too many
+// runs its last tile as two 32-row halves (the first two workgroups of its next round: shader engines 0 and 1), which ends
+// the launch half a tile time earlier.
 inline unsigned pm_row_grid(int M) { return 8u * (unsigned)((((int64_t)M + PM_TILE_ROWS - 1) / PM_TILE_ROWS + 7) / 8 + 1); }
 PM_HD inline bool pm_row_tile(int M, int bid, int& m0, int& rows) {
   const int ntile = (M + PM_TILE_ROWS - 1) / PM_TILE_ROWS;
   const int q = ntile >> 3, r = ntile & 7, x = bid & 7, k = bid >> 3;
   const int c = q + (x < r ? 1 : 0), first = x * q + pm_imin(x, r);
-  const int E = ntile - 8 * PM_CUS_PER_XCD;
+  const int rounds = ntile > 0 ? (ntile - 1) / (8 * PM_CUS_PER_XCD) : 0, E = ntile - rounds * 8 * PM_CUS_PER_XCD;
   rows = PM_TILE_ROWS;
-  if (E > 0 && E <= 8 && x < E) {                        // (then q = 32 and c = 33)
+  if (rounds >= 1 && E > 0 && E <= 8 && x < E) {          // (then q = 32 rounds and c = q + 1: the last tile as two halves)
     if (k < c - 1) { m0 = (first + k) * PM_TILE_ROWS; return true; }
     if (k >= c + 1) return false;
     rows = PM_TILE_ROWS / 2;

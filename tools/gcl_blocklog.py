@@ -14,7 +14,7 @@ from polyphemus_amd import ops
 from polyphemus_amd._lib import lib
 from polyphemus_amd.synthetic import synthetic_batch
 seed = int(os.environ.get("SEED", 1235)); d = 256
-cpu = synthetic_batch(256, 2, p=0.25, seed=seed); b = cpu.to("cuda")
+cpu = synthetic_batch(int(os.environ.get("B", 256)), int(os.environ.get("NB", 2)), p=0.25, seed=seed); b = cpu.to("cuda")
 plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars, b.s_tensor.shape[0])
 N = cpu.num_nodes
 torch.manual_seed(0)
@@ -45,4 +45,4 @@ for r in rows: byk[r[4]].append((r[2]-r[1])/100.0)
 for k in sorted(byk): print("  kind (nblk*100+rows)", k, "n", len(byk[k]), "dur min/avg/max", round(min(byk[k]),1), round(sum(byk[k])/len(byk[k]),1), round(max(byk[k]),1))
 print("XCD 0 blocks (k, kind, start, end):")
 rs = sorted([r for r in rows if r[0] % 8 == 0], key=lambda r: r[0])
-print([(r[0] // 8, r[4], round((r[1]-t0)/100,1), round((r[2]-t0)/100,1)) for r in rs[20:]])
+print([(r[0] // 8, r[4], round((r[1]-t0)/100,1), round((r[2]-t0)/100,1)) for r in rs[int(os.environ.get("FROM", 20)):]])

@@ -431,11 +431,12 @@ extern "C" int pm_debug_read_trace(long long* out) {
 // The output never leaves through the MFMA waves: vmcnt retires in order, so 64 row-segment stores in front of the next
 // block's weight-fragment loads would put the write latency into every block.  Waves 4..7 take each finished block
 // from an LDS stage (64 x d fp32) and store it as whole 4*d-byte rows.
-template <int D>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int D, int NMW>
+__global__ void __launch_bounds__((NMW + 4) * 64) __attribute__((amdgpu_waves_per_eu((NMW + 4) / 4, (NMW + 4) / 4)))
 k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_list, const int* __restrict__ trk_cnt,
            const char* __restrict__ wfrag, float* __restrict__ dA, int N, int use_classes) {
-  constexpr int TN = D / 128;            // 32-column MFMA tiles per wave (its D/4 columns of a block)
+  constexpr int TN = D / (NMW * 32);     // 32-column MFMA tiles per MFMA wave (its D / NMW columns of a block)
+  constexpr int NMT = NMW * 64;          // MFMA threads
   constexpr int KS = D / 16;             // k-steps
   constexpr int RB = D * 2;              // bytes of one image row (one plane)
   constexpr int PL = BM * RB;            // one plane of the image
@@ -464,10 +465,10 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
   __syncthreads();
   STAMP2();
-  if (wave >= 4) {
+  if (wave >= NMW) {
     // ---- store waves: block q of the stage -> dA rows (one 16-byte piece per lane: a whole 4*D-byte row per D/4 lanes)
     constexpr int LPR = D / 4, RPW = 64 / LPR, NR = BM / (4 * RPW);     // lanes per row, rows per wave-instruction, per thread
-    const int st = tid - 256, c4 = st % LPR, r0 = st / LPR;
+    const int st = tid - NMT, c4 = st % LPR, r0 = st / LPR;
     int node[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) node[k] = sNode[r0 + k * 4 * RPW];
@@ -492,18 +493,18 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   // ---- the rows' dh planes -> XOR-swizzled LDS image (16-byte chunk c of row r at chunk c ^ (r & 15))
   {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
-    constexpr int CPR = D / 8, NCHK = BM * CPR / 256;            // chunks per row, chunks per thread and plane
+    constexpr int CPR = D / 8, NCHK = BM * CPR / NMT;            // chunks per row, chunks per thread and plane
     u32x4 v[3][NCHK];
 #pragma unroll
     for (int k = 0; k < NCHK; ++k) {
-      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR, n = sNode[rr];
+      const int ci = tid + k * NMT, rr = ci / CPR, ch = ci % CPR, n = sNode[rr];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         v[p][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NCHK; ++k) {
-      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR;
+      const int ci = tid + k * NMT, rr = ci / CPR, ch = ci % CPR;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         *reinterpret_cast<u32x4*>(smem + p * PL + rr * RB + ((ch ^ (rr & 15)) << 4)) = v[p][k];
@@ -514,7 +515,7 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global step gs = block index * KS + k-step
     const int qb = min(gs / KS, nblk - 1), ks = gs % KS;
     const int blk = blk_of(qb);
-    const int wrow = (blk == 0 ? grp * D : (3 + blk) * D) + wave * (D / 4);     // first stacked weight row of this wave's columns
+    const int wrow = (blk == 0 ? grp * D : (3 + blk) * D) + wave * (D / NMW);   // first stacked weight row of this wave's columns
     const int soff = __builtin_amdgcn_readfirstlane(((wrow >> 5) * KS + ks) * 3072);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -576,7 +577,7 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
       for (int r = 0; r < 16; ++r)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / 4) + j * 32 + li] = acc[i][j][r];
+          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / NMW) + j * 32 + li] = acc[i][j][r];
     STAMP2();
     __syncthreads();
   }
@@ -596,20 +597,24 @@ extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_
     return pm_wide_gcl_input_grad(dh_planes, plane_stride, plan, N, E, G, w_frag_t, use_classes, dA, (hipStream_t)stream);
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(pm_gcl_grid(N)), block(512);
+  // MFMA waves per workgroup (+ four store waves): eight at d = 256 (two per SIMD: one wave's fragment waits are covered by
+  // its partner's MFMAs, as in wide.hip); A/B: PM_GCL_DAGG_WAVES
+  static const int nmw_env = getenv("PM_GCL_DAGG_WAVES") ? atoi(getenv("PM_GCL_DAGG_WAVES")) : 0;
+  const int nmw = (d == 256 && nmw_env != 4) ? 8 : 4;
+  const dim3 grid(pm_gcl_grid(N)), block((nmw + 4) * 64);
   const size_t lds = (size_t)3 * BM * d * 2 + (size_t)BM * d * 4;
   const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
-#define LAUNCH(DD)                                                                                                     \
+#define LAUNCH(DD, NW)                                                                                                 \
   do {                                                                                                                 \
     static bool once = false;                                                                                          \
     if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_gcl_dagg<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+      hipFuncSetAttribute((const void*)k_gcl_dagg<DD, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_gcl_dagg<DD>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt,       \
+    hipLaunchKernelGGL((k_gcl_dagg<DD, NW>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt,   \
                        reinterpret_cast<const char*>(w_frag_t), dA, N, use_classes);                                   \
   } while (0)
-  if (d == 256) LAUNCH(256); else LAUNCH(128);
+  if (d == 256) { if (nmw == 8) LAUNCH(256, 8); else LAUNCH(256, 4); } else LAUNCH(128, 4);
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();

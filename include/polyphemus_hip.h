@@ -551,6 +551,15 @@ int pm_unembed_ce(const float* H, const float* w_pitch_drum /* [131,d/2] */, con
                   float grad_scale, const float* dev_scale, float* logits /* or NULL */, float* d_logits,
                   float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes /* or NULL */,
                   pm_stream_t stream);
+/* Input gradient of the three un-embeddings (autograd of model.py:561-567) in one launch: dH[rows, :d/2] = d_logits[rows,
+ * :131] @ W_pitch (drum / non-drum row lists of the plan), dH[:, d/2:] = d_logits[:, 131:] @ W_dur; d_logits [N,S,230] as
+ * pm_unembed_ce leaves it, dH [N,S,d].  Six-product bf16 chain (fp32-exact products); d/2 in {64, 128, 256}.
+ * `w_planes`: scratch of pm_unembed_dh_scratch_bytes(d) bytes; a call with prepare != 0 fills it from the weights (needed
+ * once per parameter update), a call with prepare == 0 runs the product. */
+int64_t pm_unembed_dh_scratch_bytes(int32_t d);
+int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum /* [131,d/2] */, const float* w_pitch_nd,
+                  const float* w_dur /* [99,d/2] */, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                  int32_t n_slots, float* dH, uint16_t* w_planes, int32_t prepare, pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
            float* dlog_var, double* out, pm_stream_t stream);
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,
@@ -647,7 +656,7 @@ typedef struct PmBatch {                                    /* device pointers o
   const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
-/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_NO_ROWS_TN, PM_GCL_NO_CLASSES,
+/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_NO_ROWS_TN, PM_NO_UNEMBED_DH, PM_GCL_NO_CLASSES,
  * PM_GCL_NO_BFRAG, PM_FUSED_CE, PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_SIDE_STREAM, PM_DEBUG) are read once, when the library is loaded;
  * this re-reads them (host only) so that one process can run one batch through two kernel sets. */
 int pm_vae_step_reload_switches(void);

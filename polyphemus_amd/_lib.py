@@ -94,6 +94,8 @@ _SIGS = {
     "pm_content_ce": "ppppiifppppps",
     "pm_content_ce_scaled": "ppppiifpppppps",
     "pm_unembed_ce": "pppppppppiiiiifpppppppps",
+    "pm_unembed_dh": "pppppiiiiippis",
+    "pm_unembed_dh_scratch_bytes": "i",
     "pm_unembed_scratch_bytes": "i",
     "pm_kld": "ppiifppps",
     "pm_bce_logits": "pplfpps",
@@ -117,7 +119,8 @@ _SIGS = {
     "pm_vae_step_reload_switches": "",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
-_RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes"}
+_RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
+          "pm_unembed_dh_scratch_bytes"}
 ABI_VERSION = 4          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])

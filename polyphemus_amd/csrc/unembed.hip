@@ -20,6 +20,7 @@
 // 195-220 us per launch at configs[1] against 97 us (three products) + 62 us (k_content_ce) of the unfused path, which
 // is why round 2 left the fusion off by default.
 #include "gcl_tiles.h"
+#include <string.h>
 
 namespace {
 constexpr int UBM = 64, UBK = 32, UNB = 5;             // rows per tile, k per stage, 32-column blocks of the widest job
@@ -551,5 +552,180 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
   hipMemsetAsync(out, 0, 2 * sizeof(double), st);
   if (nb > 768) nb = 768;                              // persistent: ~3 resident workgroups per CU and job
   hipLaunchKernelGGL(k_unembed_ce, dim3(nb, 3), dim3(256), 0, st, a);
+  return pm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input gradient of the three un-embeddings in ONE launch: dH[rows_j, koff_j : koff_j + d/2] = d_logits[rows_j, block_j] @ W_j
+// (autograd of model.py:561-567; j = pitch of the drum rows, pitch of the other rows, duration of all rows).  The fp32
+// tile GEMMs it replaces (three launches over 81 k rows with K = 131 / 99: nine k-tiles per 64x64 tile, prologue- and
+// epilogue-bound: 94 us at configs[1]) stage 4-byte pieces; here a workgroup takes 64 rows of a job's row list, splits their
+// d_logits block into three bf16 planes in LDS once and contracts it with the weight as fragment-major planes straight from
+// L2 (k = vocabulary index, zero-padded to a multiple of 16), DH / 32 MFMA waves of 32 columns each.
+namespace {
+constexpr int DHK = 144;                               // k extent of the image: the pitch vocabulary (131) padded to 16
+constexpr int DHP = DHK * 2 + 16;                      // bytes per image row (one plane): 304
+struct UnembedDhArgs {
+  UnembedJob job[3];                                   // W / rowmap / dyn_rows / V / koff / coff as in the forward
+  const float* dlogits; float* dH; const char* wplanes; int woff[3];
+  int R, d, dh;
+};
+}  // namespace
+// weight planes for k_unembed_dh: job j's W [V, dh] as kind-1 fragment blocks [k-step][32-column tile] (pm_split_planes_frag
+// layout), rows k >= V zero
+__global__ void __launch_bounds__(256) k_unembed_dh_wplanes(UnembedDhArgs a, uint16_t* __restrict__ out) {
+  const UnembedJob jb = a.job[blockIdx.y];
+  uint16_t* dst = out + a.woff[blockIdx.y] / 2;
+  const int ks_n = (jb.V + 15) >> 4, chunks = ks_n * 2 * a.dh;   // 8 consecutive k of one column
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
+    const int n = c % a.dh, k0 = (c / a.dh) * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = k0 + e < jb.V ? jb.W[(int64_t)(k0 + e) * a.dh + n] : 0.f;
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
+    const int blk = (k0 >> 4) * (a.dh / 32) + (n >> 5), lane = ((k0 >> 3) & 1) * 32 + (n & 31);
+    uint16_t* o = dst + (int64_t)blk * 1536 + lane * 8;
+    *reinterpret_cast<u32x4*>(o) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(o + 512) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    *reinterpret_cast<u32x4*>(o + 1024) = u32x4{p3[0], p3[1], p3[2], p3[3]};
+  }
+}
+template <int DH>
+__global__ void __launch_bounds__(DH * 2) k_unembed_dh(UnembedDhArgs a) {
+  constexpr int NW = DH / 32, NTHR = NW * 64;          // MFMA waves = 32-column tiles of the output; all waves also stage
+  __shared__ __attribute__((aligned(16))) char img[3 * UBM * DHP];
+  __shared__ int s_row[UBM];
+  const UnembedJob jb = a.job[blockIdx.y];
+  const char* const wf = a.wplanes + a.woff[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int M = jb.dyn_rows ? *jb.dyn_rows : a.R;
+  const int ks_n = (jb.V + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wf), 0, GCL_OOB, 0x00020000);
+  // columns [V, 16 ks_n) of the image stay zero for the whole kernel
+  for (int i = tid; i < 3 * UBM * 16; i += NTHR) {
+    const int p = i / (UBM * 16), r = (i / 16) % UBM, c = jb.V + (i & 15);
+    if (c < ks_n * 16) *reinterpret_cast<uint16_t*>(img + (p * UBM + r) * DHP + c * 2) = 0;
+  }
+  for (int m0 = blockIdx.x * UBM; m0 < M; m0 += gridDim.x * UBM) {
+    if (tid < UBM) {
+      const int r = m0 + tid;
+      s_row[tid] = r < M ? (jb.rowmap ? jb.rowmap[r] : r) : -1;
+    }
+    __syncthreads();
+    // ---- the rows' d_logits block -> three bf16 planes; a wave takes rows wave, wave + NW, ..: lanes over the columns
+    for (int r0 = wave; r0 < UBM; r0 += 4 * NW) {
+      float v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * NW, rg = r < UBM ? s_row[r] : -1;
+        const float* src = a.dlogits + (int64_t)(rg < 0 ? 0 : rg) * PM_N_TOK + jb.coff;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int c = lane + 64 * q;
+          v[u][q] = (rg >= 0 && c < jb.V) ? src[c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * NW;
+        if (r >= UBM) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int c = lane + 64 * q;
+          if (c >= jb.V) continue;
+          unsigned h1, h2, h3;
+          pm_split3_pair(v[u][q], 0.f, h1, h2, h3);
+          char* dst = img + r * DHP + c * 2;
+          *reinterpret_cast<uint16_t*>(dst) = (uint16_t)h1;
+          *reinterpret_cast<uint16_t*>(dst + UBM * DHP) = (uint16_t)h2;
+          *reinterpret_cast<uint16_t*>(dst + 2 * UBM * DHP) = (uint16_t)h3;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- products: this wave's 32 output columns for all 64 rows
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // weight fragments two k-steps ahead (past the last step: the last block again, never used)
+    auto bload = [&](bf16x8 (&dst)[3], int ks) {
+      const int soff = __builtin_amdgcn_readfirstlane(((ks < ks_n ? ks : ks_n - 1) * NW + wave) * 3072);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + p * 1024, 0));
+    };
+    bf16x8 bq[2][3];
+    bload(bq[0], 0);
+    bload(bq[1], 1);
+#pragma unroll
+    for (int ks = 0; ks < DHK / 16; ++ks) {
+      if (ks < ks_n) {                                           // (wave-uniform; the duration job has 7 of the 9 steps)
+        bf16x8 av[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            av[p][i] = *reinterpret_cast<const bf16x8*>(img + (p * UBM + i * 32 + li) * DHP + (ks * 16 + lh * 8) * 2);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[t6]][i], bq[ks & 1][PB[t6]], acc[i], 0, 0, 0);
+        bload(bq[ks & 1], ks + 2);
+      }
+    }
+    // ---- dH rows: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rg = s_row[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        if (rg >= 0) a.dH[(int64_t)rg * a.d + jb.koff + wave * 32 + li] = acc[i][r];
+      }
+    __syncthreads();                                             // the image and the row list are rewritten by the next tile
+  }
+}
+
+// scratch of pm_unembed_dh at width d: the three weights as kind-1 fragment planes (9 + 9 + 7 k-steps of d/2 columns)
+extern "C" int64_t pm_unembed_dh_scratch_bytes(int32_t d) { return (int64_t)(9 + 9 + 7) * (d / 2 / 32) * 3072; }
+// `prepare` != 0: only the weight planes (parameters only: the step issues it with its other weight preparation);
+// 0: the product (the planes must be current)
+extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
+                             const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
+                             uint16_t* w_planes, int32_t prepare, pm_stream_t stream) {
+  if (!w_pitch_drum || !w_pitch_nd || !w_dur || !w_planes || N <= 0 || d <= 0 || n_slots < 1 || n_slots > PM_N_SLOTS ||
+      ((uintptr_t)w_planes % 16))
+    return PM_E_INVALID;
+  const int dh = d / 2;
+  if (dh != 64 && dh != 128 && dh != 256) return PM_E_UNSUPPORTED;
+  if (!prepare && (!d_logits || !dH || !plan)) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  UnembedDhArgs a;
+  memset(&a, 0, sizeof(a));
+  a.job[0].W = w_pitch_drum; a.job[0].V = PM_N_PITCH;
+  a.job[1].W = w_pitch_nd; a.job[1].V = PM_N_PITCH;
+  a.job[2].W = w_dur; a.job[2].V = PM_N_DUR; a.job[2].koff = dh; a.job[2].coff = PM_N_PITCH;
+  a.woff[0] = 0; a.woff[1] = 9 * (dh / 32) * 3072; a.woff[2] = 18 * (dh / 32) * 3072;
+  a.dh = dh; a.d = d;
+  if (prepare) {
+    hipLaunchKernelGGL(k_unembed_dh_wplanes, dim3(8, 3), dim3(256), 0, st, a, w_planes);
+    return pm_check_launch();
+  }
+  const int64_t R = (int64_t)N * n_slots;
+  if (R * PM_N_TOK >= ((int64_t)1 << 31) || R * (int64_t)d >= ((int64_t)1 << 31)) return PM_E_UNSUPPORTED;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  a.job[0].rowmap = pv.row_list; a.job[0].dyn_rows = pv.group_cnt + 2;
+  a.job[1].rowmap = pv.row_list + (int64_t)N * PM_N_SLOTS; a.job[1].dyn_rows = pv.group_cnt + 3;
+  a.dlogits = d_logits; a.dH = dH; a.wplanes = reinterpret_cast<const char*>(w_planes); a.R = (int)R;
+  int nb = (int)pm_cdiv(R, UBM);
+  if (nb > 512) nb = 512;
+  if (dh == 256) hipLaunchKernelGGL(k_unembed_dh<256>, dim3(nb, 3), dim3(512), 0, st, a);
+  else if (dh == 128) hipLaunchKernelGGL(k_unembed_dh<128>, dim3(nb, 3), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_unembed_dh<64>, dim3(nb, 3), dim3(128), 0, st, a);
   return pm_check_launch();
 }

@@ -22,7 +22,8 @@ namespace {
 //   PM_GCL_FUSED=0      the round-1 kernels (segment-reduce forward + grouped planes products, tile kernels for the chord
 //                       products) instead of gcl.hip / linear.hip / wide.hip
 //   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products;
-//                       PM_NO_ROWS_TN=1: only the chord weight gradients back on the fp32 tile GEMM
+//                       PM_NO_ROWS_TN=1: only the chord weight gradients back on the fp32 tile GEMM;
+//                       PM_NO_UNEMBED_DH=1: the un-embedding's input gradient as three fp32 tile GEMMs
 //   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
 //   PM_SIDE_STREAM=m    bit mask of the branch sites (BR_* below) issued on the library's second stream (default: all;
@@ -30,7 +31,7 @@ namespace {
 //   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
 //                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
 struct StepCfg {
-  bool gcl_fused, no_dw, no_rows_w, no_rows_tn, no_classes, no_bfrag, fused_ce, debug;
+  bool gcl_fused, no_dw, no_rows_w, no_rows_tn, no_unembed_dh, no_classes, no_bfrag, fused_ce, debug;
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -42,6 +43,7 @@ static StepCfg read_cfg() {
   k.no_dw = flag("PM_GCL_NO_DW", false);
   k.no_rows_w = flag("PM_NO_ROWS_W", false);
   k.no_rows_tn = flag("PM_NO_ROWS_TN", false);
+  k.no_unembed_dh = flag("PM_NO_UNEMBED_DH", false);
   k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
   k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
   k.fused_ce = flag("PM_FUSED_CE", true);
@@ -110,7 +112,7 @@ struct StepState {
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
-  uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
+  uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t, *w_unembed_dh;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
   float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
   int rc;
   unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
@@ -516,6 +518,13 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
         RUN(pm_split_planes_frag(c.P + Y.dec_chord.w, S * d, d, kind, 1, (int64_t)S * d * d, (int64_t)S * d * d * 3,
                                    kind ? s.wf_dec_t : s.wf_dec, c.st));
     }
+    // the three un-embedding weights as k-major fragment planes for the input gradient of the backward (unembed.hip)
+    s.w_unembed_dh = nullptr;
+    if (cfg().fused_ce && !cfg().no_unembed_dh && (dh == 64 || dh == 128 || dh == 256)) {
+      s.w_unembed_dh = (uint16_t*)ar.take((size_t)pm_unembed_dh_scratch_bytes(d));
+      RUN(pm_unembed_dh(nullptr, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, nullptr, N, c.E, Gn, d, S,
+                          nullptr, s.w_unembed_dh, 1, c.st));
+    }
     br.mark(BR_WPREP);
     if (run) {
     RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
@@ -675,12 +684,17 @@ void backward_decoder(Ctx& c) {
   float* dH = ar.f((size_t)R * d);
   // input gradients of the three un-embeddings first (the critical chain: dH -> dxL -> the decoder's layers) ...
   const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
-  RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
-                    nullptr, 0, 1, nullptr, 0, nullptr, c.st));
-  for (int g = 0; g < 2; ++g) {
-    const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);   // (node, slot) rows of the group
-    RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
-                      1, pv.group_cnt + 2 + g, c.st));
+  if (s.w_unembed_dh)                                   // one launch on the bf16 pipe (unembed.hip)
+    RUN(pm_unembed_dh(s.dc_logits, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, s.plan, N, c.E, Gn, d, S,
+                        dH, s.w_unembed_dh, 0, c.st));
+  else {
+    RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_DUR, s.dc_logits + PM_N_PITCH, PM_N_TOK, c.P + Y.dec_dur.w, dh, dH + dh, d,
+                      nullptr, 0, 1, nullptr, 0, nullptr, c.st));
+    for (int g = 0; g < 2; ++g) {
+      const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);   // (node, slot) rows of the group
+      RUN(pm_gemm_f32(0, 0, (int)R, dh, PM_N_PITCH, s.dc_logits, PM_N_TOK, c.P + pit[g].w, dh, dH, d, nullptr, 0, 1, lst,
+                        1, pv.group_cnt + 2 + g, c.st));
+    }
   }
   float* dxL = ar.f((size_t)N * d);
   const bool chord_tn = s.wf_dec_t != nullptr;

@@ -1045,6 +1045,33 @@ def test_rows_tn_weight_grad_matches_fp64(K, M, Nn, lda, ldb, ldc):
     assert rel_err(C2[:, :Nn], want) < 2e-6
 
 
+@pytest.mark.parametrize("d,B,S", [(256, 40, 5), (128, 3, 15), (512, 24, 4), (256, 1, 7)])
+def test_unembed_input_gradient_in_one_launch(d, B, S):
+    """`pm_unembed_dh`: dH = d_logits @ W of the three un-embeddings (pitch per drum / non-drum row list, duration on all
+    rows) in one launch on the bf16 pipe, against the fp64 products; every (node, slot) row written exactly once."""
+    import ctypes
+    cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=29)
+    b = cpu.to(DEV)
+    plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars,
+                          b.s_tensor.shape[0], n_slots=S)
+    N, dh = cpu.num_nodes, d // 2
+    torch.manual_seed(d + B)
+    dl = torch.randn(N, S, 230, device=DEV)
+    Wd, Wn, Wu = (torch.randn(131, dh, device=DEV) / 11, torch.randn(131, dh, device=DEV) / 11, torch.randn(99, dh, device=DEV) / 10)
+    scratch = torch.empty(int(lib().pm_unembed_dh_scratch_bytes(d)), dtype=torch.uint8, device=DEV)
+    dH = torch.full((N, S, d), float("nan"), device=DEV)
+    for prep in (1, 0):
+        call("pm_unembed_dh", ptr(dl), ptr(Wd), ptr(Wn), ptr(Wu), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(dH), ptr(scratch),
+             prep, stream())
+    drum = b.is_drum.bool()
+    want = torch.empty(N, S, d, dtype=torch.float64, device=DEV)
+    want[drum, :, :dh] = dl[drum][:, :, :131].double() @ Wd.double()
+    want[~drum, :, :dh] = dl[~drum][:, :, :131].double() @ Wn.double()
+    want[:, :, dh:] = dl[:, :, 131:].double() @ Wu.double()
+    assert bool(torch.isfinite(dH).all())
+    assert rel_err(dH, want) < 2e-6
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

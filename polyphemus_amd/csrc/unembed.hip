@@ -559,29 +559,51 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
 // Input gradient of the three un-embeddings in ONE launch: dH[rows_j, koff_j : koff_j + d/2] = d_logits[rows_j, block_j] @ W_j
 // (autograd of model.py:561-567; j = pitch of the drum rows, pitch of the other rows, duration of all rows).  The fp32
 // tile GEMMs it replaces (three launches over 81 k rows with K = 131 / 99: nine k-tiles per 64x64 tile, prologue- and
-// epilogue-bound: 94 us at configs[1]) stage 4-byte pieces; here a workgroup takes 64 rows of a job's row list, splits their
-// d_logits block into three bf16 planes in LDS once and contracts it with the weight as fragment-major planes straight from
-// L2 (k = vocabulary index, zero-padded to a multiple of 16), DH / 32 MFMA waves of 32 columns each.
+// epilogue-bound: 94 us at configs[1]) stage 4-byte pieces.  Here the 64-row tiles of the three jobs form ONE list that
+// the workgroups (one per CU) cut into equal contiguous ranges.  Per workgroup:
+//   * two groups of four PRODUCER waves take the even / the odd tiles of the range: a tile's d_logits block is read as
+//     8-byte column pairs into registers (issued two tiles ahead), split into three bf16 planes and written to the
+//     group's own LDS image (144 k columns, the ones past the block zero);
+//   * DH / 32 CONSUMER waves of 32 output columns each contract an image with the weight as fragment-major planes
+//     (k = vocabulary index; at DH <= 128 a wave keeps the job's 9 x 3 weight fragments to itself: the two leading planes
+//     in registers, the low one in a private piece of LDS) and write the dH rows — the weight fragment is the FIRST MFMA
+//     operand, so a lane owns a row and four consecutive columns per register quad (16-byte stores); one barrier per tile.
+// Measured with realtime ticks (-DDH_LOG): 4 us per tile and workgroup at configs[1] — products 2.6, stores 1.3, a
+// producer turn 3.7 — the three add up on a SIMD (matrix and vector instructions of different waves do not overlap here,
+// as in k_gcl_fwd); 93 us -> 49-51 us per launch.
+// d_logits rows are read from an even column on: the duration block (columns 131..229) from column 130 with k shifted by
+// one (weight row k - 1; k = 0 meets a zero row), the pitch block with its 132nd column (k = 131: a zero row as well).
 namespace {
 constexpr int DHK = 144;                               // k extent of the image: the pitch vocabulary (131) padded to 16
 constexpr int DHP = DHK * 2 + 16;                      // bytes per image row (one plane): 304
+constexpr int DHKS = DHK / 16, DHPAIRS = DHK / 2;
+constexpr int DH_IMG = 3 * UBM * DHP;                  // one image: 58,368 B
+constexpr int DH_RING = 8;                             // row lists of the tiles in flight
+constexpr int DH_PT = 256;                             // threads of a producer group
+constexpr int DH_NIT = UBM * DHPAIRS / DH_PT;          // column pairs per producer thread and tile: 18
+constexpr int DH_LDS0 = 2 * DH_IMG + DH_RING * UBM * 4;   // + at DH <= 128 the consumers' low weight planes (dh_lds_bytes)
 struct UnembedDhArgs {
-  UnembedJob job[3];                                   // W / rowmap / dyn_rows / V / koff / coff as in the forward
+  UnembedJob job[3];                                   // W / rowmap / dyn_rows / V / koff as in the forward
   const float* dlogits; float* dH; const char* wplanes; int woff[3];
+  int cstart[3], npair[3], wshift[3];                  // first column read (even), pairs read per row, k - weight row
   int R, d, dh;
 };
 }  // namespace
 // weight planes for k_unembed_dh: job j's W [V, dh] as kind-1 fragment blocks [k-step][32-column tile] (pm_split_planes_frag
-// layout), rows k >= V zero
+// layout), k = weight row + wshift, rows outside the weight zero
 __global__ void __launch_bounds__(256) k_unembed_dh_wplanes(UnembedDhArgs a, uint16_t* __restrict__ out) {
   const UnembedJob jb = a.job[blockIdx.y];
+  const int ws = a.wshift[blockIdx.y];
   uint16_t* dst = out + a.woff[blockIdx.y] / 2;
-  const int ks_n = (jb.V + 15) >> 4, chunks = ks_n * 2 * a.dh;   // 8 consecutive k of one column
+  const int ks_n = (jb.V + ws + 15) >> 4, chunks = ks_n * 2 * a.dh;   // 8 consecutive k of one column
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
     const int n = c % a.dh, k0 = (c / a.dh) * 8;
     float x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = k0 + e < jb.V ? jb.W[(int64_t)(k0 + e) * a.dh + n] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      const int w = k0 + e - ws;
+      x[e] = (w >= 0 && w < jb.V) ? jb.W[(int64_t)w * a.dh + n] : 0.f;
+    }
     unsigned p1[4], p2[4], p3[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
@@ -592,102 +614,213 @@ __global__ void __launch_bounds__(256) k_unembed_dh_wplanes(UnembedDhArgs a, uin
     *reinterpret_cast<u32x4*>(o + 1024) = u32x4{p3[0], p3[1], p3[2], p3[3]};
   }
 }
+#ifdef DH_LOG
+// development builds (tools/build_variants.py unembed.hip log=-DDH_LOG): realtime ticks (100 MHz) of workgroup 100's phases
+__device__ long long g_dhlog[3][32][4];
+extern "C" int pm_debug_read_dhlog(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dhlog), sizeof(long long) * 3 * 32 * 4) == hipSuccess ? 0 : 1;
+}
+#define DH_TICK(who, it, slot, cond) do { if (blockIdx.x == 100 && (cond) && (it) < 32) g_dhlog[who][it][slot] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DH_TICK(who, it, slot, cond) do { } while (0)
+#endif
+template <int DH> constexpr int dh_lds_bytes() { return DH_LDS0 + (DH <= 128 ? DH / 32 * DHKS * 1024 : 0); }
+template <int DH> constexpr int dh_threads() { return 2 * DH_PT + DH / 32 * 64; }
 template <int DH>
-__global__ void __launch_bounds__(DH * 2) k_unembed_dh(UnembedDhArgs a) {
-  constexpr int NW = DH / 32, NTHR = NW * 64;          // MFMA waves = 32-column tiles of the output; all waves also stage
-  __shared__ __attribute__((aligned(16))) char img[3 * UBM * DHP];
-  __shared__ int s_row[UBM];
-  const UnembedJob jb = a.job[blockIdx.y];
-  const char* const wf = a.wplanes + a.woff[blockIdx.y];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int M = jb.dyn_rows ? *jb.dyn_rows : a.R;
-  const int ks_n = (jb.V + 15) >> 4;
-  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wf), 0, GCL_OOB, 0x00020000);
-  // columns [V, 16 ks_n) of the image stay zero for the whole kernel
-  for (int i = tid; i < 3 * UBM * 16; i += NTHR) {
-    const int p = i / (UBM * 16), r = (i / 16) % UBM, c = jb.V + (i & 15);
-    if (c < ks_n * 16) *reinterpret_cast<uint16_t*>(img + (p * UBM + r) * DHP + c * 2) = 0;
+__global__ void __launch_bounds__(dh_threads<DH>()) k_unembed_dh(UnembedDhArgs a) {
+  // consumer waves: a 32-column tile of the output each, both 32-row blocks of a tile (two independent accumulators)
+  constexpr int NCT = DH / 32, NB = 2;
+  static_assert(dh_threads<DH>() <= 1024, "waves");
+  constexpr bool BREG = DH <= 128;                     // the job's weight fragments stay with the wave (registers + LDS)
+  extern __shared__ __attribute__((aligned(16))) char dh_lds[];
+  char* const img0 = dh_lds;
+  int (*const s_row)[UBM] = reinterpret_cast<int (*)[UBM]>(dh_lds + 2 * DH_IMG);
+  const int tid = threadIdx.x;
+  // the tile list: job 0, job 1, job 2; this workgroup's contiguous share of it.  Everything a tile needs of its job is
+  // picked from scalars read once (an indexed read of the argument block would be a vector load)
+  int Mj[3], tn[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Mj[j] = __builtin_amdgcn_readfirstlane(a.job[j].dyn_rows ? *a.job[j].dyn_rows : a.R);
+    tn[j] = (Mj[j] + UBM - 1) / UBM;
   }
-  for (int m0 = blockIdx.x * UBM; m0 < M; m0 += gridDim.x * UBM) {
-    if (tid < UBM) {
-      const int r = m0 + tid;
-      s_row[tid] = r < M ? (jb.rowmap ? jb.rowmap[r] : r) : -1;
-    }
-    __syncthreads();
-    // ---- the rows' d_logits block -> three bf16 planes; a wave takes rows wave, wave + NW, ..: lanes over the columns
-    for (int r0 = wave; r0 < UBM; r0 += 4 * NW) {
-      float v[4][3];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + u * NW, rg = r < UBM ? s_row[r] : -1;
-        const float* src = a.dlogits + (int64_t)(rg < 0 ? 0 : rg) * PM_N_TOK + jb.coff;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int c = lane + 64 * q;
-          v[u][q] = (rg >= 0 && c < jb.V) ? src[c] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + u * NW;
-        if (r >= UBM) continue;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int c = lane + 64 * q;
-          if (c >= jb.V) continue;
-          unsigned h1, h2, h3;
-          pm_split3_pair(v[u][q], 0.f, h1, h2, h3);
-          char* dst = img + r * DHP + c * 2;
-          *reinterpret_cast<uint16_t*>(dst) = (uint16_t)h1;
-          *reinterpret_cast<uint16_t*>(dst + UBM * DHP) = (uint16_t)h2;
-          *reinterpret_cast<uint16_t*>(dst + 2 * UBM * DHP) = (uint16_t)h3;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- products: this wave's 32 output columns for all 64 rows
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    // weight fragments two k-steps ahead (past the last step: the last block again, never used)
-    auto bload = [&](bf16x8 (&dst)[3], int ks) {
-      const int soff = __builtin_amdgcn_readfirstlane(((ks < ks_n ? ks : ks_n - 1) * NW + wave) * 3072);
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        dst[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + p * 1024, 0));
+  const int t1 = tn[0], t2 = tn[0] + tn[1], T = t2 + tn[2];
+  // (T * gridDim.x < 2^31: the host bounds the rows; the quotients come out of the vector unit, hence the readfirstlane)
+  const int t_begin = __builtin_amdgcn_readfirstlane((int)((unsigned)T * blockIdx.x / gridDim.x));
+  const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)T * (blockIdx.x + 1) / gridDim.x)) - t_begin;
+  if (n <= 0) return;
+  auto pick = [](int j, auto x0, auto x1, auto x2) __attribute__((always_inline)) { return j == 0 ? x0 : j == 1 ? x1 : x2; };
+  auto job_of = [&](int k) __attribute__((always_inline)) { const int t = t_begin + k; return t < t1 ? 0 : t < t2 ? 1 : 2; };   // k = tile of this range
+  if (tid < 2 * DH_PT) {
+    // ================= producers: group g owns the tiles k = g, g + 2, .. and image g
+    const int g = tid / DH_PT, ptid = tid & (DH_PT - 1);
+    char* const img = img0 + g * DH_IMG;
+    auto row_id = [&](int k) __attribute__((always_inline)) {                         // threads < UBM: row ptid of tile k as a (node, slot) row; -1 past the list
+      if (k >= n) return -1;
+      const int j = job_of(k), r = (t_begin + k - pick(j, 0, t1, t2)) * UBM + ptid;
+      const int32_t* rm = pick(j, a.job[0].rowmap, a.job[1].rowmap, a.job[2].rowmap);
+      return r < pick(j, Mj[0], Mj[1], Mj[2]) ? (rm ? rm[r] : r) : -1;
     };
+    // row ids two turns ahead without a wait of their own: the read is unconditional (clamped to a valid tile and row, a
+    // readable stand-in where the job has no row list) and its result stays raw until the next turn picks it up — after
+    // the wait for the d_logits block that is due there anyway
+    struct RowReq { int raw, r; bool mapped; };
+    auto row_request = [&](int k) __attribute__((always_inline)) {
+      const int kc = k < n ? k : n - 1, j = job_of(kc), M = pick(j, Mj[0], Mj[1], Mj[2]);
+      const int r = (t_begin + kc - pick(j, 0, t1, t2)) * UBM + ptid;
+      const int32_t* rm = pick(j, a.job[0].rowmap, a.job[1].rowmap, a.job[2].rowmap);
+      RowReq q;
+      q.mapped = rm != nullptr;
+      q.raw = (q.mapped ? rm : reinterpret_cast<const int32_t*>(a.dlogits))[r < M ? r : M - 1];
+      q.r = (k < n && r < M) ? r : -1;
+      return q;
+    };
+    auto row_of = [](const RowReq& q) __attribute__((always_inline)) { return q.r < 0 ? -1 : (q.mapped ? q.raw : q.r); };
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dlogits), 0, GCL_OOB, 0x00020000);
+    float2 pv[DH_NIT];
+    auto issue = [&](int k) __attribute__((always_inline)) {       // tile k's d_logits block -> pv (flat index over (row, pair of 72))
+      const int j = job_of(k), npair = pick(j, a.npair[0], a.npair[1], a.npair[2]);
+      const int c0 = pick(j, a.cstart[0], a.cstart[1], a.cstart[2]);
+      const int* rows = s_row[k & (DH_RING - 1)];
+#pragma unroll
+      for (int it = 0; it < DH_NIT; ++it) {                        // (no branches: pairs past the block and rows past the list read 0)
+        const int idx = it * DH_PT + ptid, r = idx / DHPAIRS, pr = idx - r * DHPAIRS;
+        const int rg = rows[r];
+        pv[it] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+            lrs, (rg >= 0 && pr < npair) ? (rg * PM_N_TOK + c0 + 2 * pr) * 4 : GCL_OOB, 0, 0));
+      }
+    };
+    auto to_image = [&]() __attribute__((always_inline)) {         // pv -> three bf16 planes (all 72 pairs of a row: zeros past the block)
+#pragma unroll
+      for (int it = 0; it < DH_NIT; ++it) {
+        const int idx = it * DH_PT + ptid, r = idx / DHPAIRS, pr = idx - r * DHPAIRS;
+        unsigned h1, h2, h3;
+        pm_split3_pair(pv[it].x, pv[it].y, h1, h2, h3);
+        char* dst = img + r * DHP + pr * 4;
+        *reinterpret_cast<unsigned*>(dst) = h1;
+        *reinterpret_cast<unsigned*>(dst + UBM * DHP) = h2;
+        *reinterpret_cast<unsigned*>(dst + 2 * UBM * DHP) = h3;
+      }
+    };
+    // a group's turn for tile k (during the products of tile k - 1): image <- tile k, row list of tile k + 4 published,
+    // row ids of tile k + 6 requested, block of tile k + 2 requested
+    RowReq nq = {0, -1, false};
+    auto turn = [&](int k) __attribute__((always_inline)) {
+      DH_TICK(1 + g, k >> 1, 0, ptid == 0);
+      if (k < n) to_image();
+      DH_TICK(1 + g, k >> 1, 1, ptid == 0);
+      if (ptid < UBM) {
+        s_row[(k + 4) & (DH_RING - 1)][ptid] = row_of(nq);
+        nq = row_request(k + 6);
+      }
+      if (k + 2 < n) issue(k + 2);
+      DH_TICK(1 + g, k >> 1, 2, ptid == 0);
+    };
+    if (ptid < UBM) {
+      s_row[g][ptid] = row_id(g);
+      s_row[g + 2][ptid] = row_id(g + 2);
+    }
+    __syncthreads();
+    if (g < n) issue(g);
+    if (ptid < UBM) nq = row_request(g + 4);
+    if (g == 0) turn(0);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      if (((i + 1) & 1) == g) turn(i + 1);
+      __syncthreads();
+    }
+    return;
+  }
+  // ================= consumers
+  const int ctid = tid - 2 * DH_PT, lane = ctid & 63, wave = ctid >> 6, li = lane & 31, lh = lane >> 5;
+  // (the two leading planes of the nine k-steps in registers: 72; the low plane, used once per step, in a wave-private
+  // piece of LDS)
+  bf16x8 breg[BREG ? DHKS : 1][2];
+  char* const bl2 = dh_lds + DH_LDS0 + wave * (DHKS * 1024) + lane * 16;
+  int jcur = -1, ks_n = 0, koff = 0, dcol = 0;
+  __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wplanes), 0, GCL_OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.dH, 0, GCL_OOB, 0x00020000);
+  auto bload = [&](bf16x8 (&dst)[3], int ks) __attribute__((always_inline)) {          // (past the last step: the last block again, never used)
+    const int soff = __builtin_amdgcn_readfirstlane(((ks < ks_n ? ks : ks_n - 1) * NCT + wave) * 3072);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      dst[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + p * 1024, 0));
+  };
+  __syncthreads();
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    const int j = job_of(i);
+    if (j != jcur) {                                   // (workgroup-uniform) a new job: its weight
+      jcur = j;
+      ks_n = pick(j, a.job[0].V + a.wshift[0], a.job[1].V + a.wshift[1], a.job[2].V + a.wshift[2]) + 15 >> 4;
+      koff = pick(j, a.job[0].koff, a.job[1].koff, a.job[2].koff);
+      dcol = koff + wave * 32 + 4 * lh;
+      brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wplanes + pick(j, a.woff[0], a.woff[1], a.woff[2])), 0, GCL_OOB,
+                                              0x00020000);
+      if constexpr (BREG) {
+#pragma unroll
+        for (int ks = 0; ks < DHKS; ++ks) {
+          bf16x8 b3[3];
+          bload(b3, ks);
+          breg[ks][0] = b3[0]; breg[ks][1] = b3[1];
+          *reinterpret_cast<bf16x8*>(bl2 + ks * 1024) = b3[2];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) here: placed after the join it would also wait for dH stores
+      }
+    }
+    DH_TICK(0, i, 0, ctid == 0);
+    const char* const img = img0 + (i & 1) * DH_IMG;
+    const int* const rows = s_row[i & (DH_RING - 1)];
     bf16x8 bq[2][3];
-    bload(bq[0], 0);
-    bload(bq[1], 1);
+    f32x16 acc[NB];
 #pragma unroll
-    for (int ks = 0; ks < DHK / 16; ++ks) {
-      if (ks < ks_n) {                                           // (wave-uniform; the duration job has 7 of the 9 steps)
-        bf16x8 av[3][2];
+    for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+      for (int r = 0; r < 16; ++r) acc[bi][r] = 0.f;
+    if constexpr (!BREG) {
+      bload(bq[0], 0);
+      bload(bq[1], 1);
+    }
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            av[p][i] = *reinterpret_cast<const bf16x8*>(img + (p * UBM + i * 32 + li) * DHP + (ks * 16 + lh * 8) * 2);
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+    for (int ks = 0; ks < DHKS; ++ks) {
+      if (ks < ks_n) {                                             // (wave-uniform; the duration job has 7 of the 9 steps)
+        bf16x8 av[NB][3];
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            av[bi][p] = *reinterpret_cast<const bf16x8*>(img + (p * UBM + bi * 32 + li) * DHP + (ks * 16 + lh * 8) * 2);
+        bf16x8 b2;
+        if constexpr (BREG) b2 = *reinterpret_cast<const bf16x8*>(bl2 + ks * 1024);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first
 #pragma unroll
         for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[t6]][i], bq[ks & 1][PB[t6]], acc[i], 0, 0, 0);
-        bload(bq[ks & 1], ks + 2);
+          for (int bi = 0; bi < NB; ++bi) {
+            // (the weight fragment as the FIRST operand: the accumulators hold the transposed tile — a lane owns one dH row
+            // and four consecutive columns per register quad, so the rows leave in 16-byte pieces)
+            if constexpr (BREG) acc[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PB[t6] == 2 ? b2 : breg[ks][PB[t6] & 1], av[bi][PA[t6]], acc[bi], 0, 0, 0);
+            else acc[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][PB[t6]], av[bi][PA[t6]], acc[bi], 0, 0, 0);
+          }
+        if constexpr (!BREG) bload(bq[ks & 1], ks + 2);
       }
     }
-    // ---- dH rows: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    DH_TICK(0, i, 1, ctid == 0);
+    // dH rows: C/D map of the 32x32 MFMA (transposed tile): dH row = lane & 31, column = (reg & 3) + 8 * (reg >> 2) + 4 *
+    // (lane >> 5); rows past the list go to the out-of-range offset
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int bi = 0; bi < NB; ++bi) {
+      const int rg = rows[bi * 32 + li];
+      const int off = rg >= 0 ? (rg * a.d + dcol) * 4 : GCL_OOB;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rg = s_row[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-        if (rg >= 0) a.dH[(int64_t)rg * a.d + jb.koff + wave * 32 + li] = acc[i][r];
-      }
-    __syncthreads();                                             // the image and the row list are rewritten by the next tile
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[bi][4 * q]), __float_as_uint(acc[bi][4 * q + 1]),
+                                                     __float_as_uint(acc[bi][4 * q + 2]), __float_as_uint(acc[bi][4 * q + 3])},
+                                               drs, off, q * 32, 0);
+    }
+    DH_TICK(0, i, 2, ctid == 0);
+    __syncthreads();
+    DH_TICK(0, i, 3, ctid == 0);
   }
 }
 
@@ -712,20 +845,32 @@ extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, c
   a.job[2].W = w_dur; a.job[2].V = PM_N_DUR; a.job[2].koff = dh; a.job[2].coff = PM_N_PITCH;
   a.woff[0] = 0; a.woff[1] = 9 * (dh / 32) * 3072; a.woff[2] = 18 * (dh / 32) * 3072;
   a.dh = dh; a.d = d;
+  // column pairs read per row: the pitch block with its 132nd column, the duration block from column 130 on
+  a.cstart[0] = a.cstart[1] = 0; a.npair[0] = a.npair[1] = (PM_N_PITCH + 1) / 2;
+  a.cstart[2] = PM_N_PITCH - 1; a.npair[2] = (PM_N_DUR + 1) / 2; a.wshift[2] = 1;
   if (prepare) {
     hipLaunchKernelGGL(k_unembed_dh_wplanes, dim3(8, 3), dim3(256), 0, st, a, w_planes);
     return pm_check_launch();
   }
   const int64_t R = (int64_t)N * n_slots;
-  if (R * PM_N_TOK >= ((int64_t)1 << 31) || R * (int64_t)d >= ((int64_t)1 << 31)) return PM_E_UNSUPPORTED;
+  if (R * PM_N_TOK * 4 >= ((int64_t)1 << 31) || R * (int64_t)d * 4 >= ((int64_t)1 << 31)) return PM_E_UNSUPPORTED;   // (32-bit byte offsets)
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   a.job[0].rowmap = pv.row_list; a.job[0].dyn_rows = pv.group_cnt + 2;
   a.job[1].rowmap = pv.row_list + (int64_t)N * PM_N_SLOTS; a.job[1].dyn_rows = pv.group_cnt + 3;
   a.dlogits = d_logits; a.dH = dH; a.wplanes = reinterpret_cast<const char*>(w_planes); a.R = (int)R;
-  int nb = (int)pm_cdiv(R, UBM);
-  if (nb > 512) nb = 512;
-  if (dh == 256) hipLaunchKernelGGL(k_unembed_dh<256>, dim3(nb, 3), dim3(512), 0, st, a);
-  else if (dh == 128) hipLaunchKernelGGL(k_unembed_dh<128>, dim3(nb, 3), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_unembed_dh<64>, dim3(nb, 3), dim3(128), 0, st, a);
+  // one workgroup per CU (two images: 119 KB of LDS) and an equal share of the tile list each
+  int nb = (int)(2 * pm_cdiv(R, UBM) + 1);
+  if (nb > 256) nb = 256;
+#define LAUNCH(DHV)                                                                                                  \
+  do {                                                                                                               \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      hipFuncSetAttribute((const void*)k_unembed_dh<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, dh_lds_bytes<DHV>()); \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k_unembed_dh<DHV>, dim3(nb), dim3(dh_threads<DHV>()), dh_lds_bytes<DHV>(), st, a);            \
+  } while (0)
+  if (dh == 256) LAUNCH(256); else if (dh == 128) LAUNCH(128); else LAUNCH(64);
+#undef LAUNCH
   return pm_check_launch();
 }

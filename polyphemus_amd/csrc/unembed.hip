@@ -70,16 +70,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_UNE
   }
   double lacc = 0;
   float lloss = 0.f;                                              // <= 16 terms per tile and lane, folded into fp64 per tile
+  // row ids and target tokens one tile ahead (threads < UBM): the row id is requested at the top of the previous tile, the
+  // token it points at after that tile's products — two dependent round trips off the front of every tile
+  auto row_of = [&](int m) __attribute__((always_inline)) {
+    const int r = m + tid;
+    return r < M ? (jb.rowmap ? jb.rowmap[r] : r) : -1;
+  };
+  auto tok_of = [&](int rg) __attribute__((always_inline)) {
+    if (rg < 0) return jb.pad;
+    const int n = rg / a.S, s = rg - n * a.S + 1;
+    return a.tok[((int64_t)n * 16 + s) * 2 + jb.kind];
+  };
+  int rg_n = -1, tg_n = jb.pad;
+  if (tid < UBM) {
+    rg_n = row_of(blockIdx.x * UBM);
+    tg_n = tok_of(rg_n);
+  }
   for (int m0 = blockIdx.x * UBM; m0 < M; m0 += gridDim.x * UBM) {
-    if (tid < UBM) {                                   // row ids and target tokens of the tile
-      const int r = m0 + tid;
-      int rg = -1, tg = jb.pad;
-      if (r < M) {
-        rg = jb.rowmap ? jb.rowmap[r] : r;
-        const int n = rg / a.S, s = rg - n * a.S + 1;
-        tg = a.tok[((int64_t)n * 16 + s) * 2 + jb.kind];
-      }
-      s_row[tid] = rg; s_tgt[tid] = tg;
+    if (tid < UBM) {
+      s_row[tid] = rg_n; s_tgt[tid] = tg_n;
+      rg_n = row_of(m0 + gridDim.x * UBM);             // (-1 past the list)
     }
     __syncthreads();
     f32x16 acc[3];
@@ -279,16 +289,26 @@ __global__ void __launch_bounds__(PNW * 64) __attribute__((amdgpu_waves_per_eu(3
   float lloss = 0.f;
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.H), 0, GCL_OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wf), 0, GCL_OOB, 0x00020000);
+  // row ids and target tokens one tile ahead (threads < UBM): the row id is requested at the top of the previous tile, the
+  // token it points at after that tile's products — two dependent round trips off the front of every tile
+  auto row_of = [&](int m) __attribute__((always_inline)) {
+    const int r = m + tid;
+    return r < M ? (jb.rowmap ? jb.rowmap[r] : r) : -1;
+  };
+  auto tok_of = [&](int rg) __attribute__((always_inline)) {
+    if (rg < 0) return jb.pad;
+    const int n = rg / a.S, s = rg - n * a.S + 1;
+    return a.tok[((int64_t)n * 16 + s) * 2 + jb.kind];
+  };
+  int rg_n = -1, tg_n = jb.pad;
+  if (tid < UBM) {
+    rg_n = row_of(blockIdx.x * UBM);
+    tg_n = tok_of(rg_n);
+  }
   for (int m0 = blockIdx.x * UBM; m0 < M; m0 += gridDim.x * UBM) {
-    if (tid < UBM) {                                   // row ids and target tokens of the tile
-      const int r = m0 + tid;
-      int rg = -1, tg = jb.pad;
-      if (r < M) {
-        rg = jb.rowmap ? jb.rowmap[r] : r;
-        const int n = rg / a.S, s = rg - n * a.S + 1;
-        tg = a.tok[((int64_t)n * 16 + s) * 2 + jb.kind];
-      }
-      s_row[tid] = rg; s_tgt[tid] = tg;
+    if (tid < UBM) {
+      s_row[tid] = rg_n; s_tgt[tid] = tg_n;
+      rg_n = row_of(m0 + gridDim.x * UBM);             // (-1 past the list)
     }
     __syncthreads();
     // ---- the tile's rows of H (this job's half of the d columns): fp32 -> three bf16 planes -> swizzled LDS image
@@ -355,6 +375,7 @@ __global__ void __launch_bounds__(PNW * 64) __attribute__((amdgpu_waves_per_eu(3
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (tid < UBM) tg_n = tok_of(rg_n);
     __syncthreads();                                              // every wave has read the image: the logits tile replaces it
     if (wave < nblk) {
       // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

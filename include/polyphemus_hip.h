@@ -555,7 +555,8 @@ int pm_unembed_ce(const float* H, const float* w_pitch_drum /* [131,d/2] */, con
  * :131] @ W_pitch (drum / non-drum row lists of the plan), dH[:, d/2:] = d_logits[:, 131:] @ W_dur; d_logits [N,S,230] as
  * pm_unembed_ce leaves it, dH [N,S,d].  Six-product bf16 chain (fp32-exact products); d/2 in {64, 128, 256}.
  * `w_planes`: scratch of pm_unembed_dh_scratch_bytes(d) bytes; a call with prepare != 0 fills it from the weights (needed
- * once per parameter update), a call with prepare == 0 runs the product. */
+ * once per parameter update), a call with prepare == 0 runs the product.  PM_E_UNSUPPORTED when N * n_slots * max(d, 230) * 4
+ * >= 2^31 (32-bit byte offsets into d_logits and dH): the caller then runs the three products as GEMMs. */
 int64_t pm_unembed_dh_scratch_bytes(int32_t d);
 int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum /* [131,d/2] */, const float* w_pitch_nd,
                   const float* w_dur /* [99,d/2] */, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,

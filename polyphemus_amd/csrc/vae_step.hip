@@ -521,7 +521,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     // the three un-embedding weights as k-major fragment planes for the input gradient of the backward (unembed.hip)
     s.w_unembed_dh = nullptr;
     if (cfg().fused_ce && !cfg().no_unembed_dh && (dh == 64 || dh == 128 || dh == 256) &&
-        (int64_t)N * S * d * 4 < ((int64_t)1 << 31)) {              // (the kernel's 32-bit byte offsets into dH)
+        (int64_t)N * S * (d > PM_N_TOK ? d : PM_N_TOK) * 4 < ((int64_t)1 << 31)) {   // (the kernel's 32-bit byte offsets into d_logits and dH)
       s.w_unembed_dh = (uint16_t*)ar.take((size_t)pm_unembed_dh_scratch_bytes(d));
       RUN(pm_unembed_dh(nullptr, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, nullptr, N, c.E, Gn, d, S,
                           nullptr, s.w_unembed_dh, 1, c.st));

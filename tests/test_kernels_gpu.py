@@ -1072,6 +1072,15 @@ def test_unembed_input_gradient_in_one_launch(d, B, S):
     assert rel_err(dH, want) < 2e-6
 
 
+def test_unembed_input_gradient_refuses_offsets_beyond_32_bits():
+    """`pm_unembed_dh` addresses d_logits and dH with 32-bit byte offsets: sizes beyond that are refused before anything is
+    launched (the step then takes the GEMM path, `vae_step.hip`)."""
+    d, S, N = 256, 5, 500_000                                      # 2.5 M rows x 1 KB of dH each
+    x = torch.zeros(16, device=DEV)
+    rc = lib().pm_unembed_dh(ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), N, 1, 1, d, S, ptr(x), ptr(x), 0, stream())
+    assert rc == -3                                                # PM_E_UNSUPPORTED
+
+
 def test_launch_profiler_class_mask_and_stride():
     """`pm_prof_configure` (bench.py's roofline timing): only the selected classes are bracketed, every stride-th
     launch of each; durations and algorithmic work come back per class."""

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
       w[e] = 0; id[e] = 0;
       if (e < cnt) {
         w[e] = g.csr_src[b + e] | (g.csr_dist[b + e] << 27);
-        if (DROP) id[e] = g.csr_eid[b + e];
+        if (DROP) id[e] = (int)pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]);   // (the edge's dropout key, once per edge)
       }
     }
     int4* dst = reinterpret_cast<int4*>(sSlot + (rr * 3 + j) * 8);
@@ -229,12 +229,11 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
     STAMP();
     if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
     STAMP();
-    auto msg = [&](float4 xe, int dist, int eid) {
+    auto msg = [&](float4 xe, int dist, uint32_t key) {            // key = pm_edge_key(seed, layer, edge id)
       const float4 tv = *reinterpret_cast<const float4*>(sT + dist * D + f);
       float4 m = make_float4(fmaxf(xe.x * tv.x, 0.f), fmaxf(xe.y * tv.y, 0.f), fmaxf(xe.z * tv.z, 0.f),
                              fmaxf(xe.w * tv.w, 0.f));
       if (DROP) {
-        const uint32_t key = pm_edge_key(g.seed, g.layer_uid, (uint32_t)eid);
         const uint32_t gh = pm_group_hash(key, f >> 2);
         m.x = (pm_lane_hash(gh, 0) >> 8) >= g.thresh ? m.x * g.scale : 0.f;
         m.y = (pm_lane_hash(gh, 1) >> 8) >= g.thresh ? m.y * g.scale : 0.f;
@@ -251,7 +250,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
       for (int e = 0; e < EMAX; ++e) {
         // (slot empty in both rows of the wave: nothing to add — skipping it saves the dropout hashes)
         if (__builtin_amdgcn_ballot_w64(e < ecnt[ps]) == 0) continue;
-        const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? sSlot[(rr * 3 + blk) * 8 + 5 + e] : 0);
+        const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? (uint32_t)sSlot[(rr * 3 + blk) * 8 + 5 + e] : 0u);
         acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
       }
       // 1 / max(count, 1) for count <= 3: the correctly rounded quotients, as the division gives them
@@ -270,7 +269,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
         for (int e = 0; e < cnt; ++e) {
           const int sn = g.csr_src[b + e];
           const float4 m = msg(*reinterpret_cast<const float4*>(g.x + (int64_t)sn * D + f), g.csr_dist[b + e],
-                               DROP ? g.csr_eid[b + e] : 0);
+                               DROP ? pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]) : 0u);
           acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
         }
         const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);

@@ -194,12 +194,11 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);       // every gather of the chunk is in flight before the first one is waited for
         if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
-        auto msg = [&](float4 xe, int dist, int eid) {
+        auto msg = [&](float4 xe, int dist, uint32_t key) {        // key = pm_edge_key(seed, layer, edge id)
           const float4 tv = *reinterpret_cast<const float4*>(tab + dist * CH + q * 4);
           float4 m = make_float4(fmaxf(xe.x * tv.x, 0.f), fmaxf(xe.y * tv.y, 0.f), fmaxf(xe.z * tv.z, 0.f),
                                  fmaxf(xe.w * tv.w, 0.f));
           if (DROP) {
-            const uint32_t key = pm_edge_key(g.seed, g.layer_uid, (uint32_t)eid);
             const uint32_t gh = pm_group_hash(key, f >> 2);
             m.x = (pm_lane_hash(gh, 0) >> 8) >= g.thresh ? m.x * g.scale : 0.f;
             m.y = (pm_lane_hash(gh, 1) >> 8) >= g.thresh ? m.y * g.scale : 0.f;
@@ -215,7 +214,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
 #pragma unroll
           for (int e = 0; e < EMAXW; ++e) {
             if (__builtin_amdgcn_ballot_w64(e < ecnt[ps]) == 0) continue;      // slot empty in both rows of the wave
-            const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? sSlot[(rr * 3 + blk) * 8 + 5 + e] : 0);
+            const float4 m = msg(xv[ps][e], (unsigned)ew[ps][e] >> 27, DROP ? (uint32_t)sSlot[(rr * 3 + blk) * 8 + 5 + e] : 0u);
             acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
           }
           // 1 / max(count, 1) for count <= 3: the correctly rounded quotients, as the division gives them
@@ -233,7 +232,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
             for (int e = 0; e < cnt; ++e) {
               const int sn = g.csr_src[b + e];
               const float4 m = msg(*reinterpret_cast<const float4*>(g.x + (int64_t)sn * D + f), g.csr_dist[b + e],
-                                   DROP ? g.csr_eid[b + e] : 0);
+                                   DROP ? pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]) : 0u);
               acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
             }
             const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
@@ -401,7 +400,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
           w[e] = 0; id[e] = 0;
           if (e < cnt) {
             w[e] = g.csr_src[b + e] | (g.csr_dist[b + e] << 27);
-            if (DROP) id[e] = g.csr_eid[b + e];
+            if (DROP) id[e] = (int)pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]);   // (the edge's dropout key, once per edge)
           }
         }
         int4* dst = reinterpret_cast<int4*>(sSlot + (rr * 3 + j) * 8);

@@ -50,7 +50,15 @@ constexpr int EMAX = 3;       // edges per (node, relation) gathered in one go (
 #define GCL_NPW 8
 #endif
 constexpr int NPW = GCL_NPW;               // producer waves (waves 4 .. 4 + NPW - 1); two image rows per wave and pass
-constexpr int NTHR = (4 + NPW) * 64;       // threads per workgroup
+#ifndef GCL_NCW
+#define GCL_NCW 8
+#endif
+#ifndef GCL_DAGG_BDEPTH
+#define GCL_DAGG_BDEPTH 4     // k-steps of weight fragments in flight in k_gcl_dagg (one column tile per wave at d = 256: 4 beats 2)
+#endif
+// consumer (MFMA) waves of k_gcl_fwd: D / (32 NCW) column tiles each; eight only where a wave keeps a whole tile (d = 256)
+template <int D> constexpr int gcl_ncw() { return D == 256 ? GCL_NCW : 4; }
+template <int D> constexpr int gcl_fwd_threads() { return (gcl_ncw<D>() + NPW) * 64; }
 constexpr int RPP = NPW * 2;               // image rows per producer pass
 constexpr int NPS = BM / RPP;              // passes per chunk
 
@@ -67,9 +75,10 @@ struct GclArgs {
 }  // namespace
 
 template <int D, bool DROP>
-__global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + NPW) / 4, (4 + NPW) / 4))) k_gcl_fwd(GclArgs g) {
+__global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_waves_per_eu((gcl_ncw<D>() + NPW) / 4, (gcl_ncw<D>() + NPW) / 4))) k_gcl_fwd(GclArgs g) {
+  constexpr int NCW = gcl_ncw<D>(), NTHR = gcl_fwd_threads<D>();
   constexpr int NCH = D / CH;            // chunks per relation block
-  constexpr int TN = D / 128;            // 32-column MFMA tiles per consumer wave (its D/4 columns)
+  constexpr int TN = D / (NCW * 32);     // 32-column MFMA tiles per consumer wave
   constexpr int BFN = D / 32;            // column tiles of the weight
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const img0 = smem;                                   // two images
@@ -129,6 +138,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
   // Row metadata (consumer waves, while the producers build the self block): four threads per row, three of them fetch
   // one relation block's CSR range and its first EMAX edges — a chain of two global reads per thread, no barrier between.
   auto load_metadata = [&]() {
+    if (tid >= 4 * BM) return;                                  // (four threads per row)
     const int rr = tid >> 2, j = tid & 3, n = sNode[rr];
     if (j == 3) return;
     const int rel = j == 0 ? grp : 3 + j;
@@ -162,7 +172,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
     if (!g.planes) return;
     const int blk = chunk_blk(c), half = c % NCH;
     const char* img = img0 + (c & 1) * IMG;
-    const int pt = tid - 256, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
+    const int pt = tid - NCW * 64, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
     const int ps_b = (int)(g.plane_stride * 2);
 #pragma unroll
     for (int ps = 0; ps < BM / (NPW * 4); ++ps) {
@@ -194,7 +204,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
 #pragma clang fp contract(off)   // (bit-identical to k_segreduce_fwd, whatever the code shape around the adds)
     const int blk = chunk_blk(c), half = c % NCH;
     char* const img = img0 + (c & 1) * IMG;
-    const int pt = tid - 256, q = pt & 31, prow = pt >> 5;      // 32 lanes per row, RPP rows per pass
+    const int pt = tid - NCW * 64, q = pt & 31, prow = pt >> 5;      // 32 lanes per row, RPP rows per pass
     const int f = half * CH + q * 4;                             // first of this lane's four features
     if (blk == 3) {                                              // self block: the node's own row
       float4 xs[NPS];
@@ -278,7 +288,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
     }
   };
 
-  if (wave >= 4) {                                             // producers: one image ahead of the consumers
+  if (wave >= NCW) {                                           // producers: one image ahead of the consumers
 #pragma unroll 1
     for (int c = 0; c <= nchunk; ++c) {
       if (c < nchunk) build(c);
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((4 + 
 // planes of its rows (64 x d x 3 bf16) are loaded into LDS once, then the four waves walk the output blocks
 // [track | onset | next | self] (a block = d columns; blocks no row of the tile receives edges of are skipped, as the
 // grouped product skips them), each wave 64 rows by d/4 columns, B fragments straight from the fragment-major
-// transposed weight planes in L2, GCL_BDEPTH k-steps ahead.  Same products, same k order as the grouped product.
+// transposed weight planes in L2, GCL_DAGG_BDEPTH k-steps ahead.  Same products, same k order as the grouped product.
 #if GCL_TRACE
 __device__ long long g_gcl_trace[256];
 extern "C" int pm_debug_read_trace(long long* out) {
@@ -522,9 +532,10 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
       for (int p = 0; p < 3; ++p)
         dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * KS * 3072 + p * 1024, 0));
   };
-  bf16x8 bq[GCL_BDEPTH][3][TN];
+  constexpr int BD = TN == 1 ? GCL_DAGG_BDEPTH : 2;            // (two column tiles per wave: four steps in flight spill)
+  bf16x8 bq[BD][3][TN];
 #pragma unroll
-  for (int s = 0; s < GCL_BDEPTH; ++s) bload(bq[s], s);
+  for (int s = 0; s < BD; ++s) bload(bq[s], s);
   STAMP2();
   __syncthreads();
   STAMP2();
@@ -562,8 +573,8 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
-      bload(bq[ks % GCL_BDEPTH], qb * KS + ks + GCL_BDEPTH);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % BD][PB[t6]][j], acc[i][j], 0, 0, 0);
+      bload(bq[ks % BD], qb * KS + ks + BD);
       __builtin_amdgcn_sched_barrier(0);
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -842,7 +853,7 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
   a.seed = seed; a.layer_uid = layer_uid; a.thresh = pm_keep_threshold(dropout_p);
   a.scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(pm_gcl_grid(N)), block(NTHR);
+  const dim3 grid(pm_gcl_grid(N));
   const size_t lds = gcl_lds_bytes(d, drop);
   // profiler work: the product's flops (as the GEMM classes); the kernel's algorithmic HBM bytes are x read + h written
   // + A' planes written (when kept) + edges + the weight planes once = 8dN (+ 24dN) + 12E + 42d^2 (bench.py)
@@ -854,7 +865,7 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
       hipFuncSetAttribute((const void*)k_gcl_fwd<DD, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_gcl_fwd<DD, DR>), grid, block, lds, st, a);                                                  \
+    hipLaunchKernelGGL((k_gcl_fwd<DD, DR>), grid, dim3(gcl_fwd_threads<DD>()), lds, st, a);                            \
   } while (0)
   if (d == 256) { if (drop) LAUNCH(256, true); else LAUNCH(256, false); }
   else { if (drop) LAUNCH(128, true); else LAUNCH(128, false); }

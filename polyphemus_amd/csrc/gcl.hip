@@ -647,8 +647,12 @@ namespace {
 constexpr int DW_MAP = 4096;              // row-list entries of a K slice kept in LDS
 }  // namespace
 
+#ifndef GCL_DW_NMW
+#define GCL_DW_NMW 4                      // MFMA waves of k_gcl_dw: 4 = a 64x64 quarter of the tile each; 8 = 64x32 each, two per SIMD: no gain (LOG)
+#endif
+constexpr int DW_NMW = GCL_DW_NMW, DW_NTHR = (DW_NMW + 4) * 64;
 template <int D>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(DW_NTHR) __attribute__((amdgpu_waves_per_eu((DW_NMW + 4) / 4, (DW_NMW + 4) / 4)))
 k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restrict__ dhp, int64_t dps,
          const int* __restrict__ trk_list, const int* __restrict__ trk_cnt, float* __restrict__ dW, int N, int nsplit,
          int use_classes) {
@@ -681,18 +685,19 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
   int nst = 0;
   STAMP2();
   // loaders: thread -> 16-byte chunk ch of rows r0 and r0 + 16 of each tile, three planes, both operands
-  const int lt = tid - 256, ch = lt & 15, r0 = lt >> 4;
+  const int lt = tid - DW_NMW * 64, ch = lt & 15, r0 = lt >> 4;
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ap), 0, GCL_OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
   const int acol = (ft * DW_T + ch * 8) * 2, dcol = (ct * DW_T + ch * 8) * 2;
   const int aps_b = (int)(aps * 2), dps_b = (int)(dps * 2);
-  // MFMA waves: 64x64 quarter (wr, wc) of the tile
-  const int li = lane & 31, lh = lane >> 5, wr = wave >> 1, wc = wave & 1;
-  f32x16 acc[2][2];
+  // MFMA waves: part (wr, wc) of the tile: 64 rows x DW_WN 32-column tiles
+  constexpr int DW_WN = 8 / DW_NMW, DW_WCOLS = DW_WN * 32, DW_WPR = DW_T / DW_WCOLS;   // column tiles, columns per wave, waves per row of parts
+  const int li = lane & 31, lh = lane >> 5, wr = wave / DW_WPR, wc = wave % DW_WPR;
+  f32x16 acc[2][DW_WN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < DW_WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // The slice's row list goes through LDS in segments of DW_MAP entries (one segment at the bench sizes); the tile ring
@@ -701,10 +706,10 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
   for (int s0 = kbeg; s0 < kend; s0 += DW_MAP) {
     const int slen = min(DW_MAP, kend - s0), nt = (slen + DW_KT - 1) / DW_KT;
     if (s0 > kbeg) __syncthreads();                              // the previous segment's list and tiles are done with
-    for (int i = tid; i < nt * DW_KT; i += 512) sMap[i] = i < slen ? list[s0 + i] : -1;
+    for (int i = tid; i < nt * DW_KT; i += DW_NTHR) sMap[i] = i < slen ? list[s0 + i] : -1;
     __syncthreads();
     STAMP2();
-    if (wave >= 4) {
+    if (wave >= DW_NMW) {
       auto issue = [&](u32x4 (&v)[2][2][3], int t) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -753,28 +758,28 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
         const char* st = smem + (t & 1) * DW_STAGE;
 #pragma unroll
         for (int ks = 0; ks < DW_KT / 16; ++ks) {
-          bf16x8 a[3][2], b[3][2];
+          bf16x8 a[3][2], b[3][DW_WN];
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
-              b[p][i] = dw_frag(st + (3 + p) * DW_PLANE, wc * 64 + i * 32, ks, lane);
-            }
+            for (int i = 0; i < 2; ++i) a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < DW_WN; ++j) b[p][j] = dw_frag(st + (3 + p) * DW_PLANE, wc * DW_WCOLS + j * 32, ks, lane);
+          }
           constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
           for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-              for (int j = 0; j < 2; ++j)
+              for (int j = 0; j < DW_WN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
       }
     }
   }
-  if (wave >= 4) return;
+  if (wave >= DW_NMW) return;
   STAMP2();
   // ---- epilogue: the tile is one K slice's (and, for the shared blocks, one group's) term: float atomics
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -783,9 +788,9 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int fr = ft * DW_T + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;        // row of the stacked [4d, d] gradient
-      float* crow = dW + (int64_t)(fr < D ? grp * D + fr : 3 * D + fr) * D + ct * DW_T + wc * 64 + li;
+      float* crow = dW + (int64_t)(fr < D ? grp * D + fr : 3 * D + fr) * D + ct * DW_T + wc * DW_WCOLS + li;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
+      for (int j = 0; j < DW_WN; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
     }
   STAMP2();
 }
@@ -807,7 +812,7 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
   int nsplit = d == 512 ? 2 : (d == 256 ? 4 : 16);
   if (env_split > 0 && env_split <= 64) nsplit = env_split;
   const int per = (4 * d / DW_T) * (d / DW_T);
-  const dim3 grid((unsigned)(per * 4 * nsplit)), block(512);
+  const dim3 grid((unsigned)(per * 4 * nsplit)), block(DW_NTHR);
   const size_t lds = 2 * DW_STAGE + DW_MAP * 4;
   const int pe = pm_prof_open(st, PM_PROF_GCL_DW, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD)                                                                                                     \

@@ -40,4 +40,7 @@ for sd in 1234 1235 1236 1237; do python bench.py --steps 10 --warmup 3 --no-cpu
 for m in 0 65535; do PM_SIDE_STREAM=$m python tools/phase_times.py; done > "$O/phase_times.txt" 2>&1
 pmc d256 B256_d256_nb2_L8
 pmc d512 B256_d512_nb2_L8 --d 512
+# the bench line once more with this run's PMC files in place (bench.py reports roofline.traffic only when their source digest matches)
+cp "$O/pmc_traffic_d256.json" profiles/pmc_traffic.json; cp "$O/pmc_traffic_d512.json" profiles/pmc_traffic_d512.json
+python bench.py > "$O/bench.json" 2> "$O/bench.err"
 tail -3 "$O/pytest_gpu.log"; tail -2 "$O/smoke.log"; python tools/benchline.py final < "$O/bench.json"; python tools/benchline.py d512 < "$O/bench_d512.json"; python tools/benchline.py dense < "$O/bench_dense.json"; python tools/benchline.py lmd16 < "$O/bench_lmd16.json"

@@ -20,11 +20,16 @@
 // the weight comes as fragment-major planes (pm_split_planes_frag; kind 0: W [Nout, K] used as B[n][k], kind 1: W [K, ldw]
 // used as B[k][n]); store waves write finished blocks (+ bias) as whole rows.  The in-kernel split (x6) tile kernel
 // it replaces re-splits every operand element once per 128x128 tile that uses it.
+#ifndef ROWS_NMW
+#define ROWS_NMW 4                        // MFMA waves of k_rows_w / k_rows_wk at d = 256: 4 = two 32-column tiles each; 8 = one each, two per SIMD: no gain (LOG)
+#endif
+template <int D> constexpr int rows_nmw() { return D == 256 ? ROWS_NMW : 4; }
+template <int D> constexpr int rows_threads() { return (rows_nmw<D>() + 4) * 64; }
 template <int D, int BKIND>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(rows_threads<D>()) __attribute__((amdgpu_waves_per_eu((rows_nmw<D>() + 4) / 4, (rows_nmw<D>() + 4) / 4)))
 k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ wfrag, int wtiles, int nblk,
          const float* __restrict__ bias, float* __restrict__ C, int ldc) {
-  constexpr int TN = D / 128, KS = D / 16, RB = D * 2, PL = BM * RB;
+  constexpr int NMW = rows_nmw<D>(), WC = D / NMW, TN = WC / 32, KS = D / 16, RB = D * 2, PL = BM * RB;   // WC: output columns per MFMA wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
   int m0 = 0, rows = BM;
@@ -32,10 +37,10 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
   const bool full = rows > BM / 2;
   N = min(N, m0 + rows);                                         // (rows past a half tile: out of range like rows past the end)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  if (wave >= 4) {
+  if (wave >= NMW) {
     // ---- store waves: block q of the stage (+ bias) -> C rows, 16 bytes per lane
     constexpr int LPR = D / 4, RPW = 64 / LPR, NR = BM / (4 * RPW);
-    const int st = tid - 256, c4 = st % LPR, r0 = st / LPR;
+    const int st = tid - NMW * 64, c4 = st % LPR, r0 = st / LPR;
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, GCL_OOB, 0x00020000);
     __syncthreads();                                           // (image filled)
 #pragma unroll 1
@@ -58,18 +63,18 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
   // ---- the tile's rows: fp32 -> three bf16 planes -> XOR-swizzled LDS image (16-byte chunk c of row r at c ^ (r & 15))
   {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, GCL_OOB, 0x00020000);
-    constexpr int CPR = D / 8, NCHK = BM * CPR / 256;            // 8-value chunks per row, chunks per thread
+    constexpr int CPR = D / 8, NST = NMW * 64, NCHK = BM * CPR / NST;   // 8-value chunks per row, staging threads, chunks per thread
     u32x4 v[NCHK][2];
 #pragma unroll
     for (int k = 0; k < NCHK; ++k) {
-      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR, row = m0 + rr;
+      const int ci = tid + k * NST, rr = ci / CPR, ch = ci % CPR, row = m0 + rr;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         v[k][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, row < N ? (int)(((int64_t)row * ldx + ch * 8 + h * 4) * 4) : GCL_OOB, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NCHK; ++k) {
-      const int ci = tid + k * 256, rr = ci / CPR, ch = ci % CPR;
+      const int ci = tid + k * NST, rr = ci / CPR, ch = ci % CPR;
       unsigned p1[4], p2[4], p3[4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -85,7 +90,7 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
   auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global step gs = block index * KS + k-step
     const int qb = min(gs / KS, nblk - 1), ks = gs % KS;
-    const int n0 = qb * D + wave * (D / 4);                      // first output column of this wave in block qb
+    const int n0 = qb * D + wave * WC;                           // first output column of this wave in block qb
     // kind 0: blocks ordered [32-column tile of W rows][k-step]; kind 1: [k-step][32-column tile], wtiles tiles per k-step
     const int soff = __builtin_amdgcn_readfirstlane(BKIND == 0 ? ((n0 >> 5) * KS + ks) * 3072 : (ks * wtiles + (n0 >> 5)) * 3072);
 #pragma unroll
@@ -142,7 +147,7 @@ k_rows_w(const float* __restrict__ X, int ldx, int N, const char* __restrict__ w
       for (int r = 0; r < 16; ++r)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / 4) + j * 32 + li] = acc[i][j][r];
+          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * WC + j * 32 + li] = acc[i][j][r];
     __syncthreads();
   }
   };
@@ -161,7 +166,7 @@ extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int3
   if (K == 512)                 // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_rows_times_weight(X, ldx, N, w_frag, kind, w_tiles, Nout, bias, C, ldc, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(pm_row_grid(N)), block(512);
+  const dim3 grid(pm_row_grid(N));
   const size_t lds = (size_t)3 * BM * K * 2 + (size_t)BM * K * 4;
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
 #define LAUNCH(DD, KD)                                                                                                 \
@@ -171,7 +176,7 @@ extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int3
       hipFuncSetAttribute((const void*)k_rows_w<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_rows_w<DD, KD>), grid, block, lds, st, X, ldx, N, reinterpret_cast<const char*>(w_frag),     \
+    hipLaunchKernelGGL((k_rows_w<DD, KD>), grid, dim3(rows_threads<DD>()), lds, st, X, ldx, N, reinterpret_cast<const char*>(w_frag), \
                        w_tiles, Nout / K, bias, C, ldc);                                                               \
   } while (0)
   if (K == 256) { if (kind == 0) LAUNCH(256, 0); else LAUNCH(256, 1); }
@@ -187,10 +192,10 @@ extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int3
 // without the gather — four producer waves split 64 x 128 fp32 chunks of the tile's rows into bf16 planes in a 2-image
 // LDS ring, four MFMA waves contract them with weight fragments straight from L2; output rows through LDS.
 template <int D, int BKIND>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(rows_threads<D>()) __attribute__((amdgpu_waves_per_eu((rows_nmw<D>() + 4) / 4, (rows_nmw<D>() + 4) / 4)))
 k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __restrict__ wfrag, int wpitch,
           float* __restrict__ C, int ldc) {
-  constexpr int TN = D / 128, HS = D + 8;
+  constexpr int NMW = rows_nmw<D>(), WC = D / NMW, TN = WC / 32, HS = D + 8, NTHR = rows_threads<D>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const sH = reinterpret_cast<float*>(smem);            // [BM][HS] output tile (epilogue; over the images)
   const int nchunk = K / CH;
@@ -199,9 +204,9 @@ k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __rest
   const bool full = rows > BM / 2;
   N = min(N, m0 + rows);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave >= 4) {
+  if (wave >= NMW) {
     // ---- producers: chunk c (128 features of the 64 rows) -> planes image c & 1; 32 lanes per row, 8 rows per pass
-    const int pt = tid - 256, q = pt & 31, prow = pt >> 5;
+    const int pt = tid - NMW * 64, q = pt & 31, prow = pt >> 5;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, GCL_OOB, 0x00020000);
     auto issue = [&](float4 (&xs)[8], int c) {
 #pragma unroll
@@ -254,7 +259,7 @@ k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wfrag), 0, GCL_OOB, 0x00020000);
-    const int n0 = wave * (D / 4);
+    const int n0 = wave * WC;
     auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {             // fragments of global k-step gs (16 rows of K)
       const int kk = min(gs, nchunk * 8 - 1);
       // kind 0: W [D, .] as B[n][k], wpitch = k-steps per 32-row tile of W; kind 1: W [K, D] as B[k][n], D/32 tiles per k-step
@@ -312,9 +317,11 @@ k_rows_wk(const float* __restrict__ X, int ldx, int N, int K, const char* __rest
   }
   __syncthreads();
   // ---- all waves: rows out, 4*D bytes per row and wave-instruction group
-  constexpr int NG = 512 / D, RG = BM / NG;
+  constexpr int NG = 512 / D, RG = BM / NG;                      // (the first 512 threads)
+  static_assert(NTHR >= 512, "row groups");
   const int col = tid % D, rg = tid / D;
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, GCL_OOB, 0x00020000);
+  if (tid >= 512) return;
 #pragma unroll 8
   for (int k = 0; k < RG; ++k) {
     const int rr = rg * RG + k, row = m0 + rr;
@@ -332,7 +339,7 @@ extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N
   if (Nout == 512)              // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_rows_times_weight_longk(X, ldx, N, K, w_frag, kind, w_pitch, C, ldc, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(pm_row_grid(N)), block(512);
+  const dim3 grid(pm_row_grid(N));
   const size_t lds = 2 * IMG;
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
 #define LAUNCH(DD, KD)                                                                                                 \
@@ -342,7 +349,7 @@ extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N
       hipFuncSetAttribute((const void*)k_rows_wk<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_rows_wk<DD, KD>), grid, block, lds, st, X, ldx, N, K, reinterpret_cast<const char*>(w_frag), \
+    hipLaunchKernelGGL((k_rows_wk<DD, KD>), grid, dim3(rows_threads<DD>()), lds, st, X, ldx, N, K, reinterpret_cast<const char*>(w_frag), \
                        w_pitch, C, ldc);                                                                               \
   } while (0)
   if (Nout == 256) { if (kind == 0) LAUNCH(256, 0); else LAUNCH(256, 1); }

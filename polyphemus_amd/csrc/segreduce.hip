@@ -193,6 +193,12 @@ extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int
 // the LDS float atomics, which bound the kernel there — 2.01 -> 0.74 ms per launch at d = 512, 2.08 M edges.  At d = 256 it
 // costs nothing; the d = 512 kernel with the norm sums is at its 128-VGPR budget (12 spilled registers, 85 -> 92 us on
 // sparse graphs), so sparse batches keep the per-edge form there.
+#ifndef SEG_META_AHEAD
+#define SEG_META_AHEAD 0                  // 1: edge metadata of the next trip requested one trip ahead — measured slower (LOG)
+#endif
+#ifndef SEG_EPT
+#define SEG_EPT 4                         // out-edges of a node whose row gathers are in flight together (k_segreduce_bwd, d <= 256)
+#endif
 template <int NV, bool DROP, bool FUSE, bool RL>
 __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict__ x, const float* __restrict__ T,
                                                        const float* __restrict__ dA, const float* __restrict__ dres,
@@ -203,6 +209,9 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
                                                        int compact, float* __restrict__ dx, float* __restrict__ dT,
                                                        PmNormSums nn, int xcd_nodes, int pr) {
+  // edges per trip: four at one float4 per lane (d <= 256: 128 VGPRs, 49.7-50.1 us against 51.1-51.6 with two); wider rows
+  // keep two (four spill: 48 registers at d = 512)
+  constexpr int EPT = NV == 1 ? SEG_EPT : 2;
   // LDS image of the table gradient: element (dist, column 4q + j) at dist*d + j*(d/4) + q, so that the four
   // ds_add_f32 of a lane's float4 hit consecutive addresses across the wave (bank-conflict free)
   extern __shared__ __attribute__((aligned(16))) float sT[];   // [32][4][d/4], then per wave `pr` private rows [d]
@@ -297,37 +306,50 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       }
     }
     const int beg = colptr[n], end = colptr[n + 1];
-    for (int p = beg; p < end; p += 2) {                    // two edges per trip: their row gathers overlap
-      int dst[2], dist[2], blk[2];
-      float w[2];
-      uint32_t key[2];
+    // edge metadata through the scalar cache (p is uniform), requested at the top of their trip.  SEG_META_AHEAD=1 requests
+    // the next trip's words before this trip's rows are gathered: 55.1-55.5 us per launch against 50.5-51.1 (19 spilled
+    // SGPRs, 6 VGPRs, a copy of the words per trip)
+    struct Meta { int dst[EPT], dist[EPT], blk[EPT]; float w[EPT]; uint32_t key[EPT]; };
+    auto load_meta = [&](Meta& m, int p) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {                          // (edge metadata through the scalar cache: p is uniform)
+      for (int u = 0; u < EPT; ++u) {
         const bool live = p + u < end;
-        const int q = live ? p + u : p;                      // odd tail: edge p again with weight 0
-        dst[u] = csc_dst[q];
+        const int q = live ? p + u : end - 1;                // tail: the last edge again with weight 0 (same distance: no new run)
+        m.dst[u] = csc_dst[q];
         const int rd = csc_reldist[q];
         const int r = rd & 0xff;
-        dist[u] = rd >> 8;
-        blk[u] = compact ? (r < 4 ? 0 : r - 3) : r;          // compact: the one track block a node receives
-        w[u] = live ? csc_invcnt[q] * scale : 0.f;
-        key[u] = DROP ? pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[q]) : 0u;
+        m.dist[u] = rd >> 8;
+        m.blk[u] = compact ? (r < 4 ? 0 : r - 3) : r;        // compact: the one track block a node receives
+        m.w[u] = live ? csc_invcnt[q] * scale : 0.f;
+        m.key[u] = DROP ? pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[q]) : 0u;
       }
+    };
+    Meta mt, mn;
+    if (SEG_META_AHEAD && beg < end) load_meta(mt, beg);
+    for (int p = beg; p < end; p += EPT) {                  // EPT edges per trip: their row gathers overlap
+      if (!SEG_META_AHEAD) load_meta(mt, p);
+      else if (p + EPT < end) { load_meta(mn, p + EPT); __builtin_amdgcn_sched_barrier(0); }
+      const int (&dst)[EPT] = mt.dst, (&dist)[EPT] = mt.dist, (&blk)[EPT] = mt.blk;
+      const float (&w)[EPT] = mt.w;
+      const uint32_t (&key)[EPT] = mt.key;
       // run boundaries of the table-gradient accumulation (dist is wave-uniform: scalar branches)
-      const int prev[2] = {cur, dist[0]};
+      int prev[EPT];
+      prev[0] = cur;
+#pragma unroll
+      for (int u = 1; u < EPT; ++u) prev[u] = dist[u - 1];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if (!ok[v]) continue;
-        float4 g4[2], tv[2];
+        float4 g4[EPT], tv[EPT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < EPT; ++u) {
           g4[u] = *reinterpret_cast<const float4*>(dA + ((int64_t)dst[u] * nblk + blk[u]) * d + c[v]);
           tv[u] = *reinterpret_cast<const float4*>(T + dist[u] * d + c[v]);
         }
         const float xs[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w};
         float* ap = reinterpret_cast<float*>(&acc[v]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < EPT; ++u) {
           const float g[4] = {g4[u].x * w[u], g4[u].y * w[u], g4[u].z * w[u], g4[u].w * w[u]};
           const float ts[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
           float gt[4];
@@ -352,7 +374,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
           }
         }
       }
-      cur = dist[1];
+      cur = dist[EPT - 1];
+      if (SEG_META_AHEAD) mt = mn;
     }
     if (RL) {
 #pragma unroll

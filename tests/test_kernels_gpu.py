@@ -1045,12 +1045,16 @@ def test_rows_tn_weight_grad_matches_fp64(K, M, Nn, lda, ldb, ldc):
     assert rel_err(C2[:, :Nn], want) < 2e-6
 
 
-@pytest.mark.parametrize("d,B,S", [(256, 40, 5), (128, 3, 15), (512, 24, 4), (256, 1, 7)])
-def test_unembed_input_gradient_in_one_launch(d, B, S):
+@pytest.mark.parametrize("d,B,S,drums", [(256, 40, 5, "mixed"), (128, 3, 15, "mixed"), (512, 24, 4, "mixed"), (256, 1, 7, "mixed"),
+                                          (256, 6, 5, "none"), (256, 6, 5, "all"), (128, 300, 2, "mixed")])
+def test_unembed_input_gradient_in_one_launch(d, B, S, drums):
     """`pm_unembed_dh`: dH = d_logits @ W of the three un-embeddings (pitch per drum / non-drum row list, duration on all
-    rows) in one launch on the bf16 pipe, against the fp64 products; every (node, slot) row written exactly once."""
+    rows) in one launch on the bf16 pipe, against the fp64 products; every (node, slot) row written exactly once.  Also an
+    empty drum / non-drum row list (a job without tiles) and more tiles than workgroups (B = 300)."""
     import ctypes
     cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=29)
+    if drums != "mixed":
+        cpu.is_drum = torch.full_like(cpu.is_drum, drums == "all")
     b = cpu.to(DEV)
     plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars,
                           b.s_tensor.shape[0], n_slots=S)

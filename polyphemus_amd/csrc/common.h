@@ -66,6 +66,67 @@ __host__ __device__ static inline uint32_t pm_keep_threshold(float p) {
   return (uint32_t)(p * 16777216.0f);
 }
 
+// ---- deterministic mode (PM_DETERMINISTIC=1 / pm_set_deterministic; host side in det.hip) -------------------------------
+// Every float (fp32 / fp64) atomic of the step makes its result depend on the order in which workgroups happen to retire,
+// i.e. the same inputs give gradients (and, through split-K sums in the heads and the column statistics of the norms,
+// activations) that differ in their last bits from run to run.  In deterministic mode a launch that contains such
+// atomics gets a GATE: a zeroed device counter on which the launch's workgroups (or waves) take turns in the order of
+// their linear block index — the order in which the hardware dispatches them, so the turn a workgroup waits for always
+// belongs to a workgroup that is already resident or finished.  Sums are then added in one fixed order and two runs are
+// bit-identical.  The kernels are unchanged otherwise (a null gate is a no-op); the mode serialises the epilogues and
+// is meant for parity tests and debugging, not for throughput runs.
+// pm_det_gate(stream): nullptr when the mode is off, otherwise a counter cleared on `stream` ahead of the launch.
+unsigned* pm_det_gate(hipStream_t st);
+int pm_det_on();
+
+#ifdef __HIPCC__
+__device__ static inline unsigned pm_linear_block() {
+  return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+}
+__device__ static inline unsigned pm_linear_thread() {
+  return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+}
+// one lane spins (bounded: a lost turn must not hang the device — after ~2^22 polls the wave goes ahead unordered)
+__device__ static inline void pm_gate_spin(unsigned* gate, unsigned turn) {
+  for (int it = 0; it < (1 << 22); ++it) {
+    if (__hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == turn) return;
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+// WAVE-level turn (waves that reach the ordered section independently, e.g. consumer waves of a specialised kernel)
+__device__ static inline void pm_turn_enter(unsigned* gate, unsigned turn) {
+  if (!gate) return;
+  if (__lane_id() == 0) pm_gate_spin(gate, turn);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ static inline void pm_turn_leave(unsigned* gate, unsigned turn) {
+  if (!gate) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (__lane_id() == 0) __hip_atomic_store(gate, turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// WORKGROUP-level turn = the linear block index; every thread of the block must call both
+__device__ static inline void pm_turn_enter_block(unsigned* gate) {
+  if (!gate) return;
+  if (pm_linear_thread() == 0) pm_gate_spin(gate, pm_linear_block());
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ static inline void pm_turn_leave_block(unsigned* gate) {
+  if (!gate) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (pm_linear_thread() == 0) __hip_atomic_store(gate, pm_linear_block() + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a workgroup that returns without reaching the ordered section hands its `turns` (1 for block-level gates, the number
+// of ordered waves for wave-level gates) on; called by every thread of the block right before the early return
+__device__ static inline void pm_turn_skip_block(unsigned* gate, unsigned turns = 1) {
+  if (!gate || pm_linear_thread() != 0) return;
+  const unsigned first = pm_linear_block() * turns;
+  pm_gate_spin(gate, first);
+  __hip_atomic_store(gate, first + turns, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 #ifdef __HIPCC__
 __device__ static inline float pm_wave_sum(float v) {
 #pragma unroll

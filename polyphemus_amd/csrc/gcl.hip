@@ -69,6 +69,7 @@ struct GclArgs {
   const char* wfrag;             // fragment-major planes of the layer's [7d, d] weight (kind 1: [k-step][column tile][plane])
   uint16_t* planes; int64_t plane_stride;   // A' planes (optional)
   float* h; double* colstats;
+  unsigned* gate;                // deterministic mode (common.h): the workgroups add their column sums in turn
   int N, use_classes;
   uint32_t seed, layer_uid, thresh; float scale;
 };
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     g_blocklog[blockIdx.x][3] = -1;
   }
 #endif
-  if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+  if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) { pm_turn_skip_block(g.gate); return; }
 #ifdef GCL_BLOCKLOG
   const long long t_sched = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -402,13 +403,15 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     double* sS = reinterpret_cast<double*>(sT);                // [NG][2][D] (the distance table is no longer needed)
     if (tid < 512) { sS[(rg * 2) * D + col] = cs; sS[(rg * 2 + 1) * D + col] = cq; }
     __syncthreads();
+    pm_turn_enter_block(g.gate);
     if (tid < 2 * D) {
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < NG; ++k) v += sS[k * 2 * D + tid];
       atomicAdd(g.colstats + (int64_t)(blockIdx.x % PM_BN_REPL) * 2 * D + tid, v);
     }
-  }
+    pm_turn_leave_block(g.gate);
+  } else pm_turn_skip_block(g.gate);
 #ifdef GCL_BLOCKLOG
   __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
@@ -655,7 +658,7 @@ template <int D>
 __global__ void __launch_bounds__(DW_NTHR) __attribute__((amdgpu_waves_per_eu((DW_NMW + 4) / 4, (DW_NMW + 4) / 4)))
 k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restrict__ dhp, int64_t dps,
          const int* __restrict__ trk_list, const int* __restrict__ trk_cnt, float* __restrict__ dW, int N, int nsplit,
-         int use_classes) {
+         int use_classes, unsigned* gate) {
   constexpr int NFT = 4 * D / DW_T, NCT = D / DW_T, PER = NFT * NCT;       // tiles per (group, slice)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* const sMap = reinterpret_cast<int*>(smem + 2 * DW_STAGE);
@@ -676,10 +679,10 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
     hi = blk == 1 ? cb[3] : cb[4];
   }
   const int K = hi - lo;
-  if (K <= 0) return;
+  if (K <= 0) { pm_turn_skip_block(gate, DW_NMW); return; }       // (deterministic mode: the MFMA waves' turns go on)
   const int kper = (((K + nsplit - 1) / nsplit + DW_KT - 1) / DW_KT) * DW_KT;
   const int kbeg = zs * kper, kend = min(kbeg + kper, K);
-  if (kbeg >= kend) return;
+  if (kbeg >= kend) { pm_turn_skip_block(gate, DW_NMW); return; }
   const int* list = trk_list + (int64_t)grp * N + lo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int nst = 0;
@@ -781,6 +784,7 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
   }
   if (wave >= DW_NMW) return;
   STAMP2();
+  pm_turn_enter(gate, blockIdx.x * DW_NMW + wave);
   // ---- epilogue: the tile is one K slice's (and, for the shared blocks, one group's) term: float atomics
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 #pragma unroll
@@ -792,6 +796,7 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
 #pragma unroll
       for (int j = 0; j < DW_WN; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
     }
+  pm_turn_leave(gate, blockIdx.x * DW_NMW + wave);
   STAMP2();
 }
 
@@ -814,6 +819,7 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
   const int per = (4 * d / DW_T) * (d / DW_T);
   const dim3 grid((unsigned)(per * 4 * nsplit)), block(DW_NTHR);
   const size_t lds = 2 * DW_STAGE + DW_MAP * 4;
+  unsigned* const gate = pm_det_gate(st);
   const int pe = pm_prof_open(st, PM_PROF_GCL_DW, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD)                                                                                                     \
   do {                                                                                                                 \
@@ -823,7 +829,7 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
       once = true;                                                                                                     \
     }                                                                                                                  \
     hipLaunchKernelGGL((k_gcl_dw<DD>), grid, block, lds, st, a_planes, a_plane_stride, dh_planes, dh_plane_stride,     \
-                       pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes);                                           \
+                       pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes, gate);                                     \
   } while (0)
   if (d == 512) LAUNCH(512); else if (d == 256) LAUNCH(256); else LAUNCH(128);
 #undef LAUNCH
@@ -854,6 +860,7 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
   a.csr_eid = pv.csr_eid; a.trk_list = pv.trk_list; a.trk_cnt = pv.trk_cnt;
   a.wfrag = reinterpret_cast<const char*>(w_frag); a.planes = planes; a.plane_stride = plane_stride; a.h = h;
   a.colstats = col_stats; a.N = N; a.use_classes = use_classes;
+  a.gate = col_stats ? pm_det_gate((hipStream_t)stream) : nullptr;
   const bool drop = dropout_p > 0.f;
   a.seed = seed; a.layer_uid = layer_uid; a.thresh = pm_keep_threshold(dropout_p);
   a.scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;

@@ -57,6 +57,7 @@ struct GemmArgs {
   // MODE 3: B (a weight matrix) as fragment-major planes (pm_split_planes_frag); bf_n = K/16 (transB) or N/32 tiles
   const char* bfrag; int bf_n;
   float* colsum_a;                           // optional (transA, fp32 tiles): += sum over K of A[k, m]  (bias gradient)
+  unsigned* gate;                            // deterministic mode (common.h): the MFMA waves take turns in the epilogue
 };
 
 __device__ static inline int64_t map_row(const int32_t* map, int rpe, int r) {
@@ -352,6 +353,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
   char* const Ax0 = reinterpret_cast<char*>(smem);      // split mode: two A images (3 planes each), then two B images
   char* const Bx0 = Ax0 + 2 * StA::XBYTES;
 
+  // deterministic mode: a workgroup that leaves early hands the turns of its MFMA waves on
+#define GEMM_SKIP do { pm_turn_skip_block(g.gate, WVM * WVN); return; } while (0)
   int grp = blockIdx.y, t = blockIdx.x, zs = blockIdx.z, nwg;
   if (TA) {
     // weight gradients: XCD-aware order over the WHOLE grid (tiles x groups x K-slices).  Workgroup L runs on XCD
@@ -369,7 +372,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
     int tot = 0;
     for (int q = 0; q < g.ngroups; ++q) tot += (g.dyn_entries[q * g.dyn_boff] * g.rpe + BM - 1) / BM;
     nwg = tot * g.ntn;
-    if (t >= nwg) return;
+    if (t >= nwg) GEMM_SKIP;
     {                                        // XCD-aware order over the live tiles of all groups (see below)
       const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -407,12 +410,12 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
   // (with a device-side row count only the live row panels take part, so they still spread over all 8 XCDs)
   if (!TA && !g.packed) {
     nwg = ((M + BM - 1) / BM) * g.ntn;
-    if (t >= nwg) return;
+    if (t >= nwg) GEMM_SKIP;
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN;
-  if (m0 >= M) return;
+  if (m0 >= M) GEMM_SKIP;
   // Row classes (compact GCL): rows [b1,b3) of the group's list receive onset edges, rows [b2,b4) next edges; for all
   // other rows that block of the aggregate is identically zero.  Forward (cls_dim 1): skip those K blocks for a row
   // tile without such rows; input gradient (2): skip the output tiles nobody reads; weight gradient (3): contract
@@ -426,24 +429,26 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
       const int lo = mb == 1 ? on_lo : (mb == 2 ? nx_lo : 0), hi = mb == 1 ? on_hi : (mb == 2 ? nx_hi : K);
       g.rowmap += lo;
       K = hi - lo;
-      if (K <= 0) return;
+      if (K <= 0) GEMM_SKIP;
       kper = (((K + (int)gridDim.z - 1) / (int)gridDim.z + BK - 1) / BK) * BK;
     } else {
       use_on = m0 < on_hi && m0 + BM > on_lo;
       use_nx = m0 < nx_hi && m0 + BM > nx_lo;
       if (g.cls_dim == 2) {
         const int nb_ = n0 / g.cls_blk;
-        if ((nb_ == 1 && !use_on) || (nb_ == 2 && !use_nx)) return;
+        if ((nb_ == 1 && !use_on) || (nb_ == 2 && !use_nx)) GEMM_SKIP;
       }
     }
   }
   const int kbeg = zs * kper;
   int kend = kbeg + kper;
   if (kend > K) kend = K;
-  if (kbeg >= kend) return;
+  if (kbeg >= kend) GEMM_SKIP;
 
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (WVM * WVN);
   const bool producer = X6 && threadIdx.x >= THREADS;
+  const unsigned my_turn = pm_linear_block() * (WVM * WVN) + wave;      // deterministic mode (MFMA waves only)
+  bool in_turn = false;
   const int wr = wave / WVN, wc = wave % WVN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -752,6 +757,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
   }
   if constexpr (TA && MODE == 0) {
     if (do_cs) {
+      pm_turn_enter(g.gate, my_turn);
+      in_turn = true;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const float v = csa[i] + __shfl_xor(csa[i], 32);
@@ -764,6 +771,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
 
   }
   if (producer) return;
+#undef GEMM_SKIP
+  if (!in_turn) pm_turn_enter(g.gate, my_turn);
   // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
   const bool atomic = gridDim.z > 1;
   const bool accum = (g.flags & PM_GEMM_ACCUM) != 0;
@@ -822,6 +831,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN * (MODE == 1 ? 2 : 1))
       }
     }
   }
+  pm_turn_leave(g.gate, my_turn);
 }
 
 template <int BM, int BN, int BK, int WVM, int WVN, bool TA, bool TB, bool VA, bool VB, int MODE>
@@ -1006,6 +1016,8 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   if (!(transA && q->dyn_entries)) split_k = (int)pm_cdiv(K, kper);     // (device-side K: the kernel re-derives kper)
   dim3 grid((unsigned)tiles, (unsigned)n_groups, (unsigned)split_k);
   if (g.packed) grid = dim3((unsigned)((g.ntm + n_groups) * g.ntn), 1, (unsigned)split_k);
+  // deterministic mode: K slices, groups that share stacked rows, column statistics and the bias gradient add in turn
+  g.gate = (split_k > 1 || g.colstats || g.colsum_a || (g.c_split > 0 && n_groups > 1)) ? pm_det_gate(st) : nullptr;
   const double work = 2.0 * M * N * K * (partitioned ? 1.0 : (double)n_groups);
   const int pe = pm_prof_open(st, PM_PROF_GEMM0 + cfg * 3 + (transA ? 2 : (transB ? 1 : 0)), work);
   switch (cfg) {

@@ -370,7 +370,7 @@ extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N
 // replaces ran at 0.58-0.61 of the fp32 matrix peak (157 TFLOP/s); this one runs the six-product chain on the bf16 pipe.
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int K, int ntn, int nsplit,
-          float* __restrict__ C, int ldc, float* __restrict__ colsum_a) {
+          float* __restrict__ C, int ldc, float* __restrict__ colsum_a, unsigned* gate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntile = gridDim.x / nsplit;
   // XCD-aware order: the tiles of one K slice share its operand rows -> consecutive slabs on one XCD
@@ -382,9 +382,10 @@ k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int
   const int zs = L / ntile, within = L % ntile, ft = within / ntn, ct = within % ntn;
   const int kper = (((K + nsplit - 1) / nsplit + DW_KT - 1) / DW_KT) * DW_KT;
   const int kbeg = zs * kper, kend = min(kbeg + kper, K);
-  if (kbeg >= kend) return;
+  if (kbeg >= kend) { pm_turn_skip_block(gate, 8); return; }       // (deterministic mode: the eight waves' turns go on)
   const int nt = (kend - kbeg + DW_KT - 1) / DW_KT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned my_turn = blockIdx.x * 8 + wave;
   if (wave >= 4) {
     // ---- loaders: thread -> four consecutive columns (float4) of rows r0, r0 + 8, r0 + 16, r0 + 24 of each tile, both operands
     const int lt = tid - 256, c4 = lt & 31, r0 = lt >> 5;
@@ -438,10 +439,12 @@ k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int
       put(va, t + 2);
       __syncthreads();
     }
+    pm_turn_enter(gate, my_turn);
     if (want_cs) {
       float* dst = colsum_a + ft * DW_T + c4 * 4;
       atomicAdd(dst, cs.x); atomicAdd(dst + 1, cs.y); atomicAdd(dst + 2, cs.z); atomicAdd(dst + 3, cs.w);
     }
+    pm_turn_leave(gate, my_turn);
     return;
   }
   // ---- MFMA waves: 64x64 quarter (wr, wc) of the tile
@@ -480,6 +483,7 @@ k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int
   }
   // ---- epilogue: one K slice's term of the tile: float atomics
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  pm_turn_enter(gate, my_turn);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -489,6 +493,7 @@ k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int
 #pragma unroll
       for (int j = 0; j < 2; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
     }
+  pm_turn_leave(gate, my_turn);
 }
 
 extern "C" int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t Nn,
@@ -512,7 +517,7 @@ extern "C" int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, co
   }
   const int pe = pm_prof_open(st, PM_PROF_ROWS_TN, 2.0 * K * (double)M * Nn);
   hipLaunchKernelGGL(k_rows_tn, dim3(ntile * nsplit), dim3(512), 2 * DW_STAGE, st, A, lda, B, ldb, K, ntn, nsplit, C, ldc,
-                     colsum_a);
+                     colsum_a, pm_det_gate(st));
   pm_prof_close(st, pe);
   return pm_check_launch();
 }

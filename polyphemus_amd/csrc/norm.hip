@@ -518,7 +518,7 @@ extern "C" int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const dou
 __global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* __restrict__ x,
                                                                    const float* __restrict__ dy, int O, int C,
                                                                    BnCtx ctx, int rows_per_chunk,
-                                                                   double* __restrict__ acc3) {
+                                                                   double* __restrict__ acc3, unsigned* gate) {
   __shared__ double sh[4][64][12];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
@@ -548,12 +548,14 @@ __global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* 
 #pragma unroll
   for (int j = 0; j < 12; ++j) sh[wave][lane][j] = acc[j];
   __syncthreads();
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the row chunks add in turn)
   if (wave == 0 && ok) {
     double* dst = acc3 + (int64_t)(blockIdx.y % PM_BN_REPL) * 3 * C;
 #pragma unroll
     for (int j = 0; j < 12; ++j)
       atomicAdd(&dst[(int64_t)(j >> 2) * C + c + (j & 3)], sh[0][lane][j] + sh[1][lane][j] + sh[2][lane][j] + sh[3][lane][j]);
   }
+  pm_turn_leave_block(gate);
 }
 __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restrict__ x, const float* __restrict__ dy,
                                                             int64_t n4, int C, double count, BnCtx ctx,
@@ -613,7 +615,8 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
   const int rpc = (int)pm_cdiv(O, nc);
   nc = (int)pm_cdiv(O, rpc);
   if (!sums_ready)
-    hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3);
+    hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3,
+                       pm_det_gate(st));
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
                      (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride);
@@ -706,7 +709,7 @@ extern "C" int pm_add(const float* a, const float* b, int64_t n, float* out, pm_
 }
 // out[c] += sum_m x[m, c]   (bias gradients): 64 columns x 4 row-waves per block, one atomic per column per block
 __global__ void __launch_bounds__(256) k_colsum_acc(const float* __restrict__ x, int M, int C, int ld,
-                                                    int rows_per_chunk, float* out) {
+                                                    int rows_per_chunk, float* out, unsigned* gate) {
   __shared__ float sh[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -717,7 +720,9 @@ __global__ void __launch_bounds__(256) k_colsum_acc(const float* __restrict__ x,
   if (c < C) for (int r = r0 + wave; r < r1; r += 4) s += x[(int64_t)r * ld + c];
   sh[wave][lane] = s;
   __syncthreads();
+  pm_turn_enter_block(gate);
   if (wave == 0 && c < C) atomicAdd(&out[c], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+  pm_turn_leave_block(gate);
 }
 extern "C" int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, float* out, pm_stream_t stream) {
   if (!x || !out || M <= 0 || C <= 0 || ld < C) return PM_E_INVALID;
@@ -725,14 +730,15 @@ extern "C" int pm_colsum_acc(const float* x, int32_t M, int32_t C, int32_t ld, f
   if (nc > 128) nc = 128;
   const int rpc = (int)pm_cdiv(M, nc);
   nc = (int)pm_cdiv(M, rpc);
-  hipLaunchKernelGGL(k_colsum_acc, dim3(pm_cdiv(C, 64), nc), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, rpc, out);
+  hipLaunchKernelGGL(k_colsum_acc, dim3(pm_cdiv(C, 64), nc), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, rpc, out,
+                     pm_det_gate((hipStream_t)stream));
   return pm_check_launch();
 }
 
 __global__ void __launch_bounds__(256) k_colsum_rows_acc(const float* __restrict__ x, int C, int ld,
                                                          const int* __restrict__ rowmap, int rpe,
                                                          const int* __restrict__ dyn, int max_entries,
-                                                         int rows_per_chunk, float* out) {
+                                                         int rows_per_chunk, float* out, unsigned* gate) {
   __shared__ float sh[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -746,7 +752,9 @@ __global__ void __launch_bounds__(256) k_colsum_rows_acc(const float* __restrict
   if (c < C) for (int r = r0 + wave; r < r1; r += 4) s += x[((int64_t)rowmap[r / rpe] * rpe + r % rpe) * ld + c];
   sh[wave][lane] = s;
   __syncthreads();
+  pm_turn_enter_block(gate);
   if (wave == 0 && c < C && r0 < M) atomicAdd(&out[c], sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+  pm_turn_leave_block(gate);
 }
 extern "C" int pm_colsum_rows_acc(const float* x, int32_t C, int32_t ld, const int32_t* rowmap, int32_t rows_per_entry,
                                   const int32_t* dyn_entries, int32_t max_entries, float* out, pm_stream_t stream) {
@@ -757,7 +765,7 @@ extern "C" int pm_colsum_rows_acc(const float* x, int32_t C, int32_t ld, const i
   const int rpc = (int)pm_cdiv(M, nc);
   nc = (int)pm_cdiv(M, rpc);
   hipLaunchKernelGGL(k_colsum_rows_acc, dim3(pm_cdiv(C, 64), nc), dim3(256), 0, (hipStream_t)stream, x, C, ld, rowmap,
-                     rows_per_entry, dyn_entries, max_entries, rpc, out);
+                     rows_per_entry, dyn_entries, max_entries, rpc, out, pm_det_gate((hipStream_t)stream));
   return pm_check_launch();
 }
 

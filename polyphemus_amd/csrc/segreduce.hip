@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
                                                        const float* __restrict__ csc_invcnt, int N, int d,
                                                        uint32_t seed, uint32_t layer_uid, uint32_t thresh, float scale,
                                                        int compact, float* __restrict__ dx, float* __restrict__ dT,
-                                                       PmNormSums nn, int xcd_nodes, int pr) {
+                                                       PmNormSums nn, int xcd_nodes, int pr, unsigned* gate) {
   // edges per trip: four at one float4 per lane (d <= 256: 128 VGPRs, 49.7-50.1 us against 51.1-51.6 with two); wider rows
   // keep two (four spill: 48 registers at d = 512)
   constexpr int EPT = NV == 1 ? SEG_EPT : 2;
@@ -428,6 +428,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     sT[(r + 1) * d + (col & 3) * dq + (col >> 2)] += t;
   }
   __syncthreads();
+  // deterministic mode (common.h): ONE wave per workgroup (its LDS adds are in program order) and the workgroups flush in turn
+  pm_turn_enter_block(gate);
   for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {       // i runs over dT (coalesced atomics)
     const int col = i % d;
     const float v = sT[i - col + (col & 3) * dq + (col >> 2)];
@@ -462,6 +464,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       atomicAdd(&dst[i], t);
     }
   }
+  pm_turn_leave_block(gate);
 }
 
 // > 64 KiB of dynamic LDS needs the attribute: set once per instantiation and size
@@ -487,9 +490,11 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   hipStream_t st = (hipStream_t)stream;
   // 16-wave workgroups, one per CU: 4096 waves hide the colptr -> edge -> row-gather latency chain while only 256
   // LDS tables are flushed with global atomics (measured: 48 us; 4-wave workgroups x 768: 59 us; x 1024: 61 us)
-  const int threads = N >= 4096 ? 1024 : 256;
+  // (deterministic mode: one wave per workgroup — several waves would race on the LDS table —, 512 workgroups)
+  unsigned* const gate = pm_det_gate(st);
+  const int threads = gate ? 64 : (N >= 4096 ? 1024 : 256);
   int nblk = (int)pm_cdiv(N, threads / 64);
-  if (nblk > 256) nblk = 256;
+  if (nblk > (gate ? 512 : 256)) nblk = gate ? 512 : 256;
   const dim3 grid(nblk), block(threads);
   int xcd_nodes = 0;                                    // nodes per XCD, a multiple of the waves per workgroup
   if (seg_xcd_aware() && nblk >= 16 && (nblk & 7) == 0) xcd_nodes = (int)pm_cdiv(pm_cdiv(N, 8), threads / 64) * (threads / 64);
@@ -508,7 +513,7 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
 #define LAUNCH(NV, DR, FU, RL)                                                                                       \
   do { seg_bwd_lds_attr<NV, DR, FU, RL>(lds);                                                                     \
   hipLaunchKernelGGL((k_segreduce_bwd<NV, DR, FU, RL>), grid, block, lds, st, x, T, dA, dres, pv.colptr, pv.csc_dst,  \
-                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes, pr); } while (0)
+                     pv.csc_reldist, pv.csc_eid, pv.csc_invcnt, N, d, seed, layer_uid, thresh, scale, compact, dx, dT, nv_, xcd_nodes, pr, gate); } while (0)
   // run-length form: always at d <= 256 (free), on dense graphs (mean out-degree >= 16) at any width
   const bool rl = d <= 256 || (int64_t)E >= 16 * (int64_t)N;
 #define LAUNCH2(NV, DR) do { if (nn) { if (rl) LAUNCH(NV, DR, true, true); else LAUNCH(NV, DR, true, false); }       \

@@ -36,6 +36,7 @@ struct UnembedArgs {
   const float* H; const int* tok; const int* hist; const float* dev_scale;
   float* logits; float* dlogits; double* out;
   int R, S, d, dh; float grad_scale;
+  unsigned* gate;                                      // deterministic mode (common.h): workgroups add bias gradients / losses in turn
 };
 
 #ifndef PM_UNEMBED_WAVES
@@ -211,10 +212,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_UNE
     __syncthreads();                                              // s_row / s_tgt / red are rewritten by the next tile
   }
   // bias gradient: every wave holds partial sums of the columns lane + 64 q over the rows it walked
+  // (deterministic mode: workgroups in turn, and inside a workgroup the four waves one after the other)
+  pm_turn_enter_block(a.gate);
+  for (int w = 0; w < (a.gate ? 4 : 1); ++w) {
+    if (!a.gate || wave == w) {
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int c = lane + 64 * q;
-    if (jb.dbias && c < jb.V && dbacc[q] != 0.f) atomicAdd(jb.dbias + c, dbacc[q]);
+      for (int q = 0; q < 3; ++q) {
+        const int c = lane + 64 * q;
+        if (jb.dbias && c < jb.V && dbacc[q] != 0.f) atomicAdd(jb.dbias + c, dbacc[q]);
+      }
+    }
+    if (a.gate) __syncthreads();
   }
   lacc = pm_wave_sum_d(lacc);
   if (lane == 0) s_loss[wave] = lacc;
@@ -223,6 +231,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_UNE
     const double t = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
     if (t != 0) atomicAdd(&a.out[jb.kind], t / nval);
   }
+  pm_turn_leave_block(a.gate);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -483,6 +492,7 @@ __global__ void __launch_bounds__(PNW * 64) __attribute__((amdgpu_waves_per_eu(3
   if (lane == 0) s_loss[wave] = lacc;
   __syncthreads();
   const int rep = blockIdx.x % UREP;
+  pm_turn_enter_block(a.gate);
   if (tid < 192 && tid < jb.V) {
     float t = 0.f;
 #pragma unroll
@@ -495,6 +505,7 @@ __global__ void __launch_bounds__(PNW * 64) __attribute__((amdgpu_waves_per_eu(3
     for (int w = 0; w < PNW; ++w) t += s_loss[w];
     if (t != 0) atomicAdd(lossrep + rep * 2 + jb.kind, t / nval);
   }
+  pm_turn_leave_block(a.gate);
 }
 // replicas -> bias gradients (+=) and the two losses
 __global__ void __launch_bounds__(512) k_unembed_fold(UnembedArgs a, const float* __restrict__ dbrep, const double* __restrict__ lossrep) {
@@ -544,6 +555,7 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
   a.job[2] = {w_dur, b_dur, db_dur, nullptr, nullptr, PM_N_DUR, dh, PM_N_PITCH, 1, 98};
   a.H = H; a.tok = tokens; a.hist = pv.tok_hist; a.dev_scale = dev_scale; a.logits = logits; a.dlogits = d_logits; a.out = out;
   a.R = (int)R; a.S = n_slots; a.d = d; a.dh = dh; a.grad_scale = grad_scale;
+  a.gate = nullptr;
   int nb = (int)pm_cdiv(R, UBM);
   if (w_planes && (dh == 64 || dh == 128 || dh == 256) && !((uintptr_t)w_planes % 16) && !((uintptr_t)H % 16) &&
       R * (int64_t)d * 4 < 0x7fffffffLL) {
@@ -552,6 +564,7 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
     float* dbrep = reinterpret_cast<float*>(w_planes + (size_t)448 * dh * 3);
     double* lossrep = reinterpret_cast<double*>(dbrep + UREP * UREP_F);
     hipLaunchKernelGGL(k_unembed_wplanes, dim3(16, 3), dim3(256), 0, st, a, w_planes, o1, o2, dbrep, lossrep);
+    a.gate = pm_det_gate(st);
     if (nb > 512) nb = 512;
     const size_t img = (size_t)3 * UBM * dh * 2, tile = (size_t)UBM * PLDL * 4;
     const size_t lds = (img > tile ? img : tile) + 2 * UBM * sizeof(int) + PNW * sizeof(double) + (size_t)UBM * PNW * 2 * sizeof(float);
@@ -572,6 +585,7 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
   }
   hipMemsetAsync(out, 0, 2 * sizeof(double), st);
   if (nb > 768) nb = 768;                              // persistent: ~3 resident workgroups per CU and job
+  a.gate = pm_det_gate(st);
   hipLaunchKernelGGL(k_unembed_ce, dim3(nb, 3), dim3(256), 0, st, a);
   return pm_check_launch();
 }

@@ -53,6 +53,7 @@ struct WideArgs {
   int K, npass;                                             // V_ROWSWK: inner dimension; V_ROWSW: 512-column output blocks
   // epilogue
   const float* bias; float* out; int ldo; double* colstats;
+  unsigned* gate;                                           // deterministic mode (common.h): MFMA waves add the column sums in turn
 };
 }  // namespace
 
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
   bool use_on = true, use_nx = true;
   if constexpr (GCL) {
     PmTile tl;
-    if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) return;
+    if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) { pm_turn_skip_block(g.gate, NCW); return; }
     grp = tl.grp; m0 = tl.m0; rows = tl.rows;                  // rows = 64, or 32: half a tile (tile_order.h)
     M = g.trk_cnt[grp];
     list = g.trk_list + (int64_t)grp * g.N;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
       use_nx = m0 < cb[4] && m0 + rows > cb[2];
     }
   } else {
-    if (!pm_row_tile(g.M, blockIdx.x, m0, rows)) return;       // rows = 64, or 32: half a tile (tile_order.h)
+    if (!pm_row_tile(g.M, blockIdx.x, m0, rows)) { pm_turn_skip_block(g.gate, NCW); return; }   // rows = 64, or 32: half a tile (tile_order.h)
     M = min(g.M, m0 + rows);
   }
   const int nvalid = min(rows, M - m0);
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
     }
     if constexpr (VAR == V_FWD || VAR == V_FWDP) {
       if (g.colstats) {                                          // (rows past the end of the list: not part of the statistics)
+        pm_turn_enter(g.gate, blockIdx.x * NCW + cw);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           double cs = 0.0, cq = 0.0;
@@ -442,6 +444,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
             atomicAdd(dst + D, cq);
           }
         }
+        pm_turn_leave(g.gate, blockIdx.x * NCW + cw);
       }
     }
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, GCL_OOB, 0x00020000);
@@ -570,6 +573,7 @@ int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int
   a.scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
   a.wfrag = reinterpret_cast<const char*>(w_frag); a.wp = d / 32;
   a.bias = bias; a.out = h; a.ldo = d; a.colstats = col_stats;
+  a.gate = col_stats ? pm_det_gate(st) : nullptr;
   const unsigned grid = pm_gcl_grid(N);
   const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, 2.0 * N * 4.0 * d * d);
   if (a_planes_in) {

@@ -42,10 +42,25 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  * was built with; a host must refuse a library whose version differs from the header it was compiled against (struct
  * layouts — PmBatch, PmGemmDesc, PmVaeLayout —, argument lists and the dropout stream are part of the version).
  *   1: round 1.  2: round 2 (PmBatch.ce_scale, pm_attnpool_bwd +2 arguments, one hash per four channels in the dropout
- *   stream).  3: round 3 (d = 512 in the gcl / linear entry points, pm_gcl_forward_from_planes). */
-#define PM_ABI_VERSION 4
+ *   stream).  3: round 3 (d = 512 in the gcl / linear entry points, pm_gcl_forward_from_planes).
+ *   4: round 3, second half (PmGemmDesc.a_colsum — the bias gradient riding in a weight-gradient GEMM —, pm_unembed_ce's
+ *   w_planes argument, PM_PLAN_TRK_CNT grown to 32 + 4 W ints by the tile schedule, pm_unembed_dh, pm_bn_small_*,
+ *   pm_rows_tn_weight_grad, pm_gcl_tile_order / pm_row_tile_order, pm_vae_step_reload_switches).
+ *   5: round 4 (pm_set_deterministic / pm_get_deterministic; plan scratch field grown). */
+#define PM_ABI_VERSION 5
 int pm_abi_version(void);
 const char* pm_build_info(void);
+
+/* Deterministic mode (environment PM_DETERMINISTIC=1 at first use, or pm_set_deterministic).  The reference's CPU step
+ * is reproducible run to run (training.py:137-166 on ATen's CPU kernels); the HIP step by default is not, because sums
+ * across workgroups (split-K slices of the head products, column statistics of the norms, weight / bias / table
+ * gradients) are float atomics whose order follows the hardware's scheduling.  With the mode on, every launch that
+ * contains such atomics orders them by a gate (workgroups take turns in dispatch order, csrc/common.h) and the kernels
+ * whose workgroups race on an LDS table run one wave per workgroup: two runs of a step on the same inputs are then
+ * BIT-IDENTICAL in outputs, losses and gradients (tests/test_deterministic_gpu.py).  Slower (serialised epilogues):
+ * for parity tests and debugging.  Host calls, no GPU work. */
+int pm_set_deterministic(int32_t on);
+int pm_get_deterministic(void);
 
 /* ------------------------------------------------------------------ graph plan
  * Replaces the per-layer boolean-mask edge selection `edge_index[:, edge_type == i]`
@@ -677,9 +692,11 @@ int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buff
                         void* workspace, int64_t workspace_bytes, void* state, double* losses /* [4] dev */,
                         pm_stream_t stream);
 /* Introspection of the last forward (host only): info = {compact GCL, bf16-planes GEMM operands, active slots S,
- * fragment-major weight planes built (B-direct GEMM mode), N, E, G, B}.  The parity tests use it to assert that the
- * golden-pinned step IS the measured variant. */
-int pm_vae_step_info(const void* state, int32_t* info /* [8] host */);
+ * fragment-major weight planes built (B-direct GEMM mode), N, E, G, B, then the EFFECTIVE switches of the library —
+ * fused un-embedding + cross-entropy (PM_FUSED_CE), second-stream site mask (PM_SIDE_STREAM), deterministic mode,
+ * fused GCL kernels (PM_GCL_FUSED) —, 4 reserved}.  The parity tests use it to assert that the golden-pinned step IS
+ * the measured variant. */
+int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
 /* The model outputs of `VAE.forward` (model.py:665-678) as the last forward computed them, copied out of the arena
  * (async on `stream`; any pointer may be NULL): s_logits [G,4,32], c_logits [N,S,230] (active slots only), mu and
  * log_var [B,d].  Valid until the next pm_vae_step_forward on this state. */

@@ -117,11 +117,13 @@ _SIGS = {
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",
     "pm_vae_step_reload_switches": "",
+    "pm_set_deterministic": "i",
+    "pm_get_deterministic": "",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
           "pm_unembed_dh_scratch_bytes"}
-ABI_VERSION = 4          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
+ABI_VERSION = 5          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])
 
@@ -195,3 +197,13 @@ def gcl_tile_order(trk_cnt, use_classes: bool, N: int):
     out = (C.c_int32 * (3 * grid))()
     lib().pm_gcl_tile_order(C.cast(tc, C.c_void_p), int(bool(use_classes)), int(N), C.cast(out, C.c_void_p), grid)
     return [(out[3 * b], out[3 * b + 1], out[3 * b + 2]) for b in range(grid)]
+
+
+def set_deterministic(on: bool) -> None:
+    """Deterministic mode of the library (include/polyphemus_hip.h, pm_set_deterministic): every float atomic of the step
+    is ordered, two runs on the same inputs are bit-identical.  Slower; for parity tests and debugging."""
+    call("pm_set_deterministic", int(bool(on)))
+
+
+def is_deterministic() -> bool:
+    return bool(lib().pm_get_deterministic())

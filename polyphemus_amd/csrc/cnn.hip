@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_bwd_data(const float* __restric
 // Each workgroup reduces a slice of the bars in fp64 and adds its 9 (+1) partials with float atomics.
 __global__ void __launch_bounds__(256) k_conv3x3_bwd_weight(const float* __restrict__ x, const float* __restrict__ dy,
                                                             int G, int Ci, int Co, int H, int W, int up4, float* dw,
-                                                            float* db) {
+                                                            float* db, unsigned* gate) {
   __shared__ double sh[4][10];
   const int co = blockIdx.x / Ci, ci = blockIdx.x % Ci;
   const int Win = up4 ? W / 4 : W;
@@ -100,11 +100,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_bwd_weight(const float* __restr
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][j] = s;
   }
   __syncthreads();
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the bar slices add in turn)
   if (threadIdx.x < 10) {
     const double s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
     if (threadIdx.x < 9) atomicAdd(&dw[((int64_t)co * Ci + ci) * 9 + threadIdx.x], (float)s);
     else if (ci == 0 && db) atomicAdd(&db[co], (float)s);
   }
+  pm_turn_leave_block(gate);
 }
 static inline int cgrid(int64_t n) { int64_t g = pm_cdiv(n, 256); return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }
 
@@ -129,7 +131,7 @@ extern "C" int pm_conv3x3_bwd_weight(const float* x, const float* dy, int32_t G,
   if (chunks > G) chunks = G;
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(k_conv3x3_bwd_weight, dim3(Co * Ci, chunks), dim3(256), 0, (hipStream_t)stream, x, dy, G, Ci, Co,
-                     H, W, up4, dw, db);
+                     H, W, up4, dw, db, pm_det_gate((hipStream_t)stream));
   return pm_check_launch();
 }
 

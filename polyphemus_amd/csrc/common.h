@@ -11,6 +11,13 @@ static inline int pm_check_launch() {
   return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
 }
 
+// slot of per-device host state (function attributes are per device: `static bool once` flags are arrays of 16)
+static inline int pm_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+  return d;
+}
+
 static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t pm_align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 

@@ -21,7 +21,7 @@ extern "C" int pm_get_deterministic(void) {
   if (g_on < 0) { const char* v = getenv("PM_DETERMINISTIC"); g_on = (v && atoi(v) != 0) ? 1 : 0; }
   return g_on;
 }
-extern "C" int pm_set_deterministic(int on) {
+extern "C" int pm_set_deterministic(int32_t on) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_on = on ? 1 : 0;
   return PM_OK;

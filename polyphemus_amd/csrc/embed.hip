@@ -122,7 +122,7 @@ extern "C" int pm_embed_gather(const float* tables, const int32_t* tokens, const
 __global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restrict__ dX, const int* __restrict__ tok,
                                                            const int* __restrict__ group_list,
                                                            const int* __restrict__ group_cnt, int N, int d,
-                                                           int NS, float* __restrict__ S) {
+                                                           int NS, float* __restrict__ S, unsigned* gate) {
   extern __shared__ __attribute__((aligned(16))) float sS[];
   const int t = blockIdx.y, grp = t & 1, kind = t >> 1, dh = d / 2;
   const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
@@ -179,11 +179,14 @@ __global__ void __launch_bounds__(1024) k_embed_bwd_scatter(const float* __restr
     if (eacc[j].y != 0.f) atomicAdd(&sS[eos * dh + c + 1], eacc[j].y);
   }
   __syncthreads();
+  // deterministic mode (common.h): ONE wave per workgroup (its LDS adds are in program order), workgroups flush in turn
+  pm_turn_enter_block(gate);
   float* out = S + (int64_t)t * EMB_V * dh;
   for (int i = threadIdx.x; i < V * dh; i += blockDim.x) {
     const float v = sS[i];
     if (v != 0.f) atomicAdd(&out[i], v);
   }
+  pm_turn_leave_block(gate);
 }
 // The same sums on the matrix cores (d/2 a multiple of 32): S[t] = OneHot(tokens)^T x dX, the reference's own formulation
 // (the backward of Linear(131 -> d/2) on one-hot rows, model.py:344-360).  LDS float atomics run at about one lane per
@@ -199,7 +202,7 @@ constexpr int NVT = 5;                    // token tiles of 32: 5 for the pitch 
 __global__ void __launch_bounds__(512) k_embed_bwd_mfma(const float* __restrict__ dX, const int* __restrict__ tok,
                                                        const int* __restrict__ group_list,
                                                        const int* __restrict__ group_cnt, int N, int d, int NS,
-                                                       float* __restrict__ S) {
+                                                       float* __restrict__ S, unsigned* gate) {
   __shared__ int sTok[EMM_ROWS + 16], sOff[EMM_ROWS + 16];
   const int grp = blockIdx.y, kind = blockIdx.z, dh = d / 2, t = kind * 2 + grp;
   const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
@@ -274,6 +277,7 @@ __global__ void __launch_bounds__(512) k_embed_bwd_mfma(const float* __restrict_
   }
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
   float* out = S + (int64_t)t * EMB_V * dh + wave * 32 + li;
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the node slices add in turn)
 #pragma unroll
   for (int q = 0; q < NVT; ++q)
 #pragma unroll
@@ -282,6 +286,7 @@ __global__ void __launch_bounds__(512) k_embed_bwd_mfma(const float* __restrict_
       const float val = acc[q][r];
       if (v < V && val != 0.f) atomicAdd(out + (int64_t)v * dh, val);
     }
+  pm_turn_leave_block(gate);
 }
 
 extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E,
@@ -302,7 +307,7 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
     if (nb > 160) nb = 160;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_embed_bwd_mfma, dim3(nb, 2, 2), dim3(64 * (dh / 32)), 0, st, dX, tokens, pv.group_list,
-                       pv.group_cnt, N, d, n_slots, S);
+                       pv.group_cnt, N, d, n_slots, S, pm_det_gate(st));
     return pm_check_launch();
   }
   if (lds > 64 * 1024)
@@ -310,8 +315,9 @@ extern "C" int pm_embed_bwd_scatter(const float* dX, const int32_t* tokens, cons
                         (int)lds);
   int nb = (int)pm_cdiv((int64_t)N * n_slots, 16 * 64);
   if (nb > 96) nb = 96;
-  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(1024), lds, st, dX, tokens, pv.group_list, pv.group_cnt, N, d,
-                     n_slots, S);
+  unsigned* const gate = pm_det_gate(st);
+  hipLaunchKernelGGL(k_embed_bwd_scatter, dim3(nb, 4), dim3(gate ? 64 : 1024), lds, st, dX, tokens, pv.group_list, pv.group_cnt,
+                     N, d, n_slots, S, gate);
   return pm_check_launch();
 }
 
@@ -450,7 +456,7 @@ extern "C" int pm_chord_pad_fwd(const float* tables, const float* Wc, const floa
 }
 // gsum[g][o] = sum over the nodes of group g of dy[n][o]
 __global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ dy, const uint8_t* __restrict__ is_drum,
-                                                      int N, int d, int rows_per_chunk, float* gsum) {
+                                                      int N, int d, int rows_per_chunk, float* gsum, unsigned* gate) {
   __shared__ float sh[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -462,10 +468,12 @@ __global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ 
     for (int r = r0 + wave; r < r1; r += 4) { const float v = dy[(int64_t)r * d + c]; if (is_drum[r]) a0 += v; else a1 += v; }
   sh[wave][0][lane] = a0; sh[wave][1][lane] = a1;
   __syncthreads();
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the row chunks add in turn)
   if (wave == 0 && c < d) {
     atomicAdd(&gsum[c], sh[0][0][lane] + sh[1][0][lane] + sh[2][0][lane] + sh[3][0][lane]);
     atomicAdd(&gsum[d + c], sh[0][1][lane] + sh[1][1][lane] + sh[2][1][lane] + sh[3][1][lane]);
   }
+  pm_turn_leave_block(gate);
 }
 // dWc[o, s*d + c] += sum_g gsum[g][o] * Xpad_g[c]   for the tail slots s >= S
 __global__ void __launch_bounds__(256) k_chord_pad_bwd_w(const float* __restrict__ gsum, const float* __restrict__ tables,
@@ -482,7 +490,7 @@ __global__ void __launch_bounds__(256) k_chord_pad_bwd_w(const float* __restrict
 // grid = (d/64, d/16): lanes own 64 consecutive columns c (coalesced weight rows), the 4 waves of a workgroup
 // split 16 output rows o; partial sums meet in LDS and leave with one float atomic per (group, column).
 __global__ void __launch_bounds__(256) k_chord_pad_bwd_x(const float* __restrict__ gsum, const float* __restrict__ Wc,
-                                                         int d, int S, float* Stab) {
+                                                         int d, int S, float* Stab, unsigned* gate) {
   __shared__ float sh[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, dh = d / 2;
@@ -497,6 +505,7 @@ __global__ void __launch_bounds__(256) k_chord_pad_bwd_x(const float* __restrict
   }
   sh[wave][0][lane] = a0; sh[wave][1][lane] = a1;
   __syncthreads();
+  pm_turn_enter_block(gate);
   if (wave == 0 && c < d) {
     const float v0 = sh[0][0][lane] + sh[1][0][lane] + sh[2][0][lane] + sh[3][0][lane];
     const float v1 = sh[0][1][lane] + sh[1][1][lane] + sh[2][1][lane] + sh[3][1][lane];
@@ -508,6 +517,7 @@ __global__ void __launch_bounds__(256) k_chord_pad_bwd_x(const float* __restrict
       atomicAdd(&Stab[((int64_t)3 * EMB_V + 98) * dh + (c - dh)], v1);
     }
   }
+  pm_turn_leave_block(gate);
 }
 // dy = d loss / d (chord pre-activation) with the ReLU mask applied; Stab = the [4][131][d/2] token sums AFTER
 // pm_embed_bwd_scatter has filled the active slots.
@@ -524,10 +534,12 @@ extern "C" int pm_chord_pad_bwd(const float* dy, const uint8_t* is_drum, int32_t
   if (nc > 128) nc = 128;
   const int rpc = (int)pm_cdiv(N, nc);
   nc = (int)pm_cdiv(N, rpc);
-  hipLaunchKernelGGL(k_group_colsum, dim3(pm_cdiv(d, 64), nc), dim3(256), 0, st, dy, is_drum, N, d, rpc, gsum);
+  hipLaunchKernelGGL(k_group_colsum, dim3(pm_cdiv(d, 64), nc), dim3(256), 0, st, dy, is_drum, N, d, rpc, gsum,
+                     pm_det_gate(st));
   const int64_t total = (int64_t)d * (PM_N_SLOTS - n_slots) * d;
   hipLaunchKernelGGL(k_chord_pad_bwd_w, dim3((unsigned)(pm_cdiv(total, 256) > 2048 ? 2048 : pm_cdiv(total, 256))), dim3(256), 0,
                      st, gsum, tables, d, n_slots, dWc);
-  hipLaunchKernelGGL(k_chord_pad_bwd_x, dim3(pm_cdiv(d, 64), pm_cdiv(d, 16)), dim3(256), 0, st, gsum, Wc, d, n_slots, Stab);
+  hipLaunchKernelGGL(k_chord_pad_bwd_x, dim3(pm_cdiv(d, 64), pm_cdiv(d, 16)), dim3(256), 0, st, gsum, Wc, d, n_slots, Stab,
+                     pm_det_gate(st));
   return pm_check_launch();
 }

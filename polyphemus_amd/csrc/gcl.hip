@@ -619,7 +619,7 @@ extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_
   const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD, NW)                                                                                                 \
   do {                                                                                                                 \
-    static bool once = false;                                                                                          \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
       hipFuncSetAttribute((const void*)k_gcl_dagg<DD, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
       once = true;                                                                                                     \
@@ -823,7 +823,7 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
   const int pe = pm_prof_open(st, PM_PROF_GCL_DW, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD)                                                                                                     \
   do {                                                                                                                 \
-    static bool once = false;                                                                                          \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
       hipFuncSetAttribute((const void*)k_gcl_dw<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
       once = true;                                                                                                     \
@@ -872,7 +872,7 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
   const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, 2.0 * N * 4.0 * d * d);
 #define LAUNCH(DD, DR)                                                                                                 \
   do {                                                                                                                 \
-    static bool once = false;                                                                                          \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
       hipFuncSetAttribute((const void*)k_gcl_fwd<DD, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       once = true;                                                                                                     \

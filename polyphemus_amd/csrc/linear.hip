@@ -171,7 +171,7 @@ extern "C" int pm_rows_times_weight(const float* X, int32_t ldx, int32_t N, int3
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
 #define LAUNCH(DD, KD)                                                                                                 \
   do {                                                                                                                 \
-    static bool once = false;                                                                                          \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
       hipFuncSetAttribute((const void*)k_rows_w<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
       once = true;                                                                                                     \
@@ -344,7 +344,7 @@ extern "C" int pm_rows_times_weight_longk(const float* X, int32_t ldx, int32_t N
   const int pe = pm_prof_open(st, PM_PROF_ROWS_W, 2.0 * N * (double)K * Nout);
 #define LAUNCH(DD, KD)                                                                                                 \
   do {                                                                                                                 \
-    static bool once = false;                                                                                          \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
       hipFuncSetAttribute((const void*)k_rows_wk<DD, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       once = true;                                                                                                     \
@@ -440,9 +440,11 @@ k_rows_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int
       __syncthreads();
     }
     pm_turn_enter(gate, my_turn);
-    if (want_cs) {
+    if (want_cs) {                     // (lanes l and l + 32 hold the same columns: one add per column and wave)
+      cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64);
+      cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
       float* dst = colsum_a + ft * DW_T + c4 * 4;
-      atomicAdd(dst, cs.x); atomicAdd(dst + 1, cs.y); atomicAdd(dst + 2, cs.z); atomicAdd(dst + 3, cs.w);
+      if (lane < 32) { atomicAdd(dst, cs.x); atomicAdd(dst + 1, cs.y); atomicAdd(dst + 2, cs.z); atomicAdd(dst + 3, cs.w); }
     }
     pm_turn_leave(gate, my_turn);
     return;
@@ -510,7 +512,7 @@ extern "C" int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, co
   const int maxs = (int)pm_cdiv(K, 8 * DW_KT);
   if (nsplit > maxs) nsplit = maxs;
   if (nsplit < 1) nsplit = 1;
-  static bool once = false;
+  static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];
   if (!once) {
     hipFuncSetAttribute((const void*)k_rows_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;

@@ -13,7 +13,8 @@ __global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ l
                                                     const int* __restrict__ hist, const uint8_t* __restrict__ is_drum,
                                                     int64_t rows, int S, float grad_scale, float* __restrict__ dlogits,
                                                     float* db_pitch_d, float* db_pitch_nd, float* db_dur,
-                                                    double* __restrict__ out, const float* __restrict__ dev_scale) {
+                                                    double* __restrict__ out, const float* __restrict__ dev_scale,
+                                                    unsigned* gate) {
   __shared__ double sh[2][16];
   __shared__ float sb[16][2][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ l
     for (int j = 0; j < 4; ++j) { sb[wave][0][lane + 64 * j] = bacc[0][j]; sb[wave][1][lane + 64 * j] = bacc[1][j]; }
   }
   __syncthreads();
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the workgroups add in turn)
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int w = 0; w < nwv; ++w) { a += sh[0][w]; b += sh[1][w]; }
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(1024) k_content_ce(const float* __restrict__ l
       if (nd_sum != 0.f) atomicAdd(&db_pitch_nd[c], nd_sum);
     } else if (nd_sum + d_sum != 0.f) atomicAdd(&db_dur[c - PM_N_PITCH], nd_sum + d_sum);
   }
+  pm_turn_leave_block(gate);
 }
 extern "C" int pm_content_ce(const float* c_logits, const int32_t* tokens, const int32_t* tok_hist,
                              const uint8_t* is_drum, int32_t N, int32_t n_slots, float grad_scale, float* d_logits,
@@ -114,13 +117,13 @@ extern "C" int pm_content_ce_scaled(const float* c_logits, const int32_t* tokens
   int nb = (int)pm_cdiv(rows, (threads / 64) * 8);
   if (nb > 512) nb = 512;
   hipLaunchKernelGGL(k_content_ce, dim3(nb), dim3(threads), 0, st, c_logits, tokens, tok_hist, is_drum, rows, n_slots, grad_scale,
-                     d_logits, db_pitch_drum, db_pitch_nd, db_dur, out, dev_scale);
+                     d_logits, db_pitch_drum, db_pitch_nd, db_dur, out, dev_scale, pm_det_gate(st));
   return pm_check_launch();
 }
 
 // kld = mean_b( -0.5 * sum_d (1 + lv - mu^2 - exp(lv)) )   (training.py:329-331)
 __global__ void __launch_bounds__(256) k_kld(const float* __restrict__ mu, const float* __restrict__ lv, int B, int d,
-                                             float beta, float* dmu, float* dlv, double* out) {
+                                             float beta, float* dmu, float* dlv, double* out, unsigned* gate) {
   __shared__ double sh[4];
   const int64_t n = (int64_t)B * d;
   double acc = 0;
@@ -132,7 +135,9 @@ __global__ void __launch_bounds__(256) k_kld(const float* __restrict__ mu, const
   acc = pm_wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
+  pm_turn_enter_block(gate);
   if (threadIdx.x == 0) atomicAdd(&out[3], -0.5 * (sh[0] + sh[1] + sh[2] + sh[3]) / B);
+  pm_turn_leave_block(gate);
 }
 extern "C" int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu,
                       float* dlog_var, double* out, pm_stream_t stream) {
@@ -141,13 +146,13 @@ extern "C" int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t 
   hipMemsetAsync(out + 3, 0, sizeof(double), st);
   int nb = (int)pm_cdiv((int64_t)B * d, 256 * 4);
   if (nb > 256) nb = 256;
-  hipLaunchKernelGGL(k_kld, dim3(nb), dim3(256), 0, st, mu, log_var, B, d, beta, dmu, dlog_var, out);
+  hipLaunchKernelGGL(k_kld, dim3(nb), dim3(256), 0, st, mu, log_var, B, d, beta, dmu, dlog_var, out, pm_det_gate(st));
   return pm_check_launch();
 }
 
 // BCEWithLogitsLoss(reduction='none').mean()  (training.py:310-312)
 __global__ void __launch_bounds__(256) k_bce(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
-                                             float grad_scale, float* dx, double* out) {
+                                             float grad_scale, float* dx, double* out, unsigned* gate) {
   __shared__ double sh[4];
   double acc = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -158,7 +163,9 @@ __global__ void __launch_bounds__(256) k_bce(const float* __restrict__ x, const 
   acc = pm_wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
+  pm_turn_enter_block(gate);
   if (threadIdx.x == 0) atomicAdd(&out[2], (sh[0] + sh[1] + sh[2] + sh[3]) / (double)n);
+  pm_turn_leave_block(gate);
 }
 extern "C" int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits,
                              double* out, pm_stream_t stream) {
@@ -167,7 +174,7 @@ extern "C" int pm_bce_logits(const float* logits, const float* target, int64_t n
   hipMemsetAsync(out + 2, 0, sizeof(double), st);
   int nb = (int)pm_cdiv(n, 256 * 4);
   if (nb > 256) nb = 256;
-  hipLaunchKernelGGL(k_bce, dim3(nb), dim3(256), 0, st, logits, target, n, grad_scale, dlogits, out);
+  hipLaunchKernelGGL(k_bce, dim3(nb), dim3(256), 0, st, logits, target, n, grad_scale, dlogits, out, pm_det_gate(st));
   return pm_check_launch();
 }
 

@@ -7,6 +7,10 @@
 #include "common.h"
 #include "tile_order.h"
 
+// tile sums of the four exclusive scans of the plan build (rowptr, colptr, bar_ptr, drum positions), 2048 elements per tile
+static inline int64_t plan_scan_tiles(int64_t N, int64_t G) {
+  return pm_cdiv(N * PM_N_REL + 1, 2048) + 2 * pm_cdiv(N + 1, 2048) + pm_cdiv(G + 1, 2048);
+}
 void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   int64_t sz[PM_PLAN_NFIELDS];
   sz[PM_PLAN_ROWPTR] = (int64_t)N * PM_N_REL + 1;
@@ -17,9 +21,9 @@ void pm_plan_offsets(int32_t N, int32_t E, int32_t G, int64_t* off) {
   sz[PM_PLAN_GROUP_CNT] = 4; sz[PM_PLAN_TOK_HIST] = 4 * PM_N_PITCH; sz[PM_PLAN_ROW_LIST] = 2 * (int64_t)N * PM_N_SLOTS;
   sz[PM_PLAN_NODE_TREL] = N; sz[PM_PLAN_TRK_LIST] = 4 * (int64_t)N;
   sz[PM_PLAN_TRK_CNT] = 32 + 4 * (int64_t)pm_gcl_grid(N);      // counts and class boundaries, then the tile schedule of the GCL products
-  // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | scan block sums | track flags/positions 4 x [N+1]
-  sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 64 +
-                        4 * ((int64_t)N + 1);
+  // scratch: cursors [N*6 + N] | drum flags/positions [N+1] | tile sums of the four scans (+ 64) | node classes [N] |
+  // class histograms [cdiv(N, 256)][16]   (pm_plan_build carves the same expression: plan_scan_tiles)
+  sz[PM_PLAN_SCRATCH] = (int64_t)N * PM_N_REL + N + (N + 1) + plan_scan_tiles(N, G) + 64 + N + 16 * pm_cdiv(N, 256) + 16;
   int64_t o = 0;
   for (int i = 0; i < PM_PLAN_NFIELDS; ++i) { off[i] = o; o += pm_align4(sz[i]); }
   off[PM_PLAN_NFIELDS] = o;
@@ -463,10 +467,12 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
   a.cur_out = a.cur_in + (int64_t)N * PM_N_REL;
   a.drumpos = a.cur_out + N;
   int* const sums = a.drumpos + N + 1;
-  // (behind the tile sums of the four scans — the layout reserves cdiv(6N + 1, 2048) + 64 + 4 (N + 1) ints from `sums` on)
-  const int64_t scan_tiles = pm_cdiv((int64_t)N * PM_N_REL + 1, 2048) + 2 * pm_cdiv((int64_t)N + 1, 2048) + pm_cdiv((int64_t)G + 1, 2048);
+  // (behind the tile sums of the four scans; pm_plan_offsets reserves the same expression)
+  const int64_t scan_tiles = plan_scan_tiles(N, G);
   a.cls = sums + scan_tiles + 64;                                         // [N] node class, then [nb_cls][16] histograms
   a.bh = a.cls + N;
+  static_assert(CLS_T == 256 && SCAN_TILE == 2048, "pm_plan_offsets sizes the scratch field for these tile sizes");
+  if ((a.bh + 16 * pm_cdiv(N, CLS_T)) - plan > o[PM_PLAN_NFIELDS]) return PM_E_INVALID;   // (cannot happen: same expression)
   a.node_bar = plan + o[PM_PLAN_NODE_BAR]; a.tok_hist = plan + o[PM_PLAN_TOK_HIST];
   a.csr_eid = plan + o[PM_PLAN_CSR_EID]; a.csr_src = plan + o[PM_PLAN_CSR_SRC]; a.csr_dist = plan + o[PM_PLAN_CSR_DIST];
   a.csc_eid = plan + o[PM_PLAN_CSC_EID]; a.csc_dst = plan + o[PM_PLAN_CSC_DST]; a.csc_reldist = plan + o[PM_PLAN_CSC_RELDIST];

@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd1(const float* __restrict__
                                                        const float* __restrict__ gm, const float* __restrict__ gv,
                                                        float eps, const float* __restrict__ alpha,
                                                        const float* __restrict__ dout, const int* __restrict__ bar_ptr,
-                                                       int d, float* __restrict__ dgn, double* __restrict__ sums) {
+                                                       int d, float* __restrict__ dgn, double* __restrict__ sums,
+                                                       unsigned* gate) {
   __shared__ float sh[4];
   const int b = blockIdx.x;
   const int beg = bar_ptr[b], end = bar_ptr[b + 1];
@@ -118,7 +119,9 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd1(const float* __restrict__
   }
   s0 = block_sum(s0, sh);
   s1 = block_sum(s1, sh);
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the bars add in turn)
   if (threadIdx.x == 0) { atomicAdd(&sums[0], (double)s0); atomicAdd(&sums[1], (double)s1); }
+  pm_turn_leave_block(gate);
 }
 // backward 2: per node, dg_i = gamma*rstd*(dgn_i - mean(dgn) - ghat_i*mean(dgn*ghat));
 // dx_i = alpha_i*dout[bar_i] + dg_i*w;  dW += dg_i*x_i;  db += dg_i
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
                                                        int N, int d, float* __restrict__ dx, float* dW, float* db,
                                                        float* dbn_g, float* dbn_b, const float* __restrict__ xg,
                                                        float* __restrict__ dxg, const double* __restrict__ gsums,
-                                                       double gcount) {
+                                                       double gcount, unsigned* gate) {
   extern __shared__ __attribute__((aligned(16))) float sW[];   // [d] partial dW + 1 partial db
   for (int i = threadIdx.x; i <= d; i += blockDim.x) sW[i] = 0.f;
   __syncthreads();
@@ -169,17 +172,25 @@ __global__ void __launch_bounds__(256) k_attnpool_bwd2(const float* __restrict__
     }
     bacc += dg;
   }
+  // (deterministic mode, common.h: the four waves add to the LDS image one after the other, the workgroups flush in turn)
+  for (int w = 0; w < (gate ? 4 : 1); ++w) {
+    if (!gate || wave == w) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = lane * 4 + k * 256;
-    if (c >= d) continue;
-    atomicAdd(&sW[c + 0], wacc[k].x); atomicAdd(&sW[c + 1], wacc[k].y);
-    atomicAdd(&sW[c + 2], wacc[k].z); atomicAdd(&sW[c + 3], wacc[k].w);
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + k * 256;
+        if (c >= d) continue;
+        atomicAdd(&sW[c + 0], wacc[k].x); atomicAdd(&sW[c + 1], wacc[k].y);
+        atomicAdd(&sW[c + 2], wacc[k].z); atomicAdd(&sW[c + 3], wacc[k].w);
+      }
+      if (lane == 0) atomicAdd(&sW[d], bacc);
+    }
+    if (gate) __syncthreads();
   }
-  if (lane == 0) atomicAdd(&sW[d], bacc);
   __syncthreads();
+  pm_turn_enter_block(gate);
   for (int i = threadIdx.x; i < d; i += blockDim.x) atomicAdd(&dW[i], sW[i]);
   if (threadIdx.x == 0) atomicAdd(&db[0], sW[d]);
+  pm_turn_leave_block(gate);
 }
 static int attnpool_bwd_impl(const float* x, const float* g, const float* g_mean, const float* g_var, float eps,
                              const float* bn_g, const float* alpha, const float* dout, const float* gate_w,
@@ -198,14 +209,14 @@ static int attnpool_bwd_impl(const float* x, const float* g, const float* g_mean
   if (phase != 2) {                                     // phase 1: per-node gate gradients + the two local sums
     hipMemsetAsync(sums, 0, 2 * sizeof(double), st);
     hipLaunchKernelGGL(k_attnpool_bwd1, dim3(G), dim3(256), 0, st, x, g, g_mean, g_var, eps, alpha, dout, pv.bar_ptr, d,
-                       dgn, sums);
+                       dgn, sums, pm_det_gate(st));
   }
   if (phase != 1) {                                     // phase 2: dx, gate / norm parameter gradients
     int nb = (int)pm_cdiv(N, 4);
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(k_attnpool_bwd2, dim3(nb), dim3(256), sizeof(float) * (d + 1), st, x, g, g_mean, g_var, eps, bn_g,
                        alpha, dout, gate_w, pv.node_bar, dgn, sums, N, d, dx, d_gate_w, d_gate_b, d_bn_g, d_bn_b,
-                       x_gate ? x_gate : x, dx_gate, gsums, gcount);
+                       x_gate ? x_gate : x, dx_gate, gsums, gcount, pm_det_gate(st));
   }
   return pm_check_launch();
 }

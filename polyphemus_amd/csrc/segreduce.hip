@@ -470,7 +470,9 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
 // > 64 KiB of dynamic LDS needs the attribute: set once per instantiation and size
 template <int NV, bool DR, bool FU, bool RL>
 static void seg_bwd_lds_attr(size_t lds) {
-  static size_t granted = 64 * 1024;
+  static size_t granted_dev[16] = {};
+  size_t& granted = granted_dev[pm_device_slot()];
+  if (granted == 0) granted = 64 * 1024;
   if (lds > granted) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_segreduce_bwd<NV, DR, FU, RL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,5 +1,5 @@
 // tile_order.h — the order in which the workgroups of a GCL product take the plan's (track group, 64-row tile) list.
-// Plain C++ (host and device): the host-side copy is what tests/test_abi.py drives through pm_debug_gcl_tile_order.
+// Plain C++ (host and device): the host-side copy is what tests/test_abi.py drives through pm_gcl_tile_order.
 #pragma once
 #include <stdint.h>
 #ifdef __HIPCC__

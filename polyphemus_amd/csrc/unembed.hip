@@ -570,7 +570,7 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
     const size_t lds = (img > tile ? img : tile) + 2 * UBM * sizeof(int) + PNW * sizeof(double) + (size_t)UBM * PNW * 2 * sizeof(float);
 #define LAUNCH(DHV)                                                                                                    \
   do {                                                                                                                 \
-    static bool once = false;                                                                                          \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
       hipFuncSetAttribute((const void*)k_unembed_ce_planes<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       once = true;                                                                                                     \
@@ -898,7 +898,7 @@ extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, c
   if (nb > 256) nb = 256;
 #define LAUNCH(DHV)                                                                                                  \
   do {                                                                                                               \
-    static bool once = false;                                                                                        \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                        \
     if (!once) {                                                                                                     \
       hipFuncSetAttribute((const void*)k_unembed_dh<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, dh_lds_bytes<DHV>()); \
       once = true;                                                                                                   \

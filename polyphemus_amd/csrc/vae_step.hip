@@ -148,7 +148,7 @@ struct Ctx {
 // sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
 // structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
 enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_SITES };
-struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES]; bool ok; };
+struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES], idle; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
   static bool tried[16];
@@ -168,6 +168,7 @@ static Branch* branch_of_device() {
     for (int i = 0; i < BR_SITES && b.ok; ++i)
       b.ok = hipEventCreateWithFlags(&b.fork[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming) == hipSuccess;
+    if (b.ok) b.ok = hipEventCreateWithFlags(&b.idle, hipEventDisableTiming) == hipSuccess;
   }
   return b.ok ? &b : nullptr;
 }
@@ -898,6 +899,13 @@ extern "C" int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, 
   measure_step(lay, *batch, &zb, &mb);
   if (zb + mb > (size_t)workspace_bytes) return PM_E_INVALID;
   s->ar.zcap = zb; s->ar.zused = 0;
+  // A previous step that was abandoned between two of its calls (an exception in the caller) may have left a branch
+  // running on the second stream that still reads and writes the arena: this step's first write waits for whatever
+  // that stream holds.  (In a complete step every branch is joined, so the wait is already satisfied.)
+  if (cfg().side_stream) {
+    Branch* b = branch_of_device();
+    if (b && (hipEventRecord(b->idle, b->st) != hipSuccess || hipStreamWaitEvent(st, b->idle, 0) != hipSuccess)) return PM_E_LAUNCH;
+  }
   if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess) return PM_E_LAUNCH;
   Ctx c = make_ctx(s, st);
   forward(c, msg_dropout, seed_enc, seed_dec);         // (builds the plan: after the structure branch has been forked)
@@ -915,6 +923,9 @@ extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
   info[0] = c.compact; info[1] = c.planes; info[2] = c.S;
   info[3] = (s->eg.Wfn && s->dg.Wfn) ? 1 : 0;          // fragment-major weight planes built (B-direct GEMM mode available)
   info[4] = c.N; info[5] = c.E; info[6] = c.Gn; info[7] = c.B;
+  // the EFFECTIVE switches (read from the environment at load / pm_vae_step_reload_switches, not at call time)
+  info[8] = cfg().fused_ce ? 1 : 0; info[9] = cfg().side_stream; info[10] = pm_det_on(); info[11] = cfg().gcl_fused ? 1 : 0;
+  info[12] = info[13] = info[14] = info[15] = 0;
   return PM_OK;
 }
 // Model outputs of the last forward (the arena keeps them until the next pm_vae_step_forward): asynchronous

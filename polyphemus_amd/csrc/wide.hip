@@ -541,7 +541,7 @@ int wide_npw(int dflt) {
 }
 template <int VAR, bool DROP, int NPW, int BKIND>
 void launch_wide(const WideArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-  static bool once = false;
+  static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];
   if (!once) {
     hipFuncSetAttribute((const void*)k_wide<VAR, DROP, NPW, BKIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;

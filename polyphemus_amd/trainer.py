@@ -234,19 +234,20 @@ class HipTrainer:
     def step_info(self) -> dict:
         """Which variant of the native step the last `train_step` ran (`pm_vae_step_info`): compact GCL (K = 4d),
         bf16-planes GEMM operands, active token slots S, fragment-major weight planes (B-direct GEMM), batch sizes."""
-        info = (ctypes.c_int32 * 8)()
+        info = (ctypes.c_int32 * 16)()
         call("pm_vae_step_info", ctypes.addressof(self._state), ctypes.cast(info, ctypes.c_void_p))
-        keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B")
+        keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B", "fused_ce", "side_stream", "deterministic",
+                "gcl_fused")
         return dict(zip(keys, (int(v) for v in info)))
 
     def step_outputs(self):
         """`((s_logits, c_logits), mu, log_var)` of the last native `train_step` — what `VAE.forward` returns
         (model.py:676-678) — copied out of the workspace arena.  c_logits holds the active slots only: [N, S, 230]
         (the remaining slots are PAD in every node of the batch; the fused step never computes them)."""
-        if not self.keep_logits and os.environ.get("PM_FUSED_CE", "1") not in ("", "0"):
+        i = self.step_info()              # (the library's effective switches, not the environment at call time)
+        if not self.keep_logits and i["fused_ce"]:
             raise RuntimeError("step_outputs needs trainer.keep_logits = True before the step (the fused un-embedding + "
                                "cross-entropy does not store the logits otherwise)")
-        i = self.step_info()
         dev, d, nb = self.grads.device, self.vae.cfg["d"], self.vae.cfg["n_bars"]
         s_logits = torch.empty(i["B"], nb, 4, 32, device=dev)
         c_logits = torch.empty(i["N"], i["n_slots"], 230, device=dev)

@@ -281,3 +281,16 @@ def test_uniform_row_tiles_cover_every_row_once():
                 seen[r] += 1
         assert all(v == 1 for v in seen), M
         assert (halves > 0) == (0 < (ntile - 1) % 256 + 1 <= 8 and ntile > 256), (M, halves)
+
+
+def test_plan_scratch_field_holds_what_the_plan_build_carves():
+    """pm_plan_build carves cursors [7N], drum positions [N + 1], the tile sums of its four scans (+ 64), node classes
+    [N] and class histograms [cdiv(N, 256)][16] out of the plan's last field; pm_plan_offsets must reserve at least that
+    (round 3 grew the carve-out without the reservation: tiny N wrote past the plan buffer)."""
+    cdiv = lambda a, b: (a + b - 1) // b
+    for N, G in [(n, g) for n in list(range(1, 10)) + [255, 256, 257, 4097, 100000] for g in (1, 2, 7, 5000, 200000)]:
+        off = _lib.plan_layout(N, max(N, 1), G)
+        have = off[-1] - off[_lib.PLAN_FIELDS.index("scratch")]
+        tiles = cdiv(6 * N + 1, 2048) + 2 * cdiv(N + 1, 2048) + cdiv(G + 1, 2048)
+        need = 7 * N + (N + 1) + tiles + 64 + N + 16 * cdiv(N, 256)
+        assert have >= need, (N, G, have, need)

@@ -137,11 +137,12 @@ def kink_gradients(cpu_batch, sd, names, cfg, eps, msg_dropout: float = 0.0, kee
 def explain(g: torch.Tensor, ref: dict, tol: float = 1e-4, min_delta: float = 1e-4):
     """Attribution of a gradient `g` (flat fp64 over ref['used']) to the near-kink decisions of `ref`.
 
-    Only decisions whose single-flip change is at least `min_delta` of |g0| enter the fit (smaller ones cannot be told
-    from fp32 rounding; `tol` bounds what they may add up to).  A least-squares fit gives real coefficients m_k; they are
-    rounded to {0, 1} — a ReLU decision is taken or not — and the residual is evaluated with the ROUNDED coefficients.
-    Returns dict(raw = |g - g0| / |g0|, residual = |g - g0 - sum_k round(m_k) delta_k| / |g0|, flips = [(site, index, m_k)]
-    of the decisions rounded to 1, ok = residual < tol and every fitted m_k within 0.1 of its rounded value)."""
+    Only decisions whose single-flip change is at least `min_delta` of |g0| enter (smaller ones cannot be told from fp32
+    rounding; `tol` bounds what they may add up to).  A ReLU decision is taken or not, so the coefficients are BINARY:
+    a least-squares fit is rounded to {0, 1} and refined by coordinate descent (single decisions toggled while that
+    lowers the residual — the changes of two decisions on one path can be collinear, which leaves the real-valued fit
+    ambiguous).  Returns dict(raw = |g - g0| / |g0|, residual = |g - g0 - sum_k m_k delta_k| / |g0| for the binary m,
+    flips = [(site, index, 1.0)] of the decisions taken the other way, ok = residual < tol)."""
     f0, D = ref["f0"], ref["deltas"]
     den = float(f0.norm())
     b = g.double() - f0
@@ -150,9 +151,18 @@ def explain(g: torch.Tensor, ref: dict, tol: float = 1e-4, min_delta: float = 1e
     if not keep or raw < 0.3 * min_delta:
         return dict(raw=raw, residual=raw, flips=[], ok=raw < tol)
     A = D[keep].T
-    m = torch.linalg.lstsq(A, b.unsqueeze(1), driver="gelsd").solution.reshape(-1)
-    mr = m.round().clamp(0, 1)
-    res = float((b - A @ mr).norm()) / den
-    flips = [(ref["kinks"][k][0], ref["kinks"][k][1], float(v)) for k, v, r in zip(keep, m, mr) if r == 1]
-    sharp = bool(((m - mr).abs() <= 0.1).all())
-    return dict(raw=raw, residual=res, flips=flips, ok=bool(res < tol and sharp))
+    m = torch.linalg.lstsq(A, b.unsqueeze(1), driver="gelsd").solution.reshape(-1).round().clamp(0, 1)
+    r = b - A @ m
+    best = float(r.norm())
+    improved = True
+    while improved:
+        improved = False
+        for j in range(len(keep)):
+            cand = r + A[:, j] * (1.0 if m[j] == 1 else -1.0)          # toggle decision j
+            c = float(cand.norm())
+            if c < best * (1 - 1e-9):
+                m[j] = 1 - m[j]
+                r, best, improved = cand, c, True
+    res = best / den
+    flips = [(ref["kinks"][k][0], ref["kinks"][k][1], 1.0) for k, v in zip(keep, m) if v == 1]
+    return dict(raw=raw, residual=res, flips=flips, ok=bool(res < tol))

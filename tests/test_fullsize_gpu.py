@@ -83,6 +83,38 @@ def test_native_step_matches_oracle_at_full_size(name):
     assert g["hip_vs_o64"]["rel_l2"] <= (0.8 if FULLSIZE[name]["dense"] else 0.4) * g["o32_vs_o64"]["rel_l2"], g
 
 
+def test_deterministic_step_matches_fp64_oracle_at_the_bench_workload():
+    """configs[1] in DETERMINISTIC mode (bit-reproducible: what this test sees is what every run sees, unlike the default
+    mode whose realisation depends on atomics order) against the fp64 oracle, same bounds as above."""
+    from polyphemus_amd import _lib
+    from util import grad_errors, hip_fullsize_step, oracle_fullsize, rel_err
+    name = "configs1_lmd2_b256_d256"
+    spec = FULLSIZE[name]
+    _lib.set_deterministic(True)
+    try:
+        run = hip_fullsize_step(spec)
+        again = hip_fullsize_step(spec)
+    finally:
+        _lib.set_deterministic(False)
+    _expect_dedicated_kernels(run["info"])
+    for n in run["names"]:                                    # a second fresh model + step: the same bits
+        if run["grads"][n] is not None:
+            assert torch.equal(run["grads"][n], again["grads"][n]), n
+    for k, v in run["outputs"].items():
+        assert torch.equal(v, again["outputs"][k]), k
+    res, _ = oracle_fullsize(spec, run, dtypes=(("o64", torch.float64),))
+    o64, l64, g64 = res["o64"]
+    S = run["info"]["n_slots"]
+    for k in ("s_logits", "c_logits", "mu", "log_var"):
+        ref = o64[k][:, :S] if k == "c_logits" else o64[k]
+        assert rel_err(run["outputs"][k], ref) < REL_TOL, k
+    for k in ("pitch", "dur", "structure", "kld"):
+        assert abs(run["losses"][k] - l64[k]) / max(1.0, abs(l64[k])) < 1e-6, k
+    g = grad_errors(run["names"], run["grads"], g64)["hip_vs_o64"]
+    cap_w, cap_l2 = GRAD_CAPS[name]
+    assert g["worst_tensor_err"] < cap_w and g["rel_l2"] < cap_l2, g
+
+
 def _switch(**env):
     """set / clear step switches and make the library re-read them (pm_vae_step_reload_switches)"""
     from polyphemus_amd._lib import lib

@@ -102,7 +102,7 @@ def parent(a):
                 hashes[h] = hashes.get(h, 0) + 1
                 ex = kinks.explain(torch.from_numpy(g).double(), ref)
                 rows.append({"run": i, "rep": rep, "raw": ex["raw"], "residual": ex["residual"], "ok": ex["ok"],
-                             "flips": [(s, j, round(m, 3)) for s, j, m in ex["flips"]], "sha": h,
+                             "flips": [(s, j) for s, j, _ in ex["flips"]], "sha": h,
                              "losses": [float(v) for v in z["losses"][rep]]})
             os.remove(res)
         ok = [r for r in rows if "raw" in r]
@@ -112,7 +112,7 @@ def parent(a):
         first = np.array([r["raw"] for r in ok if r["rep"] == 0])
         flipsets = {}
         for r in ok:
-            key = ";".join(f"{s}:{j}" for s, j, m in r["flips"]) or "none"
+            key = ";".join(f"{s}:{j}" for s, j in r["flips"]) or "none"
             flipsets[key] = flipsets.get(key, 0) + 1
         report["settings"][name] = {
             "env": SETTINGS[name], "processes": a.n, "steps": len(ok), "errors": len(rows) - len(ok),

@@ -89,39 +89,81 @@ def executed_block_fraction(trainer, n_nodes, n_edges, G):
     return live / total if total else 1.0
 
 
-def standalone_segreduce_fwd(batch, d, p=0.1, reps=20):
+def standalone_segreduce_fwd(batch, d, p=0.1, reps=24):
     """"when the layer is fused the aggregates never reach HBM; keep the standalone kernel for this
-    measurement" — one in-process series of `pm_segreduce_fwd_planes` launches (compact [N, 4d] aggregate written as three
+    measurement" — in-process series of `pm_segreduce_fwd_planes` launches (compact [N, 4d] aggregate written as three
     bf16 planes, the form the unfused step uses) on the bench batch, HIP events on the launch stream, untimed part of
-    the run.  Algorithmic bytes: x read 4dN + planes written 6 * 4dN + 12 E."""
+    the run.  Algorithmic bytes: x read 4dN + planes written 6 * 4dN + 12 E.
+
+    Two series: (a) ROTATING operands — as many (x, planes) sets as it takes to exceed 768 MB, three times the 256 MB
+    Infinity Cache, visited round-robin, so that no launch finds its input or the lines it overwrites in the memory-side
+    cache: the HBM figure (`avg_launch_us`, `frac`); (b) the SAME 117 MB set every launch (round 3's measurement): the
+    working set fits the Infinity Cache and the rate is partly a cache figure (`same_buffers`)."""
     from polyphemus_amd import ops
     from polyphemus_amd._lib import call, ptr, stream
     plan = ops.plan_build(batch.edge_index, batch.edge_type, batch.edge_dist, batch.bars, batch.batch, batch.is_drum,
                           batch.tokens, batch.n_bars, batch.s_tensor.shape[0])
     N, E = batch.num_nodes, batch.edge_index.shape[1]
     dev = batch.edge_index.device
-    x = torch.randn(N, d, device=dev)
-    T = ops.edge_table(torch.randn(d, 32, device=dev) * 0.5, torch.randn(d, device=dev) * 0.1)
-    P = torch.empty(3, N * 4 * d, dtype=torch.int16, device=dev)
-
-    def run():
-        call("pm_segreduce_fwd_planes", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, 1, ptr(P), N * 4 * d, stream())
-
-    for _ in range(3):
-        run()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    a.record()
-    for _ in range(reps):
-        run()
-    b.record()
-    torch.cuda.synchronize()
-    us = a.elapsed_time(b) / reps * 1e3
     nbytes = 4.0 * d * N + 6.0 * 4 * d * N + 12.0 * E
+    nset = max(2, int(768e6 // nbytes) + 1)
+    xs = [torch.randn(N, d, device=dev) for _ in range(nset)]
+    T = ops.edge_table(torch.randn(d, 32, device=dev) * 0.5, torch.randn(d, device=dev) * 0.1)
+    Ps = [torch.empty(3, N * 4 * d, dtype=torch.int16, device=dev) for _ in range(nset)]
+
+    def run(i):
+        call("pm_segreduce_fwd_planes", ptr(xs[i]), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, 1, ptr(Ps[i]), N * 4 * d, stream())
+
+    def series(rotate):
+        for i in range(nset if rotate else 3):
+            run(i if rotate else 0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for i in range(reps):
+            run(i % nset if rotate else 0)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+
+    us, us_same = series(True), series(False)
     return {"kernel": "k_segreduce_fwd (stand-alone, compact aggregate as three bf16 planes)", "avg_launch_us": round(us, 2),
             "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4),
-            "from": f"{reps} back-to-back launches on the bench batch after the warm-up, events on torch's current stream (the launch stream)"}
+            "from": f"{reps} back-to-back launches over {nset} rotating operand sets ({nset * nbytes / 1e6:.0f} MB: beyond the "
+                    "256 MB Infinity Cache) after the warm-up, events on torch's current stream (the launch stream)",
+            "same_buffers": {"avg_launch_us": round(us_same, 2), "achieved": round(nbytes / us_same / 1e3, 1),
+                             "frac": round(nbytes / us_same / 1e3 / PEAK_HBM_GBS, 4),
+                             "note": "the same 117 MB operand set every launch: fits the Infinity Cache, not an HBM figure"}}
+
+
+def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers=8):
+    """The remaining single-GPU configurations of BASELINE.json through the same step (fresh model and trainer, untimed part
+    of the run): whole-step rate only."""
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.synthetic import synthetic_batch
+    from polyphemus_amd.trainer import HipTrainer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=layers, d=d, n_bars=n_bars, resolution=8)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=dev).to(dev)
+    vae.train()
+    tr = HipTrainer(vae, lr=5e-6, betas=(0.9, 0.98), eps=1e-9)
+    batch = synthetic_batch(batch_size, n_bars, p=0.25, seed=1234, dense=dense).to(dev)
+    for _ in range(warmup):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    G = batch.s_tensor.shape[0]
+    out = {"workload": name, "bar-graphs/s": round(G / dt, 1), "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "batch": batch_size, "d": d, "n_bars": n_bars, "nodes": batch.num_nodes, "edges": int(batch.edge_index.shape[1])}
+    del tr, vae, batch
+    torch.cuda.empty_cache()
+    return out
 
 
 def host_cores() -> int:
@@ -283,6 +325,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[4] dense-graph stress")
     ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic batch (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` block of the default run")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -531,8 +574,9 @@ def main():
                        "d": args.d, "gnn_n_layers": args.layers, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
                        "batch_seed": args.seed, "row_tiles_per_rank": [int(v) for v in tiles_all.tolist()],
                        "row_tiles_note": "64-row tiles of the rank's batch (seed + rank); the row-tile kernels hold one "
-                                         "workgroup per CU (256): a batch with more tiles than CUs pays a second, short "
-                                         "round in 36 launches (+11 % step time at 257-261 tiles; DESIGN.md section 5)",
+                                         "workgroup per CU (256): a batch with a few more tiles than CUs runs an XCD's extra "
+                                         "tile as two 32-row halves behind two others (csrc/tile_order.h): +0.3-3 % step time "
+                                         "at 257-261 tiles (DESIGN.md section 5)",
                        "message_dropout": 0.1, "parallelism": f"dp{world}", "weights": "default init, manual_seed(0)",
                        "step": "plan+fwd+loss+bwd+allreduce+Adam"},
             # SURVEY 8(d)'s operation count (7 products of N d^2 per GCL) and what the step executes: the compact GCL
@@ -553,6 +597,16 @@ def main():
         }
         if dp is not None:
             line["dp"] = dp
+        default_run = (args.d, args.batch, args.n_bars, args.layers, args.dense) == (256, 256, 2, 8, False)
+        if world == 1 and default_run and not args.no_other_workloads:
+            # the other single-GPU configurations of BASELINE.json, so that the driver's record carries them (untimed part)
+            del trainer, vae
+            torch.cuda.empty_cache()
+            line["other_workloads"] = [
+                other_workload("LMD16 16-bar, batch=64, d_hidden=256 (BASELINE configs[2])", 64, 256, 16, False),
+                other_workload("LMD2 2-bar, batch=256, d_hidden=512 (the reference's training.json)", 256, 512, 2, False),
+                other_workload("dense-graph stress, one GPU's shard: batch=64, d_hidden=512 (BASELINE configs[4])", 64, 512, 2, True, steps=3),
+            ]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_subprocess(cfg)
             if line["cpu_baseline"].get("value"):

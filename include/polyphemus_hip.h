@@ -703,6 +703,10 @@ int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
 int pm_vae_step_outputs(const void* state, float* s_logits, float* c_logits, float* mu, float* log_var,
                         pm_stream_t stream);
 int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
+/* Data parallel: the weight gradients of the decoder's head run on the library's second stream beside the head chain and
+ * are joined inside pm_vae_step_backward_encoder; a caller that hands the decoder's gradient bucket to an all-reduce
+ * between the two calls makes `stream` wait for them with this call first (no-op when nothing is open). */
+int pm_vae_step_join_decoder_grads(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder_tail(void* state, pm_stream_t stream);
 

@@ -196,6 +196,9 @@ extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int
 #ifndef SEG_META_AHEAD
 #define SEG_META_AHEAD 0                  // 1: edge metadata of the next trip requested one trip ahead — measured slower (LOG)
 #endif
+#ifndef SEG_WHATIF
+#define SEG_WHATIF 0                      // timing what-ifs (tools/build_variants.py; WRONG results): 1 no table flush, 2 no edge loop, 4 no norm-sum flush
+#endif
 #ifndef SEG_EPT
 #define SEG_EPT 4                         // out-edges of a node whose row gathers are in flight together (k_segreduce_bwd, d <= 256)
 #endif
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     };
     Meta mt, mn;
     if (SEG_META_AHEAD && beg < end) load_meta(mt, beg);
-    for (int p = beg; p < end; p += EPT) {                  // EPT edges per trip: their row gathers overlap
+    for (int p = (SEG_WHATIF & 2) ? end : beg; p < end; p += EPT) {                  // EPT edges per trip: their row gathers overlap
       if (!SEG_META_AHEAD) load_meta(mt, p);
       else if (p + EPT < end) { load_meta(mn, p + EPT); __builtin_amdgcn_sched_barrier(0); }
       const int (&dst)[EPT] = mt.dst, (&dist)[EPT] = mt.dist, (&blk)[EPT] = mt.blk;
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   __syncthreads();
   // deterministic mode (common.h): ONE wave per workgroup (its LDS adds are in program order) and the workgroups flush in turn
   pm_turn_enter_block(gate);
-  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {       // i runs over dT (coalesced atomics)
+  for (int i = threadIdx.x; i < ((SEG_WHATIF & 1) ? 0 : PM_N_DIST * d); i += blockDim.x) {       // i runs over dT (coalesced atomics)
     const int col = i % d;
     const float v = sT[i - col + (col & 3) * dq + (col >> 2)];
     if (v != 0.f) atomicAdd(&dT[i], v);
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     }
     const int nslot = nwv < 4 ? nwv : 4;
     double* dst = nn.acc3 + (int64_t)(blockIdx.x % PM_BN_REPL) * 3 * d;
-    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) {
+    for (int i = threadIdx.x; i < ((SEG_WHATIF & 4) ? 0 : 3 * d); i += blockDim.x) {
       double t = 0;
       for (int q = 0; q < nslot; ++q) t += sd[(int64_t)q * 3 * d + i];
       atomicAdd(&dst[i], t);

@@ -33,6 +33,9 @@ namespace {
 struct StepCfg {
   bool gcl_fused, no_dw, no_rows_w, no_rows_tn, no_unembed_dh, no_classes, no_bfrag, fused_ce, debug;
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
+  int side_delay_us;           // PM_SIDE_DELAY_US (tests): every branch starts with a kernel that spins this long on the second stream,
+                               // so a missing join shows as a wrong result instead of passing by luck of timing
+  bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
 };
@@ -49,6 +52,8 @@ static StepCfg read_cfg() {
   k.fused_ce = flag("PM_FUSED_CE", true);
   k.debug = getenv("PM_DEBUG") != nullptr;
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
+  k.late_wgrads = flag("PM_LATE_WGRADS", true);
+  k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
@@ -147,7 +152,7 @@ struct Ctx {
 // capturable.  Norms on the branch use their own reduction scratch.
 // sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
 // structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
-enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_SITES };
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_SITES };
 struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES], idle; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
@@ -172,6 +177,11 @@ static Branch* branch_of_device() {
   }
   return b.ok ? &b : nullptr;
 }
+// test aid (PM_SIDE_DELAY_US): hold a stream for `us` microseconds (s_memrealtime counts at 100 MHz)
+__global__ void k_spin_us(int us) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
 // Launches between the constructor and end() go to the second stream (when there is one; else they stay where they are)
 struct BranchScope {
   Ctx& c; hipStream_t main; double* scratch_main; Branch* b; int site;
@@ -185,7 +195,15 @@ struct BranchScope {
       return;
     }
     c.st = b->st; c.bn_scratch = c.s->bn_scratch_side;
+    if (cfg().side_delay_us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, b->st, cfg().side_delay_us);
   }
+  // The HOST issues launches in program order at ~11 us each, whatever stream they go to: a long branch issued in one
+  // piece keeps the caller's stream without work for as long as the host needs to issue it (the plan build used to start
+  // 217 us into the step, behind 27 launches of the branch).  pause() hands the following launches back to the caller's
+  // stream without closing the branch, resume() continues it (in order on the second stream; no new fork: use it only for
+  // work that does not depend on what the caller's stream has produced since the fork).
+  void pause() { if (b) { c.st = main; c.bn_scratch = scratch_main; } }
+  void resume() { if (b) { c.st = b->st; c.bn_scratch = c.s->bn_scratch_side; } }
   // an intermediate join point: what has been issued on the branch so far is what branch_join(c, at) waits for
   void mark(int at) {
     if (!b) return;
@@ -214,16 +232,24 @@ void lin(Ctx& c, const float* x, PmLin l, int M, int Nout, int Kin, float* y, bo
   RUN(pm_gemm_f32(0, 1, M, Nout, Kin, x, lda ? lda : Kin, c.P + l.w, Kin, y, ldc ? ldc : Nout, c.P + l.b,
                     (relu ? PM_GEMM_RELU : 0) | (c.s->ar.zeroed(y) ? PM_GEMM_ZEROED : 0), 1, nullptr, 0, nullptr, c.st));
 }
+// Weight-gradient products of the head chains whose launch is put off: nobody on the caller's stream waits for them, so
+// the chain issues only the input gradients and the products follow on the second stream (flush_deferred).
+struct Deferred { PmGemmDesc q[8]; int n = 0; };
+void flush_deferred(Ctx& c, Deferred& df) {
+  for (int i = 0; i < df.n; ++i) RUN(pm_gemm_f32_desc(&df.q[i], c.st));
+  df.n = 0;
+}
 // dW += dy^T x ; db += colsum(dy) ; dx = dy @ W
 void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, int Kin, float* dx, int lddy = 0,
-             int ldx = 0, int lddx = 0, bool want_bias = true) {
+             int ldx = 0, int lddx = 0, bool want_bias = true, Deferred* defer = nullptr) {
   lddy = lddy ? lddy : Nout;
   PmGemmDesc w;                              // dW += dy^T x, the bias gradient (column sums of dy) in the same launch
   memset(&w, 0, sizeof(w));
   w.transA = 1; w.M = Nout; w.N = Kin; w.K = M; w.A = dy; w.lda = lddy; w.B = x; w.ldb = ldx ? ldx : Kin;
   w.C = c.G + l.w; w.ldc = Kin; w.flags = PM_GEMM_ACCUM; w.split_k = 0; w.n_groups = 1;
   w.a_colsum = want_bias ? c.G + l.b : nullptr;
-  RUN(pm_gemm_f32_desc(&w, c.st));
+  if (defer && defer->n < 8 && cfg().late_wgrads) defer->q[defer->n++] = w;
+  else RUN(pm_gemm_f32_desc(&w, c.st));
   if (dx) RUN(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
                             c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
 }
@@ -494,25 +520,39 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.c0 = ar.f((size_t)Gn * 8 * 128); s.a0 = ar.f((size_t)Gn * 8 * 128); s.m0 = ar.f(8); s.v0 = ar.f(8);
   s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
   s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.zf((size_t)Gn * d);
+  // Second stream (forked here, at the very start of the step): everything that depends on the parameters only — first what
+  // the encoder needs (joined before the chord encoder), later what the decoder needs (joined before its first layer) —
+  // and the structure encoder (joined before the merge layer).  The host issues it in three pieces between the
+  // launches of the caller's stream (BranchScope::pause).
+  BranchScope br(c, BR_ENC_FWD);
+  const int S = c.S;                                   // token-level tensors are [N, S, .] (active slots only)
+  const bool rows_w_ok = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
+  br.pause();
+  // ---------------- the batch's plan (CSR / CSC, row lists, histograms: plan.hip) on the caller's stream, issued first
+  if (run)
+    RUN(pm_plan_build(s.bt.edge_index, s.bt.edge_type, s.bt.edge_dist, s.bt.bars, s.bt.batch, s.bt.is_drum, s.bt.tokens,
+                        nb, s.bt.n_slots, N, c.E, Gn, const_cast<int32_t*>(s.plan), c.st));
+  br.resume();
   {
-    // second stream: first everything that depends on the parameters only (joined before the chord encoder), then the
-    // structure encoder (joined before the merge layer); the caller's stream meanwhile builds the plan
-    BranchScope br(c, BR_ENC_FWD);
-    const int S = c.S;
-    const bool rows_w = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
-    gcn_prepare(c, Y.enc_gcn, s.eg);
-    gcn_prepare(c, Y.dec_gcn, s.dg);
     // chord encoder Wc [d, 15d]: kind 0 for the forward (long-K kernel, columns [0, S*d)), kind 1 for its input gradient
     s.wf_enc = s.wf_enc_t = s.wf_dec = s.wf_dec_t = nullptr;
-    if (rows_w && S < PM_N_SLOTS) {
+    if (rows_w_ok && S < PM_N_SLOTS) {
       s.wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
       s.wf_enc_t = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
       for (int kind = 0; kind < 2; ++kind)
         RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, kind, 1, (int64_t)PM_N_SLOTS * d * d,
                                    (int64_t)PM_N_SLOTS * d * d * 3, kind ? s.wf_enc_t : s.wf_enc, c.st));
     }
+    gcn_prepare(c, Y.enc_gcn, s.eg);
+    br.mark(BR_WPREP);
+  }
+  br.pause();
+  // the rest of the branch: issued by decoder_prep_and_structure_encoder() below, behind the first launches of the content encoder
+  auto decoder_prep_and_structure_encoder = [&]() {
+    br.resume();
+    gcn_prepare(c, Y.dec_gcn, s.dg);
     // chord decoder, rows [0, S*d) of its weight [15d, d]: kind 0 for the forward, kind 1 for the input gradient
-    if (rows_w) {
+    if (rows_w_ok) {
       s.wf_dec = (uint16_t*)ar.take((size_t)S * d * d * 6);
       s.wf_dec_t = (uint16_t*)ar.take((size_t)S * d * d * 6);
       for (int kind = 0; kind < 2; ++kind)
@@ -527,7 +567,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
       RUN(pm_unembed_dh(nullptr, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, nullptr, N, c.E, Gn, d, S,
                           nullptr, s.w_unembed_dh, 1, c.st));
     }
-    br.mark(BR_WPREP);
+    br.mark(BR_WPREP_DEC);
     if (run) {
     RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
     bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
@@ -538,15 +578,11 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.h1, Y.enc_lin4, Gn, d, d, s.h2, false);
     lin(c, s.h2, Y.enc_s_bars, B, d, nb * d, s.zcat + d, false, nb * d, 2 * d);           // z_s = zcat[:, d:]
     }
-  }
-  // ---------------- the batch's plan (CSR / CSC, row lists, histograms: plan.hip), while the structure encoder runs
-  if (run)
-    RUN(pm_plan_build(s.bt.edge_index, s.bt.edge_type, s.bt.edge_dist, s.bt.bars, s.bt.batch, s.bt.is_drum, s.bt.tokens,
-                        nb, s.bt.n_slots, N, c.E, Gn, const_cast<int32_t*>(s.plan), c.st));
+    br.end();
+  };
   // ---------------- content encoder (model.py:344-417)
   float* tables = ar.f((size_t)4 * PM_N_PITCH * dh);
   s.emb_stats = ar.f((size_t)4 * 2 * dh);
-  const int S = c.S;                                   // token-level tensors are [N, S, .] (active slots only)
   s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
@@ -571,6 +607,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     }
   }
   float* xL = gcn_forward(c, s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
+  decoder_prep_and_structure_encoder();                // (second stream; issued while the GPU works through the encoder's layers)
   s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);
   if (run) {
     RUN(pm_gate_fwd(xL, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
@@ -613,6 +650,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
     RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
   };
+  if (run) branch_join(c, BR_WPREP_DEC);               // the decoder's weight planes and distance table are ready
   float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
   if (run) structure_decoder();
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
@@ -700,8 +738,13 @@ void backward_decoder(Ctx& c) {
   }
   float* dxL = ar.f((size_t)N * d);
   const bool chord_tn = s.wf_dec_t != nullptr;
-  {
-    // ... their weight gradients and the chord decoder's (nobody in this call waits for them) on the second stream
+  // ... their weight gradients and the chord decoder's (nobody in this call waits for them) go to the second stream.
+  // WHEN: beside the decoder's GCL layers they cost the first layer's three kernels 174 us (67 + 94 + 146 against
+  // 46 + 46 + 41 us: those hold one workgroup per CU) for 385 us of their own; the head chain behind the layers (bar
+  // broadcast, the decoder's and the encoder's head products and norms: ~40 launches of 16-64 workgroups, ~400 us) leaves
+  // the chip all but idle, so they are issued there and joined when the decoder's gradient bucket is needed
+  // (pm_vae_step_join_decoder_grads: data parallel) or before the encoder's GCL layers (pm_vae_step_backward_encoder).
+  auto decoder_weight_grads = [&]() {
     BranchScope br(c, BR_DEC_WGRAD);
     RUN(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
                       nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
@@ -716,22 +759,30 @@ void backward_decoder(Ctx& c) {
       else
         lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, nullptr);
     }
-  }
+  };
+  const bool late_wgrads = cfg().late_wgrads;
+  if (!late_wgrads) decoder_weight_grads();
   if (chord_tn)     // dxL = dH @ W[:S*d, :] by the long-K kernel of linear.hip (weight rows as fragment-major planes, kind 1)
     RUN(pm_rows_times_weight_longk(dH, S * d, N, S * d, s.wf_dec_t, 1, 0, d, dxL, d, c.st));
   else
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);        // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
+  if (late_wgrads) decoder_weight_grads();
   float* dcb = ar.f((size_t)Gn * d);
   RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
-  lin_bwd(c, dcb, s.zr + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d);
+  Deferred df;
+  lin_bwd(c, dcb, s.zr + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d, true, &df);
   branch_join(c, BR_DEC_BWD);
   float* dzd = ar.f((size_t)B * 2 * d);
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
   s.dz = ar.zf((size_t)B * d);
-  lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz);
+  lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz, 0, 0, 0, true, &df);
   RUN(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
-  branch_join(c, BR_DEC_WGRAD);                       // (the decoder's gradient bucket is exchanged next)
+  if (df.n) {                                         // the two head products' weight gradients: behind the others on the second stream
+    BranchScope br(c, BR_DEC_WGRAD);
+    flush_deferred(c, df);
+  }
+  if (!late_wgrads) branch_join(c, BR_DEC_WGRAD);     // (late: joined by pm_vae_step_join_decoder_grads / the encoder backward)
 }
 
 void backward_encoder(Ctx& c) {
@@ -740,13 +791,14 @@ void backward_encoder(Ctx& c) {
   const PmVaeLayout& Y = s.lay;
   const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
   float* dzg = ar.zf((size_t)B * d); float* dzg2 = ar.zf((size_t)B * d);
-  lin_bwd(c, s.dmu, s.zg, Y.enc_mu, B, d, d, dzg);
-  lin_bwd(c, s.dlv, s.zg, Y.enc_lv, B, d, d, dzg2);
+  Deferred df;
+  lin_bwd(c, s.dmu, s.zg, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
+  lin_bwd(c, s.dlv, s.zg, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
   RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
   float* dm = ar.f((size_t)B * d);
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
   float* dzcat = ar.zf((size_t)B * 2 * d);
-  lin_bwd(c, dm, s.zcat, Y.enc_merge, B, d, 2 * d, dzcat);
+  lin_bwd(c, dm, s.zcat, Y.enc_merge, B, d, 2 * d, dzcat, 0, 0, 0, true, &df);
   // ---- structure branch (z_s = zcat[:, d:]): on the second stream, under the whole content-encoder backward; joined at
   // the end of backward_encoder_tail
   {
@@ -767,14 +819,20 @@ void backward_encoder(Ctx& c) {
   }
   // ---- content branch (z_c = zcat[:, :d])
   float* dpooled = ar.zf((size_t)Gn * d);
-  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d);
+  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d, true, &df);
+  if (df.n) {                                         // the four head products' weight gradients: second stream, joined below
+    BranchScope br(c, BR_ENC_HEAD_WGRAD);
+    flush_deferred(c, df);
+  }
   float* dxL = ar.f((size_t)N * d);
   float* pscr = ar.f((size_t)3 * N + 8);
   RUN(pm_attnpool_bwd(s.eg.x[c.L], s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, s.alpha, dpooled, c.P + Y.enc_gate.w,
                         s.plan, N, c.E, Gn, d, dxL, c.G + Y.enc_gate.w, c.G + Y.enc_gate.b, c.G + Y.enc_gate_bn.w,
                         c.G + Y.enc_gate_bn.b, pscr, nullptr, nullptr, c.st));
+  branch_join(c, BR_DEC_WGRAD);                       // the decoder's weight gradients, if still open (single device)
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
   RUN(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
+  branch_join(c, BR_ENC_HEAD_WGRAD);                  // (the graph encoder .. encoder head bucket is exchanged next)
   s.bk_dx0 = dx0; s.bk_dzcat = dzcat;
 }
 // Second half of the encoder backward: chord encoder, embeddings, structure branch.  Split off so that the gradients
@@ -953,6 +1011,17 @@ extern "C" int pm_vae_step_backward_decoder(void* state, pm_stream_t stream) {
   Ctx c = make_ctx(s, (hipStream_t)stream);
   backward_decoder(c);
   if (s->ar.overflow) return PM_E_INVALID;
+  s->rc = c.rc;
+  return c.rc;
+}
+// Data parallel: the caller's stream waits for the decoder's weight gradients (issued on the second stream beside the head
+// chain of pm_vae_step_backward_decoder) — call it before the decoder's gradient bucket is handed to the all-reduce.
+// Without the call they are joined inside pm_vae_step_backward_encoder, before the encoder's GCL layers.
+extern "C" int pm_vae_step_join_decoder_grads(void* state, pm_stream_t stream) {
+  StepState* s = (StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK) return PM_E_INVALID;
+  Ctx c = make_ctx(s, (hipStream_t)stream);
+  branch_join(c, BR_DEC_WGRAD);
   s->rc = c.rc;
   return c.rc;
 }

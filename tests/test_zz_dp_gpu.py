@@ -43,12 +43,20 @@ def _worker(rank, world, backend):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_mean_gradient_step():
+@pytest.mark.parametrize("side_delay_us", [0, 3000])
+def test_two_rank_step_matches_mean_gradient_step(side_delay_us):
+    """side_delay_us = 3000: every branch of the library's second stream (structure chains, weight preparation, the
+    weight gradients of the decoder head and of the chord encoder) starts 3 ms late in both ranks (PM_SIDE_DELAY_US), so
+    the gradients it produces are certainly NOT there when the caller's stream reaches the exchange unless that stream
+    waits for the branch: the native step's join-before-bucket order (pm_vae_step_join_decoder_grads before bucket 2, the
+    joins at the end of pm_vae_step_backward_encoder / _tail before buckets 1 and 0) is what makes the result right."""
+    import os
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    os.environ["PM_SIDE_DELAY_US"] = str(side_delay_us)          # read by the ranks' library at load
     try:
-        res = run_ranks(_worker, 2, (backend,), timeout=120.0)
-    except RanksHung as e:              # two processes could not share this box's device: not a parity failure
-        pytest.skip(f"2-rank {backend} run did not complete on this box:\n{e}")
+        res = run_ranks(_worker, 2, (backend,), timeout=120.0)   # a rank that hangs or dies FAILS the test (RanksHung)
+    finally:
+        os.environ.pop("PM_SIDE_DELAY_US", None)
     (p0, g0), (p1, g1) = [(torch.from_numpy(a), torch.from_numpy(b)) for a, b in res]
     assert torch.equal(p0, p1), "ranks diverged"
     assert torch.equal(g0, g1), "all-reduced gradient differs between ranks"
@@ -149,10 +157,7 @@ def test_global_token_mean_weights_the_ranks_by_their_token_counts():
     gradient equals sum_r (n_r * world / n_total) * g_r, g_r = the rank's own local-mean gradient — i.e. its mean over the
     ranks is the gradient of the token mean over the global batch (per-replica BatchNorm statistics apart)."""
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
-    try:
-        res = run_ranks(_gtm_worker, 2, (backend,), timeout=120.0)
-    except RanksHung as e:
-        pytest.skip(f"2-rank {backend} run did not complete on this box:\n{e}")
+    res = run_ranks(_gtm_worker, 2, (backend,), timeout=120.0)      # a rank that hangs or dies FAILS the test (RanksHung)
     got = torch.from_numpy(res[0])
     assert torch.equal(got, torch.from_numpy(res[1]))
     from polyphemus_amd.model import VAE
@@ -262,10 +267,7 @@ def test_sync_bn_data_parallel_step_equals_single_device_global_batch():
     12 samples — the reference's semantics, whose BatchNorm statistics and loss means span the whole batch —, and the
     running statistics agree."""
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
-    try:
-        res = run_ranks(_sync_worker, 2, (backend,), timeout=150.0)
-    except RanksHung as e:
-        pytest.skip(f"2-rank {backend} run did not complete on this box:\n{e}")
+    res = run_ranks(_sync_worker, 2, (backend,), timeout=150.0)      # a rank that hangs or dies FAILS the test (RanksHung)
     g_dp = torch.from_numpy(res[0][0]).double() / 2.0           # the buckets hold the SUM over the ranks
     assert torch.equal(torch.from_numpy(res[0][0]), torch.from_numpy(res[1][0]))
     from polyphemus_amd.graphs import collate_samples

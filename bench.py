@@ -137,7 +137,7 @@ def standalone_segreduce_fwd(batch, d, p=0.1, reps=24):
                              "note": "the same 117 MB operand set every launch: fits the Infinity Cache, not an HBM figure"}}
 
 
-def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers=8):
+def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers=8, seed=1234):
     """The remaining single-GPU configurations of BASELINE.json through the same step (fresh model and trainer, untimed part
     of the run): whole-step rate only."""
     from polyphemus_amd.model import VAE
@@ -149,7 +149,7 @@ def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers
     vae = VAE(**cfg, device=dev).to(dev)
     vae.train()
     tr = HipTrainer(vae, lr=5e-6, betas=(0.9, 0.98), eps=1e-9)
-    batch = synthetic_batch(batch_size, n_bars, p=0.25, seed=1234, dense=dense).to(dev)
+    batch = synthetic_batch(batch_size, n_bars, p=0.25, seed=seed, dense=dense).to(dev)
     for _ in range(warmup):
         tr.train_step(batch)
     torch.cuda.synchronize()
@@ -160,7 +160,8 @@ def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers
     dt = (time.perf_counter() - t0) / steps
     G = batch.s_tensor.shape[0]
     out = {"workload": name, "bar-graphs/s": round(G / dt, 1), "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
-           "batch": batch_size, "d": d, "n_bars": n_bars, "nodes": batch.num_nodes, "edges": int(batch.edge_index.shape[1])}
+           "batch": batch_size, "d": d, "n_bars": n_bars, "batch_seed": seed, "nodes": batch.num_nodes,
+           "edges": int(batch.edge_index.shape[1]), "kernel_path": {k: v for k, v in tr.step_info().items() if k not in ("N", "E", "G", "B")}}
     del tr, vae, batch
     torch.cuda.empty_cache()
     return out
@@ -449,7 +450,8 @@ def main():
         trainer.train_step(batch)
     sync()
     survey = prof_collect()
-    exec_frac = executed_block_fraction(trainer, n_nodes, n_edges, G) if trainer.step_info()["compact"] else 1.0
+    step_info = trainer.step_info()
+    exec_frac = executed_block_fraction(trainer, n_nodes, n_edges, G) if step_info["compact"] else 1.0
     seg_alone = standalone_segreduce_fwd(batch, args.d) if rank == 0 else None
     mfma_classes = [k for k in survey if k.startswith(("gemm", "gcl"))]       # every kernel class that runs on the matrix cores
     dom = max(mfma_classes, key=lambda k: survey[k]["total_ms"])
@@ -578,6 +580,11 @@ def main():
                                          "tile as two 32-row halves behind two others (csrc/tile_order.h): +0.3-3 % step time "
                                          "at 257-261 tiles (DESIGN.md section 5)",
                        "message_dropout": 0.1, "parallelism": f"dp{world}", "weights": "default init, manual_seed(0)",
+                       # which kernel set the step took (pm_vae_step_info: compact GCL, bf16 planes, fragment-major weights,
+                       # active slots, the library's effective switches) and the launches per step of every profiled class:
+                       # a shape that falls back to the round-1 kernels shows here, not only in the rate
+                       "kernel_path": dict({k: v for k, v in step_info.items() if k not in ("N", "E", "G", "B")},
+                                           launches_per_step={k: survey[k]["launches"] / SURVEY for k in sorted(survey)}),
                        "step": "plan+fwd+loss+bwd+allreduce+Adam"},
             # SURVEY 8(d)'s operation count (7 products of N d^2 per GCL) and what the step executes: the compact GCL
             # contracts K = 4d (one track block per node) and skips all-zero onset / next blocks tile by tile
@@ -603,6 +610,9 @@ def main():
             del trainer, vae
             torch.cuda.empty_cache()
             line["other_workloads"] = [
+                # ranks 1..7 of a data-parallel run draw these batches: more 64-row tiles than CUs (the default batch has exactly 256)
+                other_workload("BASELINE configs[1] with the batch of seed 1235 (258 row tiles)", 256, 256, 2, False, seed=1235),
+                other_workload("BASELINE configs[1] with the batch of seed 1236 (261 row tiles)", 256, 256, 2, False, seed=1236),
                 other_workload("LMD16 16-bar, batch=64, d_hidden=256 (BASELINE configs[2])", 64, 256, 16, False),
                 other_workload("LMD2 2-bar, batch=256, d_hidden=512 (the reference's training.json)", 256, 512, 2, False),
                 other_workload("dense-graph stress, one GPU's shard: batch=64, d_hidden=512 (BASELINE configs[4])", 64, 512, 2, True, steps=3),

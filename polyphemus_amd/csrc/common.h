@@ -93,11 +93,18 @@ __device__ static inline unsigned pm_linear_block() {
 __device__ static inline unsigned pm_linear_thread() {
   return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
 }
-// one lane spins (bounded: a lost turn must not hang the device — after ~2^22 polls the wave goes ahead unordered)
+// one lane polls, with a back-off that grows with the distance to its turn (thousands of waves polling one line as fast
+// as they can slow down the very workgroup they are waiting for: 65 us per turn measured, ~4 with the back-off);
+// bounded: a lost turn must not hang the device — after 4 s (s_memrealtime counts at 100 MHz) the wave goes ahead unordered
 __device__ static inline void pm_gate_spin(unsigned* gate, unsigned turn) {
-  for (int it = 0; it < (1 << 22); ++it) {
-    if (__hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == turn) return;
-    __builtin_amdgcn_s_sleep(16);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned cur = __hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == turn) return;
+    unsigned dist = turn - cur;
+    if (dist > 48u) dist = 48u;
+    for (unsigned i = 0; i < dist; ++i) __builtin_amdgcn_s_sleep(48);          // ~1.5 us per unit of distance
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) return;
   }
 }
 // WAVE-level turn (waves that reach the ordered section independently, e.g. consumer waves of a specialised kernel)

@@ -199,6 +199,15 @@ extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int
 #ifndef SEG_WHATIF
 #define SEG_WHATIF 0                      // timing what-ifs (tools/build_variants.py; WRONG results): 1 no table flush, 2 no edge loop, 4 no norm-sum flush
 #endif
+#ifndef SEG_KEEP
+#define SEG_KEEP 1                        // the fused norm's per-column constants in registers (d <= 256); 0: re-read per node (L1)
+#endif
+#ifndef SEG_PREFETCH
+#define SEG_PREFETCH 0                    // 1: rows and CSC offsets of the wave's next node requested one node ahead (d <= 256) — measured
+                                          // 43.5 against 44.2 us per launch with two edges per trip and the norm constants re-read
+                                          // (-DSEG_EPT=2 -DSEG_KEEP=0: no spills), 56.0 with four (20 spilled registers): the kernel is
+                                          // at the row-gather ceiling (profiles/LOG.md), not on the per-node chain; left off
+#endif
 #ifndef SEG_EPT
 #define SEG_EPT 4                         // out-edges of a node whose row gathers are in flight together (k_segreduce_bwd, d <= 256)
 #endif
@@ -236,7 +245,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   const int nwv = blockDim.x >> 6;
   // the norm's per-column constants stay in registers only at d <= 256 (NV = 1); wider rows re-read them per node
   // (L1-resident), which keeps the 16-wave workgroup inside its 128-VGPR budget (17 spilled registers before)
-  constexpr bool KEEP = NV == 1;
+  constexpr bool KEEP = NV == 1 && SEG_KEEP;
   float nm[NV][4], nrs[NV][4], nga[NV][4], nbe[NV][4];
   double ns0[NV][4], ns1[NV][4], ns2[NV][4];
   if (FUSE) {
@@ -294,10 +303,46 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       for (int j = 0; j < 4; ++j) run[v][j] = 0.f;
     }
   };
+  // NEXT-NODE PREFETCH (d <= 256): a wave walks ~4 nodes one after the other and each node is a chain of dependent
+  // round trips (CSC offsets -> edge words -> row gathers -> store, then the pre-norm row of the fused sums); with 16
+  // waves per CU the chain, not the bandwidth, set the pace (edge loop removed: 24.7 us for 83 MB = 3.4 TB/s).  The rows of
+  // the wave's next node (x, the root block of dA, the residual gradient, the pre-norm row) and its CSC offsets are
+  // requested before the current node's edges are walked, so a node costs the edge-word -> gather chain only.
+  constexpr bool PF = NV == 1 && SEG_PREFETCH;
+  float4 pf_x[NV], pf_a[NV], pf_r[NV], pf_h[NV];
+  int pf_beg = 0, pf_end = 0;
+  auto request = [&](int n, float4 (&qx)[NV], float4 (&qa)[NV], float4 (&qr)[NV], float4 (&qh)[NV], int& qb, int& qe) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (!ok[v]) continue;
+      qx[v] = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
+      qa[v] = *reinterpret_cast<const float4*>(dA + ((int64_t)n * nblk + (nblk - 1)) * d + c[v]);
+      if (dres) qr[v] = *reinterpret_cast<const float4*>(dres + (int64_t)n * d + c[v]);
+      if (FUSE) qh[v] = *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
+    }
+    qb = colptr[n]; qe = colptr[n + 1];
+  };
+  if (PF) {
+    const int n_first = __builtin_amdgcn_readfirstlane(n_lo + wave);
+    if (n_first < n_hi) request(n_first, pf_x, pf_a, pf_r, pf_h, pf_beg, pf_end);
+  }
   for (int n0 = n_lo; n0 < n_hi; n0 += n_step) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
     if (n >= n_hi) continue;
-    float4 xv[NV], acc[NV];
+    float4 xv[NV], acc[NV], hcur[NV];
+    int beg, end;
+    if (PF) {
+      float4 rcur[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { xv[v] = pf_x[v]; acc[v] = pf_a[v]; rcur[v] = pf_r[v]; hcur[v] = pf_h[v]; }
+      beg = pf_beg; end = pf_end;
+      const int nnext = n + n_step;                            // (uniform: n is)
+      if (nnext < n_hi) request(nnext, pf_x, pf_a, pf_r, pf_h, pf_beg, pf_end);
+      if (dres) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { acc[v].x += rcur[v].x; acc[v].y += rcur[v].y; acc[v].z += rcur[v].z; acc[v].w += rcur[v].w; }
+      }
+    } else {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
@@ -308,7 +353,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         acc[v].x += rv.x; acc[v].y += rv.y; acc[v].z += rv.z; acc[v].w += rv.w;
       }
     }
-    const int beg = colptr[n], end = colptr[n + 1];
+    beg = colptr[n]; end = colptr[n + 1];
+    }
     // edge metadata through the scalar cache (p is uniform), requested at the top of their trip.  SEG_META_AHEAD=1 requests
     // the next trip's words before this trip's rows are gathered: 55.1-55.5 us per launch against 50.5-51.1 (19 spilled
     // SGPRs, 6 VGPRs, a copy of the words per trip)
@@ -391,7 +437,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       if (!ok[v]) continue;
       *reinterpret_cast<float4*>(dx + (int64_t)n * d + c[v]) = acc[v];
       if (FUSE) {
-        const float4 hv = *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
+        const float4 hv = PF ? hcur[v] : *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
         const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
         const float ds[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
         float m4[4], r4[4], g4n[4], b4[4];

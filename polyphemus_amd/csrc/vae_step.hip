@@ -35,6 +35,7 @@ struct StepCfg {
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int side_delay_us;           // PM_SIDE_DELAY_US (tests): every branch starts with a kernel that spins this long on the second stream,
                                // so a missing join shows as a wrong result instead of passing by luck of timing
+  bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -53,6 +54,7 @@ static StepCfg read_cfg() {
   k.debug = getenv("PM_DEBUG") != nullptr;
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
   k.late_wgrads = flag("PM_LATE_WGRADS", true);
+  k.dw_side = flag("PM_DW_SIDE", false);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
@@ -152,7 +154,7 @@ struct Ctx {
 // capturable.  Norms on the branch use their own reduction scratch.
 // sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
 // structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
-enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_SITES };
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_SITES };
 struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES], idle; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
@@ -186,7 +188,7 @@ __global__ void k_spin_us(int us) {
 struct BranchScope {
   Ctx& c; hipStream_t main; double* scratch_main; Branch* b; int site;
   BranchScope(Ctx& c_, int site_) : c(c_), main(c_.st), scratch_main(c_.bn_scratch), b(nullptr), site(site_) {
-    if (!c.s->ar.base || !(cfg().side_stream & (1 << site_))) return;
+    if (!c.s->ar.base || site_ >= BR_SITES || !(cfg().side_stream & (1 << site_))) return;
     b = branch_of_device();
     if (!b) return;
     if (hipEventRecord(b->fork[site], main) != hipSuccess || hipStreamWaitEvent(b->st, b->fork[site], 0) != hipSuccess) {
@@ -427,7 +429,12 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   float* dh = ar.f((size_t)N * d);
   float* dA = ar.f((size_t)N * nb * d);
   const int64_t aps = (int64_t)N * nb * d, dps = (int64_t)N * d;
-  uint16_t* dhp = c.planes ? (uint16_t*)ar.take((size_t)dps * 6) : nullptr;   // dh as operand planes
+  // dh as operand planes; two buffers, alternating by layer, when the weight gradients run on the second stream (the
+  // weight gradient of layer i may then still read its planes while layer i-1's norm backward writes the other buffer)
+  uint16_t* dhp2[2];
+  dhp2[0] = c.planes ? (uint16_t*)ar.take((size_t)dps * 6) : nullptr;
+  const bool dws = cfg().dw_side && c.planes && c.compact;
+  dhp2[1] = dws ? (uint16_t*)ar.take((size_t)dps * 6) : dhp2[0];
   float* dxa = ar.f((size_t)N * d);
   float* dxb = ar.f((size_t)N * d);
   PmPlanView pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
@@ -438,6 +445,9 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const float* W = c.P + g.weight[i];
     float* dW = c.G + g.weight[i];
     const PmBn& bn = g.norm[i];
+    uint16_t* const dhp = dhp2[i & 1];
+    const int dw_site = dws ? (BR_GCL_DW0 + (i & 1)) : BR_SITES;
+    if (dws) branch_join(c, dw_site);        // (the weight gradient of layer i+2 read the dh planes this call rewrites)
     RUN(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
                           c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
                           sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1 && fuse_sums) ? 1 : 0, c.st));
@@ -445,6 +455,28 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       RUN(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       RUN(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
     } else {
+      const bool dw_first = dws;                // (second stream: issued before the input gradient, beside which it runs)
+      auto weight_grad = [&]() {
+      PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
+      w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM | PM_GEMM_PARTITION; w.split_k = 0;
+      w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;
+      w.c_group_stride = dd; w.c_split_rows = d; w.c_shared_off = 3 * dd;
+      if (c.planes) {
+        w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
+        w.B = (const float*)dhp; w.b_plane_stride = dps;
+      }
+      {
+        // PM_DW_SIDE=1 (A/B): the weight gradient of the layer on the second stream — nobody on the caller's stream waits
+        // for it; its workgroups fill the CUs that the input gradient's / the segment-reduce's unequal tiles leave idle
+        BranchScope brw(c, dw_site);
+        if (c.planes && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1) && !cfg().no_dw)      // 128x128 tiles (gcl.hip)
+          RUN(pm_gcl_weight_grad_fused(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d,
+                                         cfg().no_classes ? 0 : 1, dW, c.st));
+        else
+          RUN(pm_gemm_f32_desc(&w, c.st));
+      }
+      };
+      if (dw_first) weight_grad();
       PmGemmDesc q = gcl_desc(pv, N, d);                  // dA'[rows_t] = dh[rows_t] @ [W_t; W_4; W_5; root]^T
       q.transB = 1; q.M = N; q.N = 4 * d; q.K = d;
       q.A = dh; q.lda = d; q.B = W; q.ldb = d; q.C = dA; q.ldc = 4 * d;
@@ -459,19 +491,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
                                       cfg().no_classes ? 0 : 1, dA, c.st));
       else
         RUN(pm_gemm_f32_desc(&q, c.st));
-      PmGemmDesc w = gcl_desc(pv, N, d);                  // d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t]
-      w.transA = 1; w.M = 4 * d; w.N = d; w.K = N; w.flags = PM_GEMM_ACCUM | PM_GEMM_PARTITION; w.split_k = 0;
-      w.A = sv.A[i]; w.lda = 4 * d; w.B = dh; w.ldb = d; w.C = dW; w.ldc = d;
-      w.c_group_stride = dd; w.c_split_rows = d; w.c_shared_off = 3 * dd;
-      if (c.planes) {
-        w.operand_planes = 1; w.A = (const float*)sv.Ap[i]; w.a_plane_stride = aps;
-        w.B = (const float*)dhp; w.b_plane_stride = dps;
-      }
-      if (c.planes && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1) && !cfg().no_dw)      // 128x128 tiles (gcl.hip)
-        RUN(pm_gcl_weight_grad_fused(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d,
-                                       cfg().no_classes ? 0 : 1, dW, c.st));
-      else
-        RUN(pm_gemm_f32_desc(&w, c.st));
+      if (!dw_first) weight_grad();
     }
     float* out = (dx == dxa) ? dxb : dxa;
     if (i > 0 && fuse_sums) {                             // + the column sums of the norm backward of layer i-1
@@ -487,6 +507,8 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     }
     dx = out;
   }
+  branch_join(c, BR_GCL_DW0);
+  branch_join(c, BR_GCL_DW1);
   RUN(pm_edge_table_bwd(dT, d, c.G + g.nn_w, c.G + g.nn_b, c.st));
   return dx;
 }

@@ -423,6 +423,11 @@ int pm_bn_fold_weights(const float* W, int32_t rows, int32_t cols, const float* 
 int pm_bn_counters_update(int64_t* counters /* [n] */, const int64_t* inc /* [n] */, const int64_t* sel /* [2,n] */,
                           const int32_t* group_cnt /* [2] */, int32_t n, pm_stream_t stream);
 int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream);
+/* dh = dy * [h > 0], as fp32 (dh, may be NULL) and / or as three bf16 operand planes (planes, may be NULL; plane_stride
+ * elements apart): the backward of the GCL layer tail x' = x + relu(h) of a model built with batch_norm = False
+ * (model.py:202-206), where pm_bn_bwd_fused stands otherwise.  n % 4 == 0. */
+int pm_relu_bwd_planes(const float* dy, const float* h, int64_t n, float* dh, uint16_t* planes, int64_t plane_stride,
+                       pm_stream_t stream);
 /* y = relu(x) + res (res may be NULL): layer tail of a model built with batch_norm = False (model.py:203-206,219-230). */
 int pm_relu_residual_fwd(const float* x, const float* res, int64_t n, float* y, pm_stream_t stream);
 /* Element dropout of the cfg.dropout layers (model.py:160,199,244-247,267-270,389-390,473,479,558-559,640) on a
@@ -649,7 +654,10 @@ typedef struct PmGcn {
   PmBn norm[PM_MAX_LAYERS];
 } PmGcn;
 typedef struct PmVaeLayout {
-  int32_t d, n_bars, n_layers, reserved;
+  int32_t d, n_bars, n_layers;
+  int32_t flags;                                             /* bit 0: the model was built with batch_norm = False: the norms
+                                                                of the two GCN stacks and of the two CNNs do not exist
+                                                                (model.py:176-188,218-238,278-292; their PmBn entries are unused) */
   /* encoder (model.py:420-483) */
   PmLin enc_conv0; PmBn enc_bn1; PmLin enc_conv4; PmBn enc_bn5; PmLin enc_lin1, enc_lin4, enc_s_bars;
   PmLin enc_pitch_nd, enc_pitch_d, enc_dur; PmBn enc_bn_nd, enc_bn_d, enc_bn_dur; PmLin enc_chord;
@@ -658,6 +666,9 @@ typedef struct PmVaeLayout {
   /* decoder (model.py:486-655) */
   PmLin dec_lin; PmBn dec_bn; PmLin dec_s_bars, dec_s_lin1, dec_s_lin4, dec_conv1; PmBn dec_bn2; PmLin dec_conv4;
   PmLin dec_c_bars; PmGcn dec_gcn; PmLin dec_chord, dec_pitch_d, dec_pitch_nd, dec_dur;
+  float dropout;                                             /* cfg.dropout: p of the element dropout layers (model.py:160,199,
+                                                                244-247,267-270,389-390,473,479,558-559,640); 0 = none */
+  int32_t reserved;
 } PmVaeLayout;
 typedef struct PmBatch {                                    /* device pointers of one collated batch          */
   const int64_t* edge_index; const int32_t* edge_type; const int32_t* edge_dist;

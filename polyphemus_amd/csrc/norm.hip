@@ -683,6 +683,27 @@ extern "C" int pm_dropout_rows(const float* x, int64_t rows, int32_t cols, float
                      pm_keep_threshold(p), 1.0f / (1.0f - p), y);
   return pm_check_launch();
 }
+// dh = dy * [h > 0] as fp32 and / or as the three bf16 operand planes of the GCL backward products: the layer tail of a
+// model built with batch_norm = False (x' = x + relu(h), model.py:202-206) where pm_bn_bwd_fused stands otherwise
+__global__ void __launch_bounds__(256) k_relu_bwd_planes(const float* __restrict__ dy, const float* __restrict__ h, int64_t n4,
+                                                         float* __restrict__ dh, uint16_t* __restrict__ planes,
+                                                         int64_t plane_stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(h)[i];
+    const float4 o = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+    if (dh) reinterpret_cast<float4*>(dh)[i] = o;
+    if (planes) pm_store_planes4(planes, plane_stride, i * 4, o.x, o.y, o.z, o.w);
+  }
+}
+extern "C" int pm_relu_bwd_planes(const float* dy, const float* h, int64_t n, float* dh, uint16_t* planes,
+                                  int64_t plane_stride, pm_stream_t stream) {
+  if (!dy || !h || (!dh && !planes) || n <= 0 || (n & 3) || ((uintptr_t)dy % 16) || ((uintptr_t)h % 16) || ((uintptr_t)dh % 16) ||
+      (planes && (plane_stride < n || (plane_stride & 3) || ((uintptr_t)planes % 8))))
+    return PM_E_INVALID;
+  hipLaunchKernelGGL(k_relu_bwd_planes, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, h, n / 4, dh, planes,
+                     plane_stride);
+  return pm_check_launch();
+}
 extern "C" int pm_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, pm_stream_t stream) {
   if (!dy || !y || !dx || n <= 0) return PM_E_INVALID;
   hipLaunchKernelGGL(k_relu_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);

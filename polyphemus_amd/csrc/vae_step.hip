@@ -93,6 +93,8 @@ struct Arena {
 
 struct GcnSaved {
   float* T; float* x[PM_MAX_LAYERS + 1]; float* A[PM_MAX_LAYERS]; float* h[PM_MAX_LAYERS];
+  const float* xin[PM_MAX_LAYERS];       // layer inputs after the cfg.dropout layer (model.py:199; = x[i] without dropout)
+  uint32_t site0;                        // element-dropout stream id of layer 0
   float* mean[PM_MAX_LAYERS]; float* var[PM_MAX_LAYERS];
   uint16_t* Ap[PM_MAX_LAYERS];           // planes mode: the aggregates as three bf16 planes (A[] is then unused)
   uint16_t* Wp; int64_t wp_stride; int64_t wp_base;   // planes of the parameter range [wp_base, wp_base + wp_stride)
@@ -120,6 +122,9 @@ struct StepState {
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
   uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t, *w_unembed_dh;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
+  // cfg.dropout: the tensors behind the element dropout layers (the undropped ones when the model has none)
+  const float *a1d, *h1d, *x0d, *xLg, *zcat_d, *zg_d, *zr_d, *sbd, *u1d, *H_d;
+  uint32_t seed_enc, seed_dec;
   float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
   int rc;
   unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
@@ -130,6 +135,8 @@ struct Ctx {
   StepState* s; hipStream_t st; int rc;
   double* bn_scratch;                    // reduction scratch of the norms issued on `st` (the second stream has its own)
   int N, E, Gn, B, d, nb, L, S;          // S = active token slots (1..15)
+  bool bn;                               // cfg.batch_norm: the norms of the GCN stacks and of the CNNs exist (model.py:176-188,218-238,278-292)
+  float pdrop;                           // cfg.dropout: p of the element dropout layers (0: none)
   int compact;                           // 1: one track relation per node -> [N,4d] aggregates, K = 4d
   int planes;                            // 1 (needs compact): GCL GEMM operands as pre-split bf16 planes
   const float* P; float* G; float* Bf;
@@ -277,6 +284,17 @@ void bn_bwd(Ctx& c, const float* x, const float* dy, int O, int C, int I, PmBn b
                   dbias_pre, dx, c.bn_scratch, c.st));
 }
 
+// stream ids of the `cfg.dropout` layers (element dropout; polyphemus_amd/engine.py SITE, replayed by the oracle's ELEM_KEEP)
+enum { SITE_ENC_CNN_IN = 2001, SITE_ENC_CNN_MID, SITE_ENC_CHORD, SITE_ENC_GATE, SITE_ENC_MERGE_IN, SITE_ENC_MERGE_OUT, SITE_DEC_IN,
+       SITE_DEC_CNN_IN, SITE_DEC_CNN_MID, SITE_DEC_CHORD, SITE_ENC_GCN = 2100, SITE_DEC_GCN = 2200 };
+// nn.Dropout(cfg.dropout) of the reference at `site` on a row-major [rows, cols] tensor (model.py:160,199,244-247,267-270,
+// 389-390,473,479,558-559,640): y = x * keep / (1 - p) into `y` (may alias x); returns x itself when the model has no
+// dropout.  The backward of the layer is the same call on the gradient.
+const float* drop(Ctx& c, const float* x, int64_t rows, int cols, uint32_t site, uint32_t seed, float* y) {
+  if (!(c.pdrop > 0.f)) return x;
+  RUN(pm_dropout_rows(x, rows, cols, c.pdrop, seed, site, y, c.st));
+  return y;
+}
 static bool gcl_fused_on() { return cfg().gcl_fused; }
 // chord weight gradients on the bf16 pipe (k_rows_tn of linear.hip: the loaders split fp32 rows on the fly): measured
 // 400 against 449 us per launch at d = 512, but 140 against 117 us at d = 256 — there the loaders' split arithmetic (5.5
@@ -371,25 +389,28 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
   const int64_t aps = (int64_t)N * nb * d;                // plane stride of the aggregates (elements)
   const GcnRoute r = gcn_route(c, sv);
   const bool gcl_kernels = r.gcl_kernels, dense = r.dense;
+  sv.site0 = uid0 == 0 ? SITE_ENC_GCN : SITE_DEC_GCN;
   for (int i = 0; i < c.L; ++i) {
     if (c.planes) { sv.Ap[i] = (uint16_t*)ar.take((size_t)aps * 6); sv.A[i] = nullptr; }
     else sv.A[i] = ar.f((size_t)N * nb * d);
     sv.h[i] = ar.f((size_t)N * d); sv.x[i + 1] = ar.f((size_t)N * d);
     sv.mean[i] = ar.f(d); sv.var[i] = ar.f(d);
+    float* xdrop = c.pdrop > 0.f ? ar.f((size_t)N * d) : nullptr;
     if (!ar.base) continue;
+    sv.xin[i] = drop(c, sv.x[i], N, d, sv.site0 + i, seed, xdrop);      // model.py:199 (the residual keeps the undropped x)
     const float* W = c.P + g.weight[i];
-    double* sums = sv.pool + (size_t)i * 5 * d * PM_BN_REPL;   // the GEMM epilogue leaves the BatchNorm statistics here
+    double* sums = c.bn ? sv.pool + (size_t)i * 5 * d * PM_BN_REPL : nullptr;   // the GEMM epilogue leaves the BatchNorm statistics here
     // one kernel for aggregate + product (gcl.hip) where it applies: compact planes path, fragment-major weights
     const bool fused = gcl_kernels && !dense;
     const bool from_planes = gcl_kernels && dense && d == 512;
     if (fused)
-      RUN(pm_gcl_forward_fused(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
+      RUN(pm_gcl_forward_fused(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                  sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
                                  sv.h[i], sums, sv.Ap[i], aps, c.st));
     else if (c.planes)
-      RUN(pm_segreduce_fwd_planes(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
+      RUN(pm_segreduce_fwd_planes(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
     else
-      RUN(pm_segreduce_fwd(sv.x[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
+      RUN(pm_segreduce_fwd(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
     if (fused) {
     } else if (from_planes) {
       RUN(pm_gcl_forward_from_planes(sv.Ap[i], aps, c.s->plan, N, c.E, c.Gn, d, sv.Wfn + (int64_t)i * sv.wf_stride,
@@ -415,8 +436,11 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       RUN(pm_gemm_f32_desc(&q, c.st));
     }
     const PmBn& bn = g.norm[i];                           // x' = x + relu(BN(h))   (model.py:203-206)
-    RUN(pm_bn_apply_fused(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
-                            sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.st));
+    if (c.bn)
+      RUN(pm_bn_apply_fused(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
+                              sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.st));
+    else                                                  // batch_norm = False: x' = x + relu(h)
+      RUN(pm_relu_residual_fwd(sv.h[i], sv.x[i], (int64_t)N * d, sv.x[i + 1], c.st));
   }
   return sv.x[c.L];
 }
@@ -440,7 +464,11 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
   PmPlanView pv = pm_plan_view(c.s->plan, N, c.E, c.Gn);
   // the segment-reduce backward of layer i also accumulates the column sums of the norm backward of layer i-1; beyond
   // d = 512 that variant spills (16-wave workgroups: 128 VGPRs), so wider models take the separate column-sum pass
-  const bool fuse_sums = d <= 512;
+  // (no norm: no sums; cfg.dropout: the layer's input gradient is masked before it meets the residual gradient, so the sums
+  //  cannot be taken from the segment-reduce's registers)
+  const bool dropping = c.pdrop > 0.f;
+  const bool fuse_sums = d <= 512 && c.bn && !dropping;
+  float* dxin = dropping ? ar.f((size_t)N * d) : nullptr;
   for (int i = c.L - 1; i >= 0; --i) {
     const float* W = c.P + g.weight[i];
     float* dW = c.G + g.weight[i];
@@ -448,9 +476,14 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     uint16_t* const dhp = dhp2[i & 1];
     const int dw_site = dws ? (BR_GCL_DW0 + (i & 1)) : BR_SITES;
     if (dws) branch_join(c, dw_site);        // (the weight gradient of layer i+2 read the dh planes this call rewrites)
-    RUN(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
-                          c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
-                          sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1 && fuse_sums) ? 1 : 0, c.st));
+    if (c.bn)
+      RUN(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
+                            c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
+                            sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1 && fuse_sums) ? 1 : 0, c.st));
+    else {                                              // batch_norm = False: dh = dx * [h > 0]; GCL.bias gradient = its column sums
+      RUN(pm_relu_bwd_planes(dx, sv.h[i], (int64_t)N * d, dh, c.planes ? dhp : nullptr, dps, c.st));
+      RUN(pm_colsum_acc(dh, N, d, d, c.G + g.bias[i], c.st));
+    }
     if (!c.compact) {
       RUN(pm_gemm_f32(0, 1, N, 7 * d, d, dh, d, W, d, dA, 7 * d, nullptr, 0, 1, nullptr, 0, nullptr, c.st));
       RUN(pm_gemm_f32(1, 0, 7 * d, d, N, sv.A[i], 7 * d, dh, d, dW, d, nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
@@ -494,7 +527,13 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       if (!dw_first) weight_grad();
     }
     float* out = (dx == dxa) ? dxb : dxa;
-    if (i > 0 && fuse_sums) {                             // + the column sums of the norm backward of layer i-1
+    if (dropping) {
+      // dx_i = dx_{i+1} (residual) + dropout-mask * d(layer input): sv.xin is the DROPPED input the messages were built from
+      RUN(pm_segreduce_bwd(sv.xin[i], sv.T, dA, nullptr, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, dxin,
+                             dT, c.st));
+      drop(c, dxin, N, d, sv.site0 + i, sv.seed, dxin);
+      RUN(pm_add(dx, dxin, (int64_t)N * d, out, c.st));
+    } else if (i > 0 && fuse_sums) {                      // + the column sums of the norm backward of layer i-1
       const PmBn& pb = g.norm[i - 1];
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
@@ -522,12 +561,15 @@ Ctx make_ctx(StepState* s, hipStream_t st) {
   c.compact = (s->bt.flags & 1) ? 1 : 0;
   c.planes = (c.compact && (s->bt.flags & 2) && (s->lay.d % 8) == 0) ? 1 : 0;
   c.P = s->P; c.G = s->G; c.Bf = s->Bf;
+  c.bn = !(s->lay.flags & 1); c.pdrop = s->lay.dropout;
   return c;
 }
 
 // The forward pass + losses; with ar.base == nullptr it only measures the arena.
 void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   StepState& s = *c.s;
+  s.seed_enc = seed_enc; s.seed_dec = seed_dec;
+  const bool dropping = c.pdrop > 0.f;
   Arena& ar = s.ar;
   const PmVaeLayout& Y = s.lay;
   const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
@@ -542,6 +584,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.c0 = ar.f((size_t)Gn * 8 * 128); s.a0 = ar.f((size_t)Gn * 8 * 128); s.m0 = ar.f(8); s.v0 = ar.f(8);
   s.p0 = ar.f((size_t)Gn * 8 * 32); s.c1 = ar.f((size_t)Gn * 16 * 32); s.a1 = ar.f((size_t)Gn * 512);
   s.m1 = ar.f(16); s.v1 = ar.f(16); s.h1 = ar.f((size_t)Gn * d); s.h2 = ar.zf((size_t)Gn * d);
+  float* const a1d_buf = dropping ? ar.f((size_t)Gn * 512) : nullptr;
+  float* const h1d_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
   // Second stream (forked here, at the very start of the step): everything that depends on the parameters only — first what
   // the encoder needs (joined before the chord encoder), later what the decoder needs (joined before its first layer) —
   // and the structure encoder (joined before the merge layer).  The host issues it in three pieces between the
@@ -592,12 +636,16 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     br.mark(BR_WPREP_DEC);
     if (run) {
     RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
-    bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
+    if (c.bn) bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
+    else RUN(pm_relu_residual_fwd(s.c0, nullptr, (int64_t)Gn * 8 * 128, s.a0, c.st));       // model.py:218-238 without BatchNorm2d
     RUN(pm_maxpool4_fwd(s.a0, (int64_t)Gn * 8 * 32, s.p0, c.st));
     RUN(pm_conv3x3_fwd(s.p0, c.P + Y.enc_conv4.w, c.P + Y.enc_conv4.b, Gn, 8, 16, 4, 8, 0, s.c1, c.st));
-    bn_fwd(c, s.c1, Gn, 16, 32, Y.enc_bn5, true, nullptr, s.a1, s.m1, s.v1);
-    lin(c, s.a1, Y.enc_lin1, Gn, d, 512, s.h1, true);
-    lin(c, s.h1, Y.enc_lin4, Gn, d, d, s.h2, false);
+    if (c.bn) bn_fwd(c, s.c1, Gn, 16, 32, Y.enc_bn5, true, nullptr, s.a1, s.m1, s.v1);
+    else RUN(pm_relu_residual_fwd(s.c1, nullptr, (int64_t)Gn * 512, s.a1, c.st));
+    s.a1d = drop(c, s.a1, Gn, 512, SITE_ENC_CNN_IN, seed_enc, a1d_buf);                     // CNNEncoder.lin[0], model.py:244
+    lin(c, s.a1d, Y.enc_lin1, Gn, d, 512, s.h1, true);
+    s.h1d = drop(c, s.h1, Gn, d, SITE_ENC_CNN_MID, seed_enc, h1d_buf);                      // CNNEncoder.lin[3], model.py:247
+    lin(c, s.h1d, Y.enc_lin4, Gn, d, d, s.h2, false);
     lin(c, s.h2, Y.enc_s_bars, B, d, nb * d, s.zcat + d, false, nb * d, 2 * d);           // z_s = zcat[:, d:]
     }
     br.end();
@@ -608,6 +656,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.X = ar.f((size_t)N * S * d);
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
+  float* const x0d_buf = dropping ? ar.f((size_t)N * d) : nullptr;
+  float* const xLg_buf = dropping ? ar.f((size_t)N * d) : nullptr;
+  float* const zcatd_buf = dropping ? ar.f((size_t)B * 2 * d) : nullptr;
+  float* const zgd_buf = dropping ? ar.f((size_t)B * d) : nullptr;
   uint16_t* const wf_enc = s.wf_enc;
   if (run) {
     RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
@@ -627,12 +679,14 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                           nullptr, 0, nullptr, c.st));
       RUN(pm_chord_pad_fwd(tables, c.P + Y.enc_chord.w, c.P + Y.enc_chord.b, s.bt.is_drum, N, d, S, s.cvec, s.x0, c.st));
     }
+    s.x0d = drop(c, s.x0, N, d, SITE_ENC_CHORD, seed_enc, x0d_buf);                          // model.py:389-390 (row = node)
   }
-  float* xL = gcn_forward(c, s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
+  float* xL = gcn_forward(c, dropping ? x0d_buf : s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
   decoder_prep_and_structure_encoder();                // (second stream; issued while the GPU works through the encoder's layers)
   s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);
   if (run) {
-    RUN(pm_gate_fwd(xL, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
+    s.xLg = drop(c, xL, N, d, SITE_ENC_GATE, seed_enc, xLg_buf);                             // MLP.forward of the gate, model.py:160
+    RUN(pm_gate_fwd(s.xLg, c.P + Y.enc_gate.w, c.P + Y.enc_gate.b, N, d, s.g, c.st));
     RUN(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, c.bn_scratch, c.st));
     RUN(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
                           s.alpha, s.pooled, c.st));
@@ -643,10 +697,12 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.mu = ar.zf((size_t)B * d); s.lv = ar.zf((size_t)B * d); s.z = ar.f((size_t)B * d);
   if (run) {
     branch_join(c, BR_ENC_FWD);
-    lin(c, s.zcat, Y.enc_merge, B, d, 2 * d, s.m, false);
+    s.zcat_d = drop(c, s.zcat, B, 2 * d, SITE_ENC_MERGE_IN, seed_enc, zcatd_buf);            // Encoder.dropout_layer, model.py:473
+    lin(c, s.zcat_d, Y.enc_merge, B, d, 2 * d, s.m, false);
     bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
-    lin(c, s.zg, Y.enc_mu, B, d, d, s.mu, false);
-    lin(c, s.zg, Y.enc_lv, B, d, d, s.lv, false);
+    s.zg_d = drop(c, s.zg, B, d, SITE_ENC_MERGE_OUT, seed_enc, zgd_buf);                     // model.py:479
+    lin(c, s.zg_d, Y.enc_mu, B, d, d, s.mu, false);
+    lin(c, s.zg_d, Y.enc_lv, B, d, d, s.lv, false);
     RUN(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
   }
   // ---------------- decoder (model.py:634-655)
@@ -655,21 +711,28 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   s.c2 = ar.f((size_t)Gn * 8 * 128); s.a2 = ar.f((size_t)Gn * 8 * 128); s.m2 = ar.f(8); s.v2 = ar.f(8);
   s.s_logits = ar.f((size_t)Gn * 128); s.cb = ar.zf((size_t)Gn * d);
   float* xd0 = ar.f((size_t)N * d);
+  float* const zrd_buf = dropping ? ar.f((size_t)B * 2 * d) : nullptr;
+  float* const sbd_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
+  float* const u1d_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
   if (run) {
     lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
     bn_fwd(c, s.zd, B, 2 * d, 1, Y.dec_bn, true, nullptr, s.zr, s.dm, s.dv);
-    lin(c, s.zr + d, Y.dec_c_bars, B, nb * d, d, s.cb, false, 2 * d, 0);                  // A = zr[:, d:]
+    s.zr_d = drop(c, s.zr, B, 2 * d, SITE_DEC_IN, seed_dec, zrd_buf);                        // Decoder.dropout, model.py:640
+    lin(c, s.zr_d + d, Y.dec_c_bars, B, nb * d, d, s.cb, false, 2 * d, 0);                // A = zr[:, d:]
     RUN(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
   }
   // structure decoder: second stream, beside the chord decoder and the un-embedding (beside the decoder's first GCL layers it
   // cost one k_gcl_fwd launch 22 us for the same step time); joined before the losses
   auto structure_decoder = [&]() {
     BranchScope br(c, BR_DEC_FWD);
-    lin(c, s.zr, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                      // A = zr[:, :d]
-    lin(c, s.sb, Y.dec_s_lin1, Gn, d, d, s.u1, true);
-    lin(c, s.u1, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
+    lin(c, s.zr_d, Y.dec_s_bars, B, nb * d, d, s.sb, false, 2 * d, 0);                    // A = zr[:, :d]
+    s.sbd = drop(c, s.sb, Gn, d, SITE_DEC_CNN_IN, seed_dec, sbd_buf);                        // CNNDecoder.lin[0], model.py:267
+    lin(c, s.sbd, Y.dec_s_lin1, Gn, d, d, s.u1, true);
+    s.u1d = drop(c, s.u1, Gn, d, SITE_DEC_CNN_MID, seed_dec, u1d_buf);                       // CNNDecoder.lin[3], model.py:270
+    lin(c, s.u1d, Y.dec_s_lin4, Gn, 512, d, s.u2, true);
     RUN(pm_conv3x3_fwd(s.u2, c.P + Y.dec_conv1.w, c.P + Y.dec_conv1.b, Gn, 16, 8, 4, 32, 1, s.c2, c.st));
-    bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
+    if (c.bn) bn_fwd(c, s.c2, Gn, 8, 128, Y.dec_bn2, true, nullptr, s.a2, s.m2, s.v2);
+    else RUN(pm_relu_residual_fwd(s.c2, nullptr, (int64_t)Gn * 8 * 128, s.a2, c.st));       // model.py:278-292 without BatchNorm2d
     RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
   };
   if (run) branch_join(c, BR_WPREP_DEC);               // the decoder's weight planes and distance table are ready
@@ -689,6 +752,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
       RUN(pm_rows_times_weight(xdL, d, N, d, wf_dec, 0, 0, S * d, c.P + Y.dec_chord.b, s.H, S * d, c.st));
     } else
       lin(c, xdL, Y.dec_chord, N, S * d, d, s.H, false);          // rows [0, S*d) of chord_decoder.weight
+    drop(c, s.H, N, S * d, SITE_DEC_CHORD, seed_dec, s.H);        // ContentDecoder.dropout_layer, model.py:558-559 (in place; row = node)
     // un-embedding (model.py:561-576: duration logits for every (node, slot) row, pitch logits per drum / non-drum row
     // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits of a 64-row tile never
     // leave the CU, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
@@ -733,14 +797,17 @@ void backward_decoder(Ctx& c) {
     float* du2 = ar.f((size_t)Gn * 512); float* du1 = ar.zf((size_t)Gn * d); float* dsb = ar.zf((size_t)Gn * d);
     RUN(pm_conv3x3_bwd_weight(s.a2, s.ds_logits, Gn, 8, 1, 4, 32, 0, c.G + Y.dec_conv4.w, c.G + Y.dec_conv4.b, c.st));
     RUN(pm_conv3x3_bwd_data(s.ds_logits, c.P + Y.dec_conv4.w, Gn, 8, 1, 4, 32, 0, da2, c.st));
-    bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
+    if (c.bn) bn_bwd(c, s.c2, da2, Gn, 8, 128, Y.dec_bn2, s.m2, s.v2, true, dc2);
+    else RUN(pm_relu_bwd(da2, s.c2, (int64_t)Gn * 8 * 128, dc2, c.st));
     RUN(pm_conv3x3_bwd_weight(s.u2, dc2, Gn, 16, 8, 4, 32, 1, c.G + Y.dec_conv1.w, c.G + Y.dec_conv1.b, c.st));
     RUN(pm_conv3x3_bwd_data(dc2, c.P + Y.dec_conv1.w, Gn, 16, 8, 4, 32, 1, du2, c.st));
     RUN(pm_relu_bwd(du2, s.u2, (int64_t)Gn * 512, du2, c.st));
-    lin_bwd(c, du2, s.u1, Y.dec_s_lin4, Gn, 512, d, du1);
+    lin_bwd(c, du2, s.u1d, Y.dec_s_lin4, Gn, 512, d, du1);
+    drop(c, du1, Gn, d, SITE_DEC_CNN_MID, s.seed_dec, du1);
     RUN(pm_relu_bwd(du1, s.u1, (int64_t)Gn * d, du1, c.st));
-    lin_bwd(c, du1, s.sb, Y.dec_s_lin1, Gn, d, d, dsb);
-    lin_bwd(c, dsb, s.zr, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
+    lin_bwd(c, du1, s.sbd, Y.dec_s_lin1, Gn, d, d, dsb);
+    drop(c, dsb, Gn, d, SITE_DEC_CNN_IN, s.seed_dec, dsb);
+    lin_bwd(c, dsb, s.zr_d, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
   }
   // ---- content decoder
   float* dH = ar.f((size_t)R * d);
@@ -758,6 +825,7 @@ void backward_decoder(Ctx& c) {
                         1, pv.group_cnt + 2 + g, c.st));
     }
   }
+  drop(c, dH, N, S * d, SITE_DEC_CHORD, s.seed_dec, dH);           // backward of ContentDecoder.dropout_layer (in place)
   float* dxL = ar.f((size_t)N * d);
   const bool chord_tn = s.wf_dec_t != nullptr;
   // ... their weight gradients and the chord decoder's (nobody in this call waits for them) go to the second stream.
@@ -793,8 +861,9 @@ void backward_decoder(Ctx& c) {
   float* dcb = ar.f((size_t)Gn * d);
   RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
   Deferred df;
-  lin_bwd(c, dcb, s.zr + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d, true, &df);
+  lin_bwd(c, dcb, s.zr_d + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d, true, &df);
   branch_join(c, BR_DEC_BWD);
+  drop(c, dzr, B, 2 * d, SITE_DEC_IN, s.seed_dec, dzr);           // backward of Decoder.dropout
   float* dzd = ar.f((size_t)B * 2 * d);
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
   s.dz = ar.zf((size_t)B * d);
@@ -814,13 +883,15 @@ void backward_encoder(Ctx& c) {
   const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
   float* dzg = ar.zf((size_t)B * d); float* dzg2 = ar.zf((size_t)B * d);
   Deferred df;
-  lin_bwd(c, s.dmu, s.zg, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
-  lin_bwd(c, s.dlv, s.zg, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
+  lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
+  lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
   RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
+  drop(c, dzg, B, d, SITE_ENC_MERGE_OUT, s.seed_enc, dzg);
   float* dm = ar.f((size_t)B * d);
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
   float* dzcat = ar.zf((size_t)B * 2 * d);
-  lin_bwd(c, dm, s.zcat, Y.enc_merge, B, d, 2 * d, dzcat, 0, 0, 0, true, &df);
+  lin_bwd(c, dm, s.zcat_d, Y.enc_merge, B, d, 2 * d, dzcat, 0, 0, 0, true, &df);
+  drop(c, dzcat, B, 2 * d, SITE_ENC_MERGE_IN, s.seed_enc, dzcat);
   // ---- structure branch (z_s = zcat[:, d:]): on the second stream, under the whole content-encoder backward; joined at
   // the end of backward_encoder_tail
   {
@@ -829,14 +900,18 @@ void backward_encoder(Ctx& c) {
     float* dc1 = ar.f((size_t)Gn * 512); float* dp0 = ar.f((size_t)Gn * 8 * 32); float* da0 = ar.f((size_t)Gn * 8 * 128);
     float* dc0 = ar.f((size_t)Gn * 8 * 128);
     lin_bwd(c, dzcat + d, s.h2, Y.enc_s_bars, B, d, nb * d, dh2, 2 * d, nb * d, nb * d);
-    lin_bwd(c, dh2, s.h1, Y.enc_lin4, Gn, d, d, dh1);
+    lin_bwd(c, dh2, s.h1d, Y.enc_lin4, Gn, d, d, dh1);
+    drop(c, dh1, Gn, d, SITE_ENC_CNN_MID, s.seed_enc, dh1);
     RUN(pm_relu_bwd(dh1, s.h1, (int64_t)Gn * d, dh1, c.st));
-    lin_bwd(c, dh1, s.a1, Y.enc_lin1, Gn, d, 512, da1);
-    bn_bwd(c, s.c1, da1, Gn, 16, 32, Y.enc_bn5, s.m1, s.v1, true, dc1);
+    lin_bwd(c, dh1, s.a1d, Y.enc_lin1, Gn, d, 512, da1);
+    drop(c, da1, Gn, 512, SITE_ENC_CNN_IN, s.seed_enc, da1);
+    if (c.bn) bn_bwd(c, s.c1, da1, Gn, 16, 32, Y.enc_bn5, s.m1, s.v1, true, dc1);
+    else RUN(pm_relu_bwd(da1, s.c1, (int64_t)Gn * 512, dc1, c.st));
     RUN(pm_conv3x3_bwd_weight(s.p0, dc1, Gn, 8, 16, 4, 8, 0, c.G + Y.enc_conv4.w, c.G + Y.enc_conv4.b, c.st));
     RUN(pm_conv3x3_bwd_data(dc1, c.P + Y.enc_conv4.w, Gn, 8, 16, 4, 8, 0, dp0, c.st));
     RUN(pm_maxpool4_bwd(s.a0, dp0, (int64_t)Gn * 8 * 32, da0, c.st));
-    bn_bwd(c, s.c0, da0, Gn, 8, 128, Y.enc_bn1, s.m0, s.v0, true, dc0);
+    if (c.bn) bn_bwd(c, s.c0, da0, Gn, 8, 128, Y.enc_bn1, s.m0, s.v0, true, dc0);
+    else RUN(pm_relu_bwd(da0, s.c0, (int64_t)Gn * 8 * 128, dc0, c.st));
     RUN(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
   }
   // ---- content branch (z_c = zcat[:, :d])
@@ -848,11 +923,18 @@ void backward_encoder(Ctx& c) {
   }
   float* dxL = ar.f((size_t)N * d);
   float* pscr = ar.f((size_t)3 * N + 8);
+  const bool dropping = c.pdrop > 0.f;
+  float* dxg = dropping ? ar.f((size_t)N * d) : nullptr;       // gradient of the gate network's (dropped) input, model.py:160
   RUN(pm_attnpool_bwd(s.eg.x[c.L], s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, s.alpha, dpooled, c.P + Y.enc_gate.w,
                         s.plan, N, c.E, Gn, d, dxL, c.G + Y.enc_gate.w, c.G + Y.enc_gate.b, c.G + Y.enc_gate_bn.w,
-                        c.G + Y.enc_gate_bn.b, pscr, nullptr, nullptr, c.st));
+                        c.G + Y.enc_gate_bn.b, pscr, dropping ? s.xLg : nullptr, dxg, c.st));
+  if (dropping) {                                              // pooled path + masked gate path
+    drop(c, dxg, N, d, SITE_ENC_GATE, s.seed_enc, dxg);
+    RUN(pm_add(dxL, dxg, (int64_t)N * d, dxL, c.st));
+  }
   branch_join(c, BR_DEC_WGRAD);                       // the decoder's weight gradients, if still open (single device)
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
+  drop(c, dx0, N, d, SITE_ENC_CHORD, s.seed_enc, dx0);         // backward of ContentEncoder.dropout_layer
   RUN(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
   branch_join(c, BR_ENC_HEAD_WGRAD);                  // (the graph encoder .. encoder head bucket is exchanged next)
   s.bk_dx0 = dx0; s.bk_dzcat = dzcat;

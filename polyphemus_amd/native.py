@@ -56,7 +56,7 @@ _KIND = {"lin": PmLin, "bn": PmBn, "gcn": PmGcn}
 
 class PmVaeLayout(C.Structure):
     _fields_ = ([("d", C.c_int32), ("n_bars", C.c_int32), ("n_layers", C.c_int32), ("flags", C.c_int32)] +
-                [(f, _KIND[k]) for f, k, _ in _LAYOUT])
+                [(f, _KIND[k]) for f, k, _ in _LAYOUT] + [("dropout", C.c_float), ("reserved", C.c_int32)])
 
 
 class PmBatch(C.Structure):
@@ -73,11 +73,23 @@ def build_layout(vae) -> PmVaeLayout:
         raise ValueError(f"native step supports at most {PM_MAX_LAYERS} GNN layers")
     lay = PmVaeLayout()
     lay.d, lay.n_bars, lay.n_layers = cfg["d"], cfg["n_bars"], cfg["gnn_n_layers"]
+    has_bn = bool(cfg["batch_norm"])
+    lay.flags = 0 if has_bn else 1
+    lay.dropout = float(cfg["dropout"] or 0.0)
+    # batch_norm = False: the norm layers of the GCN stacks and of the CNNs do not exist and the nn.Sequential indices of the
+    # layers behind them shift (model.py:218-238,278-292)
+    shift = {} if has_bn else {"encoder.s_encoder.cnn_encoder.conv.4": "encoder.s_encoder.cnn_encoder.conv.3",
+                               "decoder.s_decoder.cnn_decoder.conv.4": "decoder.s_decoder.cnn_decoder.conv.3"}
+    optional = ("encoder.s_encoder.cnn_encoder.conv.1", "encoder.s_encoder.cnn_encoder.conv.5",
+                "decoder.s_decoder.cnn_decoder.conv.2")
 
     def bn(path):
+        if not has_bn and (path in optional or ".norm_layers." in path):
+            return PmBn(0, 0, 0, 0)
         return PmBn(po[path + ".weight"], po[path + ".bias"], bo[path + ".running_mean"], bo[path + ".running_var"])
 
     for field, kind, path in _LAYOUT:
+        path = shift.get(path, path)
         if kind == "lin":
             setattr(lay, field, PmLin(po[path + ".weight"], po[path + ".bias"]))
         elif kind == "bn":

@@ -68,9 +68,9 @@ class HipTrainer:
         # True: the native step also stores the content logits (`step_outputs`); off by default — the fused un-embedding +
         # cross-entropy then writes d(loss)/d(logits) only
         self.keep_logits = False
-        # the C++ step covers the configuration of training.json (batch_norm = True, dropout = 0: what bench.py measures);
-        # the two non-default constructor switches of the model (model.py:176,188,218,278) run the same kernels through
-        # the Python orchestration (engine.py)
+        # the C++ step covers every constructor switch of the model (batch_norm = False: model.py:176-188,218-238,278-292;
+        # cfg.dropout: the element dropout layers of model.py:160,199,244-247,267-270,389-390,473,479,558-559,640);
+        # `native=False` selects the Python orchestration of the same kernels (engine.py), kept for cross-checking
         self.sync_bn = bool(sync_bn)
         import torch.distributed as _dist
         _world = _dist.get_world_size(process_group) if (_dist.is_available() and _dist.is_initialized()) else 1
@@ -79,7 +79,7 @@ class HipTrainer:
         # batch.  Runs through the Python orchestration (one small all-reduce per norm and direction, one host read per
         # step); an option for parity checks, not for throughput runs.  With ONE rank the statistics are global anyway:
         # the native step stays on.
-        self.native = bool(native and vae.cfg["batch_norm"] and not vae.cfg["dropout"] and not (self.sync_bn and _world > 1))
+        self.native = bool(native and not (self.sync_bn and _world > 1))
         if iters_to_accumulate < 1:
             raise ValueError("iters_to_accumulate must be >= 1")
         self.iters_to_accumulate = int(iters_to_accumulate)            # training.py:83,149,158

@@ -259,12 +259,40 @@ def test_constructor_switches_dropout_and_batch_norm_match_oracle(batch_norm, p_
     for k in sd2:
         if "running_" in k:
             assert rel_err(sd2[k], P[k]) < REL_TOL, k
-    # the fused trainer takes the same configuration through the Python orchestration of the same kernels
+    # ---- the fused trainer: the NATIVE step (csrc/vae_step.hip) covers both switches; one training step from the same
+    # weights against the oracle's training step (same dropout masks replayed), and against the Python orchestration
     from polyphemus_amd.trainer import HipTrainer
-    tr = HipTrainer(vae, lr=1e-4)
-    assert not tr.native
-    out = tr.losses_dict(tr.train_step(g, eps.to(DEV)))
-    assert all(v == v for v in out.values())
+    steps = {}
+    for native in (True, False):
+        vae2 = VAE(**cfg, device=DEV).to(DEV)
+        vae2.load_state_dict(sd)
+        vae2.train()
+        tr = HipTrainer(vae2, lr=1e-4, native=native)
+        assert tr.native == native
+        seeds2 = {"enc": vae2._next_seed(), "dec": vae2._next_seed()}
+        vae2._step -= 2
+        out = tr.losses_dict(tr.train_step(g, eps.to(DEV)))
+        steps[native] = (out, {n: tr._G[n].detach().cpu().clone() for n in names}, seeds2)
+    assert steps[True][2] == steps[False][2]
+    seeds = steps[True][2]                                       # (keep / elem_keep read `seeds`)
+    P2, _ = vae_cpu.split_state({k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}, names)
+    opt = torch.optim.SGD([P2[n] for n in names], lr=0.0)
+    vae_cpu.ELEM_KEEP = elem_keep
+    try:
+        _, parts, g64 = vae_cpu.train_step(_as_dtype(cpu, torch.float64), P2, names, cfg, opt, eps.double(), msg_dropout=0.1,
+                                           keep_mask=keep)
+    finally:
+        vae_cpu.ELEM_KEEP = None
+    gmax = max(float(v.abs().max()) for v in g64.values() if v is not None)
+    for native in (True, False):
+        out, grads, _ = steps[native]
+        for k in ("pitch", "dur", "structure", "kld"):
+            assert abs(out[k] - float(parts[k])) <= 1e-5 * max(1.0, abs(float(parts[k]))), (native, k)
+        for n in names:
+            if g64[n] is None:
+                assert float(grads[n].abs().max()) == 0.0, (native, n)
+            else:
+                assert _grad_err(grads[n], g64[n], gmax) < REL_TOL, (native, n)
 
 
 def test_element_dropout_kernel_keep_rate_and_scale():

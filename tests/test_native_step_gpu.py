@@ -509,3 +509,35 @@ def test_loss_trajectory_follows_the_fp64_oracle():
     # (while the trajectories have not separated, the KLDs agree in order of magnitude at every step)
     for i in range(6):
         assert 0.2 < hip[i]["kld"] / ora[i]["kld"] < 5.0, (i, hip[i]["kld"], ora[i]["kld"])
+
+
+@pytest.mark.parametrize("d,batch_norm,p_cfg", [(128, True, 0.2), (128, False, 0.0), (256, False, 0.25), (64, False, 0.1)])
+def test_native_step_covers_the_constructor_switches(d, batch_norm, p_cfg):
+    """`batch_norm=False` (model.py:176-188,218-238,278-292) and `dropout != 0` (the element dropout layers) through the
+    C++ step — with the kernels of gcl.hip / linear.hip at d = 128 / 256 — against the Python orchestration of the same
+    configuration (which tests/test_model_gpu.py pins to the oracle): same counter-hash masks, so everything agrees to
+    accumulation order."""
+    B, nb, L = 12, 2, 2
+    cfg = dict(dropout=p_cfg, batch_norm=batch_norm, gnn_n_layers=L, d=d, n_bars=nb, resolution=8)
+    batch = synthetic_batch(B, nb, p=0.25, seed=21).to(DEV)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(9)).to(DEV)
+    res = []
+    for native in (True, False):
+        torch.manual_seed(0)
+        vae = VAE(**cfg, device=DEV).to(DEV)
+        vae.train()
+        tr = HipTrainer(vae, lr=5e-6, native=native, structure_loss_on_logits=True)
+        assert tr.native == native
+        loss = tr.losses_dict(tr.train_step(batch, eps))
+        res.append((loss, tr.grads.clone(), {k: v.detach().clone() for k, v in vae.state_dict().items()}))
+    (la, ga, sa), (lb, gb, sb) = res
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(lb[k])), k
+    assert rel_err(ga, gb) < 2e-3
+    live = gb.abs() > 1e-3 * gb.abs().max()
+    assert float(((ga - gb).abs()[live] / gb.abs()[live]).median()) < 1e-4
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * max(1.0, float(sb[k].abs().max())) + 4e-5, k
+        else:
+            assert torch.equal(sa[k], sb[k]), k

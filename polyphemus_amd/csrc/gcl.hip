@@ -27,6 +27,14 @@
 #include <type_traits>
 #include "wide.h"
 #ifndef GCL_TRACE
+#ifndef GCL_PLANE_AUX
+#define GCL_PLANE_AUX 2       // cache policy of the A' plane stores (buffer instruction immediate: bit 0 sc0, bit 1 nt, bit 4 sc1):
+                              // non-temporal — the 100 MB of planes a launch writes are read again only in the backward pass;
+                              // step 4.955-4.980 against 4.980-4.998 ms (same box, two runs each; nt + sc1: 4.952-4.970)
+#endif
+#ifndef GCL_WHATIF
+#define GCL_WHATIF 0
+#endif
 #define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
 #endif
 #if GCL_TRACE
@@ -148,12 +156,19 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
       b = g.rowptr[n * PM_N_REL + rel];
       cnt = g.rowptr[n * PM_N_REL + rel + 1] - b;
     }
+#if GCL_WHATIF == 2 || GCL_WHATIF == 6                      // timing what-if (WRONG results): no in-edges at all
+    cnt = 0;
+#endif
     int w[EMAX], id[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
       w[e] = 0; id[e] = 0;
       if (e < cnt) {
+#if GCL_WHATIF == 1                                      // timing what-if (WRONG results): every gather reads the row's own node (cache-hot)
+        w[e] = n | (g.csr_dist[b + e] << 27);
+#else
         w[e] = g.csr_src[b + e] | (g.csr_dist[b + e] << 27);
+#endif
         if (DROP) id[e] = (int)pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]);   // (the edge's dropout key, once per edge)
       }
     }
@@ -170,7 +185,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   // write latency into the gather's wait.  Rows past the end of the list: out-of-range offset, the store is dropped.
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
   auto store_planes = [&](int c) {
-    if (!g.planes) return;
+    if (!g.planes || GCL_WHATIF == 5) return;                   // (5: timing what-if without the A' plane stores)
     const int blk = chunk_blk(c), half = c % NCH;
     const char* img = img0 + (c & 1) * IMG;
     const int pt = tid - NCW * 64, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
@@ -182,7 +197,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(img + p * PLANE + rr * ROWB + ((ch ^ (rr & 15)) << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? off + p * ps_b : GCL_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? off + p * ps_b : GCL_OOB, 0, GCL_PLANE_AUX);
       }
     }
   };
@@ -317,6 +332,9 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   // (the block offset is wave-uniform: it rides in the instruction's scalar offset, the lane part never changes — no
   //  vector ALU work per load; past the end the last chunk is re-read and never used)
   auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global k-step gs (16 rows of the weight)
+#if GCL_WHATIF == 3 || GCL_WHATIF == 6                          // timing what-if (WRONG results): the weight fragments are loaded once and kept
+    if (gs >= GCL_BDEPTH) return;
+#endif
     const int c = min(gs >> 3, nchunk - 1), ks = gs & 7;
     const int soff = __builtin_amdgcn_readfirstlane((((krow0(c) >> 4) + ks) * BFN + ct0) * 3072);
 #pragma unroll
@@ -354,7 +372,11 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
           for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
+#if GCL_WHATIF == 4                                              // timing what-if (WRONG results): one product of the six
+              { if (t6 == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0); }
+#else
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+#endif
         bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
         __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
       }

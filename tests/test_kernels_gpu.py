@@ -1168,3 +1168,45 @@ def test_fused_unembed_ce_matches_products_plus_loss(d, B, p):
     assert rel_err(db[0], gb[drum][..., :131].sum((0, 1))) < 1e-4
     assert rel_err(db[1], gb[~drum][..., :131].sum((0, 1))) < 1e-4
     assert rel_err(db[2], gb[..., 131:].sum((0, 1))) < 1e-4
+
+
+@pytest.mark.parametrize("cells", [1, 2, 3, 4, 5, 7, 9])
+def test_plan_build_on_tiny_graphs_stays_inside_the_plan_buffer(cells):
+    """N = 1 .. 9 nodes (one sample of one bar): pm_plan_build carves tile sums, node classes and class histograms out of the
+    plan's scratch field; round 3's layout reserved less than that for N <= 4 and the kernels wrote past the caller's
+    buffer.  The plan is built into a buffer with guard words behind it, and must match the numpy plan."""
+    import numpy as np
+    from polyphemus_amd import constants as C
+    from polyphemus_amd._lib import call, plan_layout, ptr, stream
+    from polyphemus_amd.graphs import collate_samples, graph_from_structure
+    rng = np.random.default_rng(cells)
+    s = np.zeros((1, 4, 32), bool)
+    s.reshape(-1)[rng.choice(128, size=cells, replace=False)] = True
+    g = graph_from_structure(s)
+    g["tokens"] = np.full((int(s.sum()), 16, 2), 0, np.int32)
+    g["tokens"][:, 0] = (C.PITCH_SOS, C.DUR_SOS)
+    g["tokens"][:, 1] = (60, 8)
+    g["tokens"][:, 2] = (C.PITCH_EOS, C.DUR_EOS)
+    g["tokens"][:, 3:] = (C.PITCH_PAD, C.DUR_PAD)
+    g["s_tensor"] = s.astype(np.float32)
+    cpu = collate_samples([g], 1)
+    b = cpu.to(DEV)
+    N, E, G = cpu.num_nodes, cpu.edge_index.shape[1], 1
+    assert N == cells
+    off = plan_layout(N, E, G)
+    GUARD = 256
+    buf = torch.full((off[-1] + GUARD,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    drum = b.is_drum.view(torch.uint8) if b.is_drum.dtype == torch.bool else b.is_drum
+    call("pm_plan_build", ptr(b.edge_index), ptr(b.edge_type.to(torch.int32)), ptr(b.edge_dist.to(torch.int32)), ptr(b.bars),
+         ptr(b.batch), ptr(drum), ptr(b.tokens.to(torch.int32).contiguous()), 1, 15, N, E, G, ptr(buf), stream())
+    torch.cuda.synchronize()
+    assert bool((buf[off[-1]:] == 0x5A5A5A5A).all()), "pm_plan_build wrote past the end of the plan buffer"
+    src, dst = cpu.edge_index[0].numpy(), cpu.edge_index[1].numpy()
+    et = cpu.edge_type.numpy()
+    rowptr = np.zeros(N * 6 + 1, np.int64)
+    np.add.at(rowptr, dst * 6 + et + 1, 1)
+    np.testing.assert_array_equal(buf[off[0]:off[0] + N * 6 + 1].cpu().numpy(), np.cumsum(rowptr))
+    colptr = np.zeros(N + 1, np.int64)
+    np.add.at(colptr, src + 1, 1)
+    j = 4                                                     # PM_PLAN_COLPTR
+    np.testing.assert_array_equal(buf[off[j]:off[j] + N + 1].cpu().numpy(), np.cumsum(colptr))

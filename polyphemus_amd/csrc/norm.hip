@@ -284,22 +284,23 @@ extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, 
 
 // ---------------------------------------------------------------- small batches: one launch per norm and direction
 // The norms of the heads run over B = 256 rows (model.py:475,638): three launches of ~5 us each (column sums, finalize,
-// apply) for 0.25-0.5 MB of data.  Here a workgroup owns 32 columns for all rows: 8 row groups x 32 lanes, fp64 column
-// sums through LDS, then the second pass over its slab (L2-resident).  Same formulas and fp64 sums as the general path.
-__global__ void __launch_bounds__(256) k_bn_small_fwd(const float* __restrict__ x, int O, int C, BnCtx ctx,
+// apply) for 0.25-0.5 MB of data.  Here a workgroup owns 32 columns for all rows: RG row groups x 32 lanes (RG = 32 from 128
+// rows on: a thread's chain of dependent-issue row loads is then 8 long at B = 256 instead of 32 — these launches sit on the
+// critical chain between the two GCN stacks), fp64 column sums through LDS in a fixed order, then the second pass over its
+// slab (L2-resident).  Same formulas and fp64 sums as the general path.
+__global__ void __launch_bounds__(1024) k_bn_small_fwd(const float* __restrict__ x, int O, int C, BnCtx ctx,
                                                       const float* __restrict__ res, float* __restrict__ y, float* mean,
                                                       float* var, float* rmean, float* rvar, float momentum) {
-  __shared__ double sh[2][8][32];
-  const int l = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + l;
+  __shared__ double sh[2][32][32];
+  const int l = threadIdx.x & 31, rg = threadIdx.x >> 5, RG = blockDim.x >> 5, c = blockIdx.x * 32 + l;
   const bool ok = c < C;
   double s = 0, q = 0;
   if (ok)
-    for (int r = rg; r < O; r += 8) { const double v = (double)x[(int64_t)r * C + c]; s += v; q += v * v; }
+    for (int r = rg; r < O; r += RG) { const double v = (double)x[(int64_t)r * C + c]; s += v; q += v * v; }
   sh[0][rg][l] = s; sh[1][rg][l] = q;
   __syncthreads();
   s = 0; q = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { s += sh[0][k][l]; q += sh[1][k][l]; }
+  for (int k = 0; k < RG; ++k) { s += sh[0][k][l]; q += sh[1][k][l]; }
   if (!ok) return;
   const double count = (double)O, mu = s / count;
   double v = q / count - mu * mu;
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(256) k_bn_small_fwd(const float* __restrict__ 
     }
   }
   const float rstd = rsqrtf(vf + ctx.eps), ga = ctx.gamma[c], be = ctx.beta[c];
-  for (int r = rg; r < O; r += 8) {
+  for (int r = rg; r < O; r += RG) {
     const int64_t i = (int64_t)r * C + c;
     float o = (x[i] - m) * rstd * ga + be;
     if (ctx.relu) o = fmaxf(o, 0.f);
@@ -322,25 +323,24 @@ __global__ void __launch_bounds__(256) k_bn_small_fwd(const float* __restrict__ 
     y[i] = o;
   }
 }
-__global__ void __launch_bounds__(256) k_bn_small_bwd(const float* __restrict__ x, const float* __restrict__ dy, int O, int C,
+__global__ void __launch_bounds__(1024) k_bn_small_bwd(const float* __restrict__ x, const float* __restrict__ dy, int O, int C,
                                                       BnCtx ctx, float* dgamma, float* dbeta, float* dbias_pre,
                                                       float* __restrict__ dx) {
-  __shared__ double sh[3][8][32];
-  const int l = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + l;
+  __shared__ double sh[3][32][32];
+  const int l = threadIdx.x & 31, rg = threadIdx.x >> 5, RG = blockDim.x >> 5, c = blockIdx.x * 32 + l;
   const bool ok = c < C;
   const float m = ok ? ctx.mean[c] : 0.f, rstd = ok ? rsqrtf(ctx.var[c] + ctx.eps) : 1.f;
   const float ga = ok ? ctx.gamma[c] : 1.f, be = ok ? ctx.beta[c] : 0.f;
   double a = 0, b = 0, cc = 0;
   if (ok)
-    for (int r = rg; r < O; r += 8) {
+    for (int r = rg; r < O; r += RG) {
       const int64_t i = (int64_t)r * C + c;
       bn_acc<1>(x[i], dy[i], m, rstd, ga, be, ctx.relu, a, b, cc);
     }
   sh[0][rg][l] = a; sh[1][rg][l] = b; sh[2][rg][l] = cc;
   __syncthreads();
   double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { s0 += sh[0][k][l]; s1 += sh[1][k][l]; s2 += sh[2][k][l]; }
+  for (int k = 0; k < RG; ++k) { s0 += sh[0][k][l]; s1 += sh[1][k][l]; s2 += sh[2][k][l]; }
   if (!ok) return;
   const double count = (double)O, m0 = s0 / count, m1 = s1 / count;
   if (rg == 0) {
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) k_bn_small_bwd(const float* __restrict__ 
       dbias_pre[c] += (float)((double)ga * rs * ((s0 - count * m0) - m1 * s2));
     }
   }
-  for (int r = rg; r < O; r += 8) {
+  for (int r = rg; r < O; r += RG) {
     const int64_t i = (int64_t)r * C + c;
     const float xh = (x[i] - m) * rstd;
     float du = dy[i];
@@ -364,7 +364,7 @@ extern "C" int pm_bn_small_fwd(const float* x, int32_t O, int32_t C, float eps, 
                                float* running_var, float momentum, pm_stream_t stream) {
   if (!x || !gamma || !beta || !y || !mean || !var || O <= 0 || O > PM_BN_SMALL_MAX_ROWS || C <= 0) return PM_E_INVALID;
   BnCtx ctx = {nullptr, nullptr, gamma, beta, eps, relu};
-  hipLaunchKernelGGL(k_bn_small_fwd, dim3(pm_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, x, O, C, ctx, residual, y,
+  hipLaunchKernelGGL(k_bn_small_fwd, dim3(pm_cdiv(C, 32)), dim3(O >= 128 ? 1024 : 256), 0, (hipStream_t)stream, x, O, C, ctx, residual, y,
                      mean, var, running_mean, running_var, momentum);
   return pm_check_launch();
 }
@@ -373,7 +373,7 @@ extern "C" int pm_bn_small_bwd(const float* x, const float* dy, int32_t O, int32
                                float* dbias_pre, float* dx, pm_stream_t stream) {
   if (!x || !dy || !mean || !var || !gamma || !beta || !dx || O <= 0 || O > PM_BN_SMALL_MAX_ROWS || C <= 0) return PM_E_INVALID;
   BnCtx ctx = {mean, var, gamma, beta, eps, relu};
-  hipLaunchKernelGGL(k_bn_small_bwd, dim3(pm_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, x, dy, O, C, ctx, dgamma,
+  hipLaunchKernelGGL(k_bn_small_bwd, dim3(pm_cdiv(C, 32)), dim3(O >= 128 ? 1024 : 256), 0, (hipStream_t)stream, x, dy, O, C, ctx, dgamma,
                      dbeta, dbias_pre, dx);
   return pm_check_launch();
 }

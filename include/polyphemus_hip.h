@@ -718,6 +718,11 @@ int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
  * are joined inside pm_vae_step_backward_encoder; a caller that hands the decoder's gradient bucket to an all-reduce
  * between the two calls makes `stream` wait for them with this call first (no-op when nothing is open). */
 int pm_vae_step_join_decoder_grads(void* state, pm_stream_t stream);
+/* The head chain of the encoder backward as a call of its own (optional: pm_vae_step_backward_encoder runs it when it has
+ * not been called).  It returns with `stream` waiting for the decoder's weight gradients WITHOUT a stall (they have ~0.5 ms
+ * of head chain beside them): a data-parallel caller launches the decoder's gradient bucket behind it, in front of the
+ * encoder's GCN stack. */
+int pm_vae_step_backward_encoder_heads(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder(void* state, pm_stream_t stream);
 int pm_vae_step_backward_encoder_tail(void* state, pm_stream_t stream);
 

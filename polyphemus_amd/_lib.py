@@ -117,6 +117,7 @@ _SIGS = {
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",
     "pm_vae_step_join_decoder_grads": "ps",
+    "pm_vae_step_backward_encoder_heads": "ps",
     "pm_vae_step_reload_switches": "",
     "pm_relu_bwd_planes": "pplppls",
     "pm_set_deterministic": "i",

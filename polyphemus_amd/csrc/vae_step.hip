@@ -126,6 +126,7 @@ struct StepState {
   const float *a1d, *h1d, *x0d, *xLg, *zcat_d, *zg_d, *zr_d, *sbd, *u1d, *H_d;
   uint32_t seed_enc, seed_dec;
   float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
+  float *bk_dxL;                          // carried from pm_vae_step_backward_encoder_heads to pm_vae_step_backward_encoder
   int rc;
   unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
 };
@@ -876,7 +877,11 @@ void backward_decoder(Ctx& c) {
   if (!late_wgrads) branch_join(c, BR_DEC_WGRAD);     // (late: joined by pm_vae_step_join_decoder_grads / the encoder backward)
 }
 
-void backward_encoder(Ctx& c) {
+// First part of the encoder backward: the head chain (mu / log_var heads, merge layer, bars encoder, attention pooling) and the
+// fork of the structure branch.  It ends with the caller's stream waiting for the decoder's weight gradients (second stream,
+// beside this chain): a data-parallel caller hands the decoder's gradient bucket to the all-reduce right behind this call
+// (pm_vae_step_backward_encoder_heads), with the whole GCN stack of the encoder still ahead to overlap it.
+void backward_encoder_heads(Ctx& c) {
   StepState& s = *c.s;
   Arena& ar = s.ar;
   const PmVaeLayout& Y = s.lay;
@@ -932,7 +937,17 @@ void backward_encoder(Ctx& c) {
     drop(c, dxg, N, d, SITE_ENC_GATE, s.seed_enc, dxg);
     RUN(pm_add(dxL, dxg, (int64_t)N * d, dxL, c.st));
   }
-  branch_join(c, BR_DEC_WGRAD);                       // the decoder's weight gradients, if still open (single device)
+  branch_join(c, BR_DEC_WGRAD);                       // the decoder's weight gradients (issued beside the head chains)
+  s.bk_dxL = dxL; s.bk_dzcat = dzcat;
+}
+void backward_encoder(Ctx& c) {
+  StepState& s = *c.s;
+  const PmVaeLayout& Y = s.lay;
+  const int N = c.N, d = c.d;
+  if (!s.bk_dxL) backward_encoder_heads(c);
+  float* dxL = s.bk_dxL;
+  float* dzcat = s.bk_dzcat;
+  s.bk_dxL = nullptr;
   float* dx0 = gcn_backward(c, dxL, Y.enc_gcn, s.eg);
   drop(c, dx0, N, d, SITE_ENC_CHORD, s.seed_enc, dx0);         // backward of ContentEncoder.dropout_layer
   RUN(pm_relu_bwd(dx0, s.x0, (int64_t)N * d, dx0, c.st));
@@ -1126,6 +1141,15 @@ extern "C" int pm_vae_step_join_decoder_grads(void* state, pm_stream_t stream) {
   if (!s || s->magic != kMagic || s->rc != PM_OK) return PM_E_INVALID;
   Ctx c = make_ctx(s, (hipStream_t)stream);
   branch_join(c, BR_DEC_WGRAD);
+  s->rc = c.rc;
+  return c.rc;
+}
+extern "C" int pm_vae_step_backward_encoder_heads(void* state, pm_stream_t stream) {
+  StepState* s = (StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK || s->bk_dxL) return PM_E_INVALID;
+  Ctx c = make_ctx(s, (hipStream_t)stream);
+  backward_encoder_heads(c);
+  if (s->ar.overflow) return PM_E_INVALID;
   s->rc = c.rc;
   return c.rc;
 }

@@ -219,8 +219,10 @@ class HipTrainer:
                 raise RuntimeError(f"{bad} nodes receive track edges of more than one track but the batch was "
                                    "flagged track_unique (graphs.batch_flags); the compact GCL would be wrong")
         call("pm_vae_step_backward_decoder", state, st)
-        if self.buckets.active and not self.buckets.hold:    # the bucket is exchanged now: its last gradients (second stream) first
-            call("pm_vae_step_join_decoder_grads", state, st)
+        # the decoder's last weight gradients run on the library's second stream beside the head chains; the encoder's head
+        # chain ends with the caller's stream waiting for them, so the decoder bucket goes out behind it — in front of the
+        # encoder's GCN stack, which overlaps the exchange
+        call("pm_vae_step_backward_encoder_heads", state, st)
         self.buckets.launch(2)                               # decoder gradients: overlapped with the encoder backward
         call("pm_vae_step_backward_encoder", state, st)
         self.buckets.launch(1)                               # graph encoder .. encoder head: overlapped with the tail

@@ -1210,3 +1210,27 @@ def test_plan_build_on_tiny_graphs_stays_inside_the_plan_buffer(cells):
     np.add.at(colptr, src + 1, 1)
     j = 4                                                     # PM_PLAN_COLPTR
     np.testing.assert_array_equal(buf[off[j]:off[j] + N + 1].cpu().numpy(), np.cumsum(colptr))
+
+
+def test_relu_bwd_planes_matches_torch_and_the_plane_split():
+    """pm_relu_bwd_planes (the GCL layer tail's backward of a model built with batch_norm = False, model.py:202-206):
+    dh = dy * [h > 0], bit for bit against torch, as fp32 and as the exact three-plane bf16 split of that fp32 value."""
+    from polyphemus_amd._lib import call, ptr, stream
+    torch.manual_seed(4)
+    n = 4096 * 96
+    dy = torch.randn(n, device=DEV) * torch.logspace(-12, 12, n, device=DEV)
+    h = torch.randn(n, device=DEV)
+    h[::7] = 0.0                                                  # relu'(0) = 0
+    want = torch.where(h > 0, dy, torch.zeros_like(dy))
+    dh = torch.full_like(dy, float("nan"))
+    planes = torch.zeros(3, n, dtype=torch.int16, device=DEV)
+    call("pm_relu_bwd_planes", ptr(dy), ptr(h), n, ptr(dh), ptr(planes), n, stream())
+    assert torch.equal(dh, want)
+    f = lambda t: (t.to(torch.int32) << 16).view(torch.float32).double()
+    assert torch.equal((f(planes[0]) + f(planes[1]) + f(planes[2])).float(), want)
+    assert torch.equal(planes, ops.split_planes(want))
+    only = torch.zeros(3, n, dtype=torch.int16, device=DEV)      # planes only / fp32 only
+    call("pm_relu_bwd_planes", ptr(dy), ptr(h), n, None, ptr(only), n, stream())
+    assert torch.equal(only, planes)
+    with pytest.raises(Exception):
+        call("pm_relu_bwd_planes", ptr(dy), ptr(h), n - 1, ptr(dh), None, 0, stream())      # n % 4 != 0

@@ -645,6 +645,37 @@ int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_
  * `state` is a caller-owned HOST blob of pm_vae_step_state_bytes() that carries the saved-activation
  * pointers between the calls.  Training mode only (batch statistics, running stats updated). */
 #define PM_MAX_LAYERS 16
+/* ------------------------------------------------------------------ head chains (csrc/heads.hip)
+ * The layers between the two GCN stacks — Encoder.forward's merge / mu / log_var layers (model.py:472-481), the
+ * reparametrisation (model.py:671-673), Decoder.forward's first layers (model.py:637-641), the bars encoders / decoders
+ * (model.py:411-415,546-549) and their autograd — as ONE persistent launch per chain instead of ~14: a chain is a list of
+ * stages run by one resident grid (PM_HEAD_GRID workgroups), separated by grid barriers on `bar` (a zeroed device counter).
+ * Stage: acc[B, N] = init + in[B, K] @ A (+ in2[B, K2] @ A2) + bias, with A = W (w_kmajor: W[k * ldw + n]) or W^T
+ * (W[n * ldw + k], a Linear's forward); `dual`: the second product is a second accumulator (+ bias2).  Epilogues:
+ *   PM_HE_NONE         out = acc
+ *   PM_HE_BN_FWD       training-mode BatchNorm1d over the B rows (+ ReLU): out2 = acc (kept for the backward), out =
+ *                      [relu](gamma * (acc - mean) * rstd + beta); mean / var saved, running statistics updated
+ *   PM_HE_BN_BWD       its backward with acc = d(out): dgamma += , dbeta += , out = d(input)  (xpre = the saved out2)
+ *   PM_HE_REPARAM_FWD  (dual) out2 = mu = acc, out3 = log_var = acc2, out = exp(0.5 log_var) * noise + mu
+ *   PM_HE_REPARAM_BWD  dmu += acc, dlv += acc * noise * 0.5 * exp(0.5 lv); out = acc (optional)
+ * fp32 FMAs in k order, fp64 column statistics in a fixed order: deterministic.  B <= 2048; K, K2, N, leading dimensions
+ * multiples of 4, operands 16-byte aligned. */
+enum { PM_HE_NONE = 0, PM_HE_BN_FWD, PM_HE_REPARAM_FWD, PM_HE_BN_BWD, PM_HE_REPARAM_BWD };
+enum { PM_HEAD_MAX_STAGES = 6, PM_HEAD_GRID = 64 };
+typedef struct PmHeadStage {
+  const float* in; const float* W; const float* bias; const float* in2; const float* W2; const float* bias2;
+  const float* init;
+  float* out; float* out2; float* out3;
+  const float* gamma; const float* beta; float* mean; float* var; float* rmean; float* rvar;
+  const float* xpre; float* dgamma; float* dbeta;
+  const float* noise; const float* lv; float* dmu; float* dlv;
+  int32_t ld_in, ldw, ld_in2, ldw2, K, K2, N, w_kmajor, dual, ld_init, ld_out, ld_out2, ld_out3, epi, relu, ld_xpre,
+      ld_noise, ld_lv, ld_d, barrier_after;
+  float eps, momentum;
+} PmHeadStage;
+typedef struct PmHeadChain { PmHeadStage st[PM_HEAD_MAX_STAGES]; int32_t n, B; unsigned* bar; } PmHeadChain;
+int pm_head_chain(const PmHeadChain* chain, pm_stream_t stream);
+
 typedef struct PmLin { int64_t w, b; } PmLin;              /* offsets into params (and grads)            */
 typedef struct PmBn { int64_t w, b, rm, rv; } PmBn;        /* w,b: params; rm,rv: running stats in buffers */
 typedef struct PmGcn {

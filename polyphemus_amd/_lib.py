@@ -120,6 +120,7 @@ _SIGS = {
     "pm_vae_step_backward_encoder_heads": "ps",
     "pm_vae_step_reload_switches": "",
     "pm_relu_bwd_planes": "pplppls",
+    "pm_head_chain": "ps",
     "pm_set_deterministic": "i",
     "pm_get_deterministic": "",
 }

@@ -35,6 +35,7 @@ struct StepCfg {
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int side_delay_us;           // PM_SIDE_DELAY_US (tests): every branch starts with a kernel that spins this long on the second stream,
                                // so a missing join shows as a wrong result instead of passing by luck of timing
+  bool fused_heads;            // PM_FUSED_HEADS=0: the head chains as ~14 launches each instead of one persistent launch (heads.hip)
   bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
@@ -55,6 +56,7 @@ static StepCfg read_cfg() {
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
   k.late_wgrads = flag("PM_LATE_WGRADS", true);
   k.dw_side = flag("PM_DW_SIDE", false);
+  k.fused_heads = flag("PM_FUSED_HEADS", true);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
@@ -126,6 +128,7 @@ struct StepState {
   const float *a1d, *h1d, *x0d, *xLg, *zcat_d, *zg_d, *zr_d, *sbd, *u1d, *H_d;
   uint32_t seed_enc, seed_dec;
   float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
+  unsigned *bar_fwd, *bar_dec, *bar_enc;  // grid-barrier counters of the three head-chain launches (zero region)
   float *bk_dxL;                          // carried from pm_vae_step_backward_encoder_heads to pm_vae_step_backward_encoder
   int rc;
   unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
@@ -262,6 +265,22 @@ void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, 
   else RUN(pm_gemm_f32_desc(&w, c.st));
   if (dx) RUN(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
                             c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
+}
+// ---- head chains as one persistent launch each (csrc/heads.hip); not with cfg.dropout (its layers sit between the stages)
+static bool heads_fused(const Ctx& c) { return cfg().fused_heads && !(c.pdrop > 0.f) && c.B <= 2048 && (c.d % 4) == 0; }
+static PmHeadStage head_stage(const float* in, int ld_in, int K, const float* W, int ldw, int kmajor, const float* bias, float* out,
+                              int ld_out, int N, int barrier_after) {
+  PmHeadStage s;
+  memset(&s, 0, sizeof(s));
+  s.in = in; s.ld_in = ld_in; s.K = K; s.W = W; s.ldw = ldw; s.w_kmajor = kmajor; s.bias = bias; s.out = out; s.ld_out = ld_out;
+  s.N = N; s.barrier_after = barrier_after; s.epi = PM_HE_NONE; s.eps = 1e-5f; s.momentum = 0.1f;
+  return s;
+}
+static void head_bn(Ctx& c, PmHeadStage& s, int epi, PmBn bn, int col0, float* mean, float* var, bool running) {
+  s.epi = epi; s.relu = 1;
+  s.gamma = c.P + bn.w + col0; s.beta = c.P + bn.b + col0; s.mean = mean + col0; s.var = var + col0;
+  if (epi == PM_HE_BN_FWD && running) { s.rmean = c.Bf + bn.rm + col0; s.rvar = c.Bf + bn.rv + col0; }
+  if (epi == PM_HE_BN_BWD) { s.dgamma = c.G + bn.w + col0; s.dbeta = c.G + bn.b + col0; }
 }
 // training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
 void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
@@ -691,21 +710,12 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, c.bn_scratch, c.st));
     RUN(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
                           s.alpha, s.pooled, c.st));
-    lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);            // z_c = zcat[:, :d]
+    if (!heads_fused(c)) lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);   // z_c = zcat[:, :d]
   }
   // ---------------- merge + heads (model.py:472-481), reparametrisation (model.py:671-673)
   s.m = ar.zf((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
   s.mu = ar.zf((size_t)B * d); s.lv = ar.zf((size_t)B * d); s.z = ar.f((size_t)B * d);
-  if (run) {
-    branch_join(c, BR_ENC_FWD);
-    s.zcat_d = drop(c, s.zcat, B, 2 * d, SITE_ENC_MERGE_IN, seed_enc, zcatd_buf);            // Encoder.dropout_layer, model.py:473
-    lin(c, s.zcat_d, Y.enc_merge, B, d, 2 * d, s.m, false);
-    bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
-    s.zg_d = drop(c, s.zg, B, d, SITE_ENC_MERGE_OUT, seed_enc, zgd_buf);                     // model.py:479
-    lin(c, s.zg_d, Y.enc_mu, B, d, d, s.mu, false);
-    lin(c, s.zg_d, Y.enc_lv, B, d, d, s.lv, false);
-    RUN(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
-  }
+  s.bar_fwd = (unsigned*)ar.z(64); s.bar_dec = (unsigned*)ar.z(64); s.bar_enc = (unsigned*)ar.z(64);
   // ---------------- decoder (model.py:634-655)
   s.zd = ar.zf((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
   s.sb = ar.zf((size_t)Gn * d); s.u1 = ar.f((size_t)Gn * d); s.u2 = ar.f((size_t)Gn * 512);
@@ -715,7 +725,37 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   float* const zrd_buf = dropping ? ar.f((size_t)B * 2 * d) : nullptr;
   float* const sbd_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
   float* const u1d_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
-  if (run) {
+  if (run && heads_fused(c)) {
+    // the whole chain pooled -> z_c | merge -> BatchNorm -> mu, log_var -> z -> decoder's first layer -> BatchNorm -> bars decoder
+    // as ONE persistent launch of five stages (csrc/heads.hip)
+    branch_join(c, BR_ENC_FWD);                        // z_s = zcat[:, d:] comes from the structure encoder (second stream)
+    PmHeadChain ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.B = B; ch.bar = s.bar_fwd; ch.n = 5;
+    ch.st[0] = head_stage(s.pooled, nb * d, nb * d, c.P + Y.enc_c_bars.w, nb * d, 0, c.P + Y.enc_c_bars.b, s.zcat, 2 * d, d, 1);
+    ch.st[1] = head_stage(s.zcat, 2 * d, 2 * d, c.P + Y.enc_merge.w, 2 * d, 0, c.P + Y.enc_merge.b, s.zg, d, d, 1);
+    head_bn(c, ch.st[1], PM_HE_BN_FWD, Y.enc_bn_merge, 0, s.mm, s.mv, true);
+    ch.st[1].out2 = s.m; ch.st[1].ld_out2 = d;
+    ch.st[2] = head_stage(s.zg, d, d, c.P + Y.enc_mu.w, d, 0, c.P + Y.enc_mu.b, s.z, d, d, 1);
+    ch.st[2].in2 = s.zg; ch.st[2].ld_in2 = d; ch.st[2].K2 = d; ch.st[2].W2 = c.P + Y.enc_lv.w; ch.st[2].ldw2 = d;
+    ch.st[2].bias2 = c.P + Y.enc_lv.b; ch.st[2].dual = 1; ch.st[2].epi = PM_HE_REPARAM_FWD; ch.st[2].noise = s.eps;
+    ch.st[2].ld_noise = d; ch.st[2].out2 = s.mu; ch.st[2].ld_out2 = d; ch.st[2].out3 = s.lv; ch.st[2].ld_out3 = d;
+    ch.st[3] = head_stage(s.z, d, d, c.P + Y.dec_lin.w, d, 0, c.P + Y.dec_lin.b, s.zr, 2 * d, 2 * d, 1);
+    head_bn(c, ch.st[3], PM_HE_BN_FWD, Y.dec_bn, 0, s.dm, s.dv, true);
+    ch.st[3].out2 = s.zd; ch.st[3].ld_out2 = 2 * d;
+    ch.st[4] = head_stage(s.zr + d, 2 * d, d, c.P + Y.dec_c_bars.w, d, 0, c.P + Y.dec_c_bars.b, s.cb, nb * d, nb * d, 0);
+    RUN(pm_head_chain(&ch, c.st));
+    s.zcat_d = s.zcat; s.zg_d = s.zg; s.zr_d = s.zr;
+    RUN(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
+  } else if (run) {
+    branch_join(c, BR_ENC_FWD);
+    s.zcat_d = drop(c, s.zcat, B, 2 * d, SITE_ENC_MERGE_IN, seed_enc, zcatd_buf);            // Encoder.dropout_layer, model.py:473
+    lin(c, s.zcat_d, Y.enc_merge, B, d, 2 * d, s.m, false);
+    bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
+    s.zg_d = drop(c, s.zg, B, d, SITE_ENC_MERGE_OUT, seed_enc, zgd_buf);                     // model.py:479
+    lin(c, s.zg_d, Y.enc_mu, B, d, d, s.mu, false);
+    lin(c, s.zg_d, Y.enc_lv, B, d, d, s.lv, false);
+    RUN(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
     lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
     bn_fwd(c, s.zd, B, 2 * d, 1, Y.dec_bn, true, nullptr, s.zr, s.dm, s.dv);
     s.zr_d = drop(c, s.zr, B, 2 * d, SITE_DEC_IN, seed_dec, zrd_buf);                        // Decoder.dropout, model.py:640
@@ -862,14 +902,45 @@ void backward_decoder(Ctx& c) {
   float* dcb = ar.f((size_t)Gn * d);
   RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
   Deferred df;
+  float* dzd = ar.zf((size_t)B * 2 * d);
+  s.dz = ar.zf((size_t)B * d);
+  if (heads_fused(c)) {
+    // bars decoder -> BatchNorm backward -> decoder's first layer -> reparametrisation backward: one persistent launch
+    // (csrc/heads.hip); the weight gradients of the two products follow on the second stream (deferred, below)
+    lin_bwd(c, dcb, s.zr_d + d, Y.dec_c_bars, B, nb * d, d, nullptr, 0, 2 * d, 2 * d, true, &df);
+    branch_join(c, BR_DEC_BWD);
+    PmHeadChain ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.B = B; ch.bar = s.bar_dec;
+    int n = 0;
+    // content half of d(zr): d(cb) @ W, straight into the norm's backward on columns [d, 2d)
+    ch.st[n] = head_stage(dcb, nb * d, nb * d, c.P + Y.dec_c_bars.w, d, 1, nullptr, dzd + d, 2 * d, d, 0);
+    head_bn(c, ch.st[n], PM_HE_BN_BWD, Y.dec_bn, d, s.dm, s.dv, false);
+    ch.st[n].xpre = s.zd + d; ch.st[n].ld_xpre = 2 * d;
+    ++n;
+    if (s.fix_structure) {        // structure half: d(zr)[:, :d] comes from the structure decoder's backward (second stream)
+      ch.st[n] = head_stage(nullptr, 0, 0, nullptr, 0, 1, nullptr, dzd, 2 * d, d, 0);
+      ch.st[n].init = dzr; ch.st[n].ld_init = 2 * d;
+      head_bn(c, ch.st[n], PM_HE_BN_BWD, Y.dec_bn, 0, s.dm, s.dv, false);
+      ch.st[n].xpre = s.zd; ch.st[n].ld_xpre = 2 * d;
+      ++n;
+    }                             // (else that half of d(zr) is zero, and so is its d(zd): zero region)
+    ch.st[n - 1].barrier_after = 1;
+    ch.st[n] = head_stage(dzd, 2 * d, 2 * d, c.P + Y.dec_lin.w, d, 1, nullptr, s.dz, d, d, 0);
+    ch.st[n].epi = PM_HE_REPARAM_BWD; ch.st[n].noise = s.eps; ch.st[n].ld_noise = d; ch.st[n].lv = s.lv; ch.st[n].ld_lv = d;
+    ch.st[n].dmu = s.dmu; ch.st[n].dlv = s.dlv; ch.st[n].ld_d = d;
+    ++n;
+    ch.n = n;
+    RUN(pm_head_chain(&ch, c.st));
+    lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, nullptr, 0, 0, 0, true, &df);
+  } else {
   lin_bwd(c, dcb, s.zr_d + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d, true, &df);
   branch_join(c, BR_DEC_BWD);
   drop(c, dzr, B, 2 * d, SITE_DEC_IN, s.seed_dec, dzr);           // backward of Decoder.dropout
-  float* dzd = ar.f((size_t)B * 2 * d);
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
-  s.dz = ar.zf((size_t)B * d);
   lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz, 0, 0, 0, true, &df);
   RUN(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
+  }
   if (df.n) {                                         // the two head products' weight gradients: behind the others on the second stream
     BranchScope br(c, BR_DEC_WGRAD);
     flush_deferred(c, df);
@@ -888,15 +959,34 @@ void backward_encoder_heads(Ctx& c) {
   const int N = c.N, Gn = c.Gn, B = c.B, d = c.d, nb = c.nb, dh = d / 2;
   float* dzg = ar.zf((size_t)B * d); float* dzg2 = ar.zf((size_t)B * d);
   Deferred df;
+  float* dm = ar.f((size_t)B * d);
+  float* dzcat = ar.zf((size_t)B * 2 * d);
+  float* dpooled = ar.zf((size_t)Gn * d);
+  const bool fused = heads_fused(c);
+  if (fused) {
+    // mu / log_var heads -> BatchNorm backward -> merge layer -> bars encoder: one persistent launch (csrc/heads.hip)
+    PmHeadChain ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.B = B; ch.bar = s.bar_enc; ch.n = 3;
+    ch.st[0] = head_stage(s.dmu, d, d, c.P + Y.enc_mu.w, d, 1, nullptr, dm, d, d, 1);
+    ch.st[0].in2 = s.dlv; ch.st[0].ld_in2 = d; ch.st[0].K2 = d; ch.st[0].W2 = c.P + Y.enc_lv.w; ch.st[0].ldw2 = d;
+    head_bn(c, ch.st[0], PM_HE_BN_BWD, Y.enc_bn_merge, 0, s.mm, s.mv, false);
+    ch.st[0].xpre = s.m; ch.st[0].ld_xpre = d;
+    ch.st[1] = head_stage(dm, d, d, c.P + Y.enc_merge.w, 2 * d, 1, nullptr, dzcat, 2 * d, 2 * d, 1);
+    ch.st[2] = head_stage(dzcat, 2 * d, d, c.P + Y.enc_c_bars.w, nb * d, 1, nullptr, dpooled, nb * d, nb * d, 0);
+    RUN(pm_head_chain(&ch, c.st));
+    lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, nullptr, 0, 0, 0, true, &df);
+    lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, nullptr, 0, 0, 0, true, &df);
+    lin_bwd(c, dm, s.zcat_d, Y.enc_merge, B, d, 2 * d, nullptr, 0, 0, 0, true, &df);
+  } else {
   lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
   lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
   RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
   drop(c, dzg, B, d, SITE_ENC_MERGE_OUT, s.seed_enc, dzg);
-  float* dm = ar.f((size_t)B * d);
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
-  float* dzcat = ar.zf((size_t)B * 2 * d);
   lin_bwd(c, dm, s.zcat_d, Y.enc_merge, B, d, 2 * d, dzcat, 0, 0, 0, true, &df);
   drop(c, dzcat, B, 2 * d, SITE_ENC_MERGE_IN, s.seed_enc, dzcat);
+  }
   // ---- structure branch (z_s = zcat[:, d:]): on the second stream, under the whole content-encoder backward; joined at
   // the end of backward_encoder_tail
   {
@@ -920,8 +1010,7 @@ void backward_encoder_heads(Ctx& c) {
     RUN(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
   }
   // ---- content branch (z_c = zcat[:, :d])
-  float* dpooled = ar.zf((size_t)Gn * d);
-  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d, true, &df);
+  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, fused ? nullptr : dpooled, 2 * d, nb * d, nb * d, true, &df);
   if (df.n) {                                         // the four head products' weight gradients: second stream, joined below
     BranchScope br(c, BR_ENC_HEAD_WGRAD);
     flush_deferred(c, df);

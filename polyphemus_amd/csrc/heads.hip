@@ -16,7 +16,8 @@
 namespace {
 constexpr int HNC = 4;            // output columns per block
 constexpr int HMAXR = 8;          // rows per thread: B <= 8 * 256
-constexpr int HKC = 512;          // k-chunk of the weight slice staged in LDS
+constexpr int HKC = 32;           // k-chunk staged in LDS (input rows and weight slice)
+constexpr int HXP = 36;           // floats per staged input row (32 + 4: 16-byte reads of 64 rows spread over all bank groups)
 constexpr int HTHREADS = 256;
 
 __device__ static inline void grid_barrier(unsigned* bar, unsigned target) {
@@ -43,7 +44,69 @@ __device__ static inline double block_sum_d(double v, double* sh /* [4] */) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// One product pass: accum[r][j] += sum_k in[row(r), k] * A[k, c0 + j] for the workgroup's HNC columns.  The input is staged
+// through LDS in chunks of HKC k's for 256 rows (coalesced 128-byte row pieces, double-buffered: the loads of chunk t+1 are in
+// flight while chunk t is multiplied); a thread then reads ITS row's piece as 16-byte words (row pitch 36 floats: the 64 lanes
+// of a wave hit the eight 16-byte bank groups evenly) and the chunk's weight slice as broadcast words.
+__device__ static inline void head_product(const float* __restrict__ in, int ld_in, int K, const float* __restrict__ W, int ldw,
+                                           int kmajor, int c0, int B, float (&accum)[HMAXR][HNC],
+                                           float (*sX)[HTHREADS][HXP], float (*sW)[HKC][HNC]) {
+  const int tid = threadIdx.x;
+  const int nch = K / HKC;
+  for (int r = 0; r < HMAXR; ++r) {
+    const int rb = r * HTHREADS;
+    if (rb >= B) break;
+    float4 xr[HKC / 4 * HTHREADS / HTHREADS];                 // HKC / 4 = 8 pieces per thread and chunk
+    float wr = 0.f;
+    auto fetch = [&](int t) {
+      const int k0 = t * HKC;
+#pragma unroll
+      for (int i = 0; i < HKC / 4; ++i) {
+        const int idx = tid + HTHREADS * i, row = idx / (HKC / 4), g = idx % (HKC / 4);
+        xr[i] = rb + row < B ? *reinterpret_cast<const float4*>(in + (int64_t)(rb + row) * ld_in + k0 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (tid < HKC * HNC) {
+        const int kk = kmajor ? tid / HNC : tid % HKC, j = kmajor ? tid % HNC : tid / HKC;
+        wr = kmajor ? W[(int64_t)(k0 + kk) * ldw + c0 + j] : W[(int64_t)(c0 + j) * ldw + k0 + kk];
+      }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < HKC / 4; ++i) {
+        const int idx = tid + HTHREADS * i, row = idx / (HKC / 4), g = idx % (HKC / 4);
+        *reinterpret_cast<float4*>(&sX[buf][row][g * 4]) = xr[i];
+      }
+      if (tid < HKC * HNC) {
+        const int kk = kmajor ? tid / HNC : tid % HKC, j = kmajor ? tid % HNC : tid / HKC;
+        sW[buf][kk][j] = wr;
+      }
+    };
+    __syncthreads();                                            // (the previous pass has read both buffers)
+    fetch(0);
+    put(0);
+    __syncthreads();
+    for (int t = 0; t < nch; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nch) fetch(t + 1);
+#pragma unroll
+      for (int g = 0; g < HKC / 4; ++g) {
+        const float4 x = *reinterpret_cast<const float4*>(&sX[buf][tid][g * 4]);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w = *reinterpret_cast<const float4*>(&sW[buf][g * 4 + q][0]);
+          accum[r][0] = fmaf(xs[q], w.x, accum[r][0]); accum[r][1] = fmaf(xs[q], w.y, accum[r][1]);
+          accum[r][2] = fmaf(xs[q], w.z, accum[r][2]); accum[r][3] = fmaf(xs[q], w.w, accum[r][3]);
+        }
+      }
+      if (t + 1 < nch) put(buf ^ 1);
+      __syncthreads();
+    }
+  }
+}
+
 __global__ void __launch_bounds__(HTHREADS) k_head_chain(PmHeadChain ch) {
+  __shared__ __attribute__((aligned(16))) float sX[2][HTHREADS][HXP];
   __shared__ __attribute__((aligned(16))) float sW[2][HKC][HNC];
   __shared__ double sRed[4];
   const int tid = threadIdx.x, B = ch.B;
@@ -63,58 +126,10 @@ __global__ void __launch_bounds__(HTHREADS) k_head_chain(PmHeadChain ch) {
           acb[r][j] = 0.f;
         }
       }
-      const int Kmax = s.K > s.K2 ? s.K : s.K2;
-      for (int k0 = 0; k0 < Kmax; k0 += HKC) {
-        __syncthreads();
-        // weight slices of this k-chunk: sW[p][kk][j] = W_p[k0 + kk, c0 + j]
-        for (int i = tid; i < HKC * HNC; i += HTHREADS) {
-          // (consecutive threads read consecutive addresses: k-major weights run along j, the others along k)
-          const int kk = s.w_kmajor ? i / HNC : i % HKC, j = s.w_kmajor ? i % HNC : i / HKC, k = k0 + kk;
-          float wa = 0.f, wb = 0.f;
-          if (k < s.K) wa = s.w_kmajor ? s.W[(int64_t)k * s.ldw + c0 + j] : s.W[(int64_t)(c0 + j) * s.ldw + k];
-          if (s.W2 && k < s.K2) wb = s.w_kmajor ? s.W2[(int64_t)k * s.ldw2 + c0 + j] : s.W2[(int64_t)(c0 + j) * s.ldw2 + k];
-          sW[0][kk][j] = wa; sW[1][kk][j] = wb;
-        }
-        __syncthreads();
-        const int kcA = min(HKC, s.K - k0), kcB = s.W2 ? min(HKC, s.K2 - k0) : 0;
-#pragma unroll
-        for (int r = 0; r < HMAXR; ++r) {
-          const int b = tid + r * HTHREADS;
-          if (b >= B) break;
-          if (kcA > 0) {
-            const float* row = s.in + (int64_t)b * s.ld_in + k0;
-#pragma unroll 4
-            for (int kk = 0; kk < kcA; kk += 4) {
-              const float4 x = *reinterpret_cast<const float4*>(row + kk);
-              const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 w = *reinterpret_cast<const float4*>(&sW[0][kk + q][0]);
-                acc[r][0] = fmaf(xs[q], w.x, acc[r][0]); acc[r][1] = fmaf(xs[q], w.y, acc[r][1]);
-                acc[r][2] = fmaf(xs[q], w.z, acc[r][2]); acc[r][3] = fmaf(xs[q], w.w, acc[r][3]);
-              }
-            }
-          }
-          if (kcB > 0) {
-            const float* row = s.in2 + (int64_t)b * s.ld_in2 + k0;
-#pragma unroll 4
-            for (int kk = 0; kk < kcB; kk += 4) {
-              const float4 x = *reinterpret_cast<const float4*>(row + kk);
-              const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 w = *reinterpret_cast<const float4*>(&sW[1][kk + q][0]);
-                if (s.dual) {
-                  acb[r][0] = fmaf(xs[q], w.x, acb[r][0]); acb[r][1] = fmaf(xs[q], w.y, acb[r][1]);
-                  acb[r][2] = fmaf(xs[q], w.z, acb[r][2]); acb[r][3] = fmaf(xs[q], w.w, acb[r][3]);
-                } else {
-                  acc[r][0] = fmaf(xs[q], w.x, acc[r][0]); acc[r][1] = fmaf(xs[q], w.y, acc[r][1]);
-                  acc[r][2] = fmaf(xs[q], w.z, acc[r][2]); acc[r][3] = fmaf(xs[q], w.w, acc[r][3]);
-                }
-              }
-            }
-          }
-        }
+      if (s.K > 0) head_product(s.in, s.ld_in, s.K, s.W, s.ldw, s.w_kmajor, c0, B, acc, sX, sW);
+      if (s.K2 > 0) {
+        if (s.dual) head_product(s.in2, s.ld_in2, s.K2, s.W2, s.ldw2, s.w_kmajor, c0, B, acb, sX, sW);
+        else head_product(s.in2, s.ld_in2, s.K2, s.W2, s.ldw2, s.w_kmajor, c0, B, acc, sX, sW);
       }
       // ---- bias
 #pragma unroll
@@ -238,7 +253,7 @@ extern "C" int pm_head_chain(const PmHeadChain* chain, pm_stream_t stream) {
     return PM_E_INVALID;
   for (int i = 0; i < chain->n; ++i) {
     const PmHeadStage& s = chain->st[i];
-    if (!s.out || s.N <= 0 || (s.N % HNC) || (s.K % 4) || (s.K2 % 4) || (s.K > 0 && (!s.in || !s.W)) || (s.K2 > 0 && (!s.in2 || !s.W2)) ||
+    if (!s.out || s.N <= 0 || (s.N % HNC) || (s.K % HKC) || (s.K2 % HKC) || (s.K > 0 && (!s.in || !s.W)) || (s.K2 > 0 && (!s.in2 || !s.W2)) ||
         (s.ld_out % 4) || ((uintptr_t)s.out % 16) || (s.K > 0 && ((s.ld_in % 4) || ((uintptr_t)s.in % 16))) ||
         (s.K2 > 0 && ((s.ld_in2 % 4) || ((uintptr_t)s.in2 % 16))))
       return PM_E_INVALID;

@@ -658,7 +658,7 @@ int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_
  *   PM_HE_BN_BWD       its backward with acc = d(out): dgamma += , dbeta += , out = d(input)  (xpre = the saved out2)
  *   PM_HE_REPARAM_FWD  (dual) out2 = mu = acc, out3 = log_var = acc2, out = exp(0.5 log_var) * noise + mu
  *   PM_HE_REPARAM_BWD  dmu += acc, dlv += acc * noise * 0.5 * exp(0.5 lv); out = acc (optional)
- * fp32 FMAs in k order, fp64 column statistics in a fixed order: deterministic.  B <= 2048; K, K2 multiples of 32, N and
+ * fp32 FMAs in k order, fp64 column statistics in a fixed order: deterministic.  B <= 1024; K, K2 multiples of 32, N and
  * the leading dimensions multiples of 4, operands 16-byte aligned. */
 enum { PM_HE_NONE = 0, PM_HE_BN_FWD, PM_HE_REPARAM_FWD, PM_HE_BN_BWD, PM_HE_REPARAM_BWD };
 enum { PM_HEAD_MAX_STAGES = 6, PM_HEAD_GRID = 64 };

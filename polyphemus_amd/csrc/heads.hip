@@ -15,10 +15,11 @@
 
 namespace {
 constexpr int HNC = 4;            // output columns per block
-constexpr int HMAXR = 8;          // rows per thread: B <= 8 * 256
+constexpr int HMAXR = 4;          // rows per thread: B <= 4 * 256
 constexpr int HKC = 32;           // k-chunk staged in LDS (input rows and weight slice)
 constexpr int HXP = 36;           // floats per staged input row (32 + 4: 16-byte reads of 64 rows spread over all bank groups)
 constexpr int HTHREADS = 256;
+constexpr int HPD = 4;            // input chunks in flight per thread
 
 __device__ static inline void grid_barrier(unsigned* bar, unsigned target) {
   __syncthreads();
@@ -53,41 +54,41 @@ __device__ static inline void head_product(const float* __restrict__ in, int ld_
                                            float (*sX)[HTHREADS][HXP], float (*sW)[HKC][HNC]) {
   const int tid = threadIdx.x;
   const int nch = K / HKC;
+#pragma unroll 1
   for (int r = 0; r < HMAXR; ++r) {
     const int rb = r * HTHREADS;
     if (rb >= B) break;
-    float4 xr[HKC / 4 * HTHREADS / HTHREADS];                 // HKC / 4 = 8 pieces per thread and chunk
-    float wr = 0.f;
-    auto fetch = [&](int t) {
+    float a[HNC] = {0.f, 0.f, 0.f, 0.f};                        // this row block's sums (accum[r] is not indexable by a loop variable)
+    // HPD chunks in flight per thread (registers): a chunk's loads take ~1.5 us to arrive (the rows were written by other
+    // workgroups one stage ago: Infinity Cache at best) against ~0.25 us to multiply one — with one chunk ahead every chunk
+    // waited for its loads (30 us per stage)
+    float4 xr[HPD][HKC / 4];
+    float wr[HPD];
+    auto fetch = [&](int t, float4 (&xq)[HKC / 4], float& wq) __attribute__((always_inline)) {
       const int k0 = t * HKC;
 #pragma unroll
       for (int i = 0; i < HKC / 4; ++i) {
         const int idx = tid + HTHREADS * i, row = idx / (HKC / 4), g = idx % (HKC / 4);
-        xr[i] = rb + row < B ? *reinterpret_cast<const float4*>(in + (int64_t)(rb + row) * ld_in + k0 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xq[i] = rb + row < B ? *reinterpret_cast<const float4*>(in + (int64_t)(rb + row) * ld_in + k0 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      wq = 0.f;
       if (tid < HKC * HNC) {
         const int kk = kmajor ? tid / HNC : tid % HKC, j = kmajor ? tid % HNC : tid / HKC;
-        wr = kmajor ? W[(int64_t)(k0 + kk) * ldw + c0 + j] : W[(int64_t)(c0 + j) * ldw + k0 + kk];
+        wq = kmajor ? W[(int64_t)(k0 + kk) * ldw + c0 + j] : W[(int64_t)(c0 + j) * ldw + k0 + kk];
       }
     };
-    auto put = [&](int buf) {
+    auto put = [&](int buf, const float4 (&xq)[HKC / 4], float wq) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < HKC / 4; ++i) {
         const int idx = tid + HTHREADS * i, row = idx / (HKC / 4), g = idx % (HKC / 4);
-        *reinterpret_cast<float4*>(&sX[buf][row][g * 4]) = xr[i];
+        *reinterpret_cast<float4*>(&sX[buf][row][g * 4]) = xq[i];
       }
       if (tid < HKC * HNC) {
         const int kk = kmajor ? tid / HNC : tid % HKC, j = kmajor ? tid % HNC : tid / HKC;
-        sW[buf][kk][j] = wr;
+        sW[buf][kk][j] = wq;
       }
     };
-    __syncthreads();                                            // (the previous pass has read both buffers)
-    fetch(0);
-    put(0);
-    __syncthreads();
-    for (int t = 0; t < nch; ++t) {
-      const int buf = t & 1;
-      if (t + 1 < nch) fetch(t + 1);
+    auto mult = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
       for (int g = 0; g < HKC / 4; ++g) {
         const float4 x = *reinterpret_cast<const float4*>(&sX[buf][tid][g * 4]);
@@ -95,13 +96,34 @@ __device__ static inline void head_product(const float* __restrict__ in, int ld_
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 w = *reinterpret_cast<const float4*>(&sW[buf][g * 4 + q][0]);
-          accum[r][0] = fmaf(xs[q], w.x, accum[r][0]); accum[r][1] = fmaf(xs[q], w.y, accum[r][1]);
-          accum[r][2] = fmaf(xs[q], w.z, accum[r][2]); accum[r][3] = fmaf(xs[q], w.w, accum[r][3]);
+          a[0] = fmaf(xs[q], w.x, a[0]); a[1] = fmaf(xs[q], w.y, a[1]);
+          a[2] = fmaf(xs[q], w.z, a[2]); a[3] = fmaf(xs[q], w.w, a[3]);
         }
       }
-      if (t + 1 < nch) put(buf ^ 1);
-      __syncthreads();
+    };
+    __syncthreads();                                            // (the previous pass has read both buffers)
+#pragma unroll
+    for (int q = 0; q < HPD; ++q)
+      if (q < nch) fetch(q, xr[q], wr[q]);
+    put(0, xr[0], wr[0]);
+    __syncthreads();
+    for (int t0 = 0; t0 < nch; t0 += HPD) {
+#pragma unroll
+      for (int q = 0; q < HPD; ++q) {                             // (static ring positions: chunk t0 + q lives in xr[q])
+        const int t = t0 + q;
+        if (t >= nch) break;
+        if (t + HPD < nch) fetch(t + HPD, xr[q], wr[q]);         // xr[q] was stored to LDS one step ago: free
+        mult(t & 1);
+        if (t + 1 < nch) put((t + 1) & 1, xr[(q + 1) % HPD], wr[(q + 1) % HPD]);
+        __syncthreads();
+      }
     }
+#pragma unroll
+    for (int rr = 0; rr < HMAXR; ++rr)
+      if (rr == r) {
+#pragma unroll
+        for (int j = 0; j < HNC; ++j) accum[rr][j] += a[j];
+      }
   }
 }
 

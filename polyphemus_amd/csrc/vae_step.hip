@@ -267,7 +267,7 @@ void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, 
                             c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
 }
 // ---- head chains as one persistent launch each (csrc/heads.hip); not with cfg.dropout (its layers sit between the stages)
-static bool heads_fused(const Ctx& c) { return cfg().fused_heads && !(c.pdrop > 0.f) && c.B <= 2048 && (c.d % 32) == 0; }
+static bool heads_fused(const Ctx& c) { return cfg().fused_heads && !(c.pdrop > 0.f) && c.B <= 1024 && (c.d % 32) == 0; }
 static PmHeadStage head_stage(const float* in, int ld_in, int K, const float* W, int ldw, int kmajor, const float* bias, float* out,
                               int ld_out, int N, int barrier_after) {
   PmHeadStage s;

@@ -11,8 +11,16 @@
 // step's zero region).  A workgroup owns blocks of HNC = 4 output COLUMNS for all rows — a thread owns a row —, so the
 // column statistics of the norms are local to the workgroup (fp64, fixed order) and a norm needs no barrier of its own.
 // Plain fp32 FMAs in k order: no matrix cores (0.5 GFLOP per chain), no split-K, no atomics — the chain is deterministic.
+//
+// STATUS: opt-in (PM_FUSED_HEADS=1).  Parity-tested against the launch chain, but measured SLOWER: the three launches take
+// 147 + 99 + 118 us in the step (25-30 us per stage: every one of the 64 workgroups streams the stage's whole [B, K] input —
+// 0.25-0.5 MB that other CUs wrote a stage earlier — at the ~10 B/clock a single CU gets from beyond its L2) against
+// 142 + ~300 us of launch chains that overlap the weight gradients on the second stream: step 5.18-5.21 against 5.08 ms.
 #include "common.h"
 
+#ifndef HEADS_FENCE
+#define HEADS_FENCE 1             // 0: timing what-if (WRONG across XCDs): grid barriers without the L2 write-back / invalidate
+#endif
 namespace {
 constexpr int HNC = 4;            // output columns per block
 constexpr int HMAXR = 4;          // rows per thread: B <= 4 * 256
@@ -24,14 +32,18 @@ constexpr int HPD = 4;            // input chunks in flight per thread
 __device__ static inline void grid_barrier(unsigned* bar, unsigned target) {
   __syncthreads();
   if (threadIdx.x == 0) {
+#if HEADS_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(bar, HEADS_FENCE ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(8);
       if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) break;      // 4 s: never hang the device
     }
+#if HEADS_FENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   }
   __syncthreads();
 }

@@ -35,7 +35,8 @@ struct StepCfg {
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int side_delay_us;           // PM_SIDE_DELAY_US (tests): every branch starts with a kernel that spins this long on the second stream,
                                // so a missing join shows as a wrong result instead of passing by luck of timing
-  bool fused_heads;            // PM_FUSED_HEADS=0: the head chains as ~14 launches each instead of one persistent launch (heads.hip)
+  bool fused_heads;            // PM_FUSED_HEADS=1: the head chains as one persistent launch each (heads.hip) instead of ~14 launches —
+                               // built, parity-tested, and SLOWER (5.19 against 5.08 ms per step: profiles/LOG.md); off
   bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
@@ -56,7 +57,7 @@ static StepCfg read_cfg() {
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
   k.late_wgrads = flag("PM_LATE_WGRADS", true);
   k.dw_side = flag("PM_DW_SIDE", false);
-  k.fused_heads = flag("PM_FUSED_HEADS", true);
+  k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;

@@ -46,7 +46,9 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   4: round 3, second half (PmGemmDesc.a_colsum — the bias gradient riding in a weight-gradient GEMM —, pm_unembed_ce's
  *   w_planes argument, PM_PLAN_TRK_CNT grown to 32 + 4 W ints by the tile schedule, pm_unembed_dh, pm_bn_small_*,
  *   pm_rows_tn_weight_grad, pm_gcl_tile_order / pm_row_tile_order, pm_vae_step_reload_switches).
- *   5: round 4 (pm_set_deterministic / pm_get_deterministic; plan scratch field grown). */
+ *   5: round 4 (pm_set_deterministic / pm_get_deterministic; plan scratch field grown; PmVaeLayout.flags / .dropout — the
+ *   C++ step covers batch_norm = False and cfg.dropout —; pm_vae_step_info writes 16 ints; pm_relu_bwd_planes;
+ *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain). */
 #define PM_ABI_VERSION 5
 int pm_abi_version(void);
 const char* pm_build_info(void);

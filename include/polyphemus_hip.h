@@ -48,8 +48,9 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   pm_rows_tn_weight_grad, pm_gcl_tile_order / pm_row_tile_order, pm_vae_step_reload_switches).
  *   5: round 4 (pm_set_deterministic / pm_get_deterministic; plan scratch field grown; PmVaeLayout.flags / .dropout — the
  *   C++ step covers batch_norm = False and cfg.dropout —; pm_vae_step_info writes 16 ints; pm_relu_bwd_planes;
- *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain). */
-#define PM_ABI_VERSION 5
+ *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain).
+ *   6: round 4, second half (pm_gcl_input_grad_bn / PmBnBwd, pm_bn_bwd_sums: the norm backward inside the input gradient). */
+#define PM_ABI_VERSION 6
 int pm_abi_version(void);
 const char* pm_build_info(void);
 
@@ -208,6 +209,22 @@ int pm_gcl_forward_fused(const float* x /* [N,d] */, const float* T /* [32,d] */
 int pm_gcl_input_grad_fused(const uint16_t* dh_planes /* 3 planes [N,d] */, int64_t plane_stride, const int32_t* plan,
                             int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
                             float* dA /* [N,4d] */, pm_stream_t stream);
+/* The same with the BatchNorm backward in front of it (pm_bn_bwd_fused with sums_ready != 0: autograd of model.py:203-206)
+ * run in the kernel's prologue instead of as a pass of its own: a workgroup forms dh for its 64 rows from the pre-norm rows
+ * `h`, the norm's output gradient `du` and the column sums in `acc3` [PM_BN_REPL][3][d] (pm_segreduce_bwd_norm or
+ * pm_bn_bwd_sums), multiplies it as above and WRITES the three dh planes (for pm_gcl_weight_grad_fused afterwards);
+ * dgamma / dbeta / dbias_pre (+=, any may be NULL) as pm_bn_bwd_fused.  Same values as the two calls.  d in {128, 256}. */
+typedef struct PmBnBwd {
+  const float* h;        /* [N,d] input of the norm */
+  const float* du;       /* [N,d] gradient of its output */
+  const float* mean; const float* var; const float* gamma; const float* beta; /* [d] batch statistics, parameters */
+  const double* acc3;    /* [PM_BN_REPL][3][d] column sums of du', du' * xhat, xhat */
+  float* dgamma; float* dbeta; float* dbias_pre; /* [d] += or NULL */
+  float eps; int32_t relu; /* relu != 0: the norm is followed by a ReLU (du' = du * [BN(h) > 0]) */
+} PmBnBwd;
+int pm_gcl_input_grad_bn(const PmBnBwd* norm, uint16_t* dh_planes /* 3 planes [N,d], written */, int64_t plane_stride,
+                         const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t,
+                         int32_t use_classes, float* dA /* [N,4d] */, pm_stream_t stream);
 /* Weight gradient of that product, d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t] (gcl.hip): 128x128 output tiles,
  * one workgroup per (tile, track group, K slice), operands streamed by loader waves through an LDS ring, K slices added
  * with float atomics; `dW` is the layer's [7d, d] gradient (+=).  Same result as the grouped planes product with transA
@@ -411,6 +428,9 @@ int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const
                     int64_t plane_stride /* elements */,
                     int32_t sums_ready /* != 0: acc3 already holds the sums (pm_segreduce_bwd_norm) */,
                     pm_stream_t stream);
+/* The column sums of pm_bn_bwd_fused alone: acc3 [PM_BN_REPL][3][C] (caller-zeroed) += sums of du', du' * xhat, xhat. */
+int pm_bn_bwd_sums(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var, float eps,
+                   const float* gamma, const float* beta, int relu, double* acc3, pm_stream_t stream);
 /* Eval-mode BatchNorm folded into the linear map in front of it (model.py:203 under `vae.eval()`,
  * generate.py:112): with s = gamma / sqrt(running_var + eps), t = beta - running_mean * s,
  *   W_out[k, n] = W[k, n] * s[n]      (W [rows, cols] row-major, the GCL operand [weight; root] [7d, d])
@@ -738,7 +758,7 @@ int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buff
 /* Introspection of the last forward (host only): info = {compact GCL, bf16-planes GEMM operands, active slots S,
  * fragment-major weight planes built (B-direct GEMM mode), N, E, G, B, then the EFFECTIVE switches of the library —
  * fused un-embedding + cross-entropy (PM_FUSED_CE), second-stream site mask (PM_SIDE_STREAM), deterministic mode,
- * fused GCL kernels (PM_GCL_FUSED) —, 4 reserved}.  The parity tests use it to assert that the golden-pinned step IS
+ * fused GCL kernels (PM_GCL_FUSED), norm backward inside the GCL input gradient (PM_DAGG_BN) —, 3 reserved}.  The parity tests use it to assert that the golden-pinned step IS
  * the measured variant. */
 int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
 /* The model outputs of `VAE.forward` (model.py:665-678) as the last forward computed them, copied out of the arena

@@ -37,6 +37,8 @@ _SIGS = {
     "pm_segreduce_fwd_planes": "pppiiiifuuipls",
     "pm_gcl_forward_fused": "pppiiiifuuppipppls",
     "pm_gcl_input_grad_fused": "plpiiiipips",
+    "pm_gcl_input_grad_bn": "pplpiiiipips",
+    "pm_bn_bwd_sums": "ppiippfppips",
     "pm_gcl_weight_grad_fused": "plplpiiiiips",
     "pm_gcl_forward_from_planes": "plpiiiippipps",
     "pm_rows_times_weight": "piiipiiippis",
@@ -127,7 +129,7 @@ _SIGS = {
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
           "pm_unembed_dh_scratch_bytes"}
-ABI_VERSION = 5          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
+ABI_VERSION = 6          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])
 

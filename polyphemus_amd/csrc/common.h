@@ -180,6 +180,23 @@ __device__ static inline void pm_store_planes4(uint16_t* __restrict__ planes, in
   *reinterpret_cast<pm_u32x2*>(planes + plane_stride + idx) = p2;
   *reinterpret_cast<pm_u32x2*>(planes + 2 * plane_stride + idx) = p3;
 }
+// ---- BatchNorm backward, shared by norm.hip (k_bn_bwd_apply4_sums) and gcl.hip (k_gcl_dagg with the norm fused in)
+// sum over the PM_BN_REPL replicas of accumulator a of column c (acc [PM_BN_REPL][nacc][C] fp64)
+__device__ static inline double pm_repl_sum(const double* __restrict__ acc, int nacc, int C, int a, int c) {
+  double t = 0;
+#pragma unroll
+  for (int r = 0; r < PM_BN_REPL; ++r) t += acc[((int64_t)r * nacc + a) * C + c];
+  return t;
+}
+// one element of dh = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat)), du = dy * [BN(x) > 0] when the norm is followed
+// by a ReLU (autograd of model.py:203-206); m0 / m1 = the two column means
+__device__ static inline float pm_bn_bwd_elem(float x, float dy, float mean, float rstd, float ga, float be, float m0,
+                                              float m1, int relu) {
+  const float xh = (x - mean) * rstd;
+  float du = dy;
+  if (relu && !(xh * ga + be > 0.f)) du = 0.f;
+  return ga * rstd * (du - m0 - xh * m1);
+}
 __device__ static inline float pm_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

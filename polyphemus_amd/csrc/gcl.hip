@@ -21,6 +21,7 @@
 // the unfused pair moves 24dN more (the read of A').
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include "prof.h"
 
 #include "gcl_tiles.h"
@@ -34,6 +35,16 @@
 #endif
 #ifndef GCL_WHATIF
 #define GCL_WHATIF 0
+#endif
+// development (tools/build_variants.py): GCL_PACE = n puts n x 16 idle issue cycles of the MFMA wave behind every MFMA of
+// k_gcl_fwd, so that the wave does not sit in the SIMD's issue stage with an MFMA the busy matrix pipe cannot take
+#ifndef GCL_PACE
+#define GCL_PACE 0
+#endif
+#if GCL_PACE
+#define GCL_PACE_NOPS(ACC) do { _Pragma("unroll") for (int pz = 0; pz < GCL_PACE; ++pz) asm volatile("s_nop 15" : "+v"(ACC)); } while (0)
+#else
+#define GCL_PACE_NOPS(ACC) do {} while (0)
 #endif
 #define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
 #endif
@@ -375,7 +386,8 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 #if GCL_WHATIF == 4                                              // timing what-if (WRONG results): one product of the six
               { if (t6 == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0); }
 #else
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+              { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+                GCL_PACE_NOPS(acc[i][j]); }
 #endif
         bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
         __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
@@ -465,10 +477,23 @@ extern "C" int pm_debug_read_trace(long long* out) {
 // The output never leaves through the MFMA waves: vmcnt retires in order, so 64 row-segment stores in front of the next
 // block's weight-fragment loads would put the write latency into every block.  Waves 4..7 take each finished block
 // from an LDS stage (64 x d fp32) and store it as whole 4*d-byte rows.
-template <int D, int NMW>
+// BNF: the BatchNorm backward that produces dh (norm.hip k_bn_bwd_apply4_sums: 58 MB through HBM and a launch per layer) runs
+// in the prologue instead — the workgroup reads the pre-norm rows h and the incoming gradient du of its 64 nodes, forms
+// dh = gamma * rstd * (du * [BN(h) > 0] - mean(du) - xhat * mean(du * xhat)) from the column sums the segment-reduce backward
+// of the layer above accumulated (acc3), splits it into the LDS image AND, through the store waves while the first output
+// block is being multiplied, into the dh planes in HBM that the weight gradient (k_gcl_dw) reads afterwards.  Every node
+// is in exactly one tile, so the planes are written once.  Workgroup 0 adds dgamma / dbeta / the bias gradient.
+namespace {
+struct GclBn {
+  const float* h; const float* du; const float* mean; const float* var; const float* gamma; const float* beta;
+  const double* acc3; float* dgamma; float* dbeta; float* dbias_pre;
+  double count; float eps; int relu;
+};
+}  // namespace
+template <int D, int NMW, bool BNF>
 __global__ void __launch_bounds__((NMW + 4) * 64) __attribute__((amdgpu_waves_per_eu((NMW + 4) / 4, (NMW + 4) / 4)))
-k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_list, const int* __restrict__ trk_cnt,
-           const char* __restrict__ wfrag, float* __restrict__ dA, int N, int use_classes) {
+k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_list, const int* __restrict__ trk_cnt,
+           const char* __restrict__ wfrag, float* __restrict__ dA, int N, int use_classes, GclBn bn) {
   constexpr int TN = D / (NMW * 32);     // 32-column MFMA tiles per MFMA wave (its D / NMW columns of a block)
   constexpr int NMT = NMW * 64;          // MFMA threads
   constexpr int KS = D / 16;             // k-steps
@@ -478,6 +503,19 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   float* const sC = reinterpret_cast<float*>(smem + 3 * PL);   // [BM][D] stage of one output block
   int* const sNode = reinterpret_cast<int*>(sC);               // the rows' nodes (until the first block is staged)
 
+  float* const sK = sC + BM;                                   // BNF: [6][D] mean, rstd, gamma, beta, mean(du), mean(du * xhat)
+  if (BNF && blockIdx.x == 0) {                                // (as block 0 of k_bn_bwd_apply4_sums)
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+      const double s0 = pm_repl_sum(bn.acc3, 3, D, 0, c), s1 = pm_repl_sum(bn.acc3, 3, D, 1, c);
+      if (bn.dbeta) bn.dbeta[c] += (float)s0;
+      if (bn.dgamma) bn.dgamma[c] += (float)s1;
+      if (bn.dbias_pre) {
+        const double s2 = pm_repl_sum(bn.acc3, 3, D, 2, c), mm0 = s0 / bn.count, mm1 = s1 / bn.count;
+        const double rstd = 1.0 / sqrt((double)bn.var[c] + (double)bn.eps);
+        bn.dbias_pre[c] += (float)((double)bn.gamma[c] * rstd * ((s0 - bn.count * mm0) - mm1 * s2));
+      }
+    }
+  }
   PmTile tl;
   if (!pm_gcl_tile_lookup(trk_cnt, use_classes, blockIdx.x, tl)) return;
   const int grp = tl.grp, m0 = tl.m0, rows = tl.rows;          // rows = 64, or 32: half a tile (tile_order.h)
@@ -497,6 +535,13 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   int nst = 0;
   STAMP2();
   if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
+  if (BNF) {
+    for (int c = tid; c < D; c += (NMW + 4) * 64) {
+      const double s0 = pm_repl_sum(bn.acc3, 3, D, 0, c), s1 = pm_repl_sum(bn.acc3, 3, D, 1, c);
+      sK[c] = bn.mean[c]; sK[D + c] = rsqrtf(bn.var[c] + bn.eps); sK[2 * D + c] = bn.gamma[c]; sK[3 * D + c] = bn.beta[c];
+      sK[4 * D + c] = (float)(s0 / bn.count); sK[5 * D + c] = (float)(s1 / bn.count);
+    }
+  }
   __syncthreads();
   STAMP2();
   if (wave >= NMW) {
@@ -508,6 +553,21 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
     for (int k = 0; k < NR; ++k) node[k] = sNode[r0 + k * 4 * RPW];
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(dA, 0, GCL_OOB, 0x00020000);
     __syncthreads();                                           // (image filled; the stage may be written from here on)
+    if (BNF) {
+      // the image -> the dh planes in HBM (for the weight gradient), 16 bytes per lane, while the MFMA waves multiply the
+      // first block (sNode is intact until they stage it: the first barrier of the loop below)
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(dhp, 0, GCL_OOB, 0x00020000);
+      constexpr int CPR = D / 8;
+#pragma unroll 4
+      for (int ci = st; ci < BM * CPR; ci += 256) {
+        const int rr = ci / CPR, ch = ci % CPR, n = sNode[rr];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * PL + rr * RB + ((ch ^ (rr & 15)) << 4));
+          __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, 0);
+        }
+      }
+    }
 #pragma unroll 1
     for (int qb = 0; qb < nblk; ++qb) {
       __syncthreads();                                         // consumers: stage free -> they fill it
@@ -525,7 +585,44 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
     return;
   }
   // ---- the rows' dh planes -> XOR-swizzled LDS image (16-byte chunk c of row r at chunk c ^ (r & 15))
-  {
+  if constexpr (BNF) {
+    // ... computed here from the pre-norm rows and the incoming gradient: a lane owns four consecutive columns of a row
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bn.h), 0, GCL_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bn.du), 0, GCL_OOB, 0x00020000);
+    constexpr int LPR = D / 4, NE = BM * LPR / NMT, NB = NE < 8 ? NE : 8;   // lanes per row, float4 per thread, per batch
+#pragma unroll 1
+    for (int k0 = 0; k0 < NE; k0 += NB) {
+      float4 hv[NB], dv[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int e = tid + (k0 + k) * NMT, rr = e / LPR, q = e % LPR, n = sNode[rr];
+        const int off = n >= 0 ? (n * D + q * 4) * 4 : GCL_OOB;
+        hv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, off, 0, 0));
+        dv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int e = tid + (k0 + k) * NMT, rr = e / LPR, q = e % LPR;
+        const bool live = sNode[rr] >= 0;
+        const float4 km = *reinterpret_cast<const float4*>(sK + q * 4), kr = *reinterpret_cast<const float4*>(sK + D + q * 4);
+        const float4 kg = *reinterpret_cast<const float4*>(sK + 2 * D + q * 4), kb = *reinterpret_cast<const float4*>(sK + 3 * D + q * 4);
+        const float4 k0m = *reinterpret_cast<const float4*>(sK + 4 * D + q * 4), k1m = *reinterpret_cast<const float4*>(sK + 5 * D + q * 4);
+        float o0 = pm_bn_bwd_elem(hv[k].x, dv[k].x, km.x, kr.x, kg.x, kb.x, k0m.x, k1m.x, bn.relu);
+        float o1 = pm_bn_bwd_elem(hv[k].y, dv[k].y, km.y, kr.y, kg.y, kb.y, k0m.y, k1m.y, bn.relu);
+        float o2 = pm_bn_bwd_elem(hv[k].z, dv[k].z, km.z, kr.z, kg.z, kb.z, k0m.z, k1m.z, bn.relu);
+        float o3 = pm_bn_bwd_elem(hv[k].w, dv[k].w, km.w, kr.w, kg.w, kb.w, k0m.w, k1m.w, bn.relu);
+        if (!live) { o0 = 0.f; o1 = 0.f; o2 = 0.f; o3 = 0.f; }   // rows past the end of the list: a zero row, as the planes load gives
+        unsigned l1, l2, l3, u1, u2, u3;
+        pm_split3_pair(o0, o1, l1, l2, l3);
+        pm_split3_pair(o2, o3, u1, u2, u3);
+        const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+        char* dst = smem + rr * RB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
+        *reinterpret_cast<pm_u32x2*>(dst) = p1;
+        *reinterpret_cast<pm_u32x2*>(dst + PL) = p2;
+        *reinterpret_cast<pm_u32x2*>(dst + 2 * PL) = p3;
+      }
+    }
+  } else {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
     constexpr int CPR = D / 8, NCHK = BM * CPR / NMT;            // chunks per row, chunks per thread and plane
     u32x4 v[3][NCHK];
@@ -621,6 +718,37 @@ k_gcl_dagg(const uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict_
   else blocks(std::integral_constant<int, 1>{});
 }
 
+static int gcl_input_grad_impl(uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                               int32_t d, const uint16_t* w_frag_t, int32_t use_classes, float* dA, const GclBn* bn,
+                               hipStream_t st) {
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  // MFMA waves per workgroup (+ four store waves): eight at d = 256 (two per SIMD: one wave's fragment waits are covered by
+  // its partner's MFMAs, as in wide.hip); A/B: PM_GCL_DAGG_WAVES
+  static const int nmw_env = getenv("PM_GCL_DAGG_WAVES") ? atoi(getenv("PM_GCL_DAGG_WAVES")) : 0;
+  const int nmw = (d == 256 && nmw_env != 4) ? 8 : 4;
+  const dim3 grid(pm_gcl_grid(N)), block((nmw + 4) * 64);
+  const size_t lds = (size_t)3 * BM * d * 2 + (size_t)BM * d * 4;
+  GclBn none;
+  memset(&none, 0, sizeof(none));
+  const GclBn bv = bn ? *bn : none;
+  const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
+#define LAUNCH(DD, NW, BF)                                                                                             \
+  do {                                                                                                                 \
+    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                            \
+    if (!once) {                                                                                                       \
+      hipFuncSetAttribute((const void*)k_gcl_dagg<DD, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_gcl_dagg<DD, NW, BF>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt, \
+                       reinterpret_cast<const char*>(w_frag_t), dA, N, use_classes, bv);                               \
+  } while (0)
+#define LAUNCH2(DD, NW) do { if (bn) LAUNCH(DD, NW, true); else LAUNCH(DD, NW, false); } while (0)
+  if (d == 256) { if (nmw == 8) LAUNCH2(256, 8); else LAUNCH2(256, 4); } else LAUNCH2(128, 4);
+#undef LAUNCH2
+#undef LAUNCH
+  pm_prof_close(st, pe);
+  return pm_check_launch();
+}
 extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
                                        int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
                                        float* dA, pm_stream_t stream) {
@@ -630,29 +758,22 @@ extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_
     return PM_E_INVALID;
   if (d == 512)                 // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_gcl_input_grad(dh_planes, plane_stride, plan, N, E, G, w_frag_t, use_classes, dA, (hipStream_t)stream);
-  PmPlanView pv = pm_plan_view(plan, N, E, G);
-  hipStream_t st = (hipStream_t)stream;
-  // MFMA waves per workgroup (+ four store waves): eight at d = 256 (two per SIMD: one wave's fragment waits are covered by
-  // its partner's MFMAs, as in wide.hip); A/B: PM_GCL_DAGG_WAVES
-  static const int nmw_env = getenv("PM_GCL_DAGG_WAVES") ? atoi(getenv("PM_GCL_DAGG_WAVES")) : 0;
-  const int nmw = (d == 256 && nmw_env != 4) ? 8 : 4;
-  const dim3 grid(pm_gcl_grid(N)), block((nmw + 4) * 64);
-  const size_t lds = (size_t)3 * BM * d * 2 + (size_t)BM * d * 4;
-  const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
-#define LAUNCH(DD, NW)                                                                                                 \
-  do {                                                                                                                 \
-    static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
-    if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_gcl_dagg<DD, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((k_gcl_dagg<DD, NW>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt,   \
-                       reinterpret_cast<const char*>(w_frag_t), dA, N, use_classes);                                   \
-  } while (0)
-  if (d == 256) { if (nmw == 8) LAUNCH(256, 8); else LAUNCH(256, 4); } else LAUNCH(128, 4);
-#undef LAUNCH
-  pm_prof_close(st, pe);
-  return pm_check_launch();
+  return gcl_input_grad_impl(const_cast<uint16_t*>(dh_planes), plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, nullptr,
+                             (hipStream_t)stream);
+}
+// ... with the BatchNorm backward in front of it fused in (GclBn above): `dh_planes` is WRITTEN (the weight gradient reads it)
+extern "C" int pm_gcl_input_grad_bn(const PmBnBwd* nb, uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan,
+                                    int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
+                                    float* dA, pm_stream_t stream) {
+  if (!nb || !nb->h || !nb->du || !nb->mean || !nb->var || !nb->gamma || !nb->beta || !nb->acc3 || !dh_planes || !plan ||
+      !w_frag_t || !dA || N <= 0 || (d != 128 && d != 256) || plane_stride < (int64_t)N * d || (plane_stride & 7) ||
+      ((uintptr_t)dh_planes % 16) || ((uintptr_t)w_frag_t % 16) || ((uintptr_t)dA % 16) || ((uintptr_t)nb->h % 16) ||
+      ((uintptr_t)nb->du % 16) || plane_stride * 6 >= 0x7fffffffLL || (int64_t)N * 4 * d * 4 >= 0x7fffffffLL)
+    return PM_E_INVALID;
+  GclBn b;
+  b.h = nb->h; b.du = nb->du; b.mean = nb->mean; b.var = nb->var; b.gamma = nb->gamma; b.beta = nb->beta; b.acc3 = nb->acc3;
+  b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu;
+  return gcl_input_grad_impl(dh_planes, plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, &b, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -451,12 +451,7 @@ extern "C" int pm_bn_bwd_from_sums(const float* x, const float* dy, int32_t O, i
 // statistics; dgamma, dbeta and the gradient of a bias in front of the norm.
 // (accumulators are replicated PM_BN_REPL times — the producer picks the replica from its row-panel index — so that
 // no address takes more than ~64 serialized fp64 atomics; consumers add the replicas up once per workgroup into LDS)
-__device__ static inline double repl_sum(const double* __restrict__ acc, int nacc, int C, int a, int c) {
-  double t = 0;
-#pragma unroll
-  for (int r = 0; r < PM_BN_REPL; ++r) t += acc[((int64_t)r * nacc + a) * C + c];
-  return t;
-}
+// (pm_repl_sum: common.h)
 __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict__ x, int64_t n4, int C, double count,
                                                         const double* __restrict__ sums, BnCtx ctx,
                                                         const float* __restrict__ res, float* __restrict__ y,
@@ -465,8 +460,8 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
   float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const double mu = repl_sum(sums, 2, C, 0, c) / count;
-    double v = repl_sum(sums, 2, C, 1, c) / count - mu * mu;
+    const double mu = pm_repl_sum(sums, 2, C, 0, c) / count;
+    double v = pm_repl_sum(sums, 2, C, 1, c) / count - mu * mu;
     if (v < 0) v = 0;
     s_m[c] = (float)mu;
     s_sc[c] = rsqrtf((float)v + ctx.eps) * ctx.gamma[c];
@@ -566,7 +561,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
   float* const s_m = sm; float* const s_rs = sm + C; float* const s_ga = sm + 2 * C; float* const s_be = sm + 3 * C;
   float* const s_m0 = sm + 4 * C; float* const s_m1 = sm + 5 * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const double s0 = repl_sum(acc3, 3, C, 0, c), s1 = repl_sum(acc3, 3, C, 1, c);
+    const double s0 = pm_repl_sum(acc3, 3, C, 0, c), s1 = pm_repl_sum(acc3, 3, C, 1, c);
     const double m0 = s0 / count, m1 = s1 / count;
     s_m[c] = ctx.mean[c]; s_rs[c] = rsqrtf(ctx.var[c] + ctx.eps); s_ga[c] = ctx.gamma[c]; s_be[c] = ctx.beta[c];
     s_m0[c] = (float)m0; s_m1[c] = (float)m1;
@@ -574,7 +569,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
       if (dbeta) dbeta[c] += (float)s0;
       if (dgamma) dgamma[c] += (float)s1;
       if (dbias_pre) {
-        const double s2 = repl_sum(acc3, 3, C, 2, c);
+        const double s2 = pm_repl_sum(acc3, 3, C, 2, c);
         const double rstd = 1.0 / sqrt((double)ctx.var[c] + (double)ctx.eps);
         dbias_pre[c] += (float)((double)ctx.gamma[c] * rstd * ((s0 - count * m0) - m1 * s2));
       }
@@ -587,13 +582,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
     float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float rstd = s_rs[c + j], ga = s_ga[c + j];
-      const float xh = (xs[j] - s_m[c + j]) * rstd;
-      float du = ds[j];
-      if (ctx.relu && !(xh * ga + s_be[c + j] > 0.f)) du = 0.f;
-      o[j] = ga * rstd * (du - s_m0[c + j] - xh * s_m1[c + j]);
-    }
+    for (int j = 0; j < 4; ++j)
+      o[j] = pm_bn_bwd_elem(xs[j], ds[j], s_m[c + j], s_rs[c + j], s_ga[c + j], s_be[c + j], s_m0[c + j], s_m1[c + j], ctx.relu);
     if (dx_planes) pm_store_planes4(dx_planes, plane_stride, i * 4, o[0], o[1], o[2], o[3]);   // GEMM operand planes
     else reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -620,6 +610,23 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
                      (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride);
+  return pm_check_launch();
+}
+
+// the column sums alone (the apply half then runs inside the consumer: pm_gcl_input_grad_bn, gcl.hip)
+extern "C" int pm_bn_bwd_sums(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
+                              float eps, const float* gamma, const float* beta, int relu, double* acc3, pm_stream_t stream) {
+  if (!x || !dy || !mean || !var || !gamma || !beta || !acc3 || O <= 0 || C <= 0 || (C % 4) != 0 || C > 4096) return PM_E_INVALID;
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BnCtx ctx = {mean, var, gamma, beta, eps, relu};
+  int nc = (int)pm_cdiv(O, 32);
+  if (nc > BN_MAX_CHUNKS) nc = BN_MAX_CHUNKS;
+  if (nc < 1) nc = 1;
+  const int rpc = (int)pm_cdiv(O, nc);
+  nc = (int)pm_cdiv(O, rpc);
+  hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3,
+                     pm_det_gate(st));
   return pm_check_launch();
 }
 

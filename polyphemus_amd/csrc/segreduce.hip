@@ -543,9 +543,13 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   // LDS tables are flushed with global atomics (measured: 48 us; 4-wave workgroups x 768: 59 us; x 1024: 61 us)
   // (deterministic mode: one wave per workgroup — several waves would race on the LDS table —, 512 workgroups)
   unsigned* const gate = pm_det_gate(st);
-  const int threads = gate ? 64 : (N >= 4096 ? 1024 : 256);
+  // (PM_SEG_WAVES / PM_SEG_BLOCKS: development overrides of the workgroup shape, profiles/LOG.md)
+  static const int dev_waves = getenv("PM_SEG_WAVES") ? atoi(getenv("PM_SEG_WAVES")) : 0;
+  static const int dev_blocks = getenv("PM_SEG_BLOCKS") ? atoi(getenv("PM_SEG_BLOCKS")) : 0;
+  const int threads = gate ? 64 : (N >= 4096 ? (dev_waves > 0 && dev_waves <= 16 ? dev_waves * 64 : 1024) : 256);
   int nblk = (int)pm_cdiv(N, threads / 64);
-  if (nblk > (gate ? 512 : 256)) nblk = gate ? 512 : 256;
+  const int cap = gate ? 512 : (dev_blocks > 0 ? dev_blocks : 256);
+  if (nblk > cap) nblk = cap;
   const dim3 grid(nblk), block(threads);
   int xcd_nodes = 0;                                    // nodes per XCD, a multiple of the waves per workgroup
   if (seg_xcd_aware() && nblk >= 16 && (nblk & 7) == 0) xcd_nodes = (int)pm_cdiv(pm_cdiv(N, 8), threads / 64) * (threads / 64);

@@ -38,6 +38,8 @@ struct StepCfg {
   bool fused_heads;            // PM_FUSED_HEADS=1: the head chains as one persistent launch each (heads.hip) instead of ~14 launches —
                                // built, parity-tested, and SLOWER (5.19 against 5.08 ms per step: profiles/LOG.md); off
   bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
+  bool dagg_bn;                // PM_DAGG_BN=0: the norm backward of a GCN layer as its own pass (pm_bn_bwd_fused) instead of inside the
+                               // input gradient's prologue (pm_gcl_input_grad_bn; d in {128, 256})
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -57,6 +59,7 @@ static StepCfg read_cfg() {
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
   k.late_wgrads = flag("PM_LATE_WGRADS", true);
   k.dw_side = flag("PM_DW_SIDE", false);
+  k.dagg_bn = flag("PM_DAGG_BN", true);
   k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
@@ -497,7 +500,15 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     uint16_t* const dhp = dhp2[i & 1];
     const int dw_site = dws ? (BR_GCL_DW0 + (i & 1)) : BR_SITES;
     if (dws) branch_join(c, dw_site);        // (the weight gradient of layer i+2 read the dh planes this call rewrites)
-    if (c.bn)
+    // the norm backward inside the input gradient (gcl.hip k_gcl_dagg<.., true>): no pass of its own over h, dx and the planes
+    const bool in_dagg = c.bn && c.compact && c.planes && sv.Wft && (d == 128 || d == 256) && gcl_fused_on() &&
+                         gcl_fits(N, d, 1) && cfg().dagg_bn && !dws;
+    double* const acc3 = sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL;
+    const bool sums_ready = i < c.L - 1 && fuse_sums;
+    if (in_dagg) {
+      if (!sums_ready)
+        RUN(pm_bn_bwd_sums(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, acc3, c.st));
+    } else if (c.bn)
       RUN(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
                             c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
                             sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps, (i < c.L - 1 && fuse_sums) ? 1 : 0, c.st));
@@ -540,7 +551,13 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         q.B = (const float*)(sv.Wp + (g.weight[i] - sv.wp_base)); q.b_plane_stride = sv.wp_stride;
         if (sv.Wft) q.b_frag = sv.Wft + (int64_t)i * sv.wf_stride;
       }
-      if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
+      if (in_dagg) {
+        PmBnBwd nb;
+        nb.h = sv.h[i]; nb.du = dx; nb.mean = sv.mean[i]; nb.var = sv.var[i]; nb.gamma = c.P + bn.w; nb.beta = c.P + bn.b;
+        nb.acc3 = acc3; nb.dgamma = c.G + bn.w; nb.dbeta = c.G + bn.b; nb.dbias_pre = c.G + g.bias[i]; nb.eps = 1e-5f; nb.relu = 1;
+        RUN(pm_gcl_input_grad_bn(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
+                                   cfg().no_classes ? 0 : 1, dA, c.st));
+      } else if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
         RUN(pm_gcl_input_grad_fused(dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                       cfg().no_classes ? 0 : 1, dA, c.st));
       else
@@ -1192,7 +1209,8 @@ extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
   info[4] = c.N; info[5] = c.E; info[6] = c.Gn; info[7] = c.B;
   // the EFFECTIVE switches (read from the environment at load / pm_vae_step_reload_switches, not at call time)
   info[8] = cfg().fused_ce ? 1 : 0; info[9] = cfg().side_stream; info[10] = pm_det_on(); info[11] = cfg().gcl_fused ? 1 : 0;
-  info[12] = info[13] = info[14] = info[15] = 0;
+  info[12] = cfg().dagg_bn ? 1 : 0;            // (the norm backward of the GCN layers inside the input gradient kernel)
+  info[13] = info[14] = info[15] = 0;
   return PM_OK;
 }
 // Model outputs of the last forward (the arena keeps them until the next pm_vae_step_forward): asynchronous

@@ -233,6 +233,33 @@ def gcl_input_grad_fused(dh_planes, plan: Plan, d: int, w_frag_t, use_classes: b
     return dA
 
 
+class _BnBwd(ctypes.Structure):          # PmBnBwd (include/polyphemus_hip.h)
+    _fields_ = [(k, ctypes.c_void_p) for k in ("h", "du", "mean", "var", "gamma", "beta", "acc3", "dgamma", "dbeta", "dbias_pre")] + \
+               [("eps", ctypes.c_float), ("relu", ctypes.c_int32)]
+
+
+def bn_bwd_sums(h, du, mean, var, gamma, beta, eps: float = 1e-5, relu: bool = True):
+    """`pm_bn_bwd_sums`: the three column sums of the norm backward, fp64 [PM_BN_REPL, 3, C]."""
+    O, Cc = h.shape
+    acc3 = torch.zeros(8, 3, Cc, dtype=torch.float64, device=h.device)
+    call("pm_bn_bwd_sums", ptr(h), ptr(du), O, Cc, ptr(mean), ptr(var), float(eps), ptr(gamma), ptr(beta), 1 if relu else 0,
+         ptr(acc3), stream())
+    return acc3
+
+
+def gcl_input_grad_bn(h, du, mean, var, gamma, beta, acc3, plan: Plan, w_frag_t, dgamma=None, dbeta=None, dbias_pre=None,
+                      eps: float = 1e-5, relu: bool = True, use_classes: bool = True):
+    """`pm_gcl_input_grad_bn`: the norm backward inside the input gradient; returns (dA' [N, 4d], dh planes int16 [3, N*d])."""
+    N, d = h.shape
+    dA = torch.empty(N, 4 * d, dtype=F32, device=h.device)
+    planes = torch.empty(3, N * d, dtype=torch.int16, device=h.device)
+    nb = _BnBwd(ptr(h), ptr(du), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(acc3), ptr(dgamma), ptr(dbeta), ptr(dbias_pre),
+                float(eps), 1 if relu else 0)
+    call("pm_gcl_input_grad_bn", ctypes.addressof(nb), ptr(planes), planes.shape[1], ptr(plan.buf), N, plan.E, plan.G, d,
+         ptr(w_frag_t), 1 if use_classes else 0, ptr(dA), stream())
+    return dA, planes
+
+
 def gcl_weight_grad_fused(a_planes, dh_planes, plan: Plan, d: int, dW, use_classes: bool = True):
     """`pm_gcl_weight_grad_fused`: dW [7d, d] += A'^T dh per track group (stacked [W_t; W_4; W_5; root] rows);
     `a_planes` int16 [3, N*4d], `dh_planes` int16 [3, N*d]."""

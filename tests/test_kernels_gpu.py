@@ -932,6 +932,56 @@ def test_gcl_input_grad_fused_equals_grouped_product(d, B):
     assert torch.equal(dA2[keep], dA1[keep]) and bool(torch.isfinite(dA2).all())
 
 
+@pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 1), (256, "split")])
+def test_gcl_input_grad_with_the_norm_backward_inside_equals_the_two_calls(d, B):
+    """`pm_gcl_input_grad_bn` (the BatchNorm backward in the prologue of the input-gradient kernel) against
+    `pm_bn_bwd_fused` (planes out) followed by `pm_gcl_input_grad_fused`: the same dh planes, dA', dgamma, dbeta and bias
+    gradient, bit for bit, with the column sums of `pm_bn_bwd_sums`; and against an fp64 statement of the norm backward."""
+    from polyphemus_amd._lib import call, ptr, stream
+    if B == "split":
+        cpu = synthetic_batch(256, 2, p=0.25, seed=1235)
+    else:
+        cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=19)
+    b, plan = make_plan(cpu)
+    N = cpu.num_nodes
+    torch.manual_seed(6)
+    h = torch.randn(N, d, device=DEV) * 1.5 + 0.3
+    du = torch.randn(N, d, device=DEV)
+    gamma, beta = torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV) * 0.2
+    mean, var = h.mean(0), h.var(0, unbiased=False)
+    W = torch.randn(7 * d, d, device=DEV) / d ** 0.5
+    Wft = ops.split_planes_frag(W, 0)
+    acc3 = ops.bn_bwd_sums(h, du, mean, var, gamma, beta)
+    # the two calls
+    g0 = [torch.full((d,), 0.25, device=DEV) for _ in range(3)]
+    planes0 = torch.zeros(3, N * d, dtype=torch.int16, device=DEV)
+    call("pm_bn_bwd_fused", ptr(h), ptr(du), N, d, ptr(mean), ptr(var), 1e-5, ptr(gamma), ptr(beta), 1, ptr(g0[0]), ptr(g0[1]),
+         ptr(g0[2]), None, ptr(acc3), ptr(planes0), N * d, 1, stream())
+    dA0 = ops.gcl_input_grad_fused(planes0, plan, d, Wft)
+    # the one call
+    g1 = [torch.full((d,), 0.25, device=DEV) for _ in range(3)]
+    dA1, planes1 = ops.gcl_input_grad_bn(h, du, mean, var, gamma, beta, acc3, plan, Wft, dgamma=g1[0], dbeta=g1[1], dbias_pre=g1[2])
+    assert torch.equal(planes1, planes0)
+    dst, et = cpu.edge_index[1], cpu.edge_type
+    on, nx = torch.zeros(N, dtype=torch.bool), torch.zeros(N, dtype=torch.bool)
+    on[dst[et == 4]] = True
+    nx[dst[et == 5]] = True
+    keep = torch.ones(N, 4, d, dtype=torch.bool)
+    keep[~on, 1] = False
+    keep[~nx, 2] = False
+    keep = keep.view(N, 4 * d).to(DEV)
+    assert torch.equal(dA1[keep], dA0[keep])
+    for a, b_ in zip(g1, g0):
+        assert torch.equal(a, b_)
+    # fp64 statement of the norm backward (autograd of relu(BN(h)) w.r.t. h)
+    hd = h.double().requires_grad_(True)
+    xh = (hd - hd.mean(0)) / torch.sqrt(hd.var(0, unbiased=False) + 1e-5)
+    torch.relu(xh * gamma.double() + beta.double()).backward(du.double())
+    got = sum(planes1[k].view(torch.bfloat16).double() for k in range(3)).view(N, d)
+    assert rel_err(got, hd.grad) < 5e-6
+    assert rel_err(g1[1] - 0.25, (du.double() * (xh * gamma.double() + beta.double() > 0)).sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("d,B", [(128, 40), (256, 40), (256, 3), (128, 1), (512, 40), (512, 1)])
 def test_gcl_weight_grad_fused_equals_grouped_product(d, B):
     """`pm_gcl_weight_grad_fused` (128x128 tiles, loader waves + LDS ring, K slices by atomics) against the grouped planes

@@ -449,10 +449,23 @@ __global__ void __launch_bounds__(256) k_plan_finish(PlanArgs a) {
   d_class_scan(a.bh, a.nb_cls, a.N, a.trk_cnt);
 }
 
+// (pm_plan_build_marked: the same, and `after_count` — if not null — is recorded behind the counting launch, from where on
+//  the token histogram is final: the step starts the embedding tables there while the rest of the plan is built beside them)
+int pm_plan_build_marked(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
+                         const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
+                         const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
+                         int32_t* plan, hipStream_t stream, hipEvent_t after_count);
 extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
                              const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
                              const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
                              int32_t* plan, pm_stream_t stream) {
+  return pm_plan_build_marked(edge_index, edge_type, edge_dist, bars, batch, is_drum, tokens, n_bars, n_slots, N, E, G, plan,
+                              (hipStream_t)stream, nullptr);
+}
+int pm_plan_build_marked(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist,
+                         const int64_t* bars, const int64_t* batch, const uint8_t* is_drum,
+                         const int32_t* tokens, int32_t n_bars, int32_t n_slots, int32_t N, int32_t E, int32_t G,
+                         int32_t* plan, hipStream_t stream, hipEvent_t after_count) {
   if (n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   if (!edge_index || !edge_type || !edge_dist || !bars || !batch || !is_drum || !plan || N <= 0 || E <= 0 || G <= 0)
     return PM_E_INVALID;
@@ -504,6 +517,7 @@ extern "C" int pm_plan_build(const int64_t* edge_index, const int32_t* edge_type
     hipLaunchKernelGGL(k_zero_regions, dim3(nb), dim3(256), 0, st, z);
   }
   hipLaunchKernelGGL(k_plan_count, dim3(a.nb_e + a.nb_n + a.nb_tok), dim3(T), 0, st, a);                 // 2
+  if (after_count && hipEventRecord(after_count, st) != hipSuccess) return PM_E_LAUNCH;
   {                                                                                                        // 3
     ScanArrays sc;
     sc.p[0] = a.rowptr; sc.n[0] = (int64_t)N * PM_N_REL + 1;

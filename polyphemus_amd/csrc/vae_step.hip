@@ -16,6 +16,9 @@
 #include <string.h>
 #include <mutex>
 
+int pm_plan_build_marked(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist, const int64_t* bars,
+                         const int64_t* batch, const uint8_t* is_drum, const int32_t* tokens, int32_t n_bars, int32_t n_slots,
+                         int32_t N, int32_t E, int32_t G, int32_t* plan, hipStream_t stream, hipEvent_t after_count);   // plan.hip
 namespace {
 
 // A/B switches of the step, read ONCE (first use): which kernel set the measured path takes never changes inside a run.
@@ -40,6 +43,7 @@ struct StepCfg {
   bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
   bool dagg_bn;                // PM_DAGG_BN=0: the norm backward of a GCN layer as its own pass (pm_bn_bwd_fused) instead of inside the
                                // input gradient's prologue (pm_gcl_input_grad_bn; d in {128, 256})
+  bool plan_side;              // PM_PLAN_SIDE=0: the plan build on the caller's stream in front of the content encoder (see forward())
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -60,6 +64,7 @@ static StepCfg read_cfg() {
   k.late_wgrads = flag("PM_LATE_WGRADS", true);
   k.dw_side = flag("PM_DW_SIDE", false);
   k.dagg_bn = flag("PM_DAGG_BN", true);
+  k.plan_side = flag("PM_PLAN_SIDE", true);
   k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
@@ -169,7 +174,7 @@ struct Ctx {
 // capturable.  Norms on the branch use their own reduction scratch.
 // sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
 // structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
-enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_SITES };
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_PLAN_COUNT, BR_SITES };
 struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES], idle; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
@@ -226,6 +231,12 @@ struct BranchScope {
     if (!b) return;
     if (hipEventRecord(b->join[at], b->st) != hipSuccess) c.chk(PM_E_LAUNCH);
     c.s->br_open |= 1u << at;
+  }
+  // ... recorded by the callee somewhere inside its launches (pm_plan_build_marked): the event of join point `at`
+  hipEvent_t mark_inside(int at) {
+    if (!b) return nullptr;
+    c.s->br_open |= 1u << at;
+    return b->join[at];
   }
   void end() {
     if (!b) return;
@@ -631,22 +642,37 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   BranchScope br(c, BR_ENC_FWD);
   const int S = c.S;                                   // token-level tensors are [N, S, .] (active slots only)
   const bool rows_w_ok = gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, S) && !cfg().no_rows_w;
-  br.pause();
-  // ---------------- the batch's plan (CSR / CSC, row lists, histograms: plan.hip) on the caller's stream, issued first
+  // ---------------- the batch's plan (CSR / CSC, row lists, histograms: plan.hip), issued first.  The content encoder's
+  // first launches (embedding tables, gather, chord product: ~110 us) need only the token histogram, which the plan's
+  // counting launch leaves behind; the remaining six launches of the plan (~50 us) and the encoder's weight preparation
+  // run BESIDE them on the second stream and are joined in front of the first GCL layer (PM_PLAN_SIDE=0: the plan on the
+  // caller's stream, in front of everything, as before).
+  const bool plan_side = cfg().plan_side;
+  if (!plan_side) br.pause();
   if (run)
-    RUN(pm_plan_build(s.bt.edge_index, s.bt.edge_type, s.bt.edge_dist, s.bt.bars, s.bt.batch, s.bt.is_drum, s.bt.tokens,
-                        nb, s.bt.n_slots, N, c.E, Gn, const_cast<int32_t*>(s.plan), c.st));
+    RUN(pm_plan_build_marked(s.bt.edge_index, s.bt.edge_type, s.bt.edge_dist, s.bt.bars, s.bt.batch, s.bt.is_drum, s.bt.tokens,
+                               nb, s.bt.n_slots, N, c.E, Gn, const_cast<int32_t*>(s.plan), c.st,
+                               plan_side ? br.mark_inside(BR_PLAN_COUNT) : nullptr));
+  // chord encoder Wc [d, 15d]: kind 0 for the forward (long-K kernel, columns [0, S*d)), kind 1 for its input gradient
+  s.wf_enc = s.wf_enc_t = s.wf_dec = s.wf_dec_t = nullptr;
+  const bool enc_frag = rows_w_ok && S < PM_N_SLOTS;
+  if (enc_frag) {
+    s.wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
+    s.wf_enc_t = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
+  }
+  auto chord_planes = [&](int kind) {
+    if (enc_frag)
+      RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, kind, 1, (int64_t)PM_N_SLOTS * d * d,
+                                 (int64_t)PM_N_SLOTS * d * d * 3, kind ? s.wf_enc_t : s.wf_enc, c.st));
+  };
+  if (plan_side) {                                     // (the forward's planes on the caller's stream: its chord product is ~50 us away)
+    br.pause();
+    chord_planes(0);
+  }
   br.resume();
   {
-    // chord encoder Wc [d, 15d]: kind 0 for the forward (long-K kernel, columns [0, S*d)), kind 1 for its input gradient
-    s.wf_enc = s.wf_enc_t = s.wf_dec = s.wf_dec_t = nullptr;
-    if (rows_w_ok && S < PM_N_SLOTS) {
-      s.wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
-      s.wf_enc_t = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
-      for (int kind = 0; kind < 2; ++kind)
-        RUN(pm_split_planes_frag(c.P + Y.enc_chord.w, d, PM_N_SLOTS * d, kind, 1, (int64_t)PM_N_SLOTS * d * d,
-                                   (int64_t)PM_N_SLOTS * d * d * 3, kind ? s.wf_enc_t : s.wf_enc, c.st));
-    }
+    if (!plan_side) chord_planes(0);
+    chord_planes(1);
     gcn_prepare(c, Y.enc_gcn, s.eg);
     br.mark(BR_WPREP);
   }
@@ -700,6 +726,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   float* const zgd_buf = dropping ? ar.f((size_t)B * d) : nullptr;
   uint16_t* const wf_enc = s.wf_enc;
   if (run) {
+    branch_join(c, BR_PLAN_COUNT);                     // the token histogram of the plan (second stream) is final
     RUN(pm_embed_tables(c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                           c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_d.b,
                           c.P + Y.enc_bn_nd.w, c.P + Y.enc_bn_nd.b, c.P + Y.enc_bn_dur.w, c.P + Y.enc_bn_dur.b,
@@ -707,7 +734,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                           c.Bf + Y.enc_bn_dur.rm, c.Bf + Y.enc_bn_dur.rv, pv.tok_hist, d, 1, 1e-5f, 0.1f, tables,
                           s.emb_stats, c.st));
     RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
-    branch_join(c, BR_WPREP);                          // weight planes and distance tables are ready
+    if (!plan_side) branch_join(c, BR_WPREP);          // weight planes and distance tables are ready
     if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
     else {             // x0 = relu(X[:, :S] @ Wc[:, :S*d]^T + (bias + all-PAD tail slots, one vector per node group))
       if (wf_enc) {                // long-K kernel of linear.hip: Wc [d, 15d] as fragment-major planes (kind 0), columns [0, S*d)
@@ -719,6 +746,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     }
     s.x0d = drop(c, s.x0, N, d, SITE_ENC_CHORD, seed_enc, x0d_buf);                          // model.py:389-390 (row = node)
   }
+  if (run) branch_join(c, BR_WPREP);                   // the plan, the GCL weight planes and the distance table are ready
   float* xL = gcn_forward(c, dropping ? x0d_buf : s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
   decoder_prep_and_structure_encoder();                // (second stream; issued while the GPU works through the encoder's layers)
   s.g = ar.f(N); s.gm = ar.f(4); s.gv = ar.f(4); s.alpha = ar.f(N); s.pooled = ar.f((size_t)Gn * d);

@@ -282,6 +282,12 @@ extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, 
   return pm_check_launch();
 }
 
+// workgroup size of the two kernels below for O >= 128 rows (PM_BN_SMALL_THREADS: development A/B, profiles/LOG.md)
+static int bn_small_threads() {
+  static const int t = getenv("PM_BN_SMALL_THREADS") ? atoi(getenv("PM_BN_SMALL_THREADS")) : 1024;
+  return (t == 256 || t == 512) ? t : 1024;
+}
+
 // ---------------------------------------------------------------- small batches: one launch per norm and direction
 // The norms of the heads run over B = 256 rows (model.py:475,638): three launches of ~5 us each (column sums, finalize,
 // apply) for 0.25-0.5 MB of data.  Here a workgroup owns 32 columns for all rows: RG row groups x 32 lanes (RG = 32 from 128
@@ -364,7 +370,7 @@ extern "C" int pm_bn_small_fwd(const float* x, int32_t O, int32_t C, float eps, 
                                float* running_var, float momentum, pm_stream_t stream) {
   if (!x || !gamma || !beta || !y || !mean || !var || O <= 0 || O > PM_BN_SMALL_MAX_ROWS || C <= 0) return PM_E_INVALID;
   BnCtx ctx = {nullptr, nullptr, gamma, beta, eps, relu};
-  hipLaunchKernelGGL(k_bn_small_fwd, dim3(pm_cdiv(C, 32)), dim3(O >= 128 ? 1024 : 256), 0, (hipStream_t)stream, x, O, C, ctx, residual, y,
+  hipLaunchKernelGGL(k_bn_small_fwd, dim3(pm_cdiv(C, 32)), dim3(O >= 128 ? bn_small_threads() : 256), 0, (hipStream_t)stream, x, O, C, ctx, residual, y,
                      mean, var, running_mean, running_var, momentum);
   return pm_check_launch();
 }
@@ -373,7 +379,7 @@ extern "C" int pm_bn_small_bwd(const float* x, const float* dy, int32_t O, int32
                                float* dbias_pre, float* dx, pm_stream_t stream) {
   if (!x || !dy || !mean || !var || !gamma || !beta || !dx || O <= 0 || O > PM_BN_SMALL_MAX_ROWS || C <= 0) return PM_E_INVALID;
   BnCtx ctx = {mean, var, gamma, beta, eps, relu};
-  hipLaunchKernelGGL(k_bn_small_bwd, dim3(pm_cdiv(C, 32)), dim3(O >= 128 ? 1024 : 256), 0, (hipStream_t)stream, x, dy, O, C, ctx, dgamma,
+  hipLaunchKernelGGL(k_bn_small_bwd, dim3(pm_cdiv(C, 32)), dim3(O >= 128 ? bn_small_threads() : 256), 0, (hipStream_t)stream, x, dy, O, C, ctx, dgamma,
                      dbeta, dbias_pre, dx);
   return pm_check_launch();
 }
@@ -452,6 +458,10 @@ extern "C" int pm_bn_bwd_from_sums(const float* x, const float* dy, int32_t O, i
 // (accumulators are replicated PM_BN_REPL times — the producer picks the replica from its row-panel index — so that
 // no address takes more than ~64 serialized fp64 atomics; consumers add the replicas up once per workgroup into LDS)
 // (pm_repl_sum: common.h)
+#ifndef BN_APPLY_U
+#define BN_APPLY_U 0                      // pieces of x requested ahead of the sums reduction: measured 4.950 (4) / 4.946 (2) against 4.934 ms
+                                          // per step (0) — other workgroups already cover that latency; left off
+#endif
 __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict__ x, int64_t n4, int C, double count,
                                                         const double* __restrict__ sums, BnCtx ctx,
                                                         const float* __restrict__ res, float* __restrict__ y,
@@ -459,6 +469,21 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
                                                         float momentum) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
   float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
+  // (BN_APPLY_U > 0: a thread's first pieces of x and of the residual are requested BEFORE the workgroup reduces the
+  //  replicated sums — 16 fp64 loads per column — so that the reduction's latency has loads in flight under it)
+  constexpr int U = BN_APPLY_U;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4 xq[U > 0 ? U : 1], rq[U > 0 ? U : 1];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = i0 + u * stride;
+    xq[u] = make_float4(0.f, 0.f, 0.f, 0.f); rq[u] = xq[u];
+    if (i < n4) {
+      xq[u] = reinterpret_cast<const float4*>(x)[i];
+      if (res) rq[u] = reinterpret_cast<const float4*>(res)[i];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const double mu = pm_repl_sum(sums, 2, C, 0, c) / count;
     double v = pm_repl_sum(sums, 2, C, 1, c) / count - mu * mu;
@@ -477,9 +502,8 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
     }
   }
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  auto apply = [&](int64_t i, float4 xv, float4 rv) {
     const int c = (int)((i * 4) % C);
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
     const float4 m = *reinterpret_cast<const float4*>(s_m + c), sc = *reinterpret_cast<const float4*>(s_sc + c);
     const float4 be = *reinterpret_cast<const float4*>(s_be + c);
     float o[4] = {(xv.x - m.x) * sc.x + be.x, (xv.y - m.y) * sc.y + be.y, (xv.z - m.z) * sc.z + be.z,
@@ -488,11 +512,19 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
     }
-    if (res) {
-      const float4 rv = reinterpret_cast<const float4*>(res)[i];
-      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-    }
+    if (res) { o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
     reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = i0 + u * stride;
+    if (i < n4) apply(i, xq[u], rq[u]);
+  }
+  for (int64_t i = i0 + U * stride; i < n4; i += stride) {
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = reinterpret_cast<const float4*>(res)[i];
+    apply(i, xv, rv);
   }
 }
 extern "C" int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, float eps,
@@ -510,12 +542,13 @@ extern "C" int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const dou
 }
 
 // column sums (du, du*xhat, xhat) of the backward straight into acc[PM_BN_REPL][3][C] (fp64 atomics)
-__global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* __restrict__ x,
+// (eight waves per workgroup, two rows of a wave in flight: 255 x 4 waves read the 33 MB of a 16 k x 256 layer at 1.9 TB/s — 17 us)
+__global__ void __launch_bounds__(512) k_colreduce_rows_bwd_atomic(const float* __restrict__ x,
                                                                    const float* __restrict__ dy, int O, int C,
                                                                    BnCtx ctx, int rows_per_chunk,
                                                                    double* __restrict__ acc3, unsigned* gate) {
-  __shared__ double sh[4][64][12];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double sh[8][64][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
   const bool ok = c < C;
   double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -531,13 +564,26 @@ __global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* 
   int r1 = r0 + rows_per_chunk;
   if (r1 > O) r1 = O;
   if (ok) {
-    for (int r = r0 + wave; r < r1; r += 4) {
+    for (int r = r0 + wave; r < r1; r += 2 * nw) {
+      const int rb = r + nw;
+      const bool two = rb < r1;
       const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * C + c);
       const float4 dv = *reinterpret_cast<const float4*>(dy + (int64_t)r * C + c);
+      float4 xw = make_float4(0.f, 0.f, 0.f, 0.f), dw = xw;
+      if (two) {
+        xw = *reinterpret_cast<const float4*>(x + (int64_t)rb * C + c);
+        dw = *reinterpret_cast<const float4*>(dy + (int64_t)rb * C + c);
+      }
       bn_acc<1>(xv.x, dv.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4], acc[8]);
       bn_acc<1>(xv.y, dv.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5], acc[9]);
       bn_acc<1>(xv.z, dv.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6], acc[10]);
       bn_acc<1>(xv.w, dv.w, m[3], rs[3], ga[3], be[3], ctx.relu, acc[3], acc[7], acc[11]);
+      if (two) {
+        bn_acc<1>(xw.x, dw.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4], acc[8]);
+        bn_acc<1>(xw.y, dw.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5], acc[9]);
+        bn_acc<1>(xw.z, dw.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6], acc[10]);
+        bn_acc<1>(xw.w, dw.w, m[3], rs[3], ga[3], be[3], ctx.relu, acc[3], acc[7], acc[11]);
+      }
     }
   }
 #pragma unroll
@@ -547,8 +593,11 @@ __global__ void __launch_bounds__(256) k_colreduce_rows_bwd_atomic(const float* 
   if (wave == 0 && ok) {
     double* dst = acc3 + (int64_t)(blockIdx.y % PM_BN_REPL) * 3 * C;
 #pragma unroll
-    for (int j = 0; j < 12; ++j)
-      atomicAdd(&dst[(int64_t)(j >> 2) * C + c + (j & 3)], sh[0][lane][j] + sh[1][lane][j] + sh[2][lane][j] + sh[3][lane][j]);
+    for (int j = 0; j < 12; ++j) {
+      double t = 0;
+      for (int w = 0; w < nw; ++w) t += sh[w][lane][j];
+      atomicAdd(&dst[(int64_t)(j >> 2) * C + c + (j & 3)], t);
+    }
   }
   pm_turn_leave_block(gate);
 }
@@ -605,7 +654,7 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
   const int rpc = (int)pm_cdiv(O, nc);
   nc = (int)pm_cdiv(O, rpc);
   if (!sums_ready)
-    hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3,
+    hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(512), 0, st, x, dy, O, C, ctx, rpc, acc3,
                        pm_det_gate(st));
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
@@ -625,7 +674,7 @@ extern "C" int pm_bn_bwd_sums(const float* x, const float* dy, int32_t O, int32_
   if (nc < 1) nc = 1;
   const int rpc = (int)pm_cdiv(O, nc);
   nc = (int)pm_cdiv(O, rpc);
-  hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(256), 0, st, x, dy, O, C, ctx, rpc, acc3,
+  hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(512), 0, st, x, dy, O, C, ctx, rpc, acc3,
                      pm_det_gate(st));
   return pm_check_launch();
 }

@@ -36,6 +36,12 @@
 #ifndef GCL_WHATIF
 #define GCL_WHATIF 0
 #endif
+#ifndef GCL_CONS_STORE
+#define GCL_CONS_STORE 0      // 1: the A' planes leave through the MFMA waves (the fragments they read for k-step ks ARE 16-byte
+                              // pieces of the plane rows; wave ks mod NCW stores them) instead of the producer waves re-reading the
+                              // finished image.  Bit-identical planes, and 126 us per launch against 66: vmcnt retires in order,
+                              // so every weight-fragment wait of the MFMA chain then includes a store's write latency
+#endif
 // development (tools/build_variants.py): GCL_PACE = n puts n x 16 idle issue cycles of the MFMA wave behind every MFMA of
 // k_gcl_fwd, so that the wave does not sit in the SIMD's issue stage with an MFMA the busy matrix pipe cannot take
 #ifndef GCL_PACE
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   // write latency into the gather's wait.  Rows past the end of the list: out-of-range offset, the store is dropped.
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
   auto store_planes = [&](int c) {
-    if (!g.planes || GCL_WHATIF == 5) return;                   // (5: timing what-if without the A' plane stores)
+    if (!g.planes || GCL_WHATIF == 5 || GCL_CONS_STORE) return; // (5: timing what-if without the A' plane stores)
     const int blk = chunk_blk(c), half = c % NCH;
     const char* img = img0 + (c & 1) * IMG;
     const int pt = tid - NCW * 64, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
@@ -362,10 +368,15 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   __syncthreads();
   STAMP();
   // (two copies of the loop, picked once: a half tile — tile_order.h — has no second 32-row block to multiply)
+  // A' planes (GCL_CONS_STORE): the rows of this lane's fragments and the plane resource
+  const __amdgpu_buffer_rsrc_t cprs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
+  const int cn0 = sNode[li], cn1 = sNode[32 + li];
+  const int cps_b = (int)(g.plane_stride * 2);
   auto consume = [&](auto ni_tag) {
     constexpr int NI = decltype(ni_tag)::value;
     for (int c = 0; c < nchunk; ++c) {
       const char* img = img0 + (c & 1) * IMG;
+      const int pblk = chunk_blk(c), phalf = c % NCH;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         bf16x8 a[3][NI];
@@ -376,6 +387,16 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
             const int rr = i * 32 + li;
             a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
           }
+        if (GCL_CONS_STORE && GCL_WHATIF != 5 && g.planes && (ks % NCW) == wave) {     // (wave-uniform)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int n = i ? cn1 : cn0;
+            const int off = n >= 0 ? (n * 4 * D + pblk * D + phalf * CH + (ks * 2 + lh) * 8) * 2 : GCL_OOB;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a[p][i]), cprs, n >= 0 ? off + p * cps_b : GCL_OOB, 0, GCL_PLANE_AUX);
+          }
+        }
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
         for (int t6 = 0; t6 < 6; ++t6)

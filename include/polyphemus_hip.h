@@ -221,6 +221,9 @@ typedef struct PmBnBwd {
   const double* acc3;    /* [PM_BN_REPL][3][d] column sums of du', du' * xhat, xhat */
   float* dgamma; float* dbeta; float* dbias_pre; /* [d] += or NULL */
   float eps; int32_t relu; /* relu != 0: the norm is followed by a ReLU (du' = du * [BN(h) > 0]) */
+  int32_t add_residual;  /* != 0: the self block of dA' leaves as dA'[n, 3d:4d] + du[n] — the residual path of
+                            x_i = x_{i-1} + relu(BN(h)), so that pm_segreduce_bwd(_norm) runs with dres = NULL */
+  int32_t reserved;
 } PmBnBwd;
 int pm_gcl_input_grad_bn(const PmBnBwd* norm, uint16_t* dh_planes /* 3 planes [N,d], written */, int64_t plane_stride,
                          const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t,

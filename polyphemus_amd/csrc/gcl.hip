@@ -508,7 +508,7 @@ namespace {
 struct GclBn {
   const float* h; const float* du; const float* mean; const float* var; const float* gamma; const float* beta;
   const double* acc3; float* dgamma; float* dbeta; float* dbias_pre;
-  double count; float eps; int relu;
+  double count; float eps; int relu, add_res;
 };
 }  // namespace
 template <int D, int NMW, bool BNF>
@@ -589,17 +589,29 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
         }
       }
     }
+    // BNF with add_res: the self block leaves as dA'[n, self] + du[n] — the residual gradient of x_i = x_{i-1} + relu(BN(h))
+    // (model.py:203-206) that the segment-reduce backward would otherwise read as a stream of its own and add to the same value
+    const bool add_res = BNF && bn.add_res;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNF ? bn.du : nullptr), 0, add_res ? GCL_OOB : 0, 0x00020000);
 #pragma unroll 1
     for (int qb = 0; qb < nblk; ++qb) {
       __syncthreads();                                         // consumers: stage free -> they fill it
+      float4 rv[NR];
+      const bool addq = add_res && qb == nblk - 1;             // (the self block is the last one)
+      if (addq) {                                              // (requested while the MFMA waves fill the stage)
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+          rv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(urs, node[k] >= 0 ? (node[k] * D + c4 * 4) * 4 : GCL_OOB, 0, 0));
+      }
       __syncthreads();                                         // stage holds block qb
       STAMP2();
       const int blk = blk_of(qb);
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         const int rr = r0 + k * 4 * RPW;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(sC + rr * D + c4 * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(v, crs, node[k] >= 0 ? (int)(((int64_t)node[k] * 4 * D + blk * D + c4 * 4) * 4) : GCL_OOB, 0, 0);
+        float4 f = *reinterpret_cast<const float4*>(sC + rr * D + c4 * 4);
+        if (addq) { f.x += rv[k].x; f.y += rv[k].y; f.z += rv[k].z; f.w += rv[k].w; }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), crs, node[k] >= 0 ? (int)(((int64_t)node[k] * 4 * D + blk * D + c4 * 4) * 4) : GCL_OOB, 0, 0);
       }
       STAMP2();
     }
@@ -793,7 +805,7 @@ extern "C" int pm_gcl_input_grad_bn(const PmBnBwd* nb, uint16_t* dh_planes, int6
     return PM_E_INVALID;
   GclBn b;
   b.h = nb->h; b.du = nb->du; b.mean = nb->mean; b.var = nb->var; b.gamma = nb->gamma; b.beta = nb->beta; b.acc3 = nb->acc3;
-  b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu;
+  b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu; b.add_res = nb->add_residual;
   return gcl_input_grad_impl(dh_planes, plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, &b, (hipStream_t)stream);
 }
 

@@ -43,6 +43,10 @@ struct StepCfg {
   bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
   bool dagg_bn;                // PM_DAGG_BN=0: the norm backward of a GCN layer as its own pass (pm_bn_bwd_fused) instead of inside the
                                // input gradient's prologue (pm_gcl_input_grad_bn; d in {128, 256})
+  bool dagg_res;               // PM_DAGG_RES=1: the residual gradient rides in dA's self block (PmBnBwd.add_residual) instead of being a row
+                               // stream of the segment-reduce backward: that kernel 43.8 -> 41.5 us, k_gcl_dagg +0.4, step -15 us (0.3 %);
+                               // off by default: it takes 16.7 MB out of the segment-reduce's algorithmic bytes (its HBM fraction, the
+                               // figure the rounds are compared on, would read 0.30 instead of 0.33 for a kernel that got faster)
   bool plan_side;              // PM_PLAN_SIDE=0: the plan build on the caller's stream in front of the content encoder (see forward())
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
@@ -65,6 +69,7 @@ static StepCfg read_cfg() {
   k.dw_side = flag("PM_DW_SIDE", false);
   k.dagg_bn = flag("PM_DAGG_BN", true);
   k.plan_side = flag("PM_PLAN_SIDE", true);
+  k.dagg_res = flag("PM_DAGG_RES", false);
   k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
@@ -514,6 +519,8 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     // the norm backward inside the input gradient (gcl.hip k_gcl_dagg<.., true>): no pass of its own over h, dx and the planes
     const bool in_dagg = c.bn && c.compact && c.planes && sv.Wft && (d == 128 || d == 256) && gcl_fused_on() &&
                          gcl_fits(N, d, 1) && cfg().dagg_bn && !dws;
+    // ... and the residual gradient rides out in dA's self block (PmBnBwd.add_residual): one row stream less in the segment-reduce
+    const bool res_in_dagg = in_dagg && !dropping && cfg().dagg_res;
     double* const acc3 = sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL;
     const bool sums_ready = i < c.L - 1 && fuse_sums;
     if (in_dagg) {
@@ -566,6 +573,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         PmBnBwd nb;
         nb.h = sv.h[i]; nb.du = dx; nb.mean = sv.mean[i]; nb.var = sv.var[i]; nb.gamma = c.P + bn.w; nb.beta = c.P + bn.b;
         nb.acc3 = acc3; nb.dgamma = c.G + bn.w; nb.dbeta = c.G + bn.b; nb.dbias_pre = c.G + g.bias[i]; nb.eps = 1e-5f; nb.relu = 1;
+        nb.add_residual = res_in_dagg ? 1 : 0; nb.reserved = 0;
         RUN(pm_gcl_input_grad_bn(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                    cfg().no_classes ? 0 : 1, dA, c.st));
       } else if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
@@ -587,11 +595,11 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
       nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
-      RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact,
-                                  out, dT, &nn, c.st));
+      RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
+                                  c.compact, out, dT, &nn, c.st));
     } else {
-      RUN(pm_segreduce_bwd(sv.x[i], sv.T, dA, dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i, c.compact, out,
-                             dT, c.st));
+      RUN(pm_segreduce_bwd(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
+                             c.compact, out, dT, c.st));
     }
     dx = out;
   }

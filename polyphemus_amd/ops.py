@@ -235,7 +235,7 @@ def gcl_input_grad_fused(dh_planes, plan: Plan, d: int, w_frag_t, use_classes: b
 
 class _BnBwd(ctypes.Structure):          # PmBnBwd (include/polyphemus_hip.h)
     _fields_ = [(k, ctypes.c_void_p) for k in ("h", "du", "mean", "var", "gamma", "beta", "acc3", "dgamma", "dbeta", "dbias_pre")] + \
-               [("eps", ctypes.c_float), ("relu", ctypes.c_int32)]
+               [("eps", ctypes.c_float), ("relu", ctypes.c_int32), ("add_residual", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def bn_bwd_sums(h, du, mean, var, gamma, beta, eps: float = 1e-5, relu: bool = True):
@@ -248,13 +248,13 @@ def bn_bwd_sums(h, du, mean, var, gamma, beta, eps: float = 1e-5, relu: bool = T
 
 
 def gcl_input_grad_bn(h, du, mean, var, gamma, beta, acc3, plan: Plan, w_frag_t, dgamma=None, dbeta=None, dbias_pre=None,
-                      eps: float = 1e-5, relu: bool = True, use_classes: bool = True):
+                      eps: float = 1e-5, relu: bool = True, use_classes: bool = True, add_residual: bool = False):
     """`pm_gcl_input_grad_bn`: the norm backward inside the input gradient; returns (dA' [N, 4d], dh planes int16 [3, N*d])."""
     N, d = h.shape
     dA = torch.empty(N, 4 * d, dtype=F32, device=h.device)
     planes = torch.empty(3, N * d, dtype=torch.int16, device=h.device)
     nb = _BnBwd(ptr(h), ptr(du), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(acc3), ptr(dgamma), ptr(dbeta), ptr(dbias_pre),
-                float(eps), 1 if relu else 0)
+                float(eps), 1 if relu else 0, 1 if add_residual else 0, 0)
     call("pm_gcl_input_grad_bn", ctypes.addressof(nb), ptr(planes), planes.shape[1], ptr(plan.buf), N, plan.E, plan.G, d,
          ptr(w_frag_t), 1 if use_classes else 0, ptr(dA), stream())
     return dA, planes

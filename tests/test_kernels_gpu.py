@@ -973,6 +973,12 @@ def test_gcl_input_grad_with_the_norm_backward_inside_equals_the_two_calls(d, B)
     assert torch.equal(dA1[keep], dA0[keep])
     for a, b_ in zip(g1, g0):
         assert torch.equal(a, b_)
+    # ... with the residual gradient riding in the self block: dA'[:, 3d:] + du, everything else unchanged
+    dA2, planes2 = ops.gcl_input_grad_bn(h, du, mean, var, gamma, beta, acc3, plan, Wft, add_residual=True)
+    assert torch.equal(planes2, planes0)
+    assert torch.equal(dA2[:, 3 * d:], dA0[:, 3 * d:] + du)
+    k3 = keep[:, :3 * d]
+    assert torch.equal(dA2[:, :3 * d][k3], dA0[:, :3 * d][k3])
     # fp64 statement of the norm backward (autograd of relu(BN(h)) w.r.t. h)
     hd = h.double().requires_grad_(True)
     xh = (hd - hd.mean(0)) / torch.sqrt(hd.var(0, unbiased=False) + 1e-5)

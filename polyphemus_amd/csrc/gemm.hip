@@ -897,7 +897,10 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false, bool
   // mode (78-90 us against 99-112 us in the step); weight gradients stay on the fp32 tiles (split mode: 132 against 106 us)
   static const bool split_ungrouped = !(getenv("PM_GEMM_SPLIT_UNGROUPED") && atoi(getenv("PM_GEMM_SPLIT_UNGROUPED")) == 0);
   // (N < 128: the 128-wide split tiles would be partly empty — the duration un-embedding, N = 99: 60 us against 46 us on the fp32 tiles)
-  if ((split_on || (split_ungrouped && ungrouped && !transA && N >= 128)) && x6_ok && (double)M * N * K >= 1.0e9) {
+  // ... since round 4 the large weight gradients too: they now run beside the head chain / in the step's tail, not beside the
+  // one-workgroup-per-CU GCL kernels, and there the split tiles win (step 4.892 -> 4.859 ms; PM_GEMM_SPLIT_TN=0: fp32 tiles)
+  static const bool split_tn = !(getenv("PM_GEMM_SPLIT_TN") && atoi(getenv("PM_GEMM_SPLIT_TN")) == 0);
+  if ((split_on || (split_ungrouped && ungrouped && !transA && N >= 128) || (split_tn && transA)) && x6_ok && (double)M * N * K >= 1.0e9) {
     if (transA) return 5;
     return K >= 1024 ? 7 : 4;
   }

@@ -901,7 +901,8 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false, bool
   // one-workgroup-per-CU GCL kernels, and there the split tiles win (step 4.892 -> 4.859 ms; PM_GEMM_SPLIT_TN=0: fp32 tiles)
   static const bool split_tn = !(getenv("PM_GEMM_SPLIT_TN") && atoi(getenv("PM_GEMM_SPLIT_TN")) == 0);
   if ((split_on || (split_ungrouped && ungrouped && !transA && N >= 128) || (split_tn && transA)) && x6_ok && (double)M * N * K >= 1.0e9) {
-    if (transA) return 5;
+    static const int tn_cfg = getenv("PM_GEMM_TN_CFG") ? atoi(getenv("PM_GEMM_TN_CFG")) : 5;   // (development A/B: 4, 5, 7)
+    if (transA) return (tn_cfg == 4 || tn_cfg == 7) ? tn_cfg : 5;
     return K >= 1024 ? 7 : 4;
   }
   return K >= 1024 ? 2 : 0;
@@ -990,7 +991,8 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   if (split_k <= 0) {                                                  // auto: fill the 256 CUs when K is long
     split_k = 1;
     if (transA && tiles * n_groups < 768) {
-      static const int tn_target = getenv("PM_GEMM_TN_TARGET") ? atoi(getenv("PM_GEMM_TN_TARGET")) : 1024;
+      // (768 since the large weight gradients run on the 128x64 split tiles: 4.637 against 4.667 ms per step with 1024; 256: 5.18 ms)
+      static const int tn_target = getenv("PM_GEMM_TN_TARGET") ? atoi(getenv("PM_GEMM_TN_TARGET")) : 768;
       split_k = (int)(tn_target / (tiles * n_groups));
       const int maxs = (int)pm_cdiv(partitioned ? K / n_groups : K, 8 * BK);
       if (split_k > maxs) split_k = maxs;

@@ -339,7 +339,10 @@ static bool gcl_fused_on() { return cfg().gcl_fused; }
 // chord weight gradients on the bf16 pipe (k_rows_tn of linear.hip: the loaders split fp32 rows on the fly): measured
 // 400 against 449 us per launch at d = 512, but 140 against 117 us at d = 256 — there the loaders' split arithmetic (5.5
 // vector instructions per element, on the SIMDs the MFMA waves run on) costs more than the fp32 matrix pipe loses
-static bool rows_tn_pays(int d) { return !cfg().no_rows_tn && d >= 512 && d % 128 == 0; }
+static bool rows_tn_pays(int d) {
+  static const int min_d = getenv("PM_ROWS_TN_MIN_D") ? atoi(getenv("PM_ROWS_TN_MIN_D")) : 512;   // (development A/B)
+  return !cfg().no_rows_tn && d >= min_d && d % 128 == 0;
+}
 // widths the kernels of gcl.hip / linear.hip (128, 256) and wide.hip (512) cover
 static bool gcl_width(int d) { return d == 128 || d == 256 || d == 512; }
 // the kernels of gcl.hip / linear.hip address their operands with 32-bit byte offsets: batches beyond these sizes

@@ -49,7 +49,8 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   5: round 4 (pm_set_deterministic / pm_get_deterministic; plan scratch field grown; PmVaeLayout.flags / .dropout — the
  *   C++ step covers batch_norm = False and cfg.dropout —; pm_vae_step_info writes 16 ints; pm_relu_bwd_planes;
  *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain).
- *   6: round 4, second half (pm_gcl_input_grad_bn / PmBnBwd, pm_bn_bwd_sums: the norm backward inside the input gradient). */
+ *   6: round 4, second half (pm_gcl_input_grad_bn / PmBnBwd, pm_bn_bwd_sums: the norm backward inside the input gradient;
+ *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd: the chord encoder as table algebra). */
 #define PM_ABI_VERSION 6
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -495,6 +496,25 @@ int pm_chord_pad_fwd(const float* tables, const float* chord_w /* [d,15d] */, co
 int pm_chord_pad_bwd(const float* dy /* [N,d] */, const uint8_t* is_drum, int32_t N, int32_t d, int32_t n_slots,
                      const float* tables, const float* chord_w, float* gsum /* [2][d] scratch */,
                      float* d_chord_w /* += */, float* S /* token sums, += */, pm_stream_t stream);
+/* The chord encoder as table algebra (chord.hip; model.py:344-390): its input is a lookup of the four embedding tables, so the
+ * Linear(15 d -> d) distributes over it.  Forward: PT [2 groups][S][2 kinds][131][d] = table rows times the slot's weight
+ * block (pm_chord_tables_fwd), x0[n] = relu(cvec[group] + the 2 S looked-up rows of PT) (pm_chord_sum_fwd; cvec [2][d] =
+ * bias + the all-PAD tail slots, pm_chord_pad_vec).  Backward, dy = gradient of the pre-activation (ReLU mask applied):
+ * Gt (layout of PT, zeroed by the call) = per (group, slot, kind, token) sums of dy rows (pm_chord_sum_bwd: one-hot^T x dy on
+ * the matrix cores), from which pm_chord_tables_bwd forms d_chord_w[:, :S*d] (+=), d_chord_b (+= column sums of dy; may be
+ * NULL) and the token sums S [4][131][d/2] (cleared by the call) that pm_embed_tables_bwd takes; the tail slots
+ * follow through pm_chord_pad_bwd as before.  X [N, S, d] and its gradient are never formed. */
+int pm_chord_pad_vec(const float* tables, const float* chord_w, const float* chord_b, int32_t d, int32_t n_slots,
+                     float* cvec /* [2][d] */, pm_stream_t stream);
+int pm_chord_tables_fwd(const float* tables /* [4][131][d/2] */, const float* chord_w /* [d,15d] */, int32_t d, int32_t n_slots,
+                        float* PT, const float* chord_b /* with cvec */, float* cvec /* [2][d] or NULL: as pm_chord_pad_vec, same launch */,
+                        pm_stream_t stream);
+int pm_chord_sum_fwd(const float* PT, const float* cvec, const int32_t* tokens /* [N,16,2] */, const uint8_t* is_drum, int32_t N,
+                     int32_t d, int32_t n_slots, float* x0 /* [N,d] */, pm_stream_t stream);
+int pm_chord_sum_bwd(const float* dy /* [N,d] */, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                     int32_t d /* multiple of 32, <= 512 */, int32_t n_slots, float* Gt, pm_stream_t stream);
+int pm_chord_tables_bwd(const float* Gt, const float* tables, const float* chord_w, int32_t d, int32_t n_slots,
+                        float* d_chord_w /* += */, float* d_chord_b /* += or NULL */, float* S, pm_stream_t stream);
 int pm_embed_tables_bwd(const float* S, const float* w_pitch_drum, const float* b_pitch_drum,
                         const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur, const float* b_dur,
                         const float* bn_drum_g, const float* bn_nd_g, const float* bn_dur_g, const float* stats,
@@ -761,7 +781,7 @@ int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buff
 /* Introspection of the last forward (host only): info = {compact GCL, bf16-planes GEMM operands, active slots S,
  * fragment-major weight planes built (B-direct GEMM mode), N, E, G, B, then the EFFECTIVE switches of the library —
  * fused un-embedding + cross-entropy (PM_FUSED_CE), second-stream site mask (PM_SIDE_STREAM), deterministic mode,
- * fused GCL kernels (PM_GCL_FUSED), norm backward inside the GCL input gradient (PM_DAGG_BN) —, 3 reserved}.  The parity tests use it to assert that the golden-pinned step IS
+ * fused GCL kernels (PM_GCL_FUSED), norm backward inside the GCL input gradient (PM_DAGG_BN), chord encoder as table algebra (PM_CHORD_TABLES) —, 2 reserved}.  The parity tests use it to assert that the golden-pinned step IS
  * the measured variant. */
 int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
 /* The model outputs of `VAE.forward` (model.py:665-678) as the last forward computed them, copied out of the arena

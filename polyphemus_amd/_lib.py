@@ -38,6 +38,11 @@ _SIGS = {
     "pm_gcl_forward_fused": "pppiiiifuuppipppls",
     "pm_gcl_input_grad_fused": "plpiiiipips",
     "pm_gcl_input_grad_bn": "pplpiiiipips",
+    "pm_chord_pad_vec": "pppiips",
+    "pm_chord_tables_fwd": "ppiippps",
+    "pm_chord_sum_fwd": "ppppiiips",
+    "pm_chord_sum_bwd": "pppiiiiips",
+    "pm_chord_tables_bwd": "pppiippps",
     "pm_bn_bwd_sums": "ppiippfppips",
     "pm_gcl_weight_grad_fused": "plplpiiiiips",
     "pm_gcl_forward_from_planes": "plpiiiippipps",

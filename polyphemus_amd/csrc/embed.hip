@@ -454,6 +454,13 @@ extern "C" int pm_chord_pad_fwd(const float* tables, const float* Wc, const floa
   hipLaunchKernelGGL(k_group_bias_relu, dim3(pm_cdiv(N, 4)), dim3(256), 0, st, y, cvec, is_drum, N, d);
   return pm_check_launch();
 }
+// cvec alone (the table form of the chord encoder, chord.hip, adds it while it sums the looked-up rows); n_slots = 15: the bias
+extern "C" int pm_chord_pad_vec(const float* tables, const float* Wc, const float* bc, int32_t d, int32_t n_slots, float* cvec,
+                                pm_stream_t stream) {
+  if (!tables || !Wc || !bc || !cvec || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_chord_pad_fwd, dim3(pm_cdiv(2 * d, 4)), dim3(256), 0, (hipStream_t)stream, tables, Wc, bc, d, n_slots, cvec);
+  return pm_check_launch();
+}
 // gsum[g][o] = sum over the nodes of group g of dy[n][o]
 __global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ dy, const uint8_t* __restrict__ is_drum,
                                                       int N, int d, int rows_per_chunk, float* gsum, unsigned* gate) {

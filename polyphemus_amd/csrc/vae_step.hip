@@ -47,6 +47,8 @@ struct StepCfg {
                                // stream of the segment-reduce backward: that kernel 43.8 -> 41.5 us, k_gcl_dagg +0.4, step -15 us (0.3 %);
                                // off by default: it takes 16.7 MB out of the segment-reduce's algorithmic bytes (its HBM fraction, the
                                // figure the rounds are compared on, would read 0.30 instead of 0.33 for a kernel that got faster)
+  bool chord_tables;           // PM_CHORD_TABLES=0: the chord encoder through X [N, S, d] (gather, long-K product, weight-gradient product, token
+                               // sums of dX) instead of as table algebra (chord.hip)
   bool plan_side;              // PM_PLAN_SIDE=0: the plan build on the caller's stream in front of the content encoder (see forward())
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
@@ -69,6 +71,7 @@ static StepCfg read_cfg() {
   k.dw_side = flag("PM_DW_SIDE", false);
   k.dagg_bn = flag("PM_DAGG_BN", true);
   k.plan_side = flag("PM_PLAN_SIDE", true);
+  k.chord_tables = flag("PM_CHORD_TABLES", true);
   k.dagg_res = flag("PM_DAGG_RES", false);
   k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
@@ -137,6 +140,7 @@ struct StepState {
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
+  float* PT; int chord_tab;          // chord encoder as table algebra (chord.hip): projected tables [2][S][2][131][d]
   uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t, *w_unembed_dh;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
   // cfg.dropout: the tensors behind the element dropout layers (the undropped ones when the model has none)
   const float *a1d, *h1d, *x0d, *xLg, *zcat_d, *zg_d, *zr_d, *sbd, *u1d, *H_d;
@@ -666,7 +670,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                                plan_side ? br.mark_inside(BR_PLAN_COUNT) : nullptr));
   // chord encoder Wc [d, 15d]: kind 0 for the forward (long-K kernel, columns [0, S*d)), kind 1 for its input gradient
   s.wf_enc = s.wf_enc_t = s.wf_dec = s.wf_dec_t = nullptr;
-  const bool enc_frag = rows_w_ok && S < PM_N_SLOTS;
+  // the chord encoder as table algebra (chord.hip): no X, no weight planes of its Linear
+  const bool chord_tab = cfg().chord_tables && d % 32 == 0 && d <= 512 && (int64_t)N * d * 4 < 0x7fffffffLL;
+  s.chord_tab = chord_tab ? 1 : 0;
+  const bool enc_frag = rows_w_ok && S < PM_N_SLOTS && !chord_tab;
   if (enc_frag) {
     s.wf_enc = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
     s.wf_enc_t = (uint16_t*)ar.take((size_t)PM_N_SLOTS * d * d * 6);
@@ -728,7 +735,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   // ---------------- content encoder (model.py:344-417)
   float* tables = ar.f((size_t)4 * PM_N_PITCH * dh);
   s.emb_stats = ar.f((size_t)4 * 2 * dh);
-  s.X = ar.f((size_t)N * S * d);
+  s.X = chord_tab ? nullptr : ar.f((size_t)N * S * d);
+  s.PT = chord_tab ? ar.f((size_t)2 * S * 2 * PM_N_PITCH * d) : nullptr;
   s.x0 = ar.f((size_t)N * d);
   s.tables = tables; s.cvec = ar.f((size_t)2 * d);
   float* const x0d_buf = dropping ? ar.f((size_t)N * d) : nullptr;
@@ -744,6 +752,12 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                           c.Bf + Y.enc_bn_d.rm, c.Bf + Y.enc_bn_d.rv, c.Bf + Y.enc_bn_nd.rm, c.Bf + Y.enc_bn_nd.rv,
                           c.Bf + Y.enc_bn_dur.rm, c.Bf + Y.enc_bn_dur.rv, pv.tok_hist, d, 1, 1e-5f, 0.1f, tables,
                           s.emb_stats, c.st));
+    if (chord_tab) {
+      // x0 = relu(cvec[group] + the 2 S looked-up rows of the projected tables): two launches, no X
+      RUN(pm_chord_tables_fwd(tables, c.P + Y.enc_chord.w, d, S, s.PT, c.P + Y.enc_chord.b, s.cvec, c.st));
+      RUN(pm_chord_sum_fwd(s.PT, s.cvec, s.bt.tokens, s.bt.is_drum, N, d, S, s.x0, c.st));
+      if (!plan_side) branch_join(c, BR_WPREP);
+    } else {
     RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));
     if (!plan_side) branch_join(c, BR_WPREP);          // weight planes and distance tables are ready
     if (S == PM_N_SLOTS) lin(c, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, s.x0, true);
@@ -754,6 +768,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
         RUN(pm_gemm_f32(0, 1, N, d, S * d, s.X, S * d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, s.x0, d, nullptr, 0, 1,
                           nullptr, 0, nullptr, c.st));
       RUN(pm_chord_pad_fwd(tables, c.P + Y.enc_chord.w, c.P + Y.enc_chord.b, s.bt.is_drum, N, d, S, s.cvec, s.x0, c.st));
+    }
     }
     s.x0d = drop(c, s.x0, N, d, SITE_ENC_CHORD, seed_enc, x0d_buf);                          // model.py:389-390 (row = node)
   }
@@ -1110,10 +1125,17 @@ void backward_encoder_tail(Ctx& c) {
   float* dx0 = s.bk_dx0;
   float* dzcat = s.bk_dzcat;
   const int S = c.S;
-  float* dX = ar.f((size_t)N * S * d);
+  const bool chord_tab = s.chord_tab != 0;
+  float* dX = chord_tab ? nullptr : ar.f((size_t)N * S * d);
   float* Stab = ar.f((size_t)4 * PM_N_PITCH * dh);
   float* gsum = ar.f((size_t)2 * d);
-  if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
+  float* Gt = chord_tab ? ar.f((size_t)2 * S * 2 * PM_N_PITCH * d) : nullptr;
+  if (chord_tab) {
+    // token sums of dx0 per (group, slot, kind) on the matrix cores, then the weight / bias gradients and the tables' token
+    // sums from them (chord.hip): no dX, no 10.7 GFLOP weight-gradient product
+    RUN(pm_chord_sum_bwd(dx0, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Gt, c.st));
+    RUN(pm_chord_tables_bwd(Gt, s.tables, c.P + Y.enc_chord.w, d, S, c.G + Y.enc_chord.w, c.G + Y.enc_chord.b, Stab, c.st));
+  } else if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
     {                                        // (the weight gradient beside the input gradient: second stream, joined below)
       BranchScope br(c, BR_ENC_WGRAD);
@@ -1134,7 +1156,7 @@ void backward_encoder_tail(Ctx& c) {
       RUN(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
                         nullptr, c.st));
   }
-  RUN(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
+  if (!chord_tab) RUN(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
   RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
   PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
   RUN(pm_embed_tables_bwd(Stab, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
@@ -1249,7 +1271,8 @@ extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
   // the EFFECTIVE switches (read from the environment at load / pm_vae_step_reload_switches, not at call time)
   info[8] = cfg().fused_ce ? 1 : 0; info[9] = cfg().side_stream; info[10] = pm_det_on(); info[11] = cfg().gcl_fused ? 1 : 0;
   info[12] = cfg().dagg_bn ? 1 : 0;            // (the norm backward of the GCN layers inside the input gradient kernel)
-  info[13] = info[14] = info[15] = 0;
+  info[13] = s->chord_tab;                      // (the chord encoder as table algebra)
+  info[14] = info[15] = 0;
   return PM_OK;
 }
 // Model outputs of the last forward (the arena keeps them until the next pm_vae_step_forward): asynchronous

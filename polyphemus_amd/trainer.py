@@ -241,7 +241,7 @@ class HipTrainer:
         info = (ctypes.c_int32 * 16)()
         call("pm_vae_step_info", ctypes.addressof(self._state), ctypes.cast(info, ctypes.c_void_p))
         keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B", "fused_ce", "side_stream", "deterministic",
-                "gcl_fused", "dagg_bn")
+                "gcl_fused", "dagg_bn", "chord_tables")
         return dict(zip(keys, (int(v) for v in info)))
 
     def step_outputs(self):

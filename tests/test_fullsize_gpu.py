@@ -57,10 +57,12 @@ GRAD_CAPS = {                                            # measured (profiles/r0
 
 
 def _expect_dedicated_kernels(info, L=8):
-    """the three GCL products and the four chord products of the step ran on gcl.hip / linear.hip / wide.hip"""
+    """the three GCL products and the chord products of the step ran on gcl.hip / linear.hip / wide.hip (the chord ENCODER
+    runs as table algebra, chord.hip: the decoder's two products remain)"""
     n = info["launches"]
     assert info["compact"] == 1 and info["planes"] == 1 and info["b_frag"] == 1 and info["n_slots"] < 15, info
-    assert n["gcl_fwd"] == 2 * L and n["gcl_dagg"] == 2 * L and n["gcl_dw"] == 2 * L and n["rows_w"] == 4, info
+    assert info["chord_tables"] == 1 and info["dagg_bn"] == 1, info
+    assert n["gcl_fwd"] == 2 * L and n["gcl_dagg"] == 2 * L and n["gcl_dw"] == 2 * L and n["rows_w"] == 2, info
     assert n["planesB_nn"] == 0 and n["planesB_nt"] == 0 and n["planes_tn"] == 0, info
 
 
@@ -196,7 +198,7 @@ def test_dense_shard_at_its_real_size_properties():
     info, names = run["info"], run["names"]
     n = info["launches"]
     assert info["N"] == 16384 and info["E"] == 2080768 and info["compact"] == 1 and info["planes"] == 1, info
-    assert n["gcl_fwd"] == 16 and n["segreduce_fwd"] == 16 and n["gcl_dagg"] == 16 and n["gcl_dw"] == 16 and n["rows_w"] == 4, info
+    assert n["gcl_fwd"] == 16 and n["segreduce_fwd"] == 16 and n["gcl_dagg"] == 16 and n["gcl_dw"] == 16 and n["rows_w"] == 2, info
     assert n["planesB_nn"] == 0 and n["planesB_nt"] == 0 and n["planes_tn"] == 0, info
     for k, v in run["outputs"].items():
         assert bool(torch.isfinite(v).all()), k
@@ -249,7 +251,7 @@ def test_offset_limit_takes_the_round1_kernels_and_agrees(d):
     segment-reduce + grouped-product kernels and returns the same losses, outputs and (up to ReLU kinks) gradients."""
     spec = dict(B=24, nb=2, d=d, L=2, p=0.25, dense=False, msg_p=0.1, seed=7)
     a, b = _same_step_up_to_relu_kinks(spec, dict(PM_GCL_OFFSET_LIMIT=1 << 20))
-    assert a["info"]["launches"]["gcl_fwd"] == 4 and a["info"]["launches"]["rows_w"] == 4, a["info"]
+    assert a["info"]["launches"]["gcl_fwd"] == 4 and a["info"]["launches"]["rows_w"] == 2, a["info"]
     m = b["info"]["launches"]
     assert m["gcl_fwd"] == 0 and m["gcl_dagg"] == 0 and m["gcl_dw"] == 0 and m["rows_w"] == 0, b["info"]
     assert m["planesB_nn"] == 4 and m["planesB_nt"] == 4 and m["planes_tn"] == 4 and m["segreduce_fwd"] == 4, b["info"]

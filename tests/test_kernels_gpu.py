@@ -590,6 +590,67 @@ def test_embed_fwd_bwd(small, d, training):
             assert rel_err(G32[k], P64[k].grad) < 2e-5, k
 
 
+@pytest.mark.parametrize("d,S", [(32, 15), (256, 5), (128, 3), (256, 1)])
+def test_chord_encoder_as_table_algebra(small, d, S):
+    """chord.hip: x0 = relu(b + sum_s X[:, s] @ Wc_s^T) through projected tables and row lookups, and its backward (token
+    sums of the output gradient on the matrix cores, weight / bias / table gradients from them), against the formulation
+    they replace — gather X, product, fp64 autograd — on the same tables and tokens (slots >= S: the PAD tail, closed form)."""
+    b, plan = small
+    torch.manual_seed(100 * d + S)
+    N, dh = plan.N, d // 2
+    tables = torch.randn(4, 131, dh, device=DEV) * 0.7
+    Wc = torch.randn(d, 15 * d, device=DEV) / (15 * d) ** 0.5 * 3
+    bc = torch.randn(d, device=DEV) * 0.1
+    tok = plan.tokens.view(N, 16, 2).clone()
+    tok[:, S + 1:, 0] = 130; tok[:, S + 1:, 1] = 98                      # slots beyond S: PAD in every node
+    tok = tok.contiguous()
+    # ---- the replaced formulation, fp64
+    grp = (~plan.is_drum.bool()).long()                                 # 0 drums, 1 non-drums
+    T64 = tables.double().requires_grad_(True)
+    W64, b64 = Wc.double().requires_grad_(True), bc.double().requires_grad_(True)
+    pit, dur = tok[:, 1:, 0].long(), tok[:, 1:, 1].long()
+    X = torch.cat((T64[grp[:, None], pit], T64[2 + grp[:, None], dur]), -1)       # [N, 15, d]
+    pre = X.reshape(N, 15 * d) @ W64.t() + b64
+    ref = torch.relu(pre)
+    # ---- table form
+    cvec = torch.empty(2, d, device=DEV)
+    call("pm_chord_pad_vec", ptr(tables), ptr(Wc), ptr(bc), d, S, ptr(cvec), stream())
+    PT = torch.full((2, S, 2, 131, d), float("nan"), device=DEV)
+    cvec2 = torch.empty(2, d, device=DEV)
+    call("pm_chord_tables_fwd", ptr(tables), ptr(Wc), d, S, ptr(PT), ptr(bc), ptr(cvec2), stream())
+    assert rel_err(cvec2, cvec) < 1e-6                                  # (the same vector from the tables launch)
+    x0 = torch.empty(N, d, device=DEV)
+    call("pm_chord_sum_fwd", ptr(PT), ptr(cvec), ptr(tok), ptr(plan.is_drum), N, d, S, ptr(x0), stream())
+    assert rel_err(x0, ref.detach()) < 2e-6
+    # ---- backward
+    dy = torch.randn(N, d, device=DEV) * (ref.detach() > 0).float()      # gradient of the pre-activation, ReLU mask applied
+    pre.backward(dy.double())
+    Gt = torch.full((2, S, 2, 131, d), float("nan"), device=DEV)
+    if d % 32 == 0:
+        call("pm_chord_sum_bwd", ptr(dy), ptr(tok), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(Gt), stream())
+        want = torch.zeros(2, S, 2, 131, d, dtype=torch.float64, device=DEV)
+        for s_ in range(S):
+            for kind, ids in ((0, pit), (1, dur)):
+                w_ = torch.zeros(2 * 131, d, dtype=torch.float64, device=DEV)
+                w_.index_add_(0, grp * 131 + ids[:, s_], dy.double())
+                want[:, s_, kind] = w_.view(2, 131, d)
+        assert rel_err(Gt, want) < 1e-6
+    else:
+        return
+    dW = torch.full((d, 15 * d), 0.5, device=DEV)
+    db = torch.full((d,), 0.25, device=DEV)
+    Stab = torch.zeros(4, 131, dh, device=DEV)
+    call("pm_chord_tables_bwd", ptr(Gt), ptr(tables), ptr(Wc), d, S, ptr(dW), ptr(db), ptr(Stab), stream())
+    gsum = torch.empty(2, d, device=DEV)
+    call("pm_chord_pad_bwd", ptr(dy), ptr(plan.is_drum), N, d, S, ptr(tables), ptr(Wc), ptr(gsum), ptr(dW), ptr(Stab), stream())
+    assert rel_err(dW - 0.5, W64.grad) < 2e-5
+    assert rel_err(db - 0.25, b64.grad) < 1e-5
+    tg = T64.grad.clone()
+    tg[2:, 99:] = 0                                                     # (rows of the duration tables beyond their vocabulary)
+    Stab[2:, 99:] = 0
+    assert rel_err(Stab, tg) < 2e-5
+
+
 # ------------------------------------------------------------------ pooling / broadcast
 @pytest.mark.parametrize("d", [32, 256])
 def test_attention_pool_fwd_bwd(small, d):

@@ -50,7 +50,7 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   C++ step covers batch_norm = False and cfg.dropout —; pm_vae_step_info writes 16 ints; pm_relu_bwd_planes;
  *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain).
  *   6: round 4, second half (pm_gcl_input_grad_bn / PmBnBwd, pm_bn_bwd_sums: the norm backward inside the input gradient;
- *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd: the chord encoder as table algebra). */
+ *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra). */
 #define PM_ABI_VERSION 6
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -500,10 +500,11 @@ int pm_chord_pad_bwd(const float* dy /* [N,d] */, const uint8_t* is_drum, int32_
  * Linear(15 d -> d) distributes over it.  Forward: PT [2 groups][S][2 kinds][131][d] = table rows times the slot's weight
  * block (pm_chord_tables_fwd), x0[n] = relu(cvec[group] + the 2 S looked-up rows of PT) (pm_chord_sum_fwd; cvec [2][d] =
  * bias + the all-PAD tail slots, pm_chord_pad_vec).  Backward, dy = gradient of the pre-activation (ReLU mask applied):
- * Gt (layout of PT, zeroed by the call) = per (group, slot, kind, token) sums of dy rows (pm_chord_sum_bwd: one-hot^T x dy on
- * the matrix cores), from which pm_chord_tables_bwd forms d_chord_w[:, :S*d] (+=), d_chord_b (+= column sums of dy; may be
- * NULL) and the token sums S [4][131][d/2] (cleared by the call) that pm_embed_tables_bwd takes; the tail slots
- * follow through pm_chord_pad_bwd as before.  X [N, S, d] and its gradient are never formed. */
+ * Gt (layout of PT; the CALLER clears it) += per (group, slot, kind, token) sums of dy rows (pm_chord_sum_bwd: one-hot^T x dy on
+ * the matrix cores), from which pm_chord_tables_bwd_w forms d_chord_w[:, :S*d] (+=) and d_chord_b (+= column sums of dy; may be
+ * NULL) and pm_chord_tables_bwd_x the token sums S [4][131][d/2] (+= with float atomics: the caller clears S) that
+ * pm_embed_tables_bwd takes; the tail slots follow through pm_chord_pad_bwd as before (any order: it only adds).  X [N, S, d]
+ * and its gradient are never formed. */
 int pm_chord_pad_vec(const float* tables, const float* chord_w, const float* chord_b, int32_t d, int32_t n_slots,
                      float* cvec /* [2][d] */, pm_stream_t stream);
 int pm_chord_tables_fwd(const float* tables /* [4][131][d/2] */, const float* chord_w /* [d,15d] */, int32_t d, int32_t n_slots,
@@ -513,8 +514,9 @@ int pm_chord_sum_fwd(const float* PT, const float* cvec, const int32_t* tokens /
                      int32_t d, int32_t n_slots, float* x0 /* [N,d] */, pm_stream_t stream);
 int pm_chord_sum_bwd(const float* dy /* [N,d] */, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                      int32_t d /* multiple of 32, <= 512 */, int32_t n_slots, float* Gt, pm_stream_t stream);
-int pm_chord_tables_bwd(const float* Gt, const float* tables, const float* chord_w, int32_t d, int32_t n_slots,
-                        float* d_chord_w /* += */, float* d_chord_b /* += or NULL */, float* S, pm_stream_t stream);
+int pm_chord_tables_bwd_w(const float* Gt, const float* tables, int32_t d, int32_t n_slots, float* d_chord_w /* += */,
+                          float* d_chord_b /* += or NULL */, pm_stream_t stream);
+int pm_chord_tables_bwd_x(const float* Gt, const float* chord_w, int32_t d, int32_t n_slots, float* S /* += */, pm_stream_t stream);
 int pm_embed_tables_bwd(const float* S, const float* w_pitch_drum, const float* b_pitch_drum,
                         const float* w_pitch_nd, const float* b_pitch_nd, const float* w_dur, const float* b_dur,
                         const float* bn_drum_g, const float* bn_nd_g, const float* bn_dur_g, const float* stats,

@@ -42,7 +42,8 @@ _SIGS = {
     "pm_chord_tables_fwd": "ppiippps",
     "pm_chord_sum_fwd": "ppppiiips",
     "pm_chord_sum_bwd": "pppiiiiips",
-    "pm_chord_tables_bwd": "pppiippps",
+    "pm_chord_tables_bwd_w": "ppiipps",
+    "pm_chord_tables_bwd_x": "ppiips",
     "pm_bn_bwd_sums": "ppiippfppips",
     "pm_gcl_weight_grad_fused": "plplpiiiiips",
     "pm_gcl_forward_from_planes": "plpiiiippipps",

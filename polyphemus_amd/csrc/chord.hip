@@ -88,16 +88,15 @@ __device__ inline void small_product(int M, int Nn, int K, int m0, int n0, FA a_
 }  // namespace
 
 // PT[g][s][kind][v][j] = sum_c T[kind*2+g][v][c] * Wc[j][s d + kind dh + c]; grid (v tiles x j tiles, S, 4 = kind*2+g [+ 1]).
-// With cvec != NULL the plane blockIdx.z = 4, blockIdx.y = 0 computes the constant of the all-PAD tail slots in the same launch
+// With cvec != NULL the plane blockIdx.z = 4 computes the constant of the all-PAD tail slots in the same launch
 // (embed.hip k_chord_pad_fwd: cvec[g][o] = bc[o] + sum_{s >= S} Xpad_g . Wc[o, s-block]; one wave per (group, output)).
 __global__ void __launch_bounds__(256) k_chord_tables_fwd(const float* __restrict__ tables, const float* __restrict__ Wc, int d,
                                                           int S, float* __restrict__ PT, const float* __restrict__ bc,
                                                           float* __restrict__ cvec) {
   const int dh = d / 2, ntn = (d + 63) / 64;
   if (blockIdx.z == 4) {
-    if (blockIdx.y != 0) return;
     const int lane = threadIdx.x & 63;
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < 2 * d; w += gridDim.x * 4) {
+    for (int w = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6); w < 2 * d; w += gridDim.x * gridDim.y * 4) {
       const int g = w / d, o = w % d;
       const float* wrow = Wc + (int64_t)o * PM_N_SLOTS * d;
       const float* tp = tables + ((int64_t)g * EMB_V + 130) * dh;
@@ -297,7 +296,6 @@ extern "C" int pm_chord_sum_bwd(const float* dY, const int32_t* tokens, const in
     return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   PmPlanView pv = pm_plan_view(plan, N, E, G_);
-  if (hipMemsetAsync(Gt, 0, sizeof(float) * 2 * (size_t)n_slots * 2 * EMB_V * d, st) != hipSuccess) return PM_E_LAUNCH;
   // ~640 nodes per workgroup (PM_CHORD_BWD_CHUNK: development A/B); one more workgroup than chunks: the two groups'
   // chunk counts round up separately
   static const int chunk_env = getenv("PM_CHORD_BWD_CHUNK") ? atoi(getenv("PM_CHORD_BWD_CHUNK")) : 0;
@@ -378,14 +376,18 @@ __global__ void __launch_bounds__(256) k_chord_tables_bwd_x(const float* __restr
     }
   pm_turn_leave_block(gate);
 }
-extern "C" int pm_chord_tables_bwd(const float* Gt, const float* tables, const float* Wc, int32_t d, int32_t n_slots, float* dWc,
-                                   float* db, float* Stab, pm_stream_t stream) {
-  if (!Gt || !tables || !Wc || !dWc || !Stab || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
+extern "C" int pm_chord_tables_bwd_w(const float* Gt, const float* tables, int32_t d, int32_t n_slots, float* dWc, float* db,
+                                     pm_stream_t stream) {
+  if (!Gt || !tables || !dWc || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
+  const int dh = d / 2;
+  hipLaunchKernelGGL(k_chord_tables_bwd_w, dim3((unsigned)(pm_cdiv(d, 32) * pm_cdiv(dh, 64)), n_slots, 2), dim3(256), 0,
+                     (hipStream_t)stream, Gt, tables, d, n_slots, dWc, db);
+  return pm_check_launch();
+}
+extern "C" int pm_chord_tables_bwd_x(const float* Gt, const float* Wc, int32_t d, int32_t n_slots, float* Stab, pm_stream_t stream) {
+  if (!Gt || !Wc || !Stab || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int dh = d / 2;
-  hipLaunchKernelGGL(k_chord_tables_bwd_w, dim3((unsigned)(pm_cdiv(d, 32) * pm_cdiv(dh, 64)), n_slots, 2), dim3(256), 0, st, Gt,
-                     tables, d, n_slots, dWc, db);
-  if (hipMemsetAsync(Stab, 0, sizeof(float) * 4 * EMB_V * dh, st) != hipSuccess) return PM_E_LAUNCH;
   hipLaunchKernelGGL(k_chord_tables_bwd_x, dim3((unsigned)(pm_cdiv(EMB_V, 32) * pm_cdiv(dh, 64)), 4, n_slots), dim3(256), 0, st, Gt,
                      Wc, d, n_slots, Stab, pm_det_gate(st));
   return pm_check_launch();

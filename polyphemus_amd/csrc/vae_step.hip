@@ -687,14 +687,18 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     br.pause();
     chord_planes(0);
   }
-  br.resume();
-  {
+  auto encoder_prep = [&]() {
+    br.resume();
     if (!plan_side) chord_planes(0);
     chord_planes(1);
     gcn_prepare(c, Y.enc_gcn, s.eg);
     br.mark(BR_WPREP);
-  }
-  br.pause();
+    br.pause();
+  };
+  // (table form of the chord encoder: its three launches wait for the plan's counting launch only — the host issues them
+  //  BEFORE the six launches of the weight preparation, or they would start ~25 us after the event they wait for)
+  const bool prep_late = chord_tab && plan_side;
+  if (!prep_late) encoder_prep();
   // the rest of the branch: issued by decoder_prep_and_structure_encoder() below, behind the first launches of the content encoder
   auto decoder_prep_and_structure_encoder = [&]() {
     br.resume();
@@ -772,6 +776,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     }
     s.x0d = drop(c, s.x0, N, d, SITE_ENC_CHORD, seed_enc, x0d_buf);                          // model.py:389-390 (row = node)
   }
+  if (prep_late) encoder_prep();                       // (also in the measuring pass: it carves the weight planes out of the arena)
   if (run) branch_join(c, BR_WPREP);                   // the plan, the GCL weight planes and the distance table are ready
   float* xL = gcn_forward(c, dropping ? x0d_buf : s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
   decoder_prep_and_structure_encoder();                // (second stream; issued while the GPU works through the encoder's layers)
@@ -1127,14 +1132,26 @@ void backward_encoder_tail(Ctx& c) {
   const int S = c.S;
   const bool chord_tab = s.chord_tab != 0;
   float* dX = chord_tab ? nullptr : ar.f((size_t)N * S * d);
-  float* Stab = ar.f((size_t)4 * PM_N_PITCH * dh);
+  // (table form: the token sums and the tables' sums only ever ADD — both live in the zero region the forward cleared)
+  float* Stab = chord_tab ? ar.zf((size_t)4 * PM_N_PITCH * dh) : ar.f((size_t)4 * PM_N_PITCH * dh);
   float* gsum = ar.f((size_t)2 * d);
-  float* Gt = chord_tab ? ar.f((size_t)2 * S * 2 * PM_N_PITCH * d) : nullptr;
+  float* Gt = chord_tab ? ar.zf((size_t)2 * S * 2 * PM_N_PITCH * d) : nullptr;
   if (chord_tab) {
     // token sums of dx0 per (group, slot, kind) on the matrix cores, then the weight / bias gradients and the tables' token
-    // sums from them (chord.hip): no dX, no 10.7 GFLOP weight-gradient product
+    // sums from them (chord.hip): no dX, no 10.7 GFLOP weight-gradient product.  Beside the token sums (second stream): the
+    // closed-form tail slots; behind them the two small products side by side.
+    {
+      BranchScope br(c, BR_ENC_WGRAD);
+      RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
+    }
     RUN(pm_chord_sum_bwd(dx0, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Gt, c.st));
-    RUN(pm_chord_tables_bwd(Gt, s.tables, c.P + Y.enc_chord.w, d, S, c.G + Y.enc_chord.w, c.G + Y.enc_chord.b, Stab, c.st));
+    branch_join(c, BR_ENC_WGRAD);
+    {
+      BranchScope br(c, BR_ENC_WGRAD);
+      RUN(pm_chord_tables_bwd_x(Gt, c.P + Y.enc_chord.w, d, S, Stab, c.st));
+    }
+    RUN(pm_chord_tables_bwd_w(Gt, s.tables, d, S, c.G + Y.enc_chord.w, c.G + Y.enc_chord.b, c.st));
+    branch_join(c, BR_ENC_WGRAD);
   } else if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form
     {                                        // (the weight gradient beside the input gradient: second stream, joined below)
@@ -1156,8 +1173,10 @@ void backward_encoder_tail(Ctx& c) {
       RUN(pm_gemm_f32(0, 0, N, S * d, d, dx0, d, c.P + Y.enc_chord.w, PM_N_SLOTS * d, dX, S * d, nullptr, 0, 1, nullptr, 0,
                         nullptr, c.st));
   }
-  if (!chord_tab) RUN(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
-  RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
+  if (!chord_tab) {
+    RUN(pm_embed_bwd_scatter(dX, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Stab, c.st));
+    RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
+  }
   PmPlanView pv = pm_plan_view(s.plan, N, c.E, Gn);
   RUN(pm_embed_tables_bwd(Stab, c.P + Y.enc_pitch_d.w, c.P + Y.enc_pitch_d.b, c.P + Y.enc_pitch_nd.w, c.P + Y.enc_pitch_nd.b,
                             c.P + Y.enc_dur.w, c.P + Y.enc_dur.b, c.P + Y.enc_bn_d.w, c.P + Y.enc_bn_nd.w,

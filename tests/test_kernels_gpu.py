@@ -625,7 +625,7 @@ def test_chord_encoder_as_table_algebra(small, d, S):
     # ---- backward
     dy = torch.randn(N, d, device=DEV) * (ref.detach() > 0).float()      # gradient of the pre-activation, ReLU mask applied
     pre.backward(dy.double())
-    Gt = torch.full((2, S, 2, 131, d), float("nan"), device=DEV)
+    Gt = torch.zeros(2, S, 2, 131, d, device=DEV)                       # (the caller clears it)
     if d % 32 == 0:
         call("pm_chord_sum_bwd", ptr(dy), ptr(tok), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(Gt), stream())
         want = torch.zeros(2, S, 2, 131, d, dtype=torch.float64, device=DEV)
@@ -640,7 +640,8 @@ def test_chord_encoder_as_table_algebra(small, d, S):
     dW = torch.full((d, 15 * d), 0.5, device=DEV)
     db = torch.full((d,), 0.25, device=DEV)
     Stab = torch.zeros(4, 131, dh, device=DEV)
-    call("pm_chord_tables_bwd", ptr(Gt), ptr(tables), ptr(Wc), d, S, ptr(dW), ptr(db), ptr(Stab), stream())
+    call("pm_chord_tables_bwd_w", ptr(Gt), ptr(tables), d, S, ptr(dW), ptr(db), stream())
+    call("pm_chord_tables_bwd_x", ptr(Gt), ptr(Wc), d, S, ptr(Stab), stream())
     gsum = torch.empty(2, d, device=DEV)
     call("pm_chord_pad_bwd", ptr(dy), ptr(plan.is_drum), N, d, S, ptr(tables), ptr(Wc), ptr(gsum), ptr(dW), ptr(Stab), stream())
     assert rel_err(dW - 0.5, W64.grad) < 2e-5

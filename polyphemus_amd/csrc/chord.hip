@@ -32,22 +32,24 @@ __host__ __device__ inline int64_t pt_off(int g, int s, int kind, int S, int d) 
 // values requested (registers) before the current one is multiplied; k-major LDS images, so a thread reads its two A and
 // four B values of a k as one 8-byte and one 16-byte piece.  fp32 FMA.
 // AK / BK: the operand's contiguous direction is k (true) or its row index m / n (false) — picks the coalesced staging order
-template <bool AK, bool BK, class FA, class FB, class FC>
+template <bool AK, bool BK, int KC, class FA, class FB, class FC>
 __device__ inline void small_product(int M, int Nn, int K, int m0, int n0, FA a_at, FB b_at, FC c_out) {
-  constexpr int KC = 64, PA = 34, PB = 68;                          // (pitches: aligned pieces, staggered banks for the staging writes)
+  constexpr int PA = 34, PB = 68;                                   // (pitches: aligned pieces, staggered banks for the staging writes)
+  constexpr int NA = KC / 8, NB = KC / 4;                           // values per thread and chunk
+  static_assert(KC % 8 == 0, "32 x KC and 64 x KC values over 256 threads");
   __shared__ __attribute__((aligned(16))) float sA[KC * PA], sB[KC * PB];
   const int t = threadIdx.x, tm = t >> 4, tn = t & 15;              // 16 x 16 threads, 2 x 4 outputs each
   float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  float ra[8], rb[16];
+  float ra[NA], rb[NB];
   auto request = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int idx = t + i * 256;
       const int m = AK ? idx / KC : idx & 31, k = AK ? idx % KC : idx >> 5;
       ra[i] = (m0 + m < M && k0 + k < K) ? a_at(m0 + m, k0 + k) : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int idx = t + i * 256;
       const int n = BK ? idx / KC : idx & 63, k = BK ? idx % KC : idx >> 6;
       rb[i] = (n0 + n < Nn && k0 + k < K) ? b_at(n0 + n, k0 + k) : 0.f;
@@ -56,13 +58,13 @@ __device__ inline void small_product(int M, int Nn, int K, int m0, int n0, FA a_
   request(0);
   for (int k0 = 0; k0 < K; k0 += KC) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int idx = t + i * 256;
       const int m = AK ? idx / KC : idx & 31, k = AK ? idx % KC : idx >> 5;
       sA[k * PA + m] = ra[i];
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int idx = t + i * 256;
       const int n = BK ? idx / KC : idx & 63, k = BK ? idx % KC : idx >> 6;
       sB[k * PB + n] = rb[i];
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(256) k_chord_tables_fwd(const float* __restric
   const float* T = tables + (int64_t)(kind * 2 + g) * EMB_V * dh;
   const float* W = Wc + (int64_t)s * d + kind * dh;
   float* out = PT + pt_off(g, s, kind, S, d);
-  small_product<true, true>(V, d, dh, mt * 32, nt * 64,
+  small_product<true, true, 64>(V, d, dh, mt * 32, nt * 64,
                             [&](int v, int c) { return T[(int64_t)v * dh + c]; },
                             [&](int j, int c) { return W[(int64_t)j * PM_N_SLOTS * d + c]; },
                             [&](int v, int j, float x) { out[(int64_t)v * d + j] = x; });
@@ -308,65 +310,74 @@ extern "C" int pm_chord_sum_bwd(const float* dY, const int32_t* tokens, const in
   return pm_check_launch();
 }
 
-// dWc[j][s d + kind dh + c] += sum_{g, v} G[g][s][kind][v][j] * T[kind*2+g][v][c]; grid (j tiles x c tiles, S, 2 kinds);
-// the workgroups of (s = 0, pitch, first c tile) also add the bias gradient db[j] += sum_{g, v} G[g][0][0][v][j]
+// dWc[j][s d + kind dh + c] += sum_v G[g][s][kind][v][j] * T[kind*2+g][v][c] for the workgroup's group g; grid (j tiles x c tiles,
+// S, 4 = kind*2+g): the two groups' products meet in dWc through float atomics (a workgroup's K is one vocabulary: two
+// chunks).  The workgroups of (s = 0, pitch, first c tile) also add their group's part of the bias gradient,
+// db[j] += sum_v G[g][0][0][v][j].
 __global__ void __launch_bounds__(256) k_chord_tables_bwd_w(const float* __restrict__ G, const float* __restrict__ tables, int d,
-                                                            int S, float* __restrict__ dWc, float* __restrict__ db) {
+                                                            int S, float* __restrict__ dWc, float* __restrict__ db, unsigned* gate) {
   const int dh = d / 2, ntn = (dh + 63) / 64;
-  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn, s = blockIdx.y, kind = blockIdx.z;
+  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn, s = blockIdx.y, kind = blockIdx.z >> 1, g = blockIdx.z & 1;
   const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
-  const float* G0 = G + pt_off(0, s, kind, S, d);
-  const float* G1 = G + pt_off(1, s, kind, S, d);
-  const float* T0 = tables + (int64_t)(kind * 2) * EMB_V * dh;
-  const float* T1 = T0 + (int64_t)EMB_V * dh;
+  const float* Gg = G + pt_off(g, s, kind, S, d);
+  const float* T = tables + (int64_t)(kind * 2 + g) * EMB_V * dh;
   float* out = dWc + (int64_t)s * d + kind * dh;
-  small_product<false, false>(d, dh, 2 * V, mt * 32, nt * 64,
-                              [&](int j, int k) { return k < V ? G0[(int64_t)k * d + j] : G1[(int64_t)(k - V) * d + j]; },
-                              [&](int c, int k) { return k < V ? T0[(int64_t)k * dh + c] : T1[(int64_t)(k - V) * dh + c]; },
-                              [&](int j, int c, float x) { out[(int64_t)j * PM_N_SLOTS * d + c] += x; });
-  if (db && s == 0 && kind == 0 && nt == 0) {
-    const int j = mt * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;        // 8 partial sums per column
+  float res[2][4];
+  small_product<false, false, 72>(d, dh, V, mt * 32, nt * 64,
+                                  [&](int j, int k) { return Gg[(int64_t)k * d + j]; },
+                                  [&](int c, int k) { return T[(int64_t)k * dh + c]; },
+                                  [&](int j, int c, float x) { res[(j - mt * 32) & 1][(c - nt * 64) & 3] = x; });
+  float dbv = 0.f;
+  const bool bias_part = db && s == 0 && kind == 0 && nt == 0;
+  const int jb = mt * 32 + (threadIdx.x & 31);
+  if (bias_part) {
+    const int part = threadIdx.x >> 5;                                          // 8 partial sums per column
     __shared__ float red[8][32];
     float a = 0.f;
-    if (j < d) {
-#pragma unroll 1
-      for (int gg = 0; gg < 2; ++gg) {
-        const float* Gp = gg ? G1 : G0;
-        float v[17];                                                            // (V <= 131: at most 17 rows per part, all requested at once)
+    if (jb < d) {
+      float v[17];                                                              // (V <= 131: at most 17 rows per part, all requested at once)
 #pragma unroll
-        for (int i = 0; i < 17; ++i) v[i] = part + 8 * i < V ? Gp[(int64_t)(part + 8 * i) * d + j] : 0.f;
+      for (int i = 0; i < 17; ++i) v[i] = part + 8 * i < V ? Gg[(int64_t)(part + 8 * i) * d + jb] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 17; ++i) a += v[i];
-      }
+      for (int i = 0; i < 17; ++i) a += v[i];
     }
     red[part][threadIdx.x & 31] = a;
     __syncthreads();
-    if (part == 0 && j < d) {
-      float t = 0.f;
+    if (part == 0)
 #pragma unroll
-      for (int p = 0; p < 8; ++p) t += red[p][threadIdx.x & 31];
-      db[j] += t;
-    }
+      for (int p = 0; p < 8; ++p) dbv += red[p][threadIdx.x & 31];
   }
+  const int tm = threadIdx.x >> 4, tn = threadIdx.x & 15;
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the groups add in turn)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jj = mt * 32 + tm * 2 + i, c = nt * 64 + tn * 4 + j;
+      if (jj < d && c < dh) atomicAdd(&out[(int64_t)jj * PM_N_SLOTS * d + c], res[i][j]);
+    }
+  if (bias_part && (threadIdx.x >> 5) == 0 && jb < d) atomicAdd(&db[jb], dbv);
+  pm_turn_leave_block(gate);
 }
-// S[kind*2+g][v][c] += sum_j G[g][s][kind][v][j] * Wc[j][s d + kind dh + c] for the workgroup's slot s; grid (v tiles x c tiles,
-// 4 = kind*2+g, S): the slots' partial products meet in S (zeroed by the caller) through float atomics
+// S[kind*2+g][v][c] += sum_j G[g][s][kind][v][j] * Wc[j][s d + kind dh + c] over the workgroup's (slot s, half of the j); grid
+// (v tiles x c tiles, 4 = kind*2+g, 2 S): the partial products meet in S (cleared by the caller) through float atomics
 __global__ void __launch_bounds__(256) k_chord_tables_bwd_x(const float* __restrict__ G, const float* __restrict__ Wc, int d, int S,
                                                             float* __restrict__ Stab, unsigned* gate) {
   const int dh = d / 2, ntn = (dh + 63) / 64;
-  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn, kind = blockIdx.y >> 1, g = blockIdx.y & 1, s = blockIdx.z;
+  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn, kind = blockIdx.y >> 1, g = blockIdx.y & 1, s = blockIdx.z >> 1;
+  const int j0 = (blockIdx.z & 1) * dh;                                         // this workgroup's j range: [j0, j0 + d/2)
   const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
   if (mt * 32 >= V) { pm_turn_skip_block(gate); return; }
-  const float* Gg = G + pt_off(g, s, kind, S, d);
-  const float* W = Wc + (int64_t)s * d + kind * dh;
+  const float* Gg = G + pt_off(g, s, kind, S, d) + j0;
+  const float* W = Wc + (int64_t)j0 * PM_N_SLOTS * d + (int64_t)s * d + kind * dh;
   float* out = Stab + (int64_t)(kind * 2 + g) * EMB_V * dh;
   float res[2][4];
-  small_product<true, false>(V, dh, d, mt * 32, nt * 64,
-                             [&](int v, int j) { return Gg[(int64_t)v * d + j]; },
-                             [&](int c, int j) { return W[(int64_t)j * PM_N_SLOTS * d + c]; },
-                             [&](int v, int c, float x) { res[(v - mt * 32) & 1][(c - nt * 64) & 3] = x; });
+  small_product<true, false, 64>(V, dh, dh, mt * 32, nt * 64,
+                                 [&](int v, int j) { return Gg[(int64_t)v * d + j]; },
+                                 [&](int c, int j) { return W[(int64_t)j * PM_N_SLOTS * d + c]; },
+                                 [&](int v, int c, float x) { res[(v - mt * 32) & 1][(c - nt * 64) & 3] = x; });
   const int tm = threadIdx.x >> 4, tn = threadIdx.x & 15;
-  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the slots add in turn)
+  pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the partial products add in turn)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -380,15 +391,15 @@ extern "C" int pm_chord_tables_bwd_w(const float* Gt, const float* tables, int32
                                      pm_stream_t stream) {
   if (!Gt || !tables || !dWc || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   const int dh = d / 2;
-  hipLaunchKernelGGL(k_chord_tables_bwd_w, dim3((unsigned)(pm_cdiv(d, 32) * pm_cdiv(dh, 64)), n_slots, 2), dim3(256), 0,
-                     (hipStream_t)stream, Gt, tables, d, n_slots, dWc, db);
+  hipLaunchKernelGGL(k_chord_tables_bwd_w, dim3((unsigned)(pm_cdiv(d, 32) * pm_cdiv(dh, 64)), n_slots, 4), dim3(256), 0,
+                     (hipStream_t)stream, Gt, tables, d, n_slots, dWc, db, pm_det_gate((hipStream_t)stream));
   return pm_check_launch();
 }
 extern "C" int pm_chord_tables_bwd_x(const float* Gt, const float* Wc, int32_t d, int32_t n_slots, float* Stab, pm_stream_t stream) {
   if (!Gt || !Wc || !Stab || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int dh = d / 2;
-  hipLaunchKernelGGL(k_chord_tables_bwd_x, dim3((unsigned)(pm_cdiv(EMB_V, 32) * pm_cdiv(dh, 64)), 4, n_slots), dim3(256), 0, st, Gt,
-                     Wc, d, n_slots, Stab, pm_det_gate(st));
+  hipLaunchKernelGGL(k_chord_tables_bwd_x, dim3((unsigned)(pm_cdiv(EMB_V, 32) * pm_cdiv(dh, 64)), 4, 2 * n_slots), dim3(256), 0, st,
+                     Gt, Wc, d, n_slots, Stab, pm_det_gate(st));
   return pm_check_launch();
 }

@@ -695,10 +695,15 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     br.mark(BR_WPREP);
     br.pause();
   };
-  // (table form of the chord encoder: its three launches wait for the plan's counting launch only — the host issues them
-  //  BEFORE the six launches of the weight preparation, or they would start ~25 us after the event they wait for)
-  const bool prep_late = chord_tab && plan_side;
-  if (!prep_late) encoder_prep();
+  // (table form of the chord encoder: its launches wait for the plan's counting launch only, ~35 us into the second stream's
+  //  work — the caller's stream has nothing to do until then, so the encoder's weight preparation (parameters only, ~30 us)
+  //  runs THERE, in front of that wait, and the second stream carries the plan alone)
+  const bool prep_main = chord_tab && plan_side;
+  if (prep_main) {
+    br.mark(BR_WPREP);                                 // (what the first GCL layer waits for: the plan)
+    br.pause();
+    gcn_prepare(c, Y.enc_gcn, s.eg);
+  } else encoder_prep();
   // the rest of the branch: issued by decoder_prep_and_structure_encoder() below, behind the first launches of the content encoder
   auto decoder_prep_and_structure_encoder = [&]() {
     br.resume();
@@ -776,7 +781,6 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     }
     s.x0d = drop(c, s.x0, N, d, SITE_ENC_CHORD, seed_enc, x0d_buf);                          // model.py:389-390 (row = node)
   }
-  if (prep_late) encoder_prep();                       // (also in the measuring pass: it carves the weight planes out of the arena)
   if (run) branch_join(c, BR_WPREP);                   // the plan, the GCL weight planes and the distance table are ready
   float* xL = gcn_forward(c, dropping ? x0d_buf : s.x0, Y.enc_gcn, s.eg, seed_enc, 0, msg_p);
   decoder_prep_and_structure_encoder();                // (second stream; issued while the GPU works through the encoder's layers)

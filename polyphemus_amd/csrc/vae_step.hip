@@ -233,6 +233,11 @@ struct BranchScope {
   // 217 us into the step, behind 27 launches of the branch).  pause() hands the following launches back to the caller's
   // stream without closing the branch, resume() continues it (in order on the second stream; no new fork: use it only for
   // work that does not depend on what the caller's stream has produced since the fork).
+  // the branch waits for what the caller's stream has been given so far (a second fork point inside an open branch)
+  void wait_main() {
+    if (!b) return;
+    if (hipEventRecord(b->fork[site], main) != hipSuccess || hipStreamWaitEvent(b->st, b->fork[site], 0) != hipSuccess) c.chk(PM_E_LAUNCH);
+  }
   void pause() { if (b) { c.st = main; c.bn_scratch = scratch_main; } }
   void resume() { if (b) { c.st = b->st; c.bn_scratch = c.s->bn_scratch_side; } }
   // an intermediate join point: what has been issued on the branch so far is what branch_join(c, at) waits for
@@ -1147,14 +1152,14 @@ void backward_encoder_tail(Ctx& c) {
     {
       BranchScope br(c, BR_ENC_WGRAD);
       RUN(pm_chord_pad_bwd(dx0, s.bt.is_drum, N, d, S, s.tables, c.P + Y.enc_chord.w, gsum, c.G + Y.enc_chord.w, Stab, c.st));
-    }
-    RUN(pm_chord_sum_bwd(dx0, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Gt, c.st));
-    branch_join(c, BR_ENC_WGRAD);
-    {
-      BranchScope br(c, BR_ENC_WGRAD);
+      br.pause();
+      RUN(pm_chord_sum_bwd(dx0, s.bt.tokens, s.plan, N, c.E, Gn, d, S, Gt, c.st));
+      br.wait_main();                                  // (the branch goes on behind the token sums: one join less)
+      br.resume();
       RUN(pm_chord_tables_bwd_x(Gt, c.P + Y.enc_chord.w, d, S, Stab, c.st));
+      br.pause();
+      RUN(pm_chord_tables_bwd_w(Gt, s.tables, d, S, c.G + Y.enc_chord.w, c.G + Y.enc_chord.b, c.st));
     }
-    RUN(pm_chord_tables_bwd_w(Gt, s.tables, d, S, c.G + Y.enc_chord.w, c.G + Y.enc_chord.b, c.st));
     branch_join(c, BR_ENC_WGRAD);
   } else if (S == PM_N_SLOTS) lin_bwd(c, dx0, s.X, Y.enc_chord, N, d, PM_N_SLOTS * d, dX);
   else {               // active slots through the GEMMs (weight columns [0, S*d)), the all-PAD tail in closed form

@@ -190,16 +190,27 @@ extern "C" int pm_chord_sum_fwd(const float* PT, const float* cvec, const int32_
 typedef float c_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 c_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int c_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef CHORD_WHATIF
+#define CHORD_WHATIF 0                    // timing what-ifs of k_chord_sum_bwd (WRONG results): 1 no flush, 2 no one-hot / MFMA, 3 no dY loads
+#endif
 namespace {
 constexpr int CH_ROWS = 2048;             // nodes of a workgroup's chunk staged in LDS at a time
 constexpr int CH_NVT = 5;                 // token tiles of 32: 5 for the pitch tables (131), 4 of them for the duration tables (99)
 }
 __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__ dY, const int* __restrict__ tok,
                                                        const int* __restrict__ group_list, const int* __restrict__ group_cnt,
-                                                       int N, int d, int S, int per, float* __restrict__ G, unsigned* gate) {
-  __shared__ int sTok[CH_ROWS + 16], sOff[CH_ROWS + 16];
+                                                       int N, int d, int S, int per0, int skip_pad, float* __restrict__ G,
+                                                       unsigned* gate) {
+  __shared__ int sTok[CH_ROWS + 32], sOff[CH_ROWS + 32];
+  __shared__ int sCnt[8];
   const int s = blockIdx.y, kind = blockIdx.z & 1, cblk = blockIdx.z >> 1;    // (d = 512: two column blocks of eight waves)
   const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR;
+  // skip_pad: nodes whose token of (s, kind) is PAD are left out — from the second slot on that is most of them — and the PAD
+  // row follows afterwards by subtraction (k_chord_pad_fix: every node has exactly one token per (slot, kind), so the rows of
+  // a (group, slot, kind) add up to the group's column sums of dY, which (slot 0, pitch) — never compacted — holds in full).
+  const bool compact = skip_pad && !(s == 0 && kind == 0);
+  const int pad = kind == 0 ? 130 : 98;
+  const int per = per0;
   // chunks of `per` nodes: the first ceil(cnt0 / per) workgroups take the drum group, the others the non-drum group
   const int cnt0 = group_cnt[0], cnt1 = group_cnt[1];
   const int nb0 = (cnt0 + per - 1) / per;
@@ -219,16 +230,45 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
   const int colb = ((cblk * 8 + wave) * 32 + li) * 4;
   const int nrows = i1 - i0;
   for (int r0 = 0; r0 < nrows; r0 += CH_ROWS) {
-    const int nr = min(CH_ROWS, nrows - r0);
+    int nr = min(CH_ROWS, nrows - r0);
     __syncthreads();
-    for (int k = threadIdx.x; k < CH_ROWS + 16; k += blockDim.x) {       // node k of the chunk: its token of (s, kind), byte offset of its dY row
-      int tk = -1, off = (int)0x80000000;
-      if (k < nr) {
-        const int n = list[i0 + r0 + k];
-        tk = tok[(int64_t)n * 32 + 2 + s * 2 + kind];
-        off = n * d * 4;
+    if (!compact) {
+      for (int k = threadIdx.x; k < CH_ROWS + 32; k += blockDim.x) {     // node k of the chunk: its token of (s, kind), byte offset of its dY row
+        int tk = -1, off = (int)0x80000000;
+        if (k < nr) {
+          const int n = list[i0 + r0 + k];
+          tk = tok[(int64_t)n * 32 + 2 + s * 2 + kind];
+          off = n * d * 4;
+        }
+        sTok[k] = tk; sOff[k] = off;
       }
-      sTok[k] = tk; sOff[k] = off;
+    } else {
+      // the same list without the PAD nodes, in the order of the chunk (a fixed order: deterministic mode adds in it)
+      const int nw = blockDim.x >> 6;
+      int fill = 0;
+      for (int k0 = 0; k0 < nr; k0 += blockDim.x) {
+        const int k = k0 + threadIdx.x;
+        int tk = pad, off = 0;
+        if (k < nr) {
+          const int n = list[i0 + r0 + k];
+          tk = tok[(int64_t)n * 32 + 2 + s * 2 + kind];
+          off = n * d * 4;
+        }
+        const bool keep = tk != pad;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) sCnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < nw; ++w) { const int cw = sCnt[w]; if (w < wave) before += cw; total += cw; }
+        if (keep) {
+          const int at = fill + before + __popcll(bal & ((1ull << lane) - 1ull));
+          sTok[at] = tk; sOff[at] = off;
+        }
+        fill += total;
+        __syncthreads();
+      }
+      for (int k = fill + threadIdx.x; k < min(CH_ROWS + 32, ((fill + 15) & ~15) + 32); k += blockDim.x) { sTok[k] = -1; sOff[k] = (int)0x80000000; }
+      nr = fill;
     }
     __syncthreads();
     auto fetch = [&](int (&tk)[8], float (&x)[8], int k0) {
@@ -237,7 +277,7 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
       for (int i = 0; i < 8; ++i) {
         tk[i] = sTok[kb + i];
         const int of = sOff[kb + i];
-        x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, of == (int)0x80000000 ? of : of + colb, 0, 0));
+        x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (CHORD_WHATIF == 3 || of == (int)0x80000000) ? (int)0x80000000 : of + colb, 0, 0));
       }
     };
     auto step = [&](const int (&tk)[8], const float (&x)[8]) {
@@ -254,7 +294,7 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
       const c_bf16x8 b3 = __builtin_bit_cast(c_bf16x8, c_u32x4{p3[0], p3[1], p3[2], p3[3]});
 #pragma unroll
       for (int q = 0; q < CH_NVT; ++q) {
-        if (!(live & (1u << q))) continue;                         // (wave-uniform)
+        if (!(live & (1u << q)) || CHORD_WHATIF == 2) continue;    // (wave-uniform)
         const int v = q * 32 + li;
         unsigned a[4];
 #pragma unroll
@@ -287,9 +327,40 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
     for (int r = 0; r < 16; ++r) {
       const int v = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float val = acc[q][r];
-      if (v < V && val != 0.f) atomicAdd(out + (int64_t)v * d, val);
+      if (v < V && val != 0.f && CHORD_WHATIF != 1) atomicAdd(out + (int64_t)v * d, val);
     }
   pm_turn_leave_block(gate);
+}
+// PAD rows left out by k_chord_sum_bwd: G[g][s][kind][PAD] = sum_v G[g][0][pitch][v] - sum_{v != PAD} G[g][s][kind][v]; grid (column
+// blocks of 64, 2 S variants, 2 groups); four waves split the vocabulary, fixed order of the partial sums
+__global__ void __launch_bounds__(256) k_chord_pad_fix(float* __restrict__ G, int d, int S) {
+  const int s = blockIdx.y >> 1, kind = blockIdx.y & 1, g = blockIdx.z;
+  if (s == 0 && kind == 0) return;                                              // (the complete variant)
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int V = kind == 0 ? PM_N_PITCH : PM_N_DUR, pad = kind == 0 ? 130 : 98;
+  const float* G0 = G + pt_off(g, 0, 0, S, d);
+  float* Gv = G + pt_off(g, s, kind, S, d);
+  __shared__ float red[2][4][64];
+  float a = 0.f, b = 0.f;
+  if (j < d) {
+    float x[33], y[33];                                                         // (131 rows over four parts: all requested at once)
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+      const int v = part + 4 * i;
+      x[i] = v < PM_N_PITCH ? G0[(int64_t)v * d + j] : 0.f;
+      y[i] = (v < V && v != pad) ? Gv[(int64_t)v * d + j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 33; ++i) { a += x[i]; b += y[i]; }
+  }
+  red[0][part][threadIdx.x & 63] = a; red[1][part][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (part == 0 && j < d) {
+    const int l = threadIdx.x & 63;
+    const float all = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+    const float oth = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    Gv[(int64_t)pad * d + j] = all - oth;
+  }
 }
 extern "C" int pm_chord_sum_bwd(const float* dY, const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G_,
                                 int32_t d, int32_t n_slots, float* Gt, pm_stream_t stream) {
@@ -302,11 +373,14 @@ extern "C" int pm_chord_sum_bwd(const float* dY, const int32_t* tokens, const in
   // chunk counts round up separately
   static const int chunk_env = getenv("PM_CHORD_BWD_CHUNK") ? atoi(getenv("PM_CHORD_BWD_CHUNK")) : 0;
   const int per = chunk_env > 0 ? chunk_env : 640;
+  static const bool skip_pad = !(getenv("PM_CHORD_SKIP_PAD") && atoi(getenv("PM_CHORD_SKIP_PAD")) == 0);   // 0: every node in every (slot, kind), no subtraction pass
   const int nb = (int)pm_cdiv(N, per) + 1;
   const int waves = d / 32 > 8 ? 8 : d / 32, cblks = (d / 32 + waves - 1) / waves;
   if (d / 32 != waves * cblks) return PM_E_INVALID;
   hipLaunchKernelGGL(k_chord_sum_bwd, dim3(nb, n_slots, 2 * cblks), dim3(64 * waves), 0, st, dY, tokens, pv.group_list, pv.group_cnt,
-                     N, d, n_slots, per, Gt, pm_det_gate(st));
+                     N, d, n_slots, per, skip_pad ? 1 : 0, Gt, pm_det_gate(st));
+  if (skip_pad && 2 * n_slots > 1)
+    hipLaunchKernelGGL(k_chord_pad_fix, dim3((unsigned)pm_cdiv(d, 64), 2 * n_slots, 2), dim3(256), 0, st, Gt, d, n_slots);
   return pm_check_launch();
 }
 

@@ -590,6 +590,39 @@ def test_embed_fwd_bwd(small, d, training):
             assert rel_err(G32[k], P64[k].grad) < 2e-5, k
 
 
+@pytest.mark.parametrize("drums", ["none", "all"])
+def test_chord_table_algebra_with_an_empty_node_group(drums):
+    """chord.hip when one of the two node groups (drums / non-drums) is empty: its chunks of the one-hot sums exit, its rows of
+    the token sums stay zero, the other group's results are those of the gather-and-product formulation."""
+    cpu = synthetic_batch(5, 2, p=0.25, seed=11)
+    cpu.is_drum[:] = drums == "all"
+    b, plan = make_plan(cpu)
+    d, S, N, dh = 64, 4, plan.N, 32
+    torch.manual_seed(3)
+    tables = torch.randn(4, 131, dh, device=DEV)
+    Wc = torch.randn(d, 15 * d, device=DEV) / (15 * d) ** 0.5
+    bc = torch.randn(d, device=DEV) * 0.1
+    tok = plan.tokens.view(N, 16, 2).clone()
+    tok[:, S + 1:, 0] = 130; tok[:, S + 1:, 1] = 98
+    tok = tok.contiguous()
+    g = 0 if drums == "all" else 1
+    pit, dur = tok[:, 1:, 0].long(), tok[:, 1:, 1].long()
+    X = torch.cat((tables.double()[g][pit], tables.double()[2 + g][dur]), -1).reshape(N, 15 * d)
+    ref = torch.relu(X @ Wc.double().t() + bc.double())
+    cvec, PT = torch.empty(2, d, device=DEV), torch.empty(2, S, 2, 131, d, device=DEV)
+    call("pm_chord_tables_fwd", ptr(tables), ptr(Wc), d, S, ptr(PT), ptr(bc), ptr(cvec), stream())
+    x0 = torch.empty(N, d, device=DEV)
+    call("pm_chord_sum_fwd", ptr(PT), ptr(cvec), ptr(tok), ptr(plan.is_drum), N, d, S, ptr(x0), stream())
+    assert rel_err(x0, ref) < 2e-6
+    dy = torch.randn(N, d, device=DEV)
+    Gt = torch.zeros(2, S, 2, 131, d, device=DEV)
+    call("pm_chord_sum_bwd", ptr(dy), ptr(tok), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(Gt), stream())
+    assert float(Gt[1 - g].abs().max()) == 0.0
+    want = torch.zeros(131, d, dtype=torch.float64, device=DEV).index_add_(0, pit[:, 1], dy.double())
+    assert rel_err(Gt[g, 1, 0], want) < 1e-6
+    assert rel_err(Gt[g, :, 0].sum(1), dy.double().sum(0).expand(S, d)) < 1e-5     # every (slot, kind) adds up to the column sums
+
+
 @pytest.mark.parametrize("d,S", [(32, 15), (256, 5), (128, 3), (256, 1)])
 def test_chord_encoder_as_table_algebra(small, d, S):
     """chord.hip: x0 = relu(b + sum_s X[:, s] @ Wc_s^T) through projected tables and row lookups, and its backward (token

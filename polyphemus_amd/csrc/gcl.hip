@@ -36,6 +36,9 @@
 #ifndef GCL_WHATIF
 #define GCL_WHATIF 0
 #endif
+#ifndef GCL_DAGG_PLANE_AUX
+#define GCL_DAGG_PLANE_AUX 0  // cache policy of the dh plane stores of k_gcl_dagg<.., true> (read next by k_gcl_dw): default; 2 (non-temporal) measured below
+#endif
 #ifndef GCL_CONS_STORE
 #define GCL_CONS_STORE 0      // 1: the A' planes leave through the MFMA waves (the fragments they read for k-step ks ARE 16-byte
                               // pieces of the plane rows; wave ks mod NCW stores them) instead of the producer waves re-reading the
@@ -585,7 +588,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * PL + rr * RB + ((ch ^ (rr & 15)) << 4));
-          __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, GCL_DAGG_PLANE_AUX);
         }
       }
     }

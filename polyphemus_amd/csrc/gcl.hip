@@ -36,6 +36,9 @@
 #ifndef GCL_WHATIF
 #define GCL_WHATIF 0
 #endif
+#ifndef GCL_DIRECT_EPI
+#define GCL_DIRECT_EPI 1      // k_gcl_fwd stores the h rows and adds the norm's column sums straight from the MFMA accumulators (0: through an LDS stage)
+#endif
 #ifndef GCL_DAGG_PLANE_AUX
 #define GCL_DAGG_PLANE_AUX 0  // cache policy of the dh plane stores of k_gcl_dagg<.., true> (read next by k_gcl_dw): default; 2 (non-temporal) measured below
 #endif
@@ -151,6 +154,9 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   auto chunk_blk = [&](int c) { const int q = c / NCH; return q == 0 ? 3 : (q == 1 ? 0 : (q == 2 ? (use_on ? 1 : 2) : 2)); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // epilogue straight from the accumulators (GCL_DIRECT_EPI); deterministic mode (its gate orders whole workgroups through
+  // barriers), the development traces and a launch without the norm's sums keep the LDS-staged epilogue
+  const bool direct_epi = GCL_DIRECT_EPI && !GCL_TRACE && !g.gate;
   int nst = 0;
   STAMP();
 #if GCL_TRACE
@@ -424,6 +430,41 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   if (full) consume(std::integral_constant<int, 2>{});
   else consume(std::integral_constant<int, 1>{});
 
+  if (direct_epi) {
+    // ---- h rows (+ bias) straight from the accumulators: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) +
+    // 8*(reg >> 2) + 4*(lane >> 5) — a store instruction writes 128 bytes of two rows; the column sums of the BatchNorm that
+    // follows add up in the lane (its 32 rows of a column, fp64), meet the other half-wave's through one exchange and leave
+    // with one atomic per lane (lanes 0..31 the sums, 32..63 the sums of squares: a wave owns its 32 columns outright).  No
+    // stage of the tile in LDS, no barrier, nothing left for the producer waves.
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(g.h, 0, GCL_OOB, 0x00020000);
+    int nd[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int4 v4 = *reinterpret_cast<const int4*>(sNode + i * 32 + 8 * q + 4 * lh);
+        nd[i][q * 4] = v4.x; nd[i][q * 4 + 1] = v4.y; nd[i][q * 4 + 2] = v4.z; nd[i][q * 4 + 3] = v4.w;
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int colj = (ct0 + j) * 32 + li;
+      const float bv = g.bias ? g.bias[colj] : 0.f;
+      double cs = 0.0, cq = 0.0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nd[i][r];
+          const float v = n >= 0 ? float(acc[i][j][r]) + bv : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), hrs, n >= 0 ? (n * D + colj) * 4 : GCL_OOB, 0, 0);
+          cs += (double)v; cq += (double)v * (double)v;
+        }
+      if (g.colstats) {
+        const double os = __shfl_xor(cs, 32, 64), oq = __shfl_xor(cq, 32, 64);
+        atomicAdd(g.colstats + (int64_t)(blockIdx.x % PM_BN_REPL) * 2 * D + lh * D + colj, lh == 0 ? cs + os : cq + oq);
+      }
+    }
+  } else {
   // ---- h tile (+ bias) to LDS, over the images: C/D map of the 32x32 MFMA: col = lane & 31,
   // row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5); row stride HS = D + 8 floats (the two half-waves 32 banks apart)
 #pragma unroll
@@ -436,6 +477,8 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
         sH[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * HS + (ct0 + j) * 32 + li] = acc[i][j][r] + bv;
   }
   }
+  }
+  if (direct_epi) return;                                      // (every wave: nothing of the epilogue below is left to do)
   STAMP();
   __syncthreads();
   // ---- epilogue (all waves): rows scattered to their nodes, one 4*D-byte row per store; fp64 column sums for the

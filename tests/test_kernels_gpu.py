@@ -623,7 +623,7 @@ def test_chord_table_algebra_with_an_empty_node_group(drums):
     assert rel_err(Gt[g, :, 0].sum(1), dy.double().sum(0).expand(S, d)) < 1e-5     # every (slot, kind) adds up to the column sums
 
 
-@pytest.mark.parametrize("d,S", [(32, 15), (256, 5), (128, 3), (256, 1)])
+@pytest.mark.parametrize("d,S", [(32, 15), (256, 5), (128, 3), (256, 1), (512, 2)])
 def test_chord_encoder_as_table_algebra(small, d, S):
     """chord.hip: x0 = relu(b + sum_s X[:, s] @ Wc_s^T) through projected tables and row lookups, and its backward (token
     sums of the output gradient on the matrix cores, weight / bias / table gradients from them), against the formulation

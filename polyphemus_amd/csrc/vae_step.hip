@@ -50,6 +50,7 @@ struct StepCfg {
   bool chord_tables;           // PM_CHORD_TABLES=0: the chord encoder through X [N, S, d] (gather, long-K product, weight-gradient product, token
                                // sums of dX) instead of as table algebra (chord.hip)
   bool plan_side;              // PM_PLAN_SIDE=0: the plan build on the caller's stream in front of the content encoder (see forward())
+  int late_wgrads_at;          // PM_LATE_WGRADS=2 (development A/B): forked behind the decoder's half of the head chain instead of in front of it
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -68,6 +69,7 @@ static StepCfg read_cfg() {
   k.debug = getenv("PM_DEBUG") != nullptr;
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
   k.late_wgrads = flag("PM_LATE_WGRADS", true);
+  k.late_wgrads_at = getenv("PM_LATE_WGRADS") ? atoi(getenv("PM_LATE_WGRADS")) : 1;
   k.dw_side = flag("PM_DW_SIDE", false);
   k.dagg_bn = flag("PM_DAGG_BN", true);
   k.plan_side = flag("PM_PLAN_SIDE", true);
@@ -984,7 +986,7 @@ void backward_decoder(Ctx& c) {
   else
     lin_bwd(c, dH, s.dg.x[c.L], Y.dec_chord, N, S * d, d, dxL);        // slots >= S: zero gradient (all PAD)
   float* dx0 = gcn_backward(c, dxL, Y.dec_gcn, s.dg);
-  if (late_wgrads) decoder_weight_grads();
+  if (late_wgrads && cfg().late_wgrads_at != 2) decoder_weight_grads();
   float* dcb = ar.f((size_t)Gn * d);
   RUN(pm_bar_broadcast_bwd(dx0, s.plan, N, c.E, Gn, d, dcb, c.st));
   Deferred df;
@@ -1027,6 +1029,7 @@ void backward_decoder(Ctx& c) {
   lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz, 0, 0, 0, true, &df);
   RUN(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
   }
+  if (late_wgrads && cfg().late_wgrads_at == 2) decoder_weight_grads();
   if (df.n) {                                         // the two head products' weight gradients: behind the others on the second stream
     BranchScope br(c, BR_DEC_WGRAD);
     flush_deferred(c, df);

@@ -137,7 +137,120 @@ def standalone_segreduce_fwd(batch, d, p=0.1, reps=24):
                              "note": "the same 117 MB operand set every launch: fits the Infinity Cache, not an HBM figure"}}
 
 
-def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers=8, seed=1234):
+def reference_format(batch):
+    """The batch as the reference's DataLoader hands it to `model(graph)` (data.py:179-182,235-268): edge_attrs [E, 33] (type
+    as a float in column 0, one-hot distance), c_tensor one-hot [N, 16, 230] (240 MB at configs[1]); no token ids."""
+    class Graph:
+        pass
+    g = Graph()
+    E, N = batch.edge_index.shape[1], batch.num_nodes
+    ea = torch.zeros(E, 33, device=batch.edge_index.device)
+    ea[:, 0] = batch.edge_type.float()
+    ea[torch.arange(E, device=ea.device), 1 + batch.edge_dist.long()] = 1.0
+    tok = batch.tokens.long()
+    c = torch.zeros(N, 16, 230, device=ea.device)
+    c.scatter_(2, tok[..., 0:1], 1.0)
+    c.scatter_(2, 131 + tok[..., 1:2], 1.0)
+    g.edge_index, g.edge_attrs, g.c_tensor, g.s_tensor = batch.edge_index, ea, c, batch.s_tensor
+    g.is_drum, g.bars, g.batch, g.num_nodes = batch.is_drum, batch.bars, batch.batch, N
+    return g
+
+
+def reference_losses(s_tensor, s_logits, c_tensor, c_logits, mu, log_var, beta=0.0):
+    """`PolyphemusTrainer._losses` (training.py:298-347) in the caller's torch ops, quirks included (the structure BCE on the
+    target itself, :307; beta = 0, :116) — and its seven `.item()` host reads."""
+    F = torch.nn.functional
+    c_tensor = c_tensor[..., 1:, :]
+    c_logits = c_logits.reshape(-1, c_logits.size(-1))
+    c_tensor = c_tensor.reshape(-1, c_tensor.size(-1))
+    s_in = s_tensor.reshape(-1, *s_logits.shape[2:])
+    s_loss = F.binary_cross_entropy_with_logits(s_in.reshape(-1), s_tensor.reshape(-1).float(), reduction="none").mean()
+    pitch_loss = F.cross_entropy(c_logits[:, :131], c_tensor[:, :131].argmax(dim=1), ignore_index=130)
+    dur_loss = F.cross_entropy(c_logits[:, 131:], c_tensor[:, 131:].argmax(dim=1), ignore_index=98)
+    kld = (-0.5 * torch.sum(1 + log_var - mu.pow(2) - log_var.exp(), dim=1)).mean()
+    rec = pitch_loss + dur_loss + s_loss
+    tot = rec + beta * kld
+    return tot, {"tot": tot.item(), "pitch": pitch_loss.item(), "dur": dur_loss.item(), "structure": s_loss.item(),
+                 "reconstruction": rec.item(), "kld": kld.item(), "beta*kld": beta * kld.item()}
+
+
+def reference_loop_workload(name, active_slots_only, batch_size=256, d=256, n_bars=2, layers=8, steps=10, warmup=3, seed=1234):
+    """The drop-in boundary as the UNCHANGED reference loop drives it (training.py:137-172, train.py:176-181): reference-format
+    inputs, `vae(graph)` under fp16 autocast, the reference's `_losses` in torch, `GradScaler.scale(loss).backward()`,
+    `scaler.step(torch.optim.Adam)`, `zero_grad` — `model(graph)` and its autograd node run the C++ step (model._VaeStepFn),
+    the loss, the unscale and Adam over 152 tensors are the caller's torch code.  A new batch object every step, as a
+    DataLoader gives (the one-hot -> id conversion and its host read are inside the timed region)."""
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.synthetic import synthetic_batch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=layers, d=d, n_bars=n_bars, resolution=8)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=dev).to(dev)
+    vae.train()
+    vae.active_slots_only = bool(active_slots_only)
+    opt = torch.optim.Adam(vae.parameters(), lr=5e-6, betas=(0.9, 0.98), eps=1e-9)     # train.py:181, training.json:11-18
+    scaler = torch.amp.GradScaler("cuda")                                             # training.py:123
+    g = reference_format(synthetic_batch(batch_size, n_bars, p=0.25, seed=seed).to(dev))
+    parts = None
+
+    def step():
+        nonlocal parts
+        g.__dict__.pop("_pm_inputs", None)
+        with torch.autocast("cuda", dtype=torch.float16):                             # training.py:137
+            (s_logits, c_logits), mu, log_var = vae(g)
+            tot, parts = reference_losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, log_var)
+        scaler.scale(tot).backward()                                                  # training.py:153
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+    for _ in range(warmup):
+        step()
+    first = dict(parts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    G = g.s_tensor.shape[0]
+    info = vae._native_step().info()
+    out = {"workload": name, "bar-graphs/s": round(G / dt, 1), "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "batch": batch_size, "d": d, "n_bars": n_bars, "batch_seed": seed, "decoder_head_slots": info["n_slots"],
+           "loss_after_warmup": round(first["tot"], 5), "loss_last": round(parts["tot"], 5),
+           "kernel_path": {k: v for k, v in info.items() if k not in ("N", "E", "G", "B")}}
+    del vae, opt, g
+    torch.cuda.empty_cache()
+    return out
+
+
+def generation_workload(batch_size=256, d=256, n_bars=2, layers=8, steps=10, warmup=3):
+    """The generation path of generate.py:21-37: z ~ N(0, 1) -> `vae.decoder(z, None)` (structure decoder, threshold, device-side
+    graph construction, content decoder; eval mode) -> bar-graphs generated per second."""
+    from polyphemus_amd.model import VAE
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=layers, d=d, n_bars=n_bars, resolution=8)
+    torch.manual_seed(0)
+    vae = VAE(**cfg, device=dev).to(dev)
+    vae.eval()
+    z = torch.randn(batch_size, d, device=dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            vae.decoder(z, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s_logits, c_logits = vae.decoder(z, None)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": "generation: z -> decoder(z, None) -> (s_logits, c_logits), eval mode (generate.py:21-37)",
+           "bar-graphs/s": round(batch_size * n_bars / dt, 1), "ms_per_call": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "batch": batch_size, "d": d, "n_bars": n_bars, "nodes_generated": int(c_logits.shape[0])}
+    del vae
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers=8, seed=1234, p=0.25, max_notes=4):
     """The remaining single-GPU configurations of BASELINE.json through the same step (fresh model and trainer, untimed part
     of the run): whole-step rate only."""
     from polyphemus_amd.model import VAE
@@ -149,7 +262,7 @@ def other_workload(name, batch_size, d, n_bars, dense, steps=5, warmup=2, layers
     vae = VAE(**cfg, device=dev).to(dev)
     vae.train()
     tr = HipTrainer(vae, lr=5e-6, betas=(0.9, 0.98), eps=1e-9)
-    batch = synthetic_batch(batch_size, n_bars, p=0.25, seed=seed, dense=dense).to(dev)
+    batch = synthetic_batch(batch_size, n_bars, p=p, seed=seed, dense=dense, max_notes=max_notes).to(dev)
     for _ in range(warmup):
         tr.train_step(batch)
     torch.cuda.synchronize()
@@ -616,6 +729,16 @@ def main():
                 other_workload("LMD16 16-bar, batch=64, d_hidden=256 (BASELINE configs[2])", 64, 256, 16, False),
                 other_workload("LMD2 2-bar, batch=256, d_hidden=512 (the reference's training.json)", 256, 512, 2, False),
                 other_workload("dense-graph stress, one GPU's shard: batch=64, d_hidden=512 (BASELINE configs[4])", 64, 512, 2, True, steps=3),
+                # shapes the synthetic spec of SURVEY App. D does not draw: every token slot in use (up to 14 notes per cell,
+                # constants.py:48), denser bars
+                other_workload("BASELINE configs[1] with up to 14 notes per cell: all 15 token slots active", 256, 256, 2, False, max_notes=14),
+                other_workload("BASELINE configs[1] with denser bars (p = 0.5: 65 nodes, 322 edges per bar)", 256, 256, 2, False, p=0.5),
+                # the drop-in boundary driven by the reference's own loop shape (torch loss, GradScaler, torch Adam)
+                reference_loop_workload("reference loop shape at BASELINE configs[1]: vae(graph) under fp16 autocast -> _losses (torch) -> "
+                                        "GradScaler backward -> torch.optim.Adam; decoder head over all 15 slots (as the reference)", False),
+                reference_loop_workload("the same with vae.active_slots_only = True (logits of slots that are PAD in every node are "
+                                        "not computed: same loss, same gradients)", True),
+                generation_workload(),
             ]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_subprocess(cfg)

@@ -50,8 +50,11 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   C++ step covers batch_norm = False and cfg.dropout —; pm_vae_step_info writes 16 ints; pm_relu_bwd_planes;
  *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain).
  *   6: round 4, second half (pm_gcl_input_grad_bn / PmBnBwd, pm_bn_bwd_sums: the norm backward inside the input gradient;
- *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra). */
-#define PM_ABI_VERSION 6
+ *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra).
+ *   7: round 5 (the fp16 pair operand format: PmH2, pm_absmax, pm_split_planes_frag_h2, pm_gcl_forward_fused_h2,
+ *   pm_gcl_input_grad_bn_h2, pm_gcl_weight_grad_fused_h2; PmNormSums.absmax_out; pm_bn_apply_fused_absmax; pm_vae_step_set_output_grads: the drop-in module's
+ *   `model(graph)` + autograd runs the C++ step). */
+#define PM_ABI_VERSION 7
 int pm_abi_version(void);
 const char* pm_build_info(void);
 
@@ -229,6 +232,39 @@ typedef struct PmBnBwd {
 int pm_gcl_input_grad_bn(const PmBnBwd* norm, uint16_t* dh_planes /* 3 planes [N,d], written */, int64_t plane_stride,
                          const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t,
                          int32_t use_classes, float* dA /* [N,4d] */, pm_stream_t stream);
+/* ---- the fp16 pair operand format ("h2") of the three GCL products at d in {128, 256}
+ * An fp32 product on the matrix cores needs its operands split into 16-bit pieces.  The exact three-term bf16 split above
+ * costs six MFMA products per fp32 product.  The h2 kernels use Ootomo & Yokota's error-corrected half-precision product
+ * instead: v * s = hi + lo with hi, lo fp16 (22 significant bits; s a power of two chosen from the tensor's |max| so that
+ * the five-bit exponent of fp16 is not a limit: exact to apply and to undo), and the product runs as the THREE MFMA
+ * products hi*hi + hi*lo + lo*hi with fp32 accumulation: element error <= 2^-22 relative plus the dropped lo*lo term of the
+ * same size — below the rounding an fp32 dot product of the same length accumulates — at half the matrix-core work, two
+ * thirds of the operand bytes (csrc/common.h pm_split2h_pair; parity of the step against the fp64 oracle: tests/).
+ * Planes keep the layout and strides of the three-plane format; plane 2 is unused.
+ *   absmax_in : device word holding the float bits of max |x| of the kernel's fp32 input (pm_absmax, or a producer's
+ *               absmax_out: pm_bn_apply_fused_absmax, PmNormSums.absmax_out); forward: of the layer input x, input gradient: of du
+ *   absmax_aux: forward only: the same for the distance table T
+ *   scale_out : device float the kernel WRITES: the power of two its activation planes (A' / dh) carry; the weight gradient
+ *               undoes both
+ *   w_scale   : the power of two the weight planes were built with (pm_split_planes_frag_h2) */
+typedef struct PmH2 {
+  const uint32_t* absmax_in; const uint32_t* absmax_aux; float* scale_out; float w_scale; int32_t reserved;
+} PmH2;
+/* *out = max(*out, float bits of max |x[i]|) (atomic; the word must start at 0 or at an earlier maximum) */
+int pm_absmax(const float* x, int64_t n, uint32_t* out, pm_stream_t stream);
+int pm_split_planes_frag_h2(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats, int64_t src_stride,
+                            int64_t dst_stride, float w_scale, uint16_t* out, pm_stream_t stream);
+int pm_gcl_forward_fused_h2(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                            float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag, const float* bias,
+                            int32_t use_classes, float* h, double* col_stats, uint16_t* planes, int64_t plane_stride,
+                            const PmH2* h2, pm_stream_t stream);
+int pm_gcl_input_grad_bn_h2(const PmBnBwd* norm, uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
+                            int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes, float* dA,
+                            const PmH2* h2, pm_stream_t stream);
+int pm_gcl_weight_grad_fused_h2(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
+                                int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                                int32_t use_classes, float* dW, const float* a_scale, const float* dh_scale,
+                                pm_stream_t stream);
 /* Weight gradient of that product, d[W_t; W_4; W_5; root] += A'[rows_t]^T dh[rows_t] (gcl.hip): 128x128 output tiles,
  * one workgroup per (tile, track group, K slice), operands streamed by loader waves through an LDS ring, K slices added
  * with float atomics; `dW` is the layer's [7d, d] gradient (+=).  Same result as the grouped planes product with transA
@@ -273,6 +309,7 @@ typedef struct PmNormSums {
   const float* mean; const float* var; const float* gamma; const float* beta;   /* [d] */
   float eps; int32_t relu;
   double* acc3;
+  uint32_t* absmax_out;            /* NULL, or device word: atomic max of the float bits of |dx| (PmH2.absmax_in of the layer below) */
 } PmNormSums;
 int pm_segreduce_bwd_norm(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
                           int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
@@ -425,6 +462,11 @@ int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, 
                       const float* beta, const float* residual /* or NULL */, int relu, float* y,
                       float* mean /* [C] out */, float* var /* [C] out */, float* running_mean /* or NULL */,
                       float* running_var, float momentum, pm_stream_t stream);
+/* ... which also leaves max |y| (float bits, atomic max) in *absmax_out: PmH2.absmax_in of the GCL layer that reads y */
+int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps, const float* gamma,
+                             const float* beta, const float* residual, int relu, float* y, float* mean, float* var,
+                             float* running_mean, float* running_var, float momentum, uint32_t* absmax_out,
+                             pm_stream_t stream);
 int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
                     float eps, const float* gamma, const float* beta, int relu, float* dgamma, float* dbeta,
                     float* dbias_pre /* or NULL */, float* dx /* fp32 output, or NULL with dx_planes */, double* acc3,
@@ -791,6 +833,13 @@ int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
  * log_var [B,d].  Valid until the next pm_vae_step_forward on this state. */
 int pm_vae_step_outputs(const void* state, float* s_logits, float* c_logits, float* mu, float* log_var,
                         pm_stream_t stream);
+/* The drop-in module's path — `model(graph)` called by the unchanged training.py:137-166, which computes `_losses` itself
+ * and calls `backward()`: between pm_vae_step_forward (PmBatch.flags bit 2: keep the logits) / pm_vae_step_outputs and the
+ * four backward calls the caller hands in the gradients of the four outputs (any may be NULL = zero; d_c_logits covers the
+ * step's S slots, [N, S, 230]; d_s_logits != NULL switches the structure decoder's backward on).  They replace the
+ * gradients of the step's own loss kernels. */
+int pm_vae_step_set_output_grads(void* state, const float* d_s_logits /* [G,4,32] */, const float* d_c_logits /* [N,S,230] */,
+                                 const float* d_mu /* [B,d] */, const float* d_log_var /* [B,d] */, pm_stream_t stream);
 int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
 /* Data parallel: the weight gradients of the decoder's head run on the library's second stream beside the head chain and
  * are joined inside pm_vae_step_backward_encoder; a caller that hands the decoder's gradient bucket to an all-reduce

@@ -121,6 +121,7 @@ _SIGS = {
     "pm_vae_step_forward": "pppppppfuufiplpps",
     "pm_vae_step_info": "pp",
     "pm_vae_step_outputs": "ppppps".replace(" ", ""),
+    "pm_vae_step_set_output_grads": "ppppps",
     "pm_vae_step_backward_decoder": "ps",
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",
@@ -129,13 +130,19 @@ _SIGS = {
     "pm_vae_step_reload_switches": "",
     "pm_relu_bwd_planes": "pplppls",
     "pm_head_chain": "ps",
+    "pm_absmax": "plps",
+    "pm_split_planes_frag_h2": "piiiillfps",
+    "pm_gcl_forward_fused_h2": "pppiiiifuuppippplps",
+    "pm_gcl_input_grad_bn_h2": "pplpiiiipipps",
+    "pm_gcl_weight_grad_fused_h2": "plplpiiiiippps",
+    "pm_bn_apply_fused_absmax": "piipfpppipppppfps",
     "pm_set_deterministic": "i",
     "pm_get_deterministic": "",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
           "pm_unembed_dh_scratch_bytes"}
-ABI_VERSION = 6          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
+ABI_VERSION = 7          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])
 

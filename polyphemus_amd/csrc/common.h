@@ -169,6 +169,34 @@ __device__ static inline void pm_split3_pair(float a, float b, unsigned& h1, uns
   a -= __uint_as_float(h2 << 16); b -= __uint_as_float(h2 & 0xffff0000u);
   h3 = pm_pk_bf16(a, b);
 }
+// ---- two-term fp16 split ("h2" operand format: v * s = hi + lo, both fp16; the product of two such operands runs as the
+// three MFMA products hi*hi + hi*lo + lo*hi with fp32 accumulation — Ootomo & Yokota's error-corrected half-precision
+// product).  Representation error per element <= 2^-22 |v s| while lo is a normal fp16 (|v s| >= 2^-2), 2^-25 absolute
+// below that; the dropped lo*lo term is 2^-22 relative: the accuracy of an fp32 dot product (whose sequential sum of K
+// terms rounds by ~sqrt(K) 2^-24) at half the matrix-core work of the exact three-term bf16 split above.  fp16 has five
+// exponent bits, so every operand carries a power-of-two scale s (exact to apply and to undo) chosen from the tensor's
+// |max| so that max |v s| lands near 2^13: pm_pow2_scale below.
+typedef _Float16 pm_f16x2 __attribute__((ext_vector_type(2)));
+__device__ static inline unsigned pm_pk_f16(float a, float b) {           // round to nearest even
+  pm_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pm_f16x2));
+}
+// (a, b) already scaled; |a|, |b| < 65520
+__device__ static inline void pm_split2h_pair(float a, float b, unsigned& h1, unsigned& h2) {
+  h1 = pm_pk_f16(a, b);
+  const pm_f16x2 hv = __builtin_bit_cast(pm_f16x2, h1);
+  a -= (float)hv.x; b -= (float)hv.y;                                       // exact in fp32
+  h2 = pm_pk_f16(a, b);
+}
+// the power of two s with bound * s in [2^(target-1), 2^target); 1 for a zero / non-finite bound
+__device__ static inline float pm_pow2_scale(float bound, int target) {
+  if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+  const int e = (int)((__float_as_uint(bound) >> 23) & 0xff) - 126;        // bound in [2^(e-1), 2^e)   (subnormals: e = -126)
+  int k = target - e;
+  k = k < -120 ? -120 : (k > 120 ? 120 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
+__device__ static inline float pm_clamp_f16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 // four consecutive values -> the three planes (8 bytes each) at element index idx
 __device__ static inline void pm_store_planes4(uint16_t* __restrict__ planes, int64_t plane_stride, int64_t idx, float x0,
                                                float x1, float x2, float x3) {

@@ -103,12 +103,16 @@ struct GclArgs {
   unsigned* gate;                // deterministic mode (common.h): the workgroups add their column sums in turn
   int N, use_classes;
   uint32_t seed, layer_uid, thresh; float scale;
+  // fp16 pair format (H2 kernels): |max| of x and of T as float bits, the scale the weight planes carry, where to leave
+  // the scale the A' planes were written with
+  const unsigned* mx; const unsigned* mt; float w_scale; float* sa_out;
 };
 }  // namespace
 
-template <int D, bool DROP>
+template <int D, bool DROP, bool H2>
 __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_waves_per_eu((gcl_ncw<D>() + NPW) / 4, (gcl_ncw<D>() + NPW) / 4))) k_gcl_fwd(GclArgs g) {
   constexpr int NCW = gcl_ncw<D>(), NTHR = gcl_fwd_threads<D>();
+  constexpr int NPL = H2 ? 2 : 3, T60 = H2 ? 3 : 0;     // operand planes; first product of the chain (PA / PB below)
   constexpr int NCH = D / CH;            // chunks per relation block
   constexpr int TN = D / (NCW * 32);     // 32-column MFMA tiles per consumer wave
   constexpr int BFN = D / 32;            // column tiles of the weight
@@ -134,6 +138,14 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     g_blocklog[blockIdx.x][3] = -1;
   }
 #endif
+  // H2: the power of two the aggregate is multiplied by before it is split — from the |max| of x and of T, so every
+  // workgroup derives the same one: |A'| <= |x|max * max(1, |T|max / (1 - p)) lands in [2^12, 2^13)
+  float asc = 1.f, oinv = 1.f;
+  if constexpr (H2) {
+    asc = pm_pow2_scale(__uint_as_float(*g.mx) * fmaxf(1.f, __uint_as_float(*g.mt) * g.scale), 13);
+    oinv = 1.f / (asc * g.w_scale);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *g.sa_out = asc;          // (the weight gradient of the backward pass undoes it)
+  }
   if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) { pm_turn_skip_block(g.gate); return; }
 #ifdef GCL_BLOCKLOG
   const long long t_sched = (long long)__builtin_amdgcn_s_memrealtime();
@@ -221,22 +233,32 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
       const int rr = ps * (NPW * 4) + r0, n = sNode[rr];
       const int off = n >= 0 ? (n * 4 * D + blk * D + half * CH + ch * 8) * 2 : GCL_OOB;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(img + p * PLANE + rr * ROWB + ((ch ^ (rr & 15)) << 4));
         __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? off + p * ps_b : GCL_OOB, 0, GCL_PLANE_AUX);
       }
     }
   };
   // Image row of one lane's four consecutive values: split into the three planes, 8 bytes each
+  // (H2: the values come in already scaled; two planes)
   auto put = [&](char* img, int rr, int q, float4 o) {
-    unsigned l1, l2, l3, u1, u2, u3;
-    pm_split3_pair(o.x, o.y, l1, l2, l3);
-    pm_split3_pair(o.z, o.w, u1, u2, u3);
-    const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
     char* dst = img + rr * ROWB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
-    *reinterpret_cast<pm_u32x2*>(dst) = p1;
-    *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
-    *reinterpret_cast<pm_u32x2*>(dst + 2 * PLANE) = p3;
+    if constexpr (H2) {
+      unsigned l1, l2, u1, u2;
+      pm_split2h_pair(o.x, o.y, l1, l2);
+      pm_split2h_pair(o.z, o.w, u1, u2);
+      const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2};
+      *reinterpret_cast<pm_u32x2*>(dst) = p1;
+      *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
+    } else {
+      unsigned l1, l2, l3, u1, u2, u3;
+      pm_split3_pair(o.x, o.y, l1, l2, l3);
+      pm_split3_pair(o.z, o.w, u1, u2, u3);
+      const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+      *reinterpret_cast<pm_u32x2*>(dst) = p1;
+      *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
+      *reinterpret_cast<pm_u32x2*>(dst + 2 * PLANE) = p3;
+    }
   };
   // Straight-line gather (no branch inside the eight row passes): a missing edge takes a cached word that may hold
   // anything, loads from an out-of-range offset (returns 0, no traffic) and contributes relu(0 * t) = +0 to the sum —
@@ -260,7 +282,10 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
       if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
       STAMP();
 #pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) put(img, ps * RPP + prow, q, xs[ps]);
+      for (int ps = 0; ps < NPS; ++ps) {
+        if constexpr (H2) { xs[ps].x *= asc; xs[ps].y *= asc; xs[ps].z *= asc; xs[ps].w *= asc; }
+        put(img, ps * RPP + prow, q, xs[ps]);
+      }
       return;
     }
     float4 xv[NPS][EMAX];
@@ -306,7 +331,11 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
         acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
       }
       // 1 / max(count, 1) for count <= 3: the correctly rounded quotients, as the division gives them
-      const float inv = ecnt[ps] == 2 ? 0.5f : (ecnt[ps] == 3 ? 1.0f / 3.0f : 1.0f);
+      float inv = ecnt[ps] == 2 ? 0.5f : (ecnt[ps] == 3 ? 1.0f / 3.0f : 1.0f);
+      if constexpr (H2) {                      // mean, then the operand scale (a power of two: the same bits as scaling the mean)
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+        inv = asc;
+      }
       put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
       if (ps == 0) STAMP();
     }
@@ -324,7 +353,11 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
                                DROP ? pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]) : 0u);
           acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
         }
-        const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+        float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+        if constexpr (H2) {
+          acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+          inv = asc;
+        }
         put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
       }
     }
@@ -366,7 +399,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NPL; ++p)
         dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * 3072 + p * 1024, 0));
   };
   bf16x8 bq[GCL_BDEPTH][3][TN];
@@ -390,7 +423,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
       for (int ks = 0; ks < 8; ++ks) {
         bf16x8 a[3][NI];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
             const int rr = i * 32 + li;
@@ -402,21 +435,21 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
             const int n = i ? cn1 : cn0;
             const int off = n >= 0 ? (n * 4 * D + pblk * D + phalf * CH + (ks * 2 + lh) * 8) * 2 : GCL_OOB;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NPL; ++p)
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a[p][i]), cprs, n >= 0 ? off + p * cps_b : GCL_OOB, 0, GCL_PLANE_AUX);
           }
         }
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
+        for (int t6 = T60; t6 < 6; ++t6)
 #pragma unroll
           for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #if GCL_WHATIF == 4                                              // timing what-if (WRONG results): one product of the six
-              { if (t6 == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0); }
+              { if (t6 == 0) acc[i][j] = gcl_mfma<H2>(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j]); }
 #else
-              { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j], 0, 0, 0);
+              { acc[i][j] = gcl_mfma<H2>(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j]);
                 GCL_PACE_NOPS(acc[i][j]); }
 #endif
         bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
@@ -455,7 +488,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = nd[i][r];
-          const float v = n >= 0 ? float(acc[i][j][r]) + bv : 0.f;
+          const float v = n >= 0 ? (H2 ? float(acc[i][j][r]) * oinv + bv : float(acc[i][j][r]) + bv) : 0.f;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), hrs, n >= 0 ? (n * D + colj) * 4 : GCL_OOB, 0, 0);
           cs += (double)v; cq += (double)v * (double)v;
         }
@@ -474,7 +507,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        sH[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * HS + (ct0 + j) * 32 + li] = acc[i][j][r] + bv;
+        sH[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * HS + (ct0 + j) * 32 + li] = H2 ? acc[i][j][r] * oinv + bv : acc[i][j][r] + bv;
   }
   }
   }
@@ -555,12 +588,16 @@ struct GclBn {
   const float* h; const float* du; const float* mean; const float* var; const float* gamma; const float* beta;
   const double* acc3; float* dgamma; float* dbeta; float* dbias_pre;
   double count; float eps; int relu, add_res;
+  // fp16 pair format (H2): |max| of du as float bits, the scale of the weight planes, where to leave the scale of the dh planes
+  const unsigned* mdu; float w_scale; float* sdh_out;
 };
 }  // namespace
-template <int D, int NMW, bool BNF>
+template <int D, int NMW, bool BNF, bool H2>
 __global__ void __launch_bounds__((NMW + 4) * 64) __attribute__((amdgpu_waves_per_eu((NMW + 4) / 4, (NMW + 4) / 4)))
 k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_list, const int* __restrict__ trk_cnt,
            const char* __restrict__ wfrag, float* __restrict__ dA, int N, int use_classes, GclBn bn) {
+  static_assert(!H2 || BNF, "the fp16 pair format exists for the kernel that forms dh itself");
+  constexpr int NPL = H2 ? 2 : 3, T60 = H2 ? 3 : 0;     // operand planes; first product of the chain
   constexpr int TN = D / (NMW * 32);     // 32-column MFMA tiles per MFMA wave (its D / NMW columns of a block)
   constexpr int NMT = NMW * 64;          // MFMA threads
   constexpr int KS = D / 16;             // k-steps
@@ -611,6 +648,18 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
   }
   __syncthreads();
   STAMP2();
+  // H2: dh is multiplied by a power of two before it is split, the same in every workgroup: from |du|max and the largest
+  // gamma * rstd, |dh| <= gamma rstd |du|max (2 + |xhat|max); with |xhat| <= 14 the scaled values stay below 2^13 (a
+  // standardised value beyond that would still fit fp16 up to |xhat| = 125; the split clamps)
+  float dsc = 1.f, dinv = 1.f;
+  if constexpr (H2) {
+    float gm = 0.f;
+    for (int c = lane; c < D; c += 64) gm = fmaxf(gm, fabsf(sK[2 * D + c] * sK[D + c]));
+    gm = pm_wave_max(gm);
+    dsc = pm_pow2_scale(gm * __uint_as_float(*bn.mdu) * 16.f, 13);
+    dinv = 1.f / (dsc * bn.w_scale);
+    if (tid == 0) *bn.sdh_out = dsc;                             // (every workgroup writes the same value; k_gcl_dw undoes it)
+  }
   if (wave >= NMW) {
     // ---- store waves: block q of the stage -> dA rows (one 16-byte piece per lane: a whole 4*D-byte row per D/4 lanes)
     constexpr int LPR = D / 4, RPW = 64 / LPR, NR = BM / (4 * RPW);     // lanes per row, rows per wave-instruction, per thread
@@ -629,7 +678,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
       for (int ci = st; ci < BM * CPR; ci += 256) {
         const int rr = ci / CPR, ch = ci % CPR, n = sNode[rr];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * PL + rr * RB + ((ch ^ (rr & 15)) << 4));
           __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, GCL_DAGG_PLANE_AUX);
         }
@@ -691,14 +740,23 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
         float o2 = pm_bn_bwd_elem(hv[k].z, dv[k].z, km.z, kr.z, kg.z, kb.z, k0m.z, k1m.z, bn.relu);
         float o3 = pm_bn_bwd_elem(hv[k].w, dv[k].w, km.w, kr.w, kg.w, kb.w, k0m.w, k1m.w, bn.relu);
         if (!live) { o0 = 0.f; o1 = 0.f; o2 = 0.f; o3 = 0.f; }   // rows past the end of the list: a zero row, as the planes load gives
+        char* dst = smem + rr * RB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
+        if constexpr (H2) {
+          unsigned l1, l2, u1, u2;
+          pm_split2h_pair(pm_clamp_f16(o0 * dsc), pm_clamp_f16(o1 * dsc), l1, l2);
+          pm_split2h_pair(pm_clamp_f16(o2 * dsc), pm_clamp_f16(o3 * dsc), u1, u2);
+          const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2};
+          *reinterpret_cast<pm_u32x2*>(dst) = p1;
+          *reinterpret_cast<pm_u32x2*>(dst + PL) = p2;
+        } else {
         unsigned l1, l2, l3, u1, u2, u3;
         pm_split3_pair(o0, o1, l1, l2, l3);
         pm_split3_pair(o2, o3, u1, u2, u3);
         const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
-        char* dst = smem + rr * RB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
         *reinterpret_cast<pm_u32x2*>(dst) = p1;
         *reinterpret_cast<pm_u32x2*>(dst + PL) = p2;
         *reinterpret_cast<pm_u32x2*>(dst + 2 * PL) = p3;
+        }
       }
     }
   } else {
@@ -709,14 +767,14 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
     for (int k = 0; k < NCHK; ++k) {
       const int ci = tid + k * NMT, rr = ci / CPR, ch = ci % CPR, n = sNode[rr];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NPL; ++p)
         v[p][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, n >= 0 ? (int)(((int64_t)p * dps + (int64_t)n * D + ch * 8) * 2) : GCL_OOB, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NCHK; ++k) {
       const int ci = tid + k * NMT, rr = ci / CPR, ch = ci % CPR;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NPL; ++p)
         *reinterpret_cast<u32x4*>(smem + p * PL + rr * RB + ((ch ^ (rr & 15)) << 4)) = v[p][k];
     }
   }
@@ -730,7 +788,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NPL; ++p)
         dst[p][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, soff + j * KS * 3072 + p * 1024, 0));
   };
   constexpr int BD = TN == 1 ? GCL_DAGG_BDEPTH : 2;            // (two column tiles per wave: four steps in flight spill)
@@ -743,7 +801,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
   // A fragments of k-step ks (both 32-row blocks, three planes); read one step ahead of the MFMAs that use them
   auto aload = [&](bf16x8 (&a)[3][2], int ks) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NPL; ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rr = i * 32 + li;
@@ -769,12 +827,12 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
       aload(af[(ks + 1) & 1], (ks + 1) % KS);                    // (the last step: step 0 of the next block, same image)
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
+      for (int t6 = T60; t6 < 6; ++t6)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][PA[t6]][i], bq[ks % BD][PB[t6]][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = gcl_mfma<H2>(af[ks & 1][PA[t6]][i], bq[ks % BD][PB[t6]][j], acc[i][j]);
       bload(bq[ks % BD], qb * KS + ks + BD);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -788,7 +846,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
       for (int r = 0; r < 16; ++r)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / NMW) + j * 32 + li] = acc[i][j][r];
+          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / NMW) + j * 32 + li] = H2 ? acc[i][j][r] * dinv : acc[i][j][r];
     STAMP2();
     __syncthreads();
   }
@@ -811,17 +869,17 @@ static int gcl_input_grad_impl(uint16_t* dh_planes, int64_t plane_stride, const 
   memset(&none, 0, sizeof(none));
   const GclBn bv = bn ? *bn : none;
   const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
-#define LAUNCH(DD, NW, BF)                                                                                             \
+#define LAUNCH(DD, NW, BF, HH)                                                                                         \
   do {                                                                                                                 \
     static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                            \
     if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_gcl_dagg<DD, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      hipFuncSetAttribute((const void*)k_gcl_dagg<DD, NW, BF, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_gcl_dagg<DD, NW, BF>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt, \
+    hipLaunchKernelGGL((k_gcl_dagg<DD, NW, BF, HH>), grid, block, lds, st, dh_planes, plane_stride, pv.trk_list, pv.trk_cnt, \
                        reinterpret_cast<const char*>(w_frag_t), dA, N, use_classes, bv);                               \
   } while (0)
-#define LAUNCH2(DD, NW) do { if (bn) LAUNCH(DD, NW, true); else LAUNCH(DD, NW, false); } while (0)
+#define LAUNCH2(DD, NW) do { if (bn && bn->mdu) LAUNCH(DD, NW, true, true); else if (bn) LAUNCH(DD, NW, true, false); else LAUNCH(DD, NW, false, false); } while (0)
   if (d == 256) { if (nmw == 8) LAUNCH2(256, 8); else LAUNCH2(256, 4); } else LAUNCH2(128, 4);
 #undef LAUNCH2
 #undef LAUNCH
@@ -852,6 +910,24 @@ extern "C" int pm_gcl_input_grad_bn(const PmBnBwd* nb, uint16_t* dh_planes, int6
   GclBn b;
   b.h = nb->h; b.du = nb->du; b.mean = nb->mean; b.var = nb->var; b.gamma = nb->gamma; b.beta = nb->beta; b.acc3 = nb->acc3;
   b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu; b.add_res = nb->add_residual;
+  b.mdu = nullptr; b.w_scale = 1.f; b.sdh_out = nullptr;
+  return gcl_input_grad_impl(dh_planes, plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, &b, (hipStream_t)stream);
+}
+// ... in the fp16 pair format (PmH2 of the header): `dh_planes` receives TWO fp16 planes of dh * (*h2->scale_out), `w_frag_t`
+// comes from pm_split_planes_frag_h2(kind 0) with h2->w_scale
+extern "C" int pm_gcl_input_grad_bn_h2(const PmBnBwd* nb, uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan,
+                                       int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
+                                       float* dA, const PmH2* h2, pm_stream_t stream) {
+  if (!nb || !nb->h || !nb->du || !nb->mean || !nb->var || !nb->gamma || !nb->beta || !nb->acc3 || !dh_planes || !plan ||
+      !w_frag_t || !dA || N <= 0 || (d != 128 && d != 256) || plane_stride < (int64_t)N * d || (plane_stride & 7) ||
+      ((uintptr_t)dh_planes % 16) || ((uintptr_t)w_frag_t % 16) || ((uintptr_t)dA % 16) || ((uintptr_t)nb->h % 16) ||
+      ((uintptr_t)nb->du % 16) || plane_stride * 6 >= 0x7fffffffLL || (int64_t)N * 4 * d * 4 >= 0x7fffffffLL || !h2 ||
+      !h2->absmax_in || !h2->scale_out || !(h2->w_scale > 0.f))
+    return PM_E_INVALID;
+  GclBn b;
+  b.h = nb->h; b.du = nb->du; b.mean = nb->mean; b.var = nb->var; b.gamma = nb->gamma; b.beta = nb->beta; b.acc3 = nb->acc3;
+  b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu; b.add_res = nb->add_residual;
+  b.mdu = h2->absmax_in; b.w_scale = h2->w_scale; b.sdh_out = h2->scale_out;
   return gcl_input_grad_impl(dh_planes, plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, &b, (hipStream_t)stream);
 }
 
@@ -876,11 +952,12 @@ constexpr int DW_MAP = 4096;              // row-list entries of a K slice kept 
 #define GCL_DW_NMW 4                      // MFMA waves of k_gcl_dw: 4 = a 64x64 quarter of the tile each; 8 = 64x32 each, two per SIMD: no gain (LOG)
 #endif
 constexpr int DW_NMW = GCL_DW_NMW, DW_NTHR = (DW_NMW + 4) * 64;
-template <int D>
+template <int D, bool H2>
 __global__ void __launch_bounds__(DW_NTHR) __attribute__((amdgpu_waves_per_eu((DW_NMW + 4) / 4, (DW_NMW + 4) / 4)))
 k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restrict__ dhp, int64_t dps,
          const int* __restrict__ trk_list, const int* __restrict__ trk_cnt, float* __restrict__ dW, int N, int nsplit,
-         int use_classes, unsigned* gate) {
+         int use_classes, unsigned* gate, const float* __restrict__ sa, const float* __restrict__ sdh) {
+  constexpr int NPL = H2 ? 2 : 3, T60 = H2 ? 3 : 0;     // operand planes; first product of the chain
   constexpr int NFT = 4 * D / DW_T, NCT = D / DW_T, PER = NFT * NCT;       // tiles per (group, slice)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* const sMap = reinterpret_cast<int*>(smem + 2 * DW_STAGE);
@@ -940,7 +1017,7 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
         for (int j = 0; j < 2; ++j) {
           const int n = t < nt ? sMap[t * DW_KT + r0 + j * 16] : -1;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NPL; ++p) {
             v[j][0][p] = __builtin_amdgcn_raw_buffer_load_b128(ars, n >= 0 ? n * (4 * D * 2) + acol + p * aps_b : GCL_OOB, 0, 0);
             v[j][1][p] = __builtin_amdgcn_raw_buffer_load_b128(drs, n >= 0 ? n * (D * 2) + dcol + p * dps_b : GCL_OOB, 0, 0);
           }
@@ -953,7 +1030,7 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
 #pragma unroll
           for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NPL; ++p)
               *reinterpret_cast<u32x4*>(st + (o * 3 + p) * DW_PLANE + (r0 + j * 16) * DW_PITCH + ch * 16) = v[j][o][p];
       };
       u32x4 va[2][2][3], vb[2][2][3];
@@ -985,7 +1062,7 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
         for (int ks = 0; ks < DW_KT / 16; ++ks) {
           bf16x8 a[3][2], b[3][DW_WN];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[p][i] = dw_frag(st + p * DW_PLANE, wr * 64 + i * 32, ks, lane);
 #pragma unroll
@@ -993,12 +1070,12 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
           }
           constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
-          for (int t6 = 0; t6 < 6; ++t6)
+          for (int t6 = T60; t6 < 6; ++t6)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int j = 0; j < DW_WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], b[PB[t6]][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = gcl_mfma<H2>(a[PA[t6]][i], b[PB[t6]][j], acc[i][j]);
         }
         __syncthreads();
       }
@@ -1006,6 +1083,8 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
   }
   if (wave >= DW_NMW) return;
   STAMP2();
+  float oinv = 1.f;                                              // H2: undo the two operand scales (powers of two)
+  if constexpr (H2) oinv = 1.f / (sa[0] * sdh[0]);
   pm_turn_enter(gate, blockIdx.x * DW_NMW + wave);
   // ---- epilogue: the tile is one K slice's (and, for the shared blocks, one group's) term: float atomics
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -1016,15 +1095,15 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
       const int fr = ft * DW_T + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;        // row of the stacked [4d, d] gradient
       float* crow = dW + (int64_t)(fr < D ? grp * D + fr : 3 * D + fr) * D + ct * DW_T + wc * DW_WCOLS + li;
 #pragma unroll
-      for (int j = 0; j < DW_WN; ++j) atomicAdd(crow + j * 32, acc[i][j][r]);
+      for (int j = 0; j < DW_WN; ++j) atomicAdd(crow + j * 32, H2 ? acc[i][j][r] * oinv : acc[i][j][r]);
     }
   pm_turn_leave(gate, blockIdx.x * DW_NMW + wave);
   STAMP2();
 }
 
-extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
-                                        int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
-                                        int32_t d, int32_t use_classes, float* dW, pm_stream_t stream) {
+static int gcl_weight_grad_impl(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
+                                int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                int32_t d, int32_t use_classes, float* dW, const float* sa, const float* sdh, pm_stream_t stream) {
   if (!a_planes || !dh_planes || !plan || !dW || N <= 0 || (d != 128 && d != 256 && d != 512) || a_plane_stride < (int64_t)N * 4 * d ||
       dh_plane_stride < (int64_t)N * d || (a_plane_stride & 7) || (dh_plane_stride & 7) || ((uintptr_t)a_planes % 16) ||
       ((uintptr_t)dh_planes % 16) || a_plane_stride * 6 >= 0x7fffffffLL)
@@ -1043,41 +1122,60 @@ extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plan
   const size_t lds = 2 * DW_STAGE + DW_MAP * 4;
   unsigned* const gate = pm_det_gate(st);
   const int pe = pm_prof_open(st, PM_PROF_GCL_DW, 2.0 * N * 4.0 * d * d);
-#define LAUNCH(DD)                                                                                                     \
+#define LAUNCH(DD, HH)                                                                                                 \
   do {                                                                                                                 \
     static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_gcl_dw<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
+      hipFuncSetAttribute((const void*)k_gcl_dw<DD, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_gcl_dw<DD>), grid, block, lds, st, a_planes, a_plane_stride, dh_planes, dh_plane_stride,     \
-                       pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes, gate);                                     \
+    hipLaunchKernelGGL((k_gcl_dw<DD, HH>), grid, block, lds, st, a_planes, a_plane_stride, dh_planes, dh_plane_stride, \
+                       pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes, gate, sa, sdh);                            \
   } while (0)
-  if (d == 512) LAUNCH(512); else if (d == 256) LAUNCH(256); else LAUNCH(128);
+  if (sa) { if (d == 256) LAUNCH(256, true); else LAUNCH(128, true); }
+  else if (d == 512) LAUNCH(512, false); else if (d == 256) LAUNCH(256, false); else LAUNCH(128, false);
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();
+}
+extern "C" int pm_gcl_weight_grad_fused(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
+                                        int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                        int32_t d, int32_t use_classes, float* dW, pm_stream_t stream) {
+  return gcl_weight_grad_impl(a_planes, a_plane_stride, dh_planes, dh_plane_stride, plan, N, E, G, d, use_classes, dW, nullptr,
+                              nullptr, stream);
+}
+// ... on operands in the fp16 pair format: a_scale / dh_scale = the device floats pm_gcl_forward_fused_h2 / pm_gcl_input_grad_bn_h2 left
+extern "C" int pm_gcl_weight_grad_fused_h2(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
+                                           int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                           int32_t d, int32_t use_classes, float* dW, const float* a_scale,
+                                           const float* dh_scale, pm_stream_t stream) {
+  if (!a_scale || !dh_scale || (d != 128 && d != 256)) return PM_E_INVALID;
+  return gcl_weight_grad_impl(a_planes, a_plane_stride, dh_planes, dh_plane_stride, plan, N, E, G, d, use_classes, dW, a_scale,
+                              dh_scale, stream);
 }
 
 static size_t gcl_lds_bytes(int d, bool drop) {
   return 2 * IMG + (size_t)PM_N_DIST * d * 4 + (BM + BM * 3 * 8) * 4;
 }
 
-extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
-                                    int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag,
-                                    const float* bias, int32_t use_classes, float* h, double* col_stats, uint16_t* planes,
-                                    int64_t plane_stride, pm_stream_t stream) {
+static int gcl_forward_impl(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                            int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag,
+                            const float* bias, int32_t use_classes, float* h, double* col_stats, uint16_t* planes,
+                            int64_t plane_stride, const PmH2* h2, pm_stream_t stream) {
   if (!x || !T || !plan || !w_frag || !h || N <= 0 || (d != 128 && d != 256 && d != 512) || dropout_p < 0.f || dropout_p >= 1.f ||
       ((uintptr_t)w_frag % 16) || ((uintptr_t)x % 16) || ((uintptr_t)T % 16) || (int64_t)N * d * 4 >= 0x7fffffffLL || N >= (1 << 27))
     return PM_E_INVALID;
   if (planes && (plane_stride < (int64_t)N * 4 * d || (plane_stride & 7) || ((uintptr_t)planes % 16) ||
                  plane_stride * 6 >= 0x7fffffffLL))
     return PM_E_INVALID;
+  if (h2 && (d == 512 || !h2->absmax_in || !h2->absmax_aux || !h2->scale_out || !(h2->w_scale > 0.f))) return PM_E_INVALID;
   if (d == 512)                 // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_gcl_forward(x, T, plan, N, E, G, dropout_p, seed, layer_uid, w_frag, bias, use_classes, h, col_stats,
                                planes, plane_stride, nullptr, (hipStream_t)stream);
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   GclArgs a;
+  a.mx = h2 ? h2->absmax_in : nullptr; a.mt = h2 ? h2->absmax_aux : nullptr; a.w_scale = h2 ? h2->w_scale : 1.f;
+  a.sa_out = h2 ? h2->scale_out : nullptr;
   a.x = x; a.T = T; a.bias = bias; a.rowptr = pv.rowptr; a.csr_src = pv.csr_src; a.csr_dist = pv.csr_dist;
   a.csr_eid = pv.csr_eid; a.trk_list = pv.trk_list; a.trk_cnt = pv.trk_cnt;
   a.wfrag = reinterpret_cast<const char*>(w_frag); a.planes = planes; a.plane_stride = plane_stride; a.h = h;
@@ -1092,20 +1190,39 @@ extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_
   // profiler work: the product's flops (as the GEMM classes); the kernel's algorithmic HBM bytes are x read + h written
   // + A' planes written (when kept) + edges + the weight planes once = 8dN (+ 24dN) + 12E + 42d^2 (bench.py)
   const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, 2.0 * N * 4.0 * d * d);
-#define LAUNCH(DD, DR)                                                                                                 \
+#define LAUNCH(DD, DR, HH)                                                                                             \
   do {                                                                                                                 \
     static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];                                                                                          \
     if (!once) {                                                                                                       \
-      hipFuncSetAttribute((const void*)k_gcl_fwd<DD, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      hipFuncSetAttribute((const void*)k_gcl_fwd<DD, DR, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       once = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_gcl_fwd<DD, DR>), grid, dim3(gcl_fwd_threads<DD>()), lds, st, a);                            \
+    hipLaunchKernelGGL((k_gcl_fwd<DD, DR, HH>), grid, dim3(gcl_fwd_threads<DD>()), lds, st, a);                        \
   } while (0)
-  if (d == 256) { if (drop) LAUNCH(256, true); else LAUNCH(256, false); }
-  else { if (drop) LAUNCH(128, true); else LAUNCH(128, false); }
+#define LAUNCH2(DD, DR) do { if (h2) LAUNCH(DD, DR, true); else LAUNCH(DD, DR, false); } while (0)
+  if (d == 256) { if (drop) LAUNCH2(256, true); else LAUNCH2(256, false); }
+  else { if (drop) LAUNCH2(128, true); else LAUNCH2(128, false); }
+#undef LAUNCH2
 #undef LAUNCH
   pm_prof_close(st, pe);
   return pm_check_launch();
+}
+extern "C" int pm_gcl_forward_fused(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                    int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag,
+                                    const float* bias, int32_t use_classes, float* h, double* col_stats, uint16_t* planes,
+                                    int64_t plane_stride, pm_stream_t stream) {
+  return gcl_forward_impl(x, T, plan, N, E, G, d, dropout_p, seed, layer_uid, w_frag, bias, use_classes, h, col_stats, planes,
+                          plane_stride, nullptr, stream);
+}
+// ... in the fp16 pair format (PmH2 of the header): `w_frag` from pm_split_planes_frag_h2(kind 1) with h2->w_scale; `planes`
+// receives TWO fp16 planes of A' * (*h2->scale_out).  d in {128, 256}.
+extern "C" int pm_gcl_forward_fused_h2(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
+                                       int32_t d, float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag,
+                                       const float* bias, int32_t use_classes, float* h, double* col_stats, uint16_t* planes,
+                                       int64_t plane_stride, const PmH2* h2, pm_stream_t stream) {
+  if (!h2) return PM_E_INVALID;
+  return gcl_forward_impl(x, T, plan, N, E, G, d, dropout_p, seed, layer_uid, w_frag, bias, use_classes, h, col_stats, planes,
+                          plane_stride, h2, stream);
 }
 
 // The same product with the aggregate READ from A' planes instead of built in the kernel: dense graphs (hundreds of edges

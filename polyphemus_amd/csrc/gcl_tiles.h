@@ -7,6 +7,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// One product of the split chain.  H2 = false: operands are planes of the exact three-term bf16 split (six products per
+// fp32 product); H2 = true: the two planes of the fp16 pair format of common.h (three products).  The fragments travel as
+// 16-byte registers either way.
+template <bool H2>
+__device__ inline f32x16 gcl_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 #define GCL_OOB ((int)0x80000000)     // byte offset >= num_records: the buffer load returns 0 / the store is dropped
 #ifndef GCL_BDEPTH
 #define GCL_BDEPTH 2          // k-steps of weight fragments in flight per MFMA wave

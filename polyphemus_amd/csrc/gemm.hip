@@ -1096,9 +1096,11 @@ extern "C" int pm_split_planes(const float* src, int64_t n, uint16_t* planes, in
 //   kind 0 (the product uses W as B[n][k], transB): n = W row, k = W column; blocks ordered [row tile][k-step][plane]
 //   kind 1 (the product uses W as B[k][n])        : k = W row, n = W column; blocks ordered [k-step][column tile][plane]
 // rows % 32 == 0 and cols % 32 == 0; `n_mats` matrices `src_stride` floats apart go to blocks `dst_stride` bf16 apart.
+// H2: the fp16 pair format of common.h (two planes of W * w_scale; plane 2 of the block is left alone)
+template <bool H2>
 __global__ void __launch_bounds__(256) k_split_planes_frag(const float* __restrict__ W, int rows, int cols, int kind,
                                                            int64_t src_stride, int64_t dst_stride,
-                                                           uint16_t* __restrict__ out) {
+                                                           uint16_t* __restrict__ out, float w_scale) {
   const float* src = W + (int64_t)blockIdx.y * src_stride;
   uint16_t* dst = out + (int64_t)blockIdx.y * dst_stride;
   const int64_t chunks = (int64_t)rows * cols / 8;
@@ -1121,23 +1123,60 @@ __global__ void __launch_bounds__(256) k_split_planes_frag(const float* __restri
       lane = ((k0 >> 3) & 1) * 32 + (n & 31);
     }
     unsigned p1[4], p2[4], p3[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
     uint16_t* o = dst + blk * 1536 + lane * 8;             // 3 planes x 512 bf16 per block
+    if constexpr (H2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pm_split2h_pair(pm_clamp_f16(x[2 * e] * w_scale), pm_clamp_f16(x[2 * e + 1] * w_scale), p1[e], p2[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
+      *reinterpret_cast<u32x4*>(o + 1024) = u32x4{p3[0], p3[1], p3[2], p3[3]};
+    }
     *reinterpret_cast<u32x4*>(o) = u32x4{p1[0], p1[1], p1[2], p1[3]};
     *reinterpret_cast<u32x4*>(o + 512) = u32x4{p2[0], p2[1], p2[2], p2[3]};
-    *reinterpret_cast<u32x4*>(o + 1024) = u32x4{p3[0], p3[1], p3[2], p3[3]};
   }
 }
-extern "C" int pm_split_planes_frag(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,
-                                    int64_t src_stride, int64_t dst_stride, uint16_t* out, pm_stream_t stream) {
+static int split_planes_frag_impl(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,
+                                  int64_t src_stride, int64_t dst_stride, float w_scale, uint16_t* out, pm_stream_t stream) {
   if (!W || !out || rows <= 0 || cols <= 0 || (rows % 32) || (cols % 32) || (kind != 0 && kind != 1) || n_mats <= 0 ||
       ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (src_stride % 4) || (dst_stride % 8))
     return PM_E_INVALID;
   int64_t grid = pm_cdiv((int64_t)rows * cols / 8, 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_split_planes_frag, dim3((unsigned)grid, (unsigned)n_mats), dim3(256), 0, (hipStream_t)stream, W,
-                     rows, cols, kind, src_stride, dst_stride, out);
+  if (w_scale > 0.f)
+    hipLaunchKernelGGL(k_split_planes_frag<true>, dim3((unsigned)grid, (unsigned)n_mats), dim3(256), 0, (hipStream_t)stream, W,
+                       rows, cols, kind, src_stride, dst_stride, out, w_scale);
+  else
+    hipLaunchKernelGGL(k_split_planes_frag<false>, dim3((unsigned)grid, (unsigned)n_mats), dim3(256), 0, (hipStream_t)stream, W,
+                       rows, cols, kind, src_stride, dst_stride, out, 0.f);
+  return pm_check_launch();
+}
+extern "C" int pm_split_planes_frag(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,
+                                    int64_t src_stride, int64_t dst_stride, uint16_t* out, pm_stream_t stream) {
+  return split_planes_frag_impl(W, rows, cols, kind, n_mats, src_stride, dst_stride, 0.f, out, stream);
+}
+extern "C" int pm_split_planes_frag_h2(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,
+                                       int64_t src_stride, int64_t dst_stride, float w_scale, uint16_t* out, pm_stream_t stream) {
+  if (!(w_scale > 0.f)) return PM_E_INVALID;
+  return split_planes_frag_impl(W, rows, cols, kind, n_mats, src_stride, dst_stride, w_scale, out, stream);
+}
+// max |x| of a tensor as float bits (PmH2.absmax_in): one atomic per wave
+__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+  m = pm_wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+extern "C" int pm_absmax(const float* x, int64_t n, uint32_t* out, pm_stream_t stream) {
+  if (!x || !out || n <= 0 || ((uintptr_t)x % 16)) return PM_E_INVALID;
+  int64_t grid = pm_cdiv(n / 4 + 1, 256 * 4);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n, out);
   return pm_check_launch();
 }
 

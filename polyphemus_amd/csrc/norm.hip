@@ -466,8 +466,9 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
                                                         const double* __restrict__ sums, BnCtx ctx,
                                                         const float* __restrict__ res, float* __restrict__ y,
                                                         float* mean, float* var, float* rmean, float* rvar,
-                                                        float momentum) {
+                                                        float momentum, unsigned* absmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
+  float amax = 0.f;                                               // max |y| of this thread (absmax != NULL: PmH2.absmax_in of the next layer)
   float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
   // (BN_APPLY_U > 0: a thread's first pieces of x and of the residual are requested BEFORE the workgroup reduces the
   //  replicated sums — 16 fp64 loads per column — so that the reduction's latency has loads in flight under it)
@@ -514,6 +515,7 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
     }
     if (res) { o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
     reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (absmax) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   };
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -526,18 +528,33 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
     if (res) rv = reinterpret_cast<const float4*>(res)[i];
     apply(i, xv, rv);
   }
+  if (absmax) {                                                   // non-negative floats order like their bit patterns
+    amax = pm_wave_max(amax);
+    if ((threadIdx.x & 63) == 0) atomicMax(absmax, __float_as_uint(amax));
+  }
 }
+extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps,
+                                        const float* gamma, const float* beta, const float* residual, int relu, float* y,
+                                        float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                        uint32_t* absmax_out, pm_stream_t stream);
 extern "C" int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, float eps,
                                  const float* gamma, const float* beta, const float* residual, int relu, float* y,
                                  float* mean, float* var, float* running_mean, float* running_var, float momentum,
                                  pm_stream_t stream) {
+  return pm_bn_apply_fused_absmax(x, O, C, sums, eps, gamma, beta, residual, relu, y, mean, var, running_mean, running_var,
+                                  momentum, nullptr, stream);
+}
+extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps,
+                                        const float* gamma, const float* beta, const float* residual, int relu, float* y,
+                                        float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                        uint32_t* absmax_out, pm_stream_t stream) {
   if (!x || !sums || !gamma || !beta || !y || !mean || !var || O <= 0 || C <= 0 || (C % 4) != 0 || C > 4096)
     return PM_E_INVALID;
   if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (residual && ((uintptr_t)residual % 16))) return PM_E_INVALID;
   BnCtx ctx = {nullptr, nullptr, gamma, beta, eps, relu};
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 3 * C, (hipStream_t)stream, x,
-                     n / 4, C, (double)O, sums, ctx, residual, y, mean, var, running_mean, running_var, momentum);
+                     n / 4, C, (double)O, sums, ctx, residual, y, mean, var, running_mean, running_var, momentum, absmax_out);
   return pm_check_launch();
 }
 

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   // 25 %, 19 %, 14 %, ...) go to rows PRIVATE to the wave — plain 16-byte read-add-write, no atomics, masked elements
   // simply add 0 — and only the rare long distances take the shared table; distance 0 stays in registers (z0 below)
   const int nwv0 = blockDim.x >> 6;
-  for (int i = threadIdx.x; i < (PM_N_DIST + nwv0 * pr) * d; i += blockDim.x) sT[i] = 0.f;
+  for (int i = threadIdx.x; i < (PM_N_DIST + nwv0 * pr) * d + 1; i += blockDim.x) sT[i] = 0.f;   // (+ the word behind the tables: sMax)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -267,6 +267,10 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   for (int v = 0; v < NV; ++v)
 #pragma unroll
     for (int j = 0; j < 4; ++j) z0[v][j] = 0.f;
+  // max |dx| (FUSE with nn.absmax_out: PmH2.absmax_in of the layer below): per lane, reduced per workgroup through one LDS word
+  // at the end: 256 global atomics per launch
+  float amax = 0.f;
+  unsigned* const sMax = reinterpret_cast<unsigned*>(sT + (PM_N_DIST + nwv0 * pr) * d);
   // XCD-aware node order (see k_segreduce_fwd): XCD b % 8 walks its own contiguous eighth of the nodes, so the dA rows
   // of a bar are gathered through ONE L2
   int n_lo = blockIdx.x * nwv, n_hi = N, n_step = gridDim.x * nwv;
@@ -437,6 +441,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       if (!ok[v]) continue;
       *reinterpret_cast<float4*>(dx + (int64_t)n * d + c[v]) = acc[v];
       if (FUSE) {
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[v].x), fabsf(acc[v].y))), fmaxf(fabsf(acc[v].z), fabsf(acc[v].w)));
         const float4 hv = PF ? hcur[v] : *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
         const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
         const float ds[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
@@ -469,7 +474,12 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     for (int j = 0; j < 4; ++j)
       if (z0[v][j] != 0.f) atomicAdd(&sT[j * dq + (c[v] >> 2)], z0[v][j]);
   }
+  if (FUSE && nn.absmax_out) {                                     // (non-negative floats order like their bit patterns)
+    amax = pm_wave_max(amax);
+    if (lane == 0) atomicMax(sMax, __float_as_uint(amax));
+  }
   __syncthreads();
+  if (FUSE && nn.absmax_out && threadIdx.x == 0) atomicMax(nn.absmax_out, *sMax);
   for (int i = threadIdx.x; i < pr * d; i += blockDim.x) {               // private rows of all waves -> shared image
     const int r = i / d, col = i - r * d;
     float t = 0.f;
@@ -558,7 +568,7 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   int pr = (int)((144 * 1024 / sizeof(float) / d - PM_N_DIST) / (threads / 64));
   if (pr > pr_cap) pr = pr_cap;
   if (pr < 0) pr = 0;
-  const size_t lds = sizeof(float) * (PM_N_DIST + (size_t)(threads / 64) * pr) * d;
+  const size_t lds = sizeof(float) * ((PM_N_DIST + (size_t)(threads / 64) * pr) * d + 4);     // (+ the workgroup's max |dx| word)
   const bool drop = dropout_p > 0.f;
   const uint32_t thresh = pm_keep_threshold(dropout_p);
   const float scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;

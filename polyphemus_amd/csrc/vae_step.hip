@@ -52,6 +52,8 @@ struct StepCfg {
   bool plan_side;              // PM_PLAN_SIDE=0: the plan build on the caller's stream in front of the content encoder (see forward())
   int late_wgrads_at;          // PM_LATE_WGRADS=2 (development A/B): forked behind the decoder's half of the head chain instead of in front of it
   bool late_wgrads;            // PM_LATE_WGRADS=0: the decoder's weight gradients beside its GCL layers (round 3) instead of beside the head chain
+  bool h2;                     // PM_H2=0: the GCL products of d in {128, 256} on the exact three-term bf16 split (six MFMA products per fp32
+                               // product) instead of the fp16 pair format (three; PmH2 of the header) — the parity tests run both
   int dense_deg;
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
 };
@@ -76,6 +78,7 @@ static StepCfg read_cfg() {
   k.chord_tables = flag("PM_CHORD_TABLES", true);
   k.dagg_res = flag("PM_DAGG_RES", false);
   k.fused_heads = flag("PM_FUSED_HEADS", false);
+  k.h2 = flag("PM_H2", true);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
@@ -124,7 +127,12 @@ struct GcnSaved {
   uint16_t* Wfn; uint16_t* Wft; int64_t wf_stride;
   double* pool;                          // per layer PM_BN_REPL x ([2][d] forward column sums, [3][d] backward sums), fp64
   uint32_t seed, uid0; float p;
+  // fp16 pair format of the stack's three GCL products (PmH2): on / off, and its device words (zero region):
+  // mx[i] = |max| of layer i's input as float bits (i = 0 .. L-1), mx[L] = of the distance table; mdu[i] = of the gradient
+  // arriving at layer i's norm; sA[i] / sdh[i] = the scales the layer's A' / dh planes were written with
+  bool h2; uint32_t* mx; uint32_t* mdu; float* sA; float* sdh;
 };
+constexpr float kH2WScale = 16.f;        // weight planes of the fp16 pair format: W * 2^4 (glorot-range weights land around 1)
 
 struct StepState {
   uint64_t magic;
@@ -152,6 +160,7 @@ struct StepState {
   float *bk_dxL;                          // carried from pm_vae_step_backward_encoder_heads to pm_vae_step_backward_encoder
   int rc;
   unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
+  int ext_loss;                           // pm_vae_step_set_output_grads: the gradients of the outputs came from the caller's loss
 };
 constexpr uint64_t kMagic = 0x504d5354455031ULL;
 
@@ -389,6 +398,13 @@ GcnRoute gcn_route(const Ctx& c, const GcnSaved& sv) {
   r.dense = (int64_t)c.E >= (int64_t)cfg().dense_deg * c.N;
   return r;
 }
+// The stack's three GCL products in the fp16 pair format (gcl.hip H2 kernels): the fused forward, the input gradient with the
+// norm backward inside and the tile weight gradient all have to apply (they hand each other planes), d in {128, 256}
+static bool stack_h2(const Ctx& c, const GcnSaved& sv) {
+  const GcnRoute r = gcn_route(c, sv);
+  return cfg().h2 && r.gcl_kernels && !r.dense && c.bn && (c.d == 128 || c.d == 256) && cfg().dagg_bn && !cfg().dw_side &&
+         !cfg().no_dw;
+}
 // The part of a GCN stack's forward that depends on the parameters only: the distance table of the shared edge_nn and
 // the bf16 planes of the layers' weights.  Issued at the start of the step, on the second stream.
 void gcn_prepare(Ctx& c, const PmGcn& g, GcnSaved& sv) {
@@ -398,6 +414,12 @@ void gcn_prepare(Ctx& c, const PmGcn& g, GcnSaved& sv) {
   sv.T = ar.f((size_t)PM_N_DIST * d);
   if (ar.base) RUN(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
   sv.pool = ar.zdbl((size_t)c.L * 5 * d * PM_BN_REPL);
+  {
+    uint32_t* w = (uint32_t*)ar.z(sizeof(uint32_t) * (size_t)(4 * c.L + 4));
+    sv.mx = w; sv.mdu = w ? w + c.L + 1 : nullptr; sv.sA = w ? (float*)(w + 2 * c.L + 1) : nullptr;
+    sv.sdh = w ? (float*)(w + 3 * c.L + 1) : nullptr;
+  }
+  sv.h2 = false;
   if (c.planes) {                                         // the GCL weights of this stack, split once per step
     sv.wp_base = g.weight[0];
     sv.wp_stride = (g.weight[c.L - 1] + 7 * dd - g.weight[0] + 7) & ~(int64_t)7;
@@ -414,14 +436,23 @@ void gcn_prepare(Ctx& c, const PmGcn& g, GcnSaved& sv) {
     if (even) {
       sv.Wfn = (uint16_t*)ar.take((size_t)sv.wf_stride * 2 * c.L);
       sv.Wft = (uint16_t*)ar.take((size_t)sv.wf_stride * 2 * c.L);
+      sv.h2 = stack_h2(c, sv);
       if (ar.base) {
         for (int kind = 0; kind < 2; ++kind) {
           uint16_t* dst = kind ? sv.Wfn : sv.Wft;
+          if (sv.h2) {
+            RUN(pm_split_planes_frag_h2(c.P + g.weight[0], 7 * d, d, kind, 1, 7 * dd, sv.wf_stride, kH2WScale, dst, c.st));
+            if (c.L > 1)
+              RUN(pm_split_planes_frag_h2(c.P + g.weight[1], 7 * d, d, kind, c.L - 1, lstride, sv.wf_stride, kH2WScale,
+                                            dst + sv.wf_stride, c.st));
+            continue;
+          }
           RUN(pm_split_planes_frag(c.P + g.weight[0], 7 * d, d, kind, 1, 7 * dd, sv.wf_stride, dst, c.st));
           if (c.L > 1)
             RUN(pm_split_planes_frag(c.P + g.weight[1], 7 * d, d, kind, c.L - 1, lstride, sv.wf_stride,
                                        dst + sv.wf_stride, c.st));
         }
+        if (sv.h2) RUN(pm_absmax(sv.T, (int64_t)PM_N_DIST * d, sv.mx + c.L, c.st));
       }
     }
   }
@@ -457,7 +488,15 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     // one kernel for aggregate + product (gcl.hip) where it applies: compact planes path, fragment-major weights
     const bool fused = gcl_kernels && !dense;
     const bool from_planes = gcl_kernels && dense && d == 512;
-    if (fused)
+    const bool x_tracked = sv.h2 && i > 0 && !(c.pdrop > 0.f);   // (the norm apply of layer i-1 left |x|max in mx[i])
+    if (fused && sv.h2) {
+      if (!x_tracked) RUN(pm_absmax(sv.xin[i], (int64_t)N * d, sv.mx + i, c.st));
+      PmH2 h2;
+      h2.absmax_in = sv.mx + i; h2.absmax_aux = sv.mx + c.L; h2.scale_out = sv.sA + i; h2.w_scale = kH2WScale; h2.reserved = 0;
+      RUN(pm_gcl_forward_fused_h2(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
+                                    sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
+                                    sv.h[i], sums, sv.Ap[i], aps, &h2, c.st));
+    } else if (fused)
       RUN(pm_gcl_forward_fused(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                  sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
                                  sv.h[i], sums, sv.Ap[i], aps, c.st));
@@ -491,8 +530,9 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     }
     const PmBn& bn = g.norm[i];                           // x' = x + relu(BN(h))   (model.py:203-206)
     if (c.bn)
-      RUN(pm_bn_apply_fused(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
-                              sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f, c.st));
+      RUN(pm_bn_apply_fused_absmax(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
+                                     sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f,
+                                     (sv.h2 && i + 1 < c.L && !(c.pdrop > 0.f)) ? sv.mx + i + 1 : nullptr, c.st));
     else                                                  // batch_norm = False: x' = x + relu(h)
       RUN(pm_relu_residual_fwd(sv.h[i], sv.x[i], (int64_t)N * d, sv.x[i + 1], c.st));
   }
@@ -537,6 +577,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const bool res_in_dagg = in_dagg && !dropping && cfg().dagg_res;
     double* const acc3 = sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL;
     const bool sums_ready = i < c.L - 1 && fuse_sums;
+    const bool du_tracked = sums_ready;       // (h2: pm_segreduce_bwd_norm of layer i+1 also left |dx|max in mdu[i])
     if (in_dagg) {
       if (!sums_ready)
         RUN(pm_bn_bwd_sums(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, acc3, c.st));
@@ -566,7 +607,10 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         // PM_DW_SIDE=1 (A/B): the weight gradient of the layer on the second stream — nobody on the caller's stream waits
         // for it; its workgroups fill the CUs that the input gradient's / the segment-reduce's unequal tiles leave idle
         BranchScope brw(c, dw_site);
-        if (c.planes && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1) && !cfg().no_dw)      // 128x128 tiles (gcl.hip)
+        if (sv.h2)
+          RUN(pm_gcl_weight_grad_fused_h2(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d, cfg().no_classes ? 0 : 1, dW,
+                                            sv.sA + i, sv.sdh + i, c.st));
+        else if (c.planes && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1) && !cfg().no_dw)      // 128x128 tiles (gcl.hip)
           RUN(pm_gcl_weight_grad_fused(sv.Ap[i], aps, dhp, dps, c.s->plan, N, c.E, c.Gn, d,
                                          cfg().no_classes ? 0 : 1, dW, c.st));
         else
@@ -588,6 +632,14 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         nb.h = sv.h[i]; nb.du = dx; nb.mean = sv.mean[i]; nb.var = sv.var[i]; nb.gamma = c.P + bn.w; nb.beta = c.P + bn.b;
         nb.acc3 = acc3; nb.dgamma = c.G + bn.w; nb.dbeta = c.G + bn.b; nb.dbias_pre = c.G + g.bias[i]; nb.eps = 1e-5f; nb.relu = 1;
         nb.add_residual = res_in_dagg ? 1 : 0; nb.reserved = 0;
+        if (sv.h2) {
+          // |du|max: the segment-reduce backward of the layer above left it (PmNormSums.absmax_out); the top layer's comes from elsewhere
+          if (!du_tracked) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i, c.st));
+          PmH2 h2;
+          h2.absmax_in = sv.mdu + i; h2.absmax_aux = nullptr; h2.scale_out = sv.sdh + i; h2.w_scale = kH2WScale; h2.reserved = 0;
+          RUN(pm_gcl_input_grad_bn_h2(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
+                                        cfg().no_classes ? 0 : 1, dA, &h2, c.st));
+        } else
         RUN(pm_gcl_input_grad_bn(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                    cfg().no_classes ? 0 : 1, dA, c.st));
       } else if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
@@ -609,6 +661,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
       nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
+      nn.absmax_out = sv.h2 ? sv.mdu + (i - 1) : nullptr;
       RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
                                   c.compact, out, dT, &nn, c.st));
     } else {
@@ -972,6 +1025,14 @@ void backward_decoder(Ctx& c) {
       RUN(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
                         PM_GEMM_ACCUM, 0, lst, 1, pv.group_cnt + 2 + g, c.st));
     }
+    if (s.ext_loss) {
+      // the caller's loss: the bias gradients of the three un-embeddings are the column sums of ITS d(logits) (with the
+      // step's own loss the fused un-embedding + cross-entropy kernel of the forward has already left them)
+      RUN(pm_colsum_acc(s.dc_logits + PM_N_PITCH, (int)R, PM_N_DUR, PM_N_TOK, c.G + Y.dec_dur.b, c.st));
+      for (int g = 0; g < 2; ++g)
+        RUN(pm_colsum_rows_acc(s.dc_logits, PM_N_PITCH, PM_N_TOK, pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0), 1,
+                                 pv.group_cnt + 2 + g, (int)R, c.G + pit[g].b, c.st));
+    }
     if (chord_tn) {
       if (rows_tn_pays(d))                                          // dW[:S*d] += dH^T x_L, bias gradient (linear.hip)
         RUN(pm_rows_tn_weight_grad(dH, S * d, S * d, s.dg.x[c.L], d, d, N, c.G + Y.dec_chord.w, d, c.G + Y.dec_chord.b, c.st));
@@ -1303,7 +1364,8 @@ extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
   info[8] = cfg().fused_ce ? 1 : 0; info[9] = cfg().side_stream; info[10] = pm_det_on(); info[11] = cfg().gcl_fused ? 1 : 0;
   info[12] = cfg().dagg_bn ? 1 : 0;            // (the norm backward of the GCN layers inside the input gradient kernel)
   info[13] = s->chord_tab;                      // (the chord encoder as table algebra)
-  info[14] = info[15] = 0;
+  info[14] = (s->eg.h2 ? 1 : 0) | (s->dg.h2 ? 2 : 0);     // (the GCL products of the encoder / decoder stack in the fp16 pair format)
+  info[15] = 0;
   return PM_OK;
 }
 // Model outputs of the last forward (the arena keeps them until the next pm_vae_step_forward): asynchronous
@@ -1322,6 +1384,33 @@ extern "C" int pm_vae_step_outputs(const void* state, float* s_logits, float* c_
   if (c_logits && e == hipSuccess) e = hipMemcpyAsync(c_logits, s->c_logits, sizeof(float) * N * S * PM_N_TOK, hipMemcpyDeviceToDevice, st);
   if (mu && e == hipSuccess) e = hipMemcpyAsync(mu, s->mu, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
   if (log_var && e == hipSuccess) e = hipMemcpyAsync(log_var, s->lv, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
+  return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
+}
+
+// The drop-in module's path (model.py:665-678 called by the UNCHANGED training.py:137-166): the caller computes its loss
+// from pm_vae_step_outputs with its own code (`_losses`, under autocast / GradScaler) and autograd hands the gradients of
+// the four outputs back.  They replace what the forward's own loss kernels left in the arena; the four backward calls then
+// run as in the fused trainer.  d_c_logits covers the step's S slots, [N, S, 230]; a NULL pointer is a zero gradient;
+// d_s_logits != NULL switches the structure decoder's backward on (the reference's loss never reaches it, SURVEY B-1).
+extern "C" int pm_vae_step_set_output_grads(void* state, const float* d_s_logits, const float* d_c_logits, const float* d_mu,
+                                            const float* d_log_var, pm_stream_t stream) {
+  StepState* s = (StepState*)state;
+  if (!s || s->magic != kMagic || s->rc != PM_OK || !s->dc_logits || !s->dmu || s->bk_dxL || s->bk_dx0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t N = s->bt.N, S = s->bt.n_slots, G = s->bt.G, B = s->bt.B, d = s->lay.d;
+  auto put = [&](float* dst, const float* src, size_t n) {
+    return src ? hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dst, 0, sizeof(float) * n, st);
+  };
+  hipError_t e = put(s->dc_logits, d_c_logits, N * S * PM_N_TOK);
+  if (e == hipSuccess && d_s_logits) e = put(s->ds_logits, d_s_logits, G * 128);
+  if (e == hipSuccess) e = put(s->dmu, d_mu, B * d);
+  if (e == hipSuccess) e = put(s->dlv, d_log_var, B * d);
+  const PmVaeLayout& Y = s->lay;
+  if (e == hipSuccess) e = hipMemsetAsync(s->G + Y.dec_pitch_d.b, 0, sizeof(float) * PM_N_PITCH, st);
+  if (e == hipSuccess) e = hipMemsetAsync(s->G + Y.dec_pitch_nd.b, 0, sizeof(float) * PM_N_PITCH, st);
+  if (e == hipSuccess) e = hipMemsetAsync(s->G + Y.dec_dur.b, 0, sizeof(float) * PM_N_DUR, st);
+  s->fix_structure = d_s_logits ? 1 : 0;
+  s->ext_loss = 1;
   return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
 }
 

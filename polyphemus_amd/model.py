@@ -254,6 +254,58 @@ class _ReparamFn(torch.autograd.Function):
         return dmu, dlv, None
 
 
+def _draw_eps(n_samples: int, d: int, device) -> torch.Tensor:
+    """The reparametrisation noise of `VAE.forward` (model.py:672: `torch.randn_like(mu)`); a function of its own so that
+    the parity tests can inject the reference's draw."""
+    return torch.randn(n_samples, d, device=device)
+
+
+class _VaeStepFn(torch.autograd.Function):
+    """`VAE.forward` in training mode as ONE autograd node over the C++ step (csrc/vae_step.hip, the sequence bench.py
+    measures): the forward is `pm_vae_step_forward` with the logits kept; the caller's loss (`_losses` of the unchanged
+    training.py:298-347, under autocast / GradScaler) produces the gradients of the four outputs, which
+    `pm_vae_step_set_output_grads` hands to the four native backward calls.  Parameter gradients come back as views of one
+    flat buffer laid out like `flat_params`."""
+
+    @staticmethod
+    def forward(ctx, vae, graph, eps, *params):
+        step = vae._native_step()
+        n_slots = None if vae.active_slots_only else 15
+        grads = torch.zeros_like(vae.flat_params)            # (the forward already leaves gradients of its own loss here)
+        step.forward(graph, eps, grads, keep_logits=True, n_slots=n_slots)
+        (s_logits, c_logits), mu, lv = step.outputs()
+        S = c_logits.shape[1]
+        if S < 15:                                           # slots that hold PAD in every node: not computed (opt-in)
+            full = c_logits.new_zeros(c_logits.shape[0], 15, c_logits.shape[2])
+            full[:, :S] = c_logits
+            c_logits = full
+        step.bump_counters()
+        ctx.vae, ctx.step, ctx.grads, ctx.S = vae, step, grads, S
+        ctx.ticket = vae._step_ticket = vae._step_ticket + 1
+        ctx.set_materialize_grads(False)
+        return s_logits, c_logits, mu, lv
+
+    @staticmethod
+    def backward(ctx, ds, dc, dmu, dlv):
+        vae, step = ctx.vae, ctx.step
+        if ctx.ticket != vae._step_ticket:
+            raise RuntimeError("backward through a model(graph) call that is not the model's latest: the native step keeps "
+                               "the activations of ONE forward (set vae.native_step = False to keep several graphs alive)")
+        f = lambda t: None if t is None else t.contiguous().float()
+        dc = f(dc)
+        if dc is not None and ctx.S < 15:
+            dc = dc[:, :ctx.S].contiguous()
+        step.set_output_grads(f(ds), dc, f(dmu), f(dlv))
+        step.backward_decoder()
+        step.backward_encoder_heads()
+        step.backward_encoder()
+        step.backward_encoder_tail()
+        vae._step_ticket += 1                                # (a second backward through the same forward has nothing to read)
+        g, P = ctx.grads, dict(vae.named_parameters())
+        return (None, None, None) + tuple(g[vae._offsets[n]:vae._offsets[n] + P[n].numel()].view(P[n].shape)
+                                          for n in vae._param_names)
+
+
 # --------------------------------------------------------------------------- encoder / decoder / VAE
 class Encoder(nn.Module):
     def __init__(self, **kw):
@@ -356,6 +408,13 @@ class VAE(nn.Module):
         self.seed = 0x5EED                    # BASE seed of the counter-based dropout streams (checkpointed as is)
         self.rank_salt = 0                    # data parallel: mixed into every derived seed, so ranks draw different masks;
         self._step = 0                        # set by the trainer from the rank, never stored in a checkpoint
+        # `model(graph)` in training mode runs the C++ step (one autograd node, _VaeStepFn); False: the Python orchestration
+        # of the same kernels (three autograd nodes over engine.Engine; several forwards may then be alive at once)
+        self.native_step = True
+        # True: the decoder head covers only the batch's active token slots — c_logits of slots that hold PAD in every node
+        # come back as zeros (the reference's loss ignores them: same loss, same gradients); default: all 15, as the reference
+        self.active_slots_only = False
+        self._step_ticket = 0
         self._flatten()
 
     # ---- flat parameter / buffer storage ---------------------------------------------------
@@ -401,6 +460,7 @@ class VAE(nn.Module):
                     tensors[f"{head}.layers.{i}.nn.{tail}"] = tensors[k]
         self.__dict__["engine"] = Engine(self.cfg, tensors)
         self.__dict__["engine"].msg_dropout = self.msg_dropout
+        self.__dict__["_native"] = None                      # (the flat buffers moved: the C++ step's layout is rebuilt on use)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -447,8 +507,26 @@ class VAE(nn.Module):
         self.engine.msg_dropout = self.msg_dropout
         return prepare_graph(graph, self.cfg["n_bars"])
 
+    def _native_step(self):
+        from .native import NativeStep
+        st = self.__dict__.get("_native")
+        if st is None or st.flat_ptr != self.flat_params.data_ptr():
+            st = NativeStep(self)
+            self.__dict__["_native"] = st
+        return st
+
     # ---- reference surface ------------------------------------------------------------------
     def forward(self, graph):
+        if (self.native_step and self.training and torch.is_grad_enabled() and self.flat_params.is_cuda
+                and not self.engine.syncing(True)):
+            # the training step of the unchanged training.py:137-166: forward here, `_losses` and `backward()` in the caller
+            self._check_flat()
+            n_samples = int(graph.s_tensor.numel() // (128 * self.cfg["n_bars"]))
+            eps = _draw_eps(n_samples, self.cfg["d"], self.flat_params.device)
+            with torch.autocast("cuda", enabled=False):      # the kernels are fp32 (training.py:137 turns autocast on)
+                s_logits, c_logits, mu, log_var = _VaeStepFn.apply(self, graph, eps, *self._tensors(""))
+            graph.distinct_bars = graph.bars + self.cfg["n_bars"] * graph.batch        # reference side effect, model.py:403,542
+            return (s_logits, c_logits), mu, log_var
         mu, log_var = self.encoder(graph)
         eps = torch.randn_like(mu)
         z = _ReparamFn.apply(mu, log_var, eps)

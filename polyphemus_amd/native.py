@@ -129,3 +129,155 @@ def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_
     # bit 2: the fused un-embedding + CE also stores the content logits (step_outputs, evaluation)
     b.flags = (1 if track_unique else 0) | (2 if _PLANES else 0) | (4 if keep_logits else 0)
     return b
+
+
+# --------------------------------------------------------------------------- the C++ step behind one object
+def prepare_inputs(graph, want_token_counts: bool = False):
+    """Compact device inputs of a batch — token ids, edge ids, the two host-known facts that pick the native path (active
+    slots, compact GCL) — converted once and cached on the graph.  Accepts the compact `BarGraphBatch` attributes or the
+    reference's PyG format (edge_attrs [E,33], one-hot c_tensor [N,16,230]; data.py:179-182,235-268)."""
+    from . import ops
+    c = graph.__dict__.get("_pm_inputs") if hasattr(graph, "__dict__") else None
+    if c is not None and (not want_token_counts or len(c) > 9):
+        return c
+    has = lambda k: k in getattr(graph, "__dict__", {}) or (hasattr(graph, "keys") and k in graph.keys())
+    if has("edge_type") and has("edge_dist"):
+        et, ed = graph.edge_type.to(torch.int32).contiguous(), graph.edge_dist.to(torch.int32).contiguous()
+    else:
+        et, ed = ops.edge_attrs_to_ids(graph.edge_attrs.float().contiguous())
+    tok = graph.tokens.to(torch.int32).contiguous() if has("tokens") else ops.tokens_from_onehot(
+        graph.c_tensor.float().contiguous())
+    drum = graph.is_drum.contiguous()
+    drum = drum.view(torch.uint8) if drum.dtype == torch.bool else drum
+    ei, bars, bat = (t.to(torch.int64).contiguous() for t in (graph.edge_index, graph.bars, graph.batch))
+    for t in (et, ed, tok, drum, ei, bars, bat):
+        if not t.is_cuda:
+            raise RuntimeError("the native step needs the batch on the GPU (graph.to('cuda')); there is no CPU path")
+    n_slots, unique = getattr(graph, "n_slots", None), getattr(graph, "track_unique", None)
+    if n_slots is None or unique is None:
+        from .graphs import batch_flags
+        n_slots, unique = batch_flags(tok, ei, et, tok.shape[0])
+    c = (et, ed, tok, drum, ei, bars, bat, int(n_slots), bool(unique))
+    if want_token_counts:             # non-PAD (pitch, duration) tokens of slots 1..15, on the device
+        nv = torch.stack([(tok[:, 1:, 0] != 130).sum(), (tok[:, 1:, 1] != 98).sum()]).to(torch.float32)
+        c = c + (nv,)
+    try:
+        graph.__dict__["_pm_inputs"] = c
+    except Exception:
+        pass
+    return c
+
+
+class NativeStep:
+    """One model's handle on the C++ training step (`pm_vae_step_*`, csrc/vae_step.hip): layout, host state blob, workspace
+    arena and plan buffer; the calls of a step in order.  Used by `HipTrainer` (the step's own fused loss and Adam) and by
+    the drop-in module's autograd bridge (`model.VAE.forward`: the caller's loss, `pm_vae_step_set_output_grads`)."""
+
+    def __init__(self, vae):
+        from ._lib import call, plan_layout, ptr, stream, PLAN_FIELDS
+        self._call, self._plan_layout, self._ptr, self._stream, self._fields = call, plan_layout, ptr, stream, PLAN_FIELDS
+        self.vae = vae
+        self.layout = build_layout(vae)
+        self.flat_ptr = vae.flat_params.data_ptr()
+        self.state = C.create_string_buffer(int(lib().pm_vae_step_state_bytes()))
+        self.ws = None
+        self.plan_buf = None
+        self.plan_off = None
+        self.bt = None
+        dev = vae.flat_params.device
+        self.loss_buf = torch.zeros(4, dtype=torch.float64, device=dev)
+        ci = vae._counter_index
+        emb = ["encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur"]
+        inc = torch.ones(vae.flat_counters.numel(), dtype=torch.int64, device=dev)
+        sel = torch.zeros(2, vae.flat_counters.numel(), dtype=torch.int64, device=dev)
+        for k, row in zip(emb, ((1, 0), (0, 1), (1, 1))):
+            i = ci[k + ".num_batches_tracked"]
+            inc[i] = 0
+            sel[0, i], sel[1, i] = row
+        self._nbt_inc, self._nbt_sel = inc, sel
+
+    @property
+    def addr(self) -> int:
+        return C.addressof(self.state)
+
+    def forward(self, graph, eps, grads, keep_logits: bool, beta: float = 0.0, fix_structure: bool = False,
+                n_slots=None, ce_scale=None, want_token_counts: bool = False):
+        """plan -> encoder -> reparametrisation -> decoder -> the step's own losses into `self.loss_buf` (+ their gradients
+        with respect to the outputs; the bias gradients of the un-embedding land in `grads`).  `n_slots`: token slots the
+        decoder head covers (default: the batch's active slots; 15 = every slot, as the reference computes them)."""
+        vae, L = self.vae, lib()
+        if vae.flat_params.data_ptr() != self.flat_ptr:
+            raise RuntimeError("the model's flat parameter buffer moved after the native step was built; rebuild it")
+        inputs = prepare_inputs(graph, want_token_counts)
+        et, ed, tok, drum, ei, bars, bat, act_slots, unique = inputs[:9]
+        s_tensor = graph.s_tensor
+        if s_tensor.dtype != torch.float32 or not s_tensor.is_contiguous():
+            s_tensor = s_tensor.float().contiguous()
+        s_tensor = s_tensor.reshape(-1, 4, 32)
+        bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, act_slots if n_slots is None else n_slots, unique,
+                        keep_logits=keep_logits)
+        if ce_scale is not None:
+            bt.ce_scale = ce_scale.data_ptr()
+        bt.B = bt.G // vae.cfg["n_bars"]
+        need = int(L.pm_vae_step_workspace_bytes(C.byref(self.layout), bt.N, bt.E, bt.G, bt.B, bt.n_slots))
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=grads.device)
+        off = self._plan_layout(bt.N, bt.E, bt.G)
+        if self.plan_buf is None or self.plan_buf.numel() < off[-1]:
+            self.plan_buf = torch.empty(off[-1], dtype=torch.int32, device=grads.device)
+        if eps is None:
+            eps = torch.randn(bt.B, vae.cfg["d"], device=grads.device)
+        self.bt, self.plan_off, self._keep = bt, off, (s_tensor, eps, grads, ce_scale, inputs)   # (alive until the backward is through)
+        ptr = self._ptr
+        self._call("pm_vae_step_forward", C.addressof(self.layout), ptr(vae.flat_params), ptr(vae.flat_buffers), ptr(grads),
+                   C.addressof(bt), ptr(self.plan_buf), ptr(eps), float(vae.msg_dropout), vae._next_seed(), vae._next_seed(),
+                   float(beta), int(fix_structure), ptr(self.ws), self.ws.numel(), self.addr, ptr(self.loss_buf), self._stream())
+        return self.loss_buf
+
+    def info(self) -> dict:
+        info = (C.c_int32 * 16)()
+        self._call("pm_vae_step_info", self.addr, C.cast(info, C.c_void_p))
+        keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B", "fused_ce", "side_stream", "deterministic",
+                "gcl_fused", "dagg_bn", "chord_tables", "h2")
+        return dict(zip(keys, (int(v) for v in info)))
+
+    def outputs(self):
+        """`((s_logits, c_logits), mu, log_var)` of the last forward; c_logits is [N, S, 230] for the S slots it covered."""
+        i, vae = self.info(), self.vae
+        dev, d, nb = vae.flat_params.device, vae.cfg["d"], vae.cfg["n_bars"]
+        s_logits = torch.empty(i["B"], nb, 4, 32, device=dev)
+        c_logits = torch.empty(i["N"], i["n_slots"], 230, device=dev)
+        mu, lv = torch.empty(i["B"], d, device=dev), torch.empty(i["B"], d, device=dev)
+        ptr = self._ptr
+        self._call("pm_vae_step_outputs", self.addr, ptr(s_logits), ptr(c_logits), ptr(mu), ptr(lv), self._stream())
+        return (s_logits, c_logits), mu, lv
+
+    def set_output_grads(self, ds_logits, dc_logits, dmu, dlv):
+        ptr = self._ptr
+        self._call("pm_vae_step_set_output_grads", self.addr, ptr(ds_logits), ptr(dc_logits), ptr(dmu), ptr(dlv), self._stream())
+
+    def backward_decoder(self):
+        self._call("pm_vae_step_backward_decoder", self.addr, self._stream())
+
+    def backward_encoder_heads(self):
+        self._call("pm_vae_step_backward_encoder_heads", self.addr, self._stream())
+
+    def backward_encoder(self):
+        self._call("pm_vae_step_backward_encoder", self.addr, self._stream())
+
+    def backward_encoder_tail(self):
+        self._call("pm_vae_step_backward_encoder_tail", self.addr, self._stream())
+
+    def bump_counters(self):
+        """num_batches_tracked (int64 bookkeeping of nn.BatchNorm): +1 per forward; the embedding norms only when their group
+        is non-empty, bn_dur once per non-empty group (model.py:362,375)."""
+        vae, ptr = self.vae, self._ptr
+        i = self._fields.index("group_cnt")
+        off = self.plan_off
+        self._call("pm_bn_counters_update", ptr(vae.flat_counters), ptr(self._nbt_inc), ptr(self._nbt_sel),
+                   ptr(self.plan_buf[off[i]:off[i] + 2]), vae.flat_counters.numel(), self._stream())
+
+    def plan_word(self, field: str, index: int) -> int:
+        """One int of the plan (a host read: debugging only)."""
+        j = self._fields.index(field)
+        return int(self.plan_buf[self.plan_off[j] + index].item())

@@ -14,9 +14,12 @@ from . import constants as C
 from .graphs import BarGraphBatch, collate_samples, graph_from_structure
 
 
-def disk_sample(rng: np.random.Generator, n_bars: int, p: float):
+def disk_sample(rng: np.random.Generator, n_bars: int, p: float, max_notes: int = 4):
     """One sample in the reference's `.npz` layout (preprocess.py:210):
-    c_tensor int16 [4, nb*32, 16, 2], s_tensor bool [4, nb*32]."""
+    c_tensor int16 [4, nb*32, 16, 2], s_tensor bool [4, nb*32].  `max_notes`: notes per active cell are U{1..max_notes}
+    (4; 14 fills all 15 token slots behind SOS, constants.py:48)."""
+    if not 1 <= max_notes <= C.MAX_SIMU_TOKENS - 2:
+        raise ValueError("max_notes must be in 1..14")
     T = n_bars * C.N_TIMESTEPS
     s = rng.random((C.N_TRACKS, T)) < p
     for b in range(n_bars):                         # data.py:152-153 forces [0,0] on
@@ -25,12 +28,12 @@ def disk_sample(rng: np.random.Generator, n_bars: int, p: float):
     c = np.empty((C.N_TRACKS, T, C.MAX_SIMU_TOKENS, 2), np.int16)
     c[..., 0] = C.PITCH_PAD
     c[..., 1] = C.DUR_PAD
-    k = rng.integers(1, 5, size=(C.N_TRACKS, T))
-    pitch = rng.integers(0, 128, size=(C.N_TRACKS, T, 4))
-    dur = rng.integers(0, 96, size=(C.N_TRACKS, T, 4))
+    k = rng.integers(1, max_notes + 1, size=(C.N_TRACKS, T))
+    pitch = rng.integers(0, 128, size=(C.N_TRACKS, T, max_notes))
+    dur = rng.integers(0, 96, size=(C.N_TRACKS, T, max_notes))
     c[..., 0, 0] = C.PITCH_SOS
     c[..., 0, 1] = C.DUR_SOS
-    for j in range(4):
+    for j in range(max_notes):
         has = k > j
         c[..., 1 + j, 0] = np.where(has, pitch[..., j], c[..., 1 + j, 0])
         c[..., 1 + j, 1] = np.where(has, dur[..., j], c[..., 1 + j, 1])
@@ -52,11 +55,11 @@ def sample_from_disk(c_disk: np.ndarray, s_disk: np.ndarray, n_bars: int, dense=
 
 
 def synthetic_batch(batch_size: int, n_bars: int = 2, p: float = 0.25, seed: int = 1234,
-                    dense: bool = False) -> BarGraphBatch:
+                    dense: bool = False, max_notes: int = 4) -> BarGraphBatch:
     """A collated batch of `batch_size` synthetic samples (CPU tensors)."""
     rng = np.random.default_rng(seed)
     samples = []
     for _ in range(batch_size):
-        c, s = disk_sample(rng, n_bars, 1.0 if dense else p)
+        c, s = disk_sample(rng, n_bars, 1.0 if dense else p, max_notes)
         samples.append(sample_from_disk(c, s, n_bars, dense=dense))
     return collate_samples(samples, n_bars)

@@ -29,9 +29,9 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from ._lib import call, lib, plan_layout, ptr, stream, PLAN_FIELDS
+from ._lib import call, lib, ptr, stream
 from .model import VAE, prepare_graph
-from .native import build_layout, make_batch
+from .native import NativeStep, prepare_inputs
 from .parallel import GradBuckets, broadcast_
 
 
@@ -125,124 +125,53 @@ class HipTrainer:
         if self.world > 1:
             import torch.distributed as dist
             vae.rank_salt = (0x9E3779B9 * (dist.get_rank(process_group) + 1)) & 0xFFFFFFFF
-        # native step plumbing
-        self._layout = build_layout(vae) if self.native else None
+        # native step plumbing (polyphemus_amd/native.py: layout, host state blob, arena, plan buffer)
         self._flat_ptr = flat.data_ptr()
-        self._state = ctypes.create_string_buffer(int(lib().pm_vae_step_state_bytes()))
-        self._ws: Optional[torch.Tensor] = None
-        self._plan_buf: Optional[torch.Tensor] = None
-        # num_batches_tracked of every BatchNorm: views of vae.flat_counters; +1 per step, except the three embedding
-        # norms, which follow their group counts (weights [has_drum, has_non_drum] -> bn_drums, bn_non_drums, bn_dur)
-        ci = vae._counter_index
-        emb = ["encoder.c_encoder.bn_drums", "encoder.c_encoder.bn_non_drums", "encoder.c_encoder.bn_dur"]
-        inc = torch.ones(vae.flat_counters.numel(), dtype=torch.int64, device=flat.device)
-        sel = torch.zeros(2, vae.flat_counters.numel(), dtype=torch.int64, device=flat.device)
-        for k, row in zip(emb, ((1, 0), (0, 1), (1, 1))):
-            i = ci[k + ".num_batches_tracked"]
-            inc[i] = 0
-            sel[0, i], sel[1, i] = row
-        self._nbt_inc, self._nbt_sel = inc, sel
+        self.step = NativeStep(vae) if self.native else None
+        self.loss_buf = self.step.loss_buf if self.step is not None else self.loss_buf
 
     # ------------------------------------------------------------------------------------------
-    def _prep_inputs(self, graph):
-        """Compact device inputs of a batch (token ids, edge ids) — converted once and cached on the graph."""
-        c = graph.__dict__.get("_pm_inputs") if hasattr(graph, "__dict__") else None
-        if c is None:
-            has = lambda k: k in getattr(graph, "__dict__", {}) or (hasattr(graph, "keys") and k in graph.keys())
-            if has("edge_type") and has("edge_dist"):
-                et, ed = graph.edge_type.to(torch.int32).contiguous(), graph.edge_dist.to(torch.int32).contiguous()
-            else:
-                et, ed = ops.edge_attrs_to_ids(graph.edge_attrs.float().contiguous())
-            tok = graph.tokens.to(torch.int32).contiguous() if has("tokens") else ops.tokens_from_onehot(
-                graph.c_tensor.float().contiguous())
-            drum = graph.is_drum.contiguous()
-            drum = drum.view(torch.uint8) if drum.dtype == torch.bool else drum
-            ei, bars, bat = (t.to(torch.int64).contiguous() for t in (graph.edge_index, graph.bars, graph.batch))
-            for t in (et, ed, tok, drum, ei, bars, bat):
-                if not t.is_cuda:
-                    raise RuntimeError("HipTrainer needs the batch on the GPU (graph.to('cuda')); there is no CPU path")
-            # the two host-known facts that pick the native path (active slots, compact GCL): carried by batches of
-            # `collate_samples` / `DeviceLoader`, derived once (one host read) for any other batch object
-            n_slots, unique = getattr(graph, "n_slots", None), getattr(graph, "track_unique", None)
-            if n_slots is None or unique is None:
-                from .graphs import batch_flags
-                n_slots, unique = batch_flags(tok, ei, et, tok.shape[0])
-            c = (et, ed, tok, drum, ei, bars, bat, int(n_slots), bool(unique))
-            if self.global_token_mean:        # non-PAD (pitch, duration) tokens of slots 1..15, on the device
-                nv = torch.stack([(tok[:, 1:, 0] != 130).sum(), (tok[:, 1:, 1] != 98).sum()]).to(torch.float32)
-                c = c + (nv,)
-            try:
-                graph.__dict__["_pm_inputs"] = c
-            except Exception:
-                pass
-        return c
+    @property
+    def _plan_buf(self):
+        return self.step.plan_buf
 
     def _native_forward_backward(self, graph, eps):
-        vae = self.vae
-        L = lib()
-        inputs = self._prep_inputs(graph)
-        et, ed, tok, drum, ei, bars, bat, n_slots, unique = inputs[:9]
-        s_tensor = graph.s_tensor
-        if s_tensor.dtype != torch.float32 or not s_tensor.is_contiguous():
-            s_tensor = s_tensor.float().contiguous()
-        bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, n_slots, unique, keep_logits=self.keep_logits)
+        vae, step = self.vae, self.step
         ce_scale = None
-        if self.global_token_mean and self.world > 1:
+        gtm = self.global_token_mean and self.world > 1
+        if gtm:
             import torch.distributed as dist
-            if len(inputs) < 10:
-                raise RuntimeError("batch was prepared before global_token_mean was switched on")
+            inputs = prepare_inputs(graph, want_token_counts=True)
             tot = inputs[9].clone()
             dist.all_reduce(tot, group=self.pg)
             ce_scale = (inputs[9] * float(self.world) / tot).contiguous()      # stays on the device
-            bt.ce_scale = ce_scale.data_ptr()
-        bt.B = bt.G // vae.cfg["n_bars"]
-        need = int(L.pm_vae_step_workspace_bytes(ctypes.byref(self._layout), bt.N, bt.E, bt.G, bt.B, bt.n_slots))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.grads.device)
-        off = plan_layout(bt.N, bt.E, bt.G)
-        if self._plan_buf is None or self._plan_buf.numel() < off[-1]:
-            self._plan_buf = torch.empty(off[-1], dtype=torch.int32, device=self.grads.device)
-        if eps is None:
-            eps = torch.randn(bt.B, vae.cfg["d"], device=self.grads.device)
-        st = stream()
-        call("pm_vae_step_forward", ctypes.addressof(self._layout), ptr(vae.flat_params), ptr(vae.flat_buffers),
-             ptr(self.grads), ctypes.addressof(bt), ptr(self._plan_buf), ptr(eps), float(vae.msg_dropout),
-             vae._next_seed(), vae._next_seed(), float(self.beta), int(self.fix_structure_loss), ptr(self._ws),
-             self._ws.numel(), ctypes.addressof(self._state), ptr(self.loss_buf), st)
-        state = ctypes.addressof(self._state)
-        if unique and os.environ.get("PM_DEBUG", "0") not in ("", "0"):
+        step.forward(graph, eps, self.grads, keep_logits=self.keep_logits, beta=self.beta,
+                     fix_structure=self.fix_structure_loss, ce_scale=ce_scale, want_token_counts=gtm)
+        if prepare_inputs(graph)[8] and os.environ.get("PM_DEBUG", "0") not in ("", "0"):
             # the plan kernels count the nodes that break the one-track-relation-per-node rule the compact GCL
             # relies on (plan.hip k_node_class, cnt[4]); a host read, hence only under PM_DEBUG
-            j = PLAN_FIELDS.index("trk_cnt")
-            bad = int(self._plan_buf[off[j] + 4].item())
+            bad = step.plan_word("trk_cnt", 4)
             if bad:
                 raise RuntimeError(f"{bad} nodes receive track edges of more than one track but the batch was "
                                    "flagged track_unique (graphs.batch_flags); the compact GCL would be wrong")
-        call("pm_vae_step_backward_decoder", state, st)
+        step.backward_decoder()
         # the decoder's last weight gradients run on the library's second stream beside the head chains; the encoder's head
         # chain ends with the caller's stream waiting for them, so the decoder bucket goes out behind it — in front of the
         # encoder's GCN stack, which overlaps the exchange
-        call("pm_vae_step_backward_encoder_heads", state, st)
+        step.backward_encoder_heads()
         self.buckets.launch(2)                               # decoder gradients: overlapped with the encoder backward
-        call("pm_vae_step_backward_encoder", state, st)
+        step.backward_encoder()
         self.buckets.launch(1)                               # graph encoder .. encoder head: overlapped with the tail
-        call("pm_vae_step_backward_encoder_tail", state, st)
+        step.backward_encoder_tail()
         self.buckets.launch(0)                               # chord encoder, embeddings, structure encoder
-        # num_batches_tracked (int64 bookkeeping of nn.BatchNorm): +1 per forward; the embedding norms only
-        # when their group is non-empty, bn_dur once per non-empty group (model.py:362,375)
-        i = PLAN_FIELDS.index("group_cnt")
-        call("pm_bn_counters_update", ptr(vae.flat_counters), ptr(self._nbt_inc), ptr(self._nbt_sel),
-             ptr(self._plan_buf[off[i]:off[i] + 2]), vae.flat_counters.numel(), st)
-        return self.loss_buf
+        step.bump_counters()
+        return step.loss_buf
 
     def step_info(self) -> dict:
         """Which variant of the native step the last `train_step` ran (`pm_vae_step_info`): compact GCL (K = 4d),
-        bf16-planes GEMM operands, active token slots S, fragment-major weight planes (B-direct GEMM), batch sizes."""
-        info = (ctypes.c_int32 * 16)()
-        call("pm_vae_step_info", ctypes.addressof(self._state), ctypes.cast(info, ctypes.c_void_p))
-        keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B", "fused_ce", "side_stream", "deterministic",
-                "gcl_fused", "dagg_bn", "chord_tables")
-        return dict(zip(keys, (int(v) for v in info)))
+        bf16-planes GEMM operands, active token slots S, fragment-major weight planes (B-direct GEMM), batch sizes, the
+        library's effective switches, the fp16 pair format of the GCL products (bit 0 encoder, bit 1 decoder stack)."""
+        return self.step.info()
 
     def step_outputs(self):
         """`((s_logits, c_logits), mu, log_var)` of the last native `train_step` — what `VAE.forward` returns
@@ -252,12 +181,7 @@ class HipTrainer:
         if not self.keep_logits and i["fused_ce"]:
             raise RuntimeError("step_outputs needs trainer.keep_logits = True before the step (the fused un-embedding + "
                                "cross-entropy does not store the logits otherwise)")
-        dev, d, nb = self.grads.device, self.vae.cfg["d"], self.vae.cfg["n_bars"]
-        s_logits = torch.empty(i["B"], nb, 4, 32, device=dev)
-        c_logits = torch.empty(i["N"], i["n_slots"], 230, device=dev)
-        mu, lv = torch.empty(i["B"], d, device=dev), torch.empty(i["B"], d, device=dev)
-        call("pm_vae_step_outputs", ctypes.addressof(self._state), ptr(s_logits), ptr(c_logits), ptr(mu), ptr(lv), stream())
-        return (s_logits, c_logits), mu, lv
+        return self.step.outputs()
 
     def _python_forward_backward(self, graph, eps):
         vae, eng = self.vae, self.vae.engine

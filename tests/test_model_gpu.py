@@ -92,13 +92,18 @@ def test_eval_forward_matches_reference_golden(case):
         assert rel_err(got, z[f"eval/{name}"]) < REL_TOL, name
 
 
+@pytest.mark.parametrize("path", ["model_call", "bridges"])
 @pytest.mark.parametrize("amp", [False, True])
 @pytest.mark.parametrize("case", ["lmd2_tiny", "nb3_tiny", "bnoff_tiny"])
-def test_train_step_matches_reference_golden(case, amp):
+def test_train_step_matches_reference_golden(case, amp, path, monkeypatch):
     """forward + reference loss + backward + torch Adam through the drop-in module == golden.  `amp`: the iteration
     exactly as the unchanged `PolyphemusTrainer.train` runs it on a cuda device (training.py:123,137-166): forward and
     `_losses` inside fp16 autocast, `GradScaler.scale(tot_loss).backward()`, `scaler.step`, `scaler.update` — the fp32
-    kernels ignore the autocast context and the power-of-two loss scale is exact, so the result is the golden's."""
+    kernels ignore the autocast context and the power-of-two loss scale is exact, so the result is the golden's.
+    `path`: "model_call" = `vae(graph)` as training.py:141 calls it — ONE autograd node over the C++ step (the sequence
+    bench.py measures), the reference's own draw of eps injected; "bridges" = encoder / reparametrisation / decoder called
+    one by one (generate.py's surface; the Python orchestration of the same kernels)."""
+    from polyphemus_amd import model as model_mod
     z, cfg = load_case(case)
     scaler = torch.cuda.amp.GradScaler() if amp else None
     vae = VAE(**cfg, device=DEV).to(DEV)
@@ -114,7 +119,12 @@ def test_train_step_matches_reference_golden(case, amp):
     for step in (1, 2):
         lr_sum += opt.param_groups[0]["lr"]
         with torch.autocast("cuda", dtype=torch.float16, enabled=amp):                    # training.py:137
-            s_logits, c_logits, mu, lv = hip_forward(vae, g, eps)
+            if path == "model_call":
+                monkeypatch.setattr(model_mod, "_draw_eps", lambda n, d, dev: eps.clone())
+                (s_logits, c_logits), mu, lv = vae(g)                                    # training.py:141
+                assert vae._native_step().info()["n_slots"] == 15                        # every slot, as the reference computes them
+            else:
+                s_logits, c_logits, mu, lv = hip_forward(vae, g, eps)
             tot, parts = vae_cpu.losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, lv)   # training.py:298-347
         want = json.loads(str(z[f"train{step}/losses"]))
         for k, v in want.items():

@@ -443,7 +443,8 @@ def test_gcl_kernels_match_the_segment_reduce_plus_grouped_product_step(d, L):
     (lu, gu, cu, mu_u, info_u), = run_ranks(_unfused_gcl_worker, 1, (d, L, 31), timeout=180.0)
     lf, gf, cf, mu_f, info_f = _synthetic_step(d, L, 31)
     assert info_f["compact"] == 1 and info_f["planes"] == 1 and info_f["gcl_fused"] == 1 and info_u["gcl_fused"] == 0
-    assert {k: v for k, v in info_f.items() if k != "gcl_fused"} == {k: v for k, v in info_u.items() if k != "gcl_fused"}
+    assert info_f["h2"] == 3 and info_u["h2"] == 0     # (the fp16 pair format exists for the kernels of gcl.hip only)
+    assert {k: v for k, v in info_f.items() if k not in ("gcl_fused", "h2")} == {k: v for k, v in info_u.items() if k not in ("gcl_fused", "h2")}
     for k in lf:
         assert abs(lf[k] - lu[k]) <= 2e-6 * max(1.0, abs(lu[k])), k
     assert rel_err(torch.from_numpy(cf), torch.from_numpy(cu)) < 2e-5

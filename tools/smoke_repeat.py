@@ -1,4 +1,4 @@
-"""Race or ReLU kink?  Repeats the smoke step (`__graft_entry__.smoke()`: B = 8, d = 64, L = 2, batch seed 7) in FRESH
+"""Race or ReLU kink?  Repeats the smoke step (defaults = `__graft_entry__.SMOKE`; round 3's red smoke was --d 64 --seed 7) in FRESH
 processes on the GPU under several PM_* settings and attributes every gradient to the fp64 oracle's near-kink ReLU
 decisions (oracle/kinks.py).  Test infrastructure: imports oracle/.
 
@@ -139,10 +139,11 @@ if __name__ == "__main__":
     ap.add_argument("--result", default="")
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--inproc", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--d", type=int, default=64)
-    ap.add_argument("--layers", type=int, default=2)
-    ap.add_argument("--seed", type=int, default=7)
+    import __graft_entry__ as _ge
+    ap.add_argument("--batch", type=int, default=_ge.SMOKE["batch"])
+    ap.add_argument("--d", type=int, default=_ge.SMOKE["d"])
+    ap.add_argument("--layers", type=int, default=_ge.SMOKE["layers"])
+    ap.add_argument("--seed", type=int, default=_ge.SMOKE["batch_seed"])
     ap.add_argument("--tau", type=float, default=2e-5)
     ap.add_argument("--settings", nargs="+", default=["default", "side0"])
     ap.add_argument("--tmp", default="/tmp/pm_smoke_repeat")

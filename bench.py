@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak; a split-mode fp32 product costs SIX bf16 MFMA products
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 matrix peak; an fp32 product costs SIX bf16 MFMA products on the exact
+                                   # three-term bf16 split, THREE fp16 MFMA products in the fp16 pair format (PmH2, csrc/common.h)
 # Memory-side bytes per launch (`roofline.traffic`): bench.py cannot read PMC counters itself, so they come from the
 # committed result of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
 # (tools/pmc_traffic.py writes profiles/pmc_traffic.json: per kernel class the corrected bytes, the workload and a digest
@@ -603,8 +604,11 @@ def main():
         gemm_ms = sum(survey[k]["total_ms"] for k in gemm_keys)
         gemm_tf = sum(survey[k]["work"] for k in gemm_keys) / (gemm_ms * 1e-3) / 1e12
         split = dom.startswith("gcl") or dom[8:].startswith(("planes", "x6"))   # fp32 product = 6 bf16 MFMA products (fp32 accumulate)
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
-        insn = "v_mfma_f32_32x32x16_bf16, 6 products per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
+        h2 = dom.startswith("gcl") and step_info.get("h2", 0) == 3              # ... or 3 fp16 products (fp16 pair format, d <= 256)
+        nprod = 3.0 if h2 else 6.0
+        peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
+        insn = ("v_mfma_f32_32x32x16_f16, 3 products per fp32 product (fp16 pair operands)" if h2 else
+                "v_mfma_f32_32x32x16_bf16, 6 products per fp32 product") if split else "v_mfma_f32_32x32x2_f32"
         workload_key = f"B{args.batch}_d{args.d}_nb{args.n_bars}_L{args.layers}" + ("_dense" if args.dense else "")
         sampling = (f"HIP events around every {EVENT_STRIDE}-th launch of this kernel inside the timed region "
                     f"({ds['launches']} launches sampled)")
@@ -620,7 +624,9 @@ def main():
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4), "traffic": pmc_traffic(dom, workload_key),
-                "peak_note": ("dense bf16 MFMA peak / 6 (fp32-equivalent flops)" if split else "dense fp32 MFMA peak")
+                "peak_note": ((f"dense fp16 MFMA peak / 3 (fp32-equivalent flops; the same kernel on the six-product bf16 split had a "
+                               f"roof of {round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}: {round(tf / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4)} of that)" if h2 else
+                               "dense bf16 MFMA peak / 6 (fp32-equivalent flops)") if split else "dense fp32 MFMA peak")
                              + f"; {round(tf / PEAK_FP32_MFMA_TFLOPS, 3)} of the 157.3 TFLOP/s fp32 MFMA peak",
                 "launches_per_step": survey[dom]["launches"] / SURVEY, "avg_launch_us": round(ds["avg_us"], 2),
                 "algorithmic_gflop_per_launch": round(ds["work"] / ds["launches"] / 1e9, 3), "sampling": sampling,
@@ -638,7 +644,9 @@ def main():
                                        for k in gemm_keys if k != dom}}
         ss = gst[seg_key]
         if seg_key == "gcl_fwd":        # algorithmic HBM bytes of the fused layer kernel (its profiler work is the product's flops)
-            seg_bytes = 8.0 * args.d * n_nodes + 24.0 * args.d * n_nodes + 12.0 * n_edges + 42.0 * args.d * args.d
+            # x read + h written + A' planes written (three bf16 / two fp16 planes of [N, 4d]) + edge records + the weight planes
+            npl = 2.0 if step_info.get("h2", 0) == 3 else 3.0
+            seg_bytes = 8.0 * args.d * n_nodes + 8.0 * npl * args.d * n_nodes + 12.0 * n_edges + 14.0 * npl * args.d * args.d
         else:
             seg_bytes = ss["work"] / ss["launches"]
         gbs = seg_bytes / (ss["avg_us"] * 1e-6) / 1e9
@@ -657,10 +665,11 @@ def main():
             roof_seg["note"] = ("aggregate built in LDS and contracted in the same kernel (csrc/gcl.hip): the [N,4d] planes "
                                 "are written for the backward but never read back in the forward; algorithmic bytes = x read "
                                 "+ h written + A' planes written + edges + weight planes")
-            roof_seg["mfma"] = {"achieved": round(ftf, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), "unit": "TFLOP/s",
-                                "frac": round(ftf / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
+            np_ = 3.0 if step_info.get("h2", 0) == 3 else 6.0
+            roof_seg["mfma"] = {"achieved": round(ftf, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / np_, 1), "unit": "TFLOP/s",
+                                "frac": round(ftf / (PEAK_BF16_MFMA_TFLOPS / np_), 4),
                                 "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
-                                "peak_note": "dense bf16 MFMA peak / 6 (fp32-equivalent flops)"}
+                                "peak_note": f"dense 16-bit MFMA peak / {int(np_)} (fp32-equivalent flops)"}
         sb = survey.get("segreduce_bwd")
         if sb:
             bgbs = sb["work"] / (sb["total_ms"] * 1e-3) / 1e9
@@ -679,6 +688,11 @@ def main():
             "value": round(value, 1), "unit": "bar-graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": ("fp32 storage and accumulation; the products run on the 16-bit matrix pipe with split operands: the three "
+                           "GCL products of d <= 256 as 3 fp16 MFMA products per fp32 product (fp16 pair format: 22-bit operands, "
+                           "power-of-two scales from the tensors' |max|), every other split product as 6 bf16 MFMA products (exact "
+                           "three-term split); full-size outputs 2e-6 .. 4e-6 from the fp64 oracle either way (the reference's own "
+                           "fp32 arithmetic: 1e-4 .. 3e-4), profiles/r05_*parity*.jsonl"),
             "config": {"workload": ("dense-graph stress, one GPU's shard (BASELINE configs[4])" if args.dense else
                                     "LMD2 2-bar, 4 tracks, 32 ts, batch=256 per GPU, d_hidden=256 (BASELINE configs[1]; "
                                     "configs[3] when n_gpus=8)" if (args.d, args.batch, args.n_bars) == (256, 256, 2) else

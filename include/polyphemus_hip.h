@@ -241,16 +241,20 @@ int pm_gcl_input_grad_bn(const PmBnBwd* norm, uint16_t* dh_planes /* 3 planes [N
  * same size — below the rounding an fp32 dot product of the same length accumulates — at half the matrix-core work, two
  * thirds of the operand bytes (csrc/common.h pm_split2h_pair; parity of the step against the fp64 oracle: tests/).
  * Planes keep the layout and strides of the three-plane format; plane 2 is unused.
- *   absmax_in : device word holding the float bits of max |x| of the kernel's fp32 input (pm_absmax, or a producer's
+ *   absmax_in : device words [PM_ABSMAX_SLOTS] holding float bits whose maximum is max |x| of the kernel's fp32 input (pm_absmax, or a producer's
  *               absmax_out: pm_bn_apply_fused_absmax, PmNormSums.absmax_out); forward: of the layer input x, input gradient: of du
  *   absmax_aux: forward only: the same for the distance table T
  *   scale_out : device float the kernel WRITES: the power of two its activation planes (A' / dh) carry; the weight gradient
  *               undoes both
  *   w_scale   : the power of two the weight planes were built with (pm_split_planes_frag_h2) */
+enum { PM_ABSMAX_SLOTS = 16 };   /* a tensor's |max| lives in this many words (the maximum of them counts): workgroups add theirs
+                                   with one atomic each, spread over the slots — thousands of atomics on ONE address cost a
+                                   launch ~30 us */
 typedef struct PmH2 {
   const uint32_t* absmax_in; const uint32_t* absmax_aux; float* scale_out; float w_scale; int32_t reserved;
 } PmH2;
-/* *out = max(*out, float bits of max |x[i]|) (atomic; the word must start at 0 or at an earlier maximum) */
+/* out[PM_ABSMAX_SLOTS]: slot = max(slot, float bits of the |max| a workgroup saw) (atomic; the words must start at 0 or at
+ * an earlier maximum) */
 int pm_absmax(const float* x, int64_t n, uint32_t* out, pm_stream_t stream);
 int pm_split_planes_frag_h2(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats, int64_t src_stride,
                             int64_t dst_stride, float w_scale, uint16_t* out, pm_stream_t stream);
@@ -309,7 +313,7 @@ typedef struct PmNormSums {
   const float* mean; const float* var; const float* gamma; const float* beta;   /* [d] */
   float eps; int32_t relu;
   double* acc3;
-  uint32_t* absmax_out;            /* NULL, or device word: atomic max of the float bits of |dx| (PmH2.absmax_in of the layer below) */
+  uint32_t* absmax_out;            /* NULL, or device words [PM_ABSMAX_SLOTS]: atomic max of the float bits of |dx| (PmH2.absmax_in of the layer below) */
 } PmNormSums;
 int pm_segreduce_bwd_norm(const float* x, const float* T, const float* dA, const float* dres, const int32_t* plan,
                           int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
@@ -462,7 +466,7 @@ int pm_bn_apply_fused(const float* x, int32_t O, int32_t C, const double* sums, 
                       const float* beta, const float* residual /* or NULL */, int relu, float* y,
                       float* mean /* [C] out */, float* var /* [C] out */, float* running_mean /* or NULL */,
                       float* running_var, float momentum, pm_stream_t stream);
-/* ... which also leaves max |y| (float bits, atomic max) in *absmax_out: PmH2.absmax_in of the GCL layer that reads y */
+/* ... which also leaves max |y| (float bits, atomic max) in absmax_out[PM_ABSMAX_SLOTS]: PmH2.absmax_in of the GCL layer that reads y */
 int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps, const float* gamma,
                              const float* beta, const float* residual, int relu, float* y, float* mean, float* var,
                              float* running_mean, float* running_var, float momentum, uint32_t* absmax_out,

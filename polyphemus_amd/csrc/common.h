@@ -197,6 +197,23 @@ __device__ static inline float pm_pow2_scale(float bound, int target) {
   return __uint_as_float((unsigned)(k + 127) << 23);
 }
 __device__ static inline float pm_clamp_f16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+// |max| of a tensor kept as PM_ABSMAX_SLOTS words of float bits (non-negative floats order like their bit patterns)
+__device__ static inline float pm_absmax_read(const unsigned* __restrict__ p) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int i = 0; i < PM_ABSMAX_SLOTS; ++i) m = p[i] > m ? p[i] : m;
+  return __uint_as_float(m);
+}
+// a workgroup's contribution: every thread calls it with its own maximum; `sm` is one LDS word the caller has zeroed in front
+// of an earlier barrier.  One global atomic per workgroup, on slot blockIdx.x % PM_ABSMAX_SLOTS.
+__device__ static inline void pm_absmax_block(unsigned* __restrict__ out, float v, unsigned* sm) {
+  v = fabsf(v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(sm, __float_as_uint(v));
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out + (blockIdx.x % PM_ABSMAX_SLOTS), *sm);
+}
 // four consecutive values -> the three planes (8 bytes each) at element index idx
 __device__ static inline void pm_store_planes4(uint16_t* __restrict__ planes, int64_t plane_stride, int64_t idx, float x0,
                                                float x1, float x2, float x3) {

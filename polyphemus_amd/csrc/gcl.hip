@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   // workgroup derives the same one: |A'| <= |x|max * max(1, |T|max / (1 - p)) lands in [2^12, 2^13)
   float asc = 1.f, oinv = 1.f;
   if constexpr (H2) {
-    asc = pm_pow2_scale(__uint_as_float(*g.mx) * fmaxf(1.f, __uint_as_float(*g.mt) * g.scale), 13);
+    asc = pm_pow2_scale(pm_absmax_read(g.mx) * fmaxf(1.f, pm_absmax_read(g.mt) * g.scale), 13);
     oinv = 1.f / (asc * g.w_scale);
     if (blockIdx.x == 0 && threadIdx.x == 0) *g.sa_out = asc;          // (the weight gradient of the backward pass undoes it)
   }
@@ -656,7 +656,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
     float gm = 0.f;
     for (int c = lane; c < D; c += 64) gm = fmaxf(gm, fabsf(sK[2 * D + c] * sK[D + c]));
     gm = pm_wave_max(gm);
-    dsc = pm_pow2_scale(gm * __uint_as_float(*bn.mdu) * 16.f, 13);
+    dsc = pm_pow2_scale(gm * pm_absmax_read(bn.mdu) * 16.f, 13);
     dinv = 1.f / (dsc * bn.w_scale);
     if (tid == 0) *bn.sdh_out = dsc;                             // (every workgroup writes the same value; k_gcl_dw undoes it)
   }

@@ -1162,6 +1162,9 @@ extern "C" int pm_split_planes_frag_h2(const float* W, int32_t rows, int32_t col
 }
 // max |x| of a tensor as float bits (PmH2.absmax_in): one atomic per wave
 __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  __shared__ unsigned sm;
+  if (threadIdx.x == 0) sm = 0u;
+  __syncthreads();
   float m = 0.f;
   const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -1169,13 +1172,12 @@ __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, int
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
-  m = pm_wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  pm_absmax_block(out, m, &sm);
 }
 extern "C" int pm_absmax(const float* x, int64_t n, uint32_t* out, pm_stream_t stream) {
   if (!x || !out || n <= 0 || ((uintptr_t)x % 16)) return PM_E_INVALID;
   int64_t grid = pm_cdiv(n / 4 + 1, 256 * 4);
-  if (grid > 1024) grid = 1024;
+  if (grid > 512) grid = 512;
   hipLaunchKernelGGL(k_absmax, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n, out);
   return pm_check_launch();
 }

@@ -469,6 +469,8 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
                                                         float momentum, unsigned* absmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
   float amax = 0.f;                                               // max |y| of this thread (absmax != NULL: PmH2.absmax_in of the next layer)
+  __shared__ unsigned s_amax;
+  if (threadIdx.x == 0) s_amax = 0u;                              // (the barrier behind the sums reduction orders it)
   float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
   // (BN_APPLY_U > 0: a thread's first pieces of x and of the residual are requested BEFORE the workgroup reduces the
   //  replicated sums — 16 fp64 loads per column — so that the reduction's latency has loads in flight under it)
@@ -528,10 +530,7 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
     if (res) rv = reinterpret_cast<const float4*>(res)[i];
     apply(i, xv, rv);
   }
-  if (absmax) {                                                   // non-negative floats order like their bit patterns
-    amax = pm_wave_max(amax);
-    if ((threadIdx.x & 63) == 0) atomicMax(absmax, __float_as_uint(amax));
-  }
+  if (absmax) pm_absmax_block(absmax, amax, &s_amax);            // (uniform branch: every thread of the workgroup calls it)
 }
 extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps,
                                         const float* gamma, const float* beta, const float* residual, int relu, float* y,

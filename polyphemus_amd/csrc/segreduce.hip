@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     if (lane == 0) atomicMax(sMax, __float_as_uint(amax));
   }
   __syncthreads();
-  if (FUSE && nn.absmax_out && threadIdx.x == 0) atomicMax(nn.absmax_out, *sMax);
+  if (FUSE && nn.absmax_out && threadIdx.x == 0) atomicMax(nn.absmax_out + (blockIdx.x % PM_ABSMAX_SLOTS), *sMax);
   for (int i = threadIdx.x; i < pr * d; i += blockDim.x) {               // private rows of all waves -> shared image
     const int r = i / d, col = i - r * d;
     float t = 0.f;

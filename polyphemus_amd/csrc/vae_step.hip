@@ -128,8 +128,9 @@ struct GcnSaved {
   double* pool;                          // per layer PM_BN_REPL x ([2][d] forward column sums, [3][d] backward sums), fp64
   uint32_t seed, uid0; float p;
   // fp16 pair format of the stack's three GCL products (PmH2): on / off, and its device words (zero region):
-  // mx[i] = |max| of layer i's input as float bits (i = 0 .. L-1), mx[L] = of the distance table; mdu[i] = of the gradient
-  // arriving at layer i's norm; sA[i] / sdh[i] = the scales the layer's A' / dh planes were written with
+  // mx[i * PM_ABSMAX_SLOTS ..] = |max| of layer i's input as float bits (i = 0 .. L-1), slot group L = of the distance table;
+  // mdu[i * PM_ABSMAX_SLOTS ..] = of the gradient arriving at layer i's norm; sA[i] / sdh[i] = the scales the layer's A' / dh
+  // planes were written with
   bool h2; uint32_t* mx; uint32_t* mdu; float* sA; float* sdh;
 };
 constexpr float kH2WScale = 16.f;        // weight planes of the fp16 pair format: W * 2^4 (glorot-range weights land around 1)
@@ -415,9 +416,10 @@ void gcn_prepare(Ctx& c, const PmGcn& g, GcnSaved& sv) {
   if (ar.base) RUN(pm_edge_table(c.P + g.nn_w, c.P + g.nn_b, d, sv.T, c.st));
   sv.pool = ar.zdbl((size_t)c.L * 5 * d * PM_BN_REPL);
   {
-    uint32_t* w = (uint32_t*)ar.z(sizeof(uint32_t) * (size_t)(4 * c.L + 4));
-    sv.mx = w; sv.mdu = w ? w + c.L + 1 : nullptr; sv.sA = w ? (float*)(w + 2 * c.L + 1) : nullptr;
-    sv.sdh = w ? (float*)(w + 3 * c.L + 1) : nullptr;
+    constexpr int SL = PM_ABSMAX_SLOTS;
+    uint32_t* w = (uint32_t*)ar.z(sizeof(uint32_t) * (size_t)((2 * c.L + 1) * SL + 2 * c.L));
+    sv.mx = w; sv.mdu = w ? w + (c.L + 1) * SL : nullptr; sv.sA = w ? (float*)(w + (2 * c.L + 1) * SL) : nullptr;
+    sv.sdh = w ? sv.sA + c.L : nullptr;
   }
   sv.h2 = false;
   if (c.planes) {                                         // the GCL weights of this stack, split once per step
@@ -452,7 +454,7 @@ void gcn_prepare(Ctx& c, const PmGcn& g, GcnSaved& sv) {
             RUN(pm_split_planes_frag(c.P + g.weight[1], 7 * d, d, kind, c.L - 1, lstride, sv.wf_stride,
                                        dst + sv.wf_stride, c.st));
         }
-        if (sv.h2) RUN(pm_absmax(sv.T, (int64_t)PM_N_DIST * d, sv.mx + c.L, c.st));
+        if (sv.h2) RUN(pm_absmax(sv.T, (int64_t)PM_N_DIST * d, sv.mx + c.L * PM_ABSMAX_SLOTS, c.st));
       }
     }
   }
@@ -490,9 +492,10 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     const bool from_planes = gcl_kernels && dense && d == 512;
     const bool x_tracked = sv.h2 && i > 0 && !(c.pdrop > 0.f);   // (the norm apply of layer i-1 left |x|max in mx[i])
     if (fused && sv.h2) {
-      if (!x_tracked) RUN(pm_absmax(sv.xin[i], (int64_t)N * d, sv.mx + i, c.st));
+      if (!x_tracked) RUN(pm_absmax(sv.xin[i], (int64_t)N * d, sv.mx + i * PM_ABSMAX_SLOTS, c.st));
       PmH2 h2;
-      h2.absmax_in = sv.mx + i; h2.absmax_aux = sv.mx + c.L; h2.scale_out = sv.sA + i; h2.w_scale = kH2WScale; h2.reserved = 0;
+      h2.absmax_in = sv.mx + i * PM_ABSMAX_SLOTS; h2.absmax_aux = sv.mx + c.L * PM_ABSMAX_SLOTS; h2.scale_out = sv.sA + i;
+      h2.w_scale = kH2WScale; h2.reserved = 0;
       RUN(pm_gcl_forward_fused_h2(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                     sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
                                     sv.h[i], sums, sv.Ap[i], aps, &h2, c.st));
@@ -532,7 +535,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     if (c.bn)
       RUN(pm_bn_apply_fused_absmax(sv.h[i], N, d, sums, 1e-5f, c.P + bn.w, c.P + bn.b, sv.x[i], 1, sv.x[i + 1], sv.mean[i],
                                      sv.var[i], c.Bf + bn.rm, c.Bf + bn.rv, 0.1f,
-                                     (sv.h2 && i + 1 < c.L && !(c.pdrop > 0.f)) ? sv.mx + i + 1 : nullptr, c.st));
+                                     (sv.h2 && i + 1 < c.L && !(c.pdrop > 0.f)) ? sv.mx + (i + 1) * PM_ABSMAX_SLOTS : nullptr, c.st));
     else                                                  // batch_norm = False: x' = x + relu(h)
       RUN(pm_relu_residual_fwd(sv.h[i], sv.x[i], (int64_t)N * d, sv.x[i + 1], c.st));
   }
@@ -634,9 +637,9 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         nb.add_residual = res_in_dagg ? 1 : 0; nb.reserved = 0;
         if (sv.h2) {
           // |du|max: the segment-reduce backward of the layer above left it (PmNormSums.absmax_out); the top layer's comes from elsewhere
-          if (!du_tracked) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i, c.st));
+          if (!du_tracked) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i * PM_ABSMAX_SLOTS, c.st));
           PmH2 h2;
-          h2.absmax_in = sv.mdu + i; h2.absmax_aux = nullptr; h2.scale_out = sv.sdh + i; h2.w_scale = kH2WScale; h2.reserved = 0;
+          h2.absmax_in = sv.mdu + i * PM_ABSMAX_SLOTS; h2.absmax_aux = nullptr; h2.scale_out = sv.sdh + i; h2.w_scale = kH2WScale; h2.reserved = 0;
           RUN(pm_gcl_input_grad_bn_h2(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                         cfg().no_classes ? 0 : 1, dA, &h2, c.st));
         } else
@@ -661,7 +664,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
       nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
-      nn.absmax_out = sv.h2 ? sv.mdu + (i - 1) : nullptr;
+      nn.absmax_out = sv.h2 ? sv.mdu + (i - 1) * PM_ABSMAX_SLOTS : nullptr;
       RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
                                   c.compact, out, dT, &nn, c.st));
     } else {

@@ -192,18 +192,32 @@ def reference_loop_workload(name, active_slots_only, batch_size=256, d=256, n_ba
     opt = torch.optim.Adam(vae.parameters(), lr=5e-6, betas=(0.9, 0.98), eps=1e-9)     # train.py:181, training.json:11-18
     scaler = torch.amp.GradScaler("cuda")                                             # training.py:123
     g = reference_format(synthetic_batch(batch_size, n_bars, p=0.25, seed=seed).to(dev))
+    from polyphemus_amd.native import prepare_inputs
     parts = None
+    phases = ("inputs: one-hot -> ids (+ one host read)", "forward: vae(graph)", "loss: _losses in torch (7 .item())",
+              "backward: torch loss backward + native backward", "optimizer: GradScaler unscale + torch Adam + zero_grad")
+    acc = [0.0] * len(phases)
 
-    def step():
+    def step(timed=False):
         nonlocal parts
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(phases) + 1)] if timed else None
+        mark = (lambda i: ev[i].record()) if timed else (lambda i: None)
         g.__dict__.pop("_pm_inputs", None)
+        mark(0)
+        prepare_inputs(g)                                                             # (vae(g) would do it: split out to time it)
+        mark(1)
         with torch.autocast("cuda", dtype=torch.float16):                             # training.py:137
             (s_logits, c_logits), mu, log_var = vae(g)
+            mark(2)
             tot, parts = reference_losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, log_var)
+        mark(3)
         scaler.scale(tot).backward()                                                  # training.py:153
+        mark(4)
         scaler.step(opt)
         scaler.update()
         opt.zero_grad()
+        mark(5)
+        return ev
     for _ in range(warmup):
         step()
     first = dict(parts)
@@ -213,11 +227,19 @@ def reference_loop_workload(name, active_slots_only, batch_size=256, d=256, n_ba
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    for _ in range(3):                                                                # GPU time per phase (separate, event-timed steps)
+        ev = step(timed=True)
+        torch.cuda.synchronize()
+        for i in range(len(phases)):
+            acc[i] += ev[i].elapsed_time(ev[i + 1]) / 3.0
     G = g.s_tensor.shape[0]
     info = vae._native_step().info()
     out = {"workload": name, "bar-graphs/s": round(G / dt, 1), "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
            "batch": batch_size, "d": d, "n_bars": n_bars, "batch_seed": seed, "decoder_head_slots": info["n_slots"],
            "loss_after_warmup": round(first["tot"], 5), "loss_last": round(parts["tot"], 5),
+           "gpu_ms_by_phase": {k: round(v, 3) for k, v in zip(phases, acc)},
+           "whose": "forward and backward run the C++ step behind model(graph) / autograd (plus torch's backward of the loss); inputs "
+                    "conversion is this package's; loss and optimizer are the reference loop's own torch code",
            "kernel_path": {k: v for k, v in info.items() if k not in ("N", "E", "G", "B")}}
     del vae, opt, g
     torch.cuda.empty_cache()
@@ -385,6 +407,60 @@ def launch_ranks(argv, n):
     return rc
 
 
+def preflight(backend):
+    """Multi-GPU runs: fail FAST and LEGIBLY when the communicator cannot form, instead of hanging in the first collective.
+    Before the process group exists: the facts RCCL depends on (one visible device per local rank — counting devices does not
+    initialise the GPU on this image —, dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment BEFORE the runtime
+    starts, the rendezvous address).  Returns the facts; `preflight_collective` then proves the communicator with one small
+    all-reduce under a watchdog and reports `ranks_seen`."""
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    facts = {"rank": rank, "world_size": world, "local_rank": local, "local_world_size": lws, "backend": backend,
+             "device_count": torch.cuda.device_count(), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+             "MASTER_ADDR": os.environ.get("MASTER_ADDR"), "MASTER_PORT": os.environ.get("MASTER_PORT"),
+             "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
+    problems = []
+    if backend == "nccl":
+        if facts["device_count"] < lws:
+            problems.append(f"{lws} ranks on this node but {facts['device_count']} visible GPU(s): RCCL refuses two ranks on one device")
+        if facts["HSA_ENABLE_IPC_MODE_LEGACY"] != "0":
+            problems.append("HSA_ENABLE_IPC_MODE_LEGACY is not 0: this host supports dmabuf IPC only, RCCL would fail with "
+                            "`hipIpcGetMemHandle: invalid argument` (export it before the ranks start)")
+    if world > 1 and not facts["MASTER_ADDR"]:
+        problems.append("MASTER_ADDR is not set (launch with torch.distributed.run --master-addr 127.0.0.1)")
+    if problems:
+        print(f"[bench preflight] rank {rank}: the {world}-rank communicator cannot form: " + "; ".join(problems) +
+              f" | facts: {json.dumps(facts)}", file=sys.stderr, flush=True)
+        raise SystemExit(4)
+    return facts
+
+
+def preflight_collective(facts, dev, timeout_s=90.0):
+    """One 4-byte all-reduce under a watchdog: every rank must arrive; prints `ranks_seen` (rank 0) or the reason and exits."""
+    import threading
+    import torch.distributed as dist
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout_s):
+            print(f"[bench preflight] rank {facts['rank']}: the first all-reduce did not complete within {timeout_s:.0f} s — a rank is "
+                  f"missing or RCCL could not connect the ranks | facts: {json.dumps(facts)}", file=sys.stderr, flush=True)
+            os._exit(5)
+    threading.Thread(target=watchdog, daemon=True).start()
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    seen = int(one.item())
+    done.set()
+    if seen != facts["world_size"]:
+        print(f"[bench preflight] rank {facts['rank']}: ranks_seen {seen} != WORLD_SIZE {facts['world_size']} | facts: {json.dumps(facts)}",
+              file=sys.stderr, flush=True)
+        raise SystemExit(6)
+    if facts["rank"] == 0:
+        print(f"[bench preflight] ranks_seen={seen} backend={dist.get_backend()} devices={facts['device_count']} "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={facts['HSA_ENABLE_IPC_MODE_LEGACY']}", file=sys.stderr, flush=True)
+    return seen
+
+
 def stub_main(args):
     """`--stub-step` (tests only, no GPU, no HIP): the launcher, rendezvous, barrier / max-over-ranks timing and JSON
     contract of the real bench with the training step replaced by a bucketed gloo all-reduce of a small CPU buffer."""
@@ -459,13 +535,17 @@ def main():
     from polyphemus_amd.synthetic import synthetic_batch
     from polyphemus_amd.trainer import HipTrainer
 
-    rank, local, world = parallel.init_from_env(os.environ.get("PM_DIST_BACKEND", "nccl"))
+    backend = os.environ.get("PM_DIST_BACKEND", "nccl")
+    facts = preflight(backend) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
+    rank, local, world = parallel.init_from_env(backend)
     if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local % torch.cuda.device_count())     # (PM_DIST_BACKEND=gloo: ranks may share a GPU)
     torch.cuda.set_device(dev)
+    if facts is not None:
+        preflight_collective(facts, dev)
     cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=args.layers, d=args.d, n_bars=args.n_bars, resolution=8)
 
     torch.manual_seed(0)

@@ -53,7 +53,7 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra).
  *   7: round 5 (the fp16 pair operand format: PmH2, pm_absmax, pm_split_planes_frag_h2, pm_gcl_forward_fused_h2,
  *   pm_gcl_input_grad_bn_h2, pm_gcl_weight_grad_fused_h2; PmNormSums.absmax_out; pm_bn_apply_fused_absmax; pm_vae_step_set_output_grads: the drop-in module's
- *   `model(graph)` + autograd runs the C++ step). */
+ *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads). */
 #define PM_ABI_VERSION 7
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -134,6 +134,12 @@ int pm_edge_attrs_to_ids(const float* edge_attrs /* [E,33] */, int32_t E, int32_
                          int32_t* edge_dist, pm_stream_t stream);
 int pm_tokens_from_onehot(const float* c_tensor /* [N,16,230] */, int32_t N, int32_t* tokens /* [N,16,2] */,
                           pm_stream_t stream);
+/* The host-known facts of a batch that does not carry them (a foreign PyG batch: PmBatch.n_slots and flags bit 0):
+ * out[0] = last token slot 1..15 holding a non-PAD token in some node (0: none), out[1] != 0: some node receives track
+ * edges of more than one track relation (the compact GCL does not apply), out[2] != 0: a token id, edge type or node id is
+ * out of range.  `seen` [N] and `out` [3] are caller-zeroed device ints; the caller reads `out` (its one host sync). */
+int pm_batch_flags(const int32_t* tokens /* [N,16,2] */, const int64_t* edge_index /* [2,E] */, const int32_t* edge_type,
+                   int32_t N, int32_t E, int32_t* seen, int32_t* out, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ device-side graph construction
  * `graph_from_tensor` + the PyG collate of the reference (data.py:24-204) for a whole batch of bars on
@@ -674,6 +680,11 @@ int64_t pm_unembed_dh_scratch_bytes(int32_t d);
 int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum /* [131,d/2] */, const float* w_pitch_nd,
                   const float* w_dur /* [99,d/2] */, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
                   int32_t n_slots, float* dH, uint16_t* w_planes, int32_t prepare, pm_stream_t stream);
+/* Bias gradients (+=) of the three un-embeddings (model.py:561-567) from a given d(loss)/d(logits) [N, S, 230]: column sums
+ * of the pitch columns over the drum nodes' / the other nodes' rows and of the duration columns over all rows. */
+int pm_unembed_bias_grads(const float* d_logits, const uint8_t* is_drum /* [N] */, int32_t N, int32_t S,
+                          float* db_pitch_drums /* [131] */, float* db_pitch_non_drums /* [131] */, float* db_dur /* [99] */,
+                          pm_stream_t stream);
 int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu /* or NULL, += */,
            float* dlog_var, double* out, pm_stream_t stream);
 int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits /* or NULL */,
@@ -837,6 +848,23 @@ int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
  * log_var [B,d].  Valid until the next pm_vae_step_forward on this state. */
 int pm_vae_step_outputs(const void* state, float* s_logits, float* c_logits, float* mu, float* log_var,
                         pm_stream_t stream);
+/* Introspection for parity tools (host only, no GPU work): where the last forward keeps an activation inside the workspace
+ * the caller passed to pm_vae_step_forward — the tensors the backward takes its ReLU decisions from.  stack: 0 = the encoder's
+ * GCN, 1 = the decoder's; *byte_offset is relative to the workspace pointer, *numel in floats. */
+enum { PM_SAVED_GCN_H = 0,      /* [N,d] pre-norm output of GCL layer `layer` */
+       PM_SAVED_GCN_X,          /* [N,d] layer input x_layer (layer = n_layers: the stack's output) */
+       PM_SAVED_GCN_XIN,        /* [N,d] the same behind the cfg.dropout layer (= X when the model has no dropout) */
+       PM_SAVED_GCN_MEAN, PM_SAVED_GCN_VAR,   /* [d] batch statistics of the layer's norm */
+       PM_SAVED_GCN_T,          /* [32,d] distance table of the stack's edge network */
+       PM_SAVED_X0,             /* [N,d] chord encoder output (after its ReLU) */
+       PM_SAVED_MERGE_PRE, PM_SAVED_MERGE_MEAN, PM_SAVED_MERGE_VAR,   /* encoder.bn_linear_merge: input [B,d], statistics [d] */
+       PM_SAVED_DEC_PRE, PM_SAVED_DEC_MEAN, PM_SAVED_DEC_VAR,         /* decoder.batch_norm: input [B,2d], statistics [2d] */
+       PM_SAVED_ENC_CNN_LIN1 }; /* [G,d] CNNEncoder.lin[1] output (after its ReLU) */
+int pm_vae_step_saved(const void* state, int32_t what, int32_t stack, int32_t layer, int64_t* byte_offset, int64_t* numel);
+/* out[r, c] = 1 where the backward of a norm followed by a ReLU lets the gradient through: (x - mean) * rsqrt(var + eps) *
+ * gamma + beta > 0, evaluated by the expression the backward kernels use (csrc/common.h pm_bn_bwd_elem). */
+int pm_bn_relu_decisions(const float* x /* [rows,C] */, const float* mean, const float* var, const float* gamma, const float* beta,
+                         float eps, int64_t rows, int32_t C, uint8_t* out /* [rows,C] */, pm_stream_t stream);
 /* The drop-in module's path — `model(graph)` called by the unchanged training.py:137-166, which computes `_losses` itself
  * and calls `backward()`: between pm_vae_step_forward (PmBatch.flags bit 2: keep the logits) / pm_vae_step_outputs and the
  * four backward calls the caller hands in the gradients of the four outputs (any may be NULL = zero; d_c_logits covers the

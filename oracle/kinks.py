@@ -38,11 +38,15 @@ class _FProxy:
 
 class ReluProbe:
     """Context manager: records the pre-activations of every ReLU the oracle executes (call order = site index) and
-    inverts the decisions listed in `flips` {site: LongTensor of flat element indices}."""
+    inverts the decisions listed in `flips` {site: LongTensor of flat element indices}; `forced` {site: bool tensor of the
+    site's shape} replaces a site's decisions altogether (relu(x) becomes x * mask: the decisions another implementation took)."""
 
-    def __init__(self, flips: Optional[Dict[int, torch.Tensor]] = None, keep: bool = True):
+    def __init__(self, flips: Optional[Dict[int, torch.Tensor]] = None, keep: bool = True,
+                 forced: Optional[Dict[int, torch.Tensor]] = None):
         self.flips = flips or {}
+        self.forced = forced or {}
         self.keep = keep
+        self.disagree: Dict[int, int] = {}     # per forced site: decisions that differ from the oracle's own
         self.pre: List[torch.Tensor] = []
         self.count = 0
 
@@ -51,6 +55,11 @@ class ReluProbe:
         self.count += 1
         if self.keep:
             self.pre.append(x.detach().clone())
+        if i in self.forced:
+            mask = self.forced[i]
+            assert mask.shape == x.shape, (i, tuple(mask.shape), tuple(x.shape))
+            self.disagree[i] = int((mask != (x.detach() > 0)).sum())
+            return x * mask.to(x.dtype)
         if i not in self.flips:
             return _F.relu(x)
         mask = x.detach() > 0
@@ -78,9 +87,24 @@ def fp64_inputs(cpu_batch, sd, names):
     return b64, P, names
 
 
-def _step(cpu_batch, sd, names, cfg, eps, msg_dropout, keep_mask, flips=None, keep=False):
+def relu_sites(cfg) -> List[str]:
+    """Names of the oracle's ReLU sites in call order (vae_cpu.vae_forward with batch_norm = True): the index space of
+    `ReluProbe.flips / .forced`."""
+    assert cfg["batch_norm"]
+    L = cfg["gnn_n_layers"]
+
+    def gcn(tag):
+        out = []
+        for i in range(L):
+            out += [f"{tag}.{i}.msg.{r}" for r in range(6)] + [f"{tag}.{i}.norm"]
+        return out
+    return (["enc_cnn.bn1", "enc_cnn.bn5", "enc_cnn.lin1", "enc_chord.drums", "enc_chord.non_drums"] + gcn("enc_gcn") +
+            ["enc_merge", "dec_bn", "dec_cnn.lin1", "dec_cnn.lin4", "dec_cnn.bn2"] + gcn("dec_gcn"))
+
+
+def _step(cpu_batch, sd, names, cfg, eps, msg_dropout, keep_mask, flips=None, keep=False, forced=None):
     b64, P, names = fp64_inputs(cpu_batch, sd, names)
-    with ReluProbe(flips, keep) as probe:
+    with ReluProbe(flips, keep, forced) as probe:
         (s_logits, c_logits), mu, log_var = vae_cpu.vae_forward(b64, P, cfg, True, eps.double(), msg_dropout, keep_mask)
         tot, parts = vae_cpu.losses(b64.s_tensor, s_logits, b64.c_tensor, c_logits, mu, log_var)
     tot.backward()

@@ -27,6 +27,7 @@ _SIGS = {
     "pm_plan_build": "pppppppiiiiips",
     "pm_edge_attrs_to_ids": "pipps",
     "pm_tokens_from_onehot": "pips",
+    "pm_batch_flags": "pppiipps",
     "pm_edge_table": "ppips",
     "pm_edge_table_bwd": "pipps",
     "pm_graph_count": "pippppps",
@@ -106,6 +107,7 @@ _SIGS = {
     "pm_unembed_dh_scratch_bytes": "i",
     "pm_unembed_scratch_bytes": "i",
     "pm_kld": "ppiifppps",
+    "pm_unembed_bias_grads": "ppiippps",
     "pm_bce_logits": "pplfpps",
     "pm_content_accuracy": "pppips",
     "pm_structure_metrics": "pplps",
@@ -122,6 +124,8 @@ _SIGS = {
     "pm_vae_step_info": "pp",
     "pm_vae_step_outputs": "ppppps".replace(" ", ""),
     "pm_vae_step_set_output_grads": "ppppps",
+    "pm_vae_step_saved": "piiipp",
+    "pm_bn_relu_decisions": "pppppflips",
     "pm_vae_step_backward_decoder": "ps",
     "pm_vae_step_backward_encoder": "ps",
     "pm_vae_step_backward_encoder_tail": "ps",

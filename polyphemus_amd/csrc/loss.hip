@@ -122,6 +122,73 @@ extern "C" int pm_content_ce_scaled(const float* c_logits, const int32_t* tokens
 }
 
 // kld = mean_b( -0.5 * sum_d (1 + lv - mu^2 - exp(lv)) )   (training.py:329-331)
+// Bias gradients of the three un-embeddings from an EXTERNAL d(loss)/d(logits) [N, S, 230] (the drop-in module's autograd
+// path, pm_vae_step_set_output_grads): column sums of the 131 pitch columns per node group (drums / the others) and of the 99
+// duration columns, one pass over the rows, eight rows of a wave in flight; per workgroup one LDS merge and 361 atomics.
+// (The step's own loss leaves these sums in the fused un-embedding + cross-entropy kernel of the forward.)
+__global__ void __launch_bounds__(256) k_unembed_bias_grads(const float* __restrict__ dl, const uint8_t* __restrict__ is_drum,
+                                                            int64_t R, int S, float* __restrict__ db_pd, float* __restrict__ db_pnd,
+                                                            float* __restrict__ db_dur, unsigned* gate) {
+  __shared__ float sh[3][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 3 * 256; i += 256) (&sh[0][0])[i] = 0.f;
+  __syncthreads();
+  float a[2][4];                                              // [group][column lane + 64 k]: columns 0..229 (pitch | duration)
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[g][k] = 0.f;
+  constexpr int U = 8;
+  const int64_t nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+  for (int64_t r0 = w0 * U; r0 < R; r0 += nw * U) {
+    float v[U][4];
+    int grp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u;
+      const bool ok = r < R;
+      grp[u] = ok ? (is_drum[r / S] ? 0 : 1) : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        v[u][k] = (ok && c < PM_N_TOK) ? dl[r * PM_N_TOK + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // duration columns (c >= 131) do not depend on the group: they all go to slot 1
+        const int c = lane + 64 * k;
+        if (c >= PM_N_PITCH || grp[u]) a[1][k] += v[u][k]; else a[0][k] += v[u][k];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    if (c < PM_N_PITCH) { atomicAdd(&sh[0][c], a[0][k]); atomicAdd(&sh[1][c], a[1][k]); }
+    else if (c < PM_N_TOK) atomicAdd(&sh[2][c - PM_N_PITCH], a[0][k] + a[1][k]);
+  }
+  __syncthreads();
+  pm_turn_enter_block(gate);
+  for (int i = threadIdx.x; i < 2 * PM_N_PITCH + PM_N_DUR; i += 256) {
+    if (i < PM_N_PITCH) atomicAdd(db_pd + i, sh[0][i]);
+    else if (i < 2 * PM_N_PITCH) atomicAdd(db_pnd + i - PM_N_PITCH, sh[1][i - PM_N_PITCH]);
+    else atomicAdd(db_dur + i - 2 * PM_N_PITCH, sh[2][i - 2 * PM_N_PITCH]);
+  }
+  pm_turn_leave_block(gate);
+}
+extern "C" int pm_unembed_bias_grads(const float* d_logits, const uint8_t* is_drum, int32_t N, int32_t S, float* db_pitch_drums,
+                                     float* db_pitch_non_drums, float* db_dur, pm_stream_t stream) {
+  if (!d_logits || !is_drum || !db_pitch_drums || !db_pitch_non_drums || !db_dur || N <= 0 || S < 1 || S > PM_N_SLOTS) return PM_E_INVALID;
+  const int64_t R = (int64_t)N * S;
+  int grid = (int)pm_cdiv(R, 4 * 8 * 8);
+  grid = grid > 512 ? 512 : (grid < 1 ? 1 : grid);
+  hipLaunchKernelGGL(k_unembed_bias_grads, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_logits, is_drum, R, S, db_pitch_drums,
+                     db_pitch_non_drums, db_dur, pm_det_gate((hipStream_t)stream));
+  return pm_check_launch();
+}
+
 __global__ void __launch_bounds__(256) k_kld(const float* __restrict__ mu, const float* __restrict__ lv, int B, int d,
                                              float beta, float* dmu, float* dlv, double* out, unsigned* gate) {
   __shared__ double sh[4];

@@ -700,6 +700,26 @@ __global__ void k_relu_bwd(const float* __restrict__ dy, const float* __restrict
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+// the ReLU decision of a norm's backward, by the backward's own expression (pm_bn_bwd_elem): parity tools impose it on the oracle
+__global__ void __launch_bounds__(256) k_bn_relu_decisions(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int64_t n, int C,
+                                                           uint8_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    // dy = 1, m0 = m1 = 0: the element's value is gamma * rstd where the gradient passes and 0 where the ReLU blocks it
+    const float rstd = rsqrtf(var[c] + eps);
+    const float xh = (x[i] - mean[c]) * rstd;
+    out[i] = (xh * gamma[c] + beta[c] > 0.f) ? 1 : 0;
+  }
+}
+extern "C" int pm_bn_relu_decisions(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                                    float eps, int64_t rows, int32_t C, uint8_t* out, pm_stream_t stream) {
+  if (!x || !mean || !var || !gamma || !beta || !out || rows <= 0 || C <= 0) return PM_E_INVALID;
+  hipLaunchKernelGGL(k_bn_relu_decisions, dim3(ew_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
+                     eps, rows * (int64_t)C, C, out);
+  return pm_check_launch();
+}
 __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = a[i] + b[i];

@@ -576,6 +576,44 @@ __global__ void __launch_bounds__(256) k_tokens_from_onehot(const float* __restr
   }
   if (lane == 0) { tok[row * 2] = bi; tok[row * 2 + 1] = di; }
 }
+// The host-known facts of a batch that did not come from this package's collate (a foreign PyG batch): active token slots,
+// "every node receives track edges of at most one relation" (the compact-GCL premise), ids in range — graphs.batch_flags in
+// two launches instead of ~15 torch ops.  out = {last live slot (1..15, 0: none), #nodes with several track relations, bad ids};
+// `seen` [N] and `out` [3] are caller-zeroed.
+__global__ void __launch_bounds__(256) k_batch_flags_scan(const int* __restrict__ tok, const int64_t* __restrict__ ei,
+                                                          const int* __restrict__ et, int N, int E, int* __restrict__ seen,
+                                                          int* __restrict__ out) {
+  int last = 0, bad = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < (int64_t)N * 16; i += stride) {                    // (node, slot) pairs
+    const int p = tok[i * 2], q = tok[i * 2 + 1], s = (int)(i & 15);
+    if (p < 0 || p >= PM_N_PITCH || q < 0 || q >= PM_N_DUR) bad = 1;
+    if (s >= 1 && (p != PM_N_PITCH - 1 || q != PM_N_DUR - 1) && s > last) last = s;   // PAD = the last id of either vocabulary
+  }
+  for (int64_t e = i0; e < E; e += stride) {
+    const int t = et[e];
+    const int64_t u = ei[e], v = ei[(int64_t)E + e];
+    if (t < 0 || t >= PM_N_REL || u < 0 || u >= N || v < 0 || v >= N) { bad = 1; continue; }
+    if (t < 4) atomicOr(seen + v, 1 << t);
+  }
+  for (int o = 32; o > 0; o >>= 1) { last = max(last, __shfl_xor(last, o, 64)); bad |= __shfl_xor(bad, o, 64); }
+  if ((threadIdx.x & 63) == 0) { if (last) atomicMax(out, last); if (bad) atomicOr(out + 2, 1); }
+}
+__global__ void __launch_bounds__(256) k_batch_flags_nodes(const int* __restrict__ seen, int N, int* __restrict__ out) {
+  int multi = 0;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+    multi |= __popc(seen[n]) > 1;
+  for (int o = 32; o > 0; o >>= 1) multi |= __shfl_xor(multi, o, 64);
+  if ((threadIdx.x & 63) == 0 && multi) atomicOr(out + 1, 1);
+}
+extern "C" int pm_batch_flags(const int32_t* tokens, const int64_t* edge_index, const int32_t* edge_type, int32_t N, int32_t E,
+                              int32_t* seen, int32_t* out, pm_stream_t stream) {
+  if (!tokens || !edge_index || !edge_type || !seen || !out || N <= 0 || E <= 0) return PM_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_batch_flags_scan, dim3(512), dim3(256), 0, st, tokens, edge_index, edge_type, N, E, seen, out);
+  hipLaunchKernelGGL(k_batch_flags_nodes, dim3(128), dim3(256), 0, st, seen, N, out);
+  return pm_check_launch();
+}
 extern "C" int pm_tokens_from_onehot(const float* c_tensor, int32_t N, int32_t* tokens, pm_stream_t stream) {
   if (!c_tensor || !tokens || N <= 0) return PM_E_INVALID;
   const int64_t rows = (int64_t)N * 16;

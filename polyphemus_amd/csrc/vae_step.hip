@@ -1031,10 +1031,7 @@ void backward_decoder(Ctx& c) {
     if (s.ext_loss) {
       // the caller's loss: the bias gradients of the three un-embeddings are the column sums of ITS d(logits) (with the
       // step's own loss the fused un-embedding + cross-entropy kernel of the forward has already left them)
-      RUN(pm_colsum_acc(s.dc_logits + PM_N_PITCH, (int)R, PM_N_DUR, PM_N_TOK, c.G + Y.dec_dur.b, c.st));
-      for (int g = 0; g < 2; ++g)
-        RUN(pm_colsum_rows_acc(s.dc_logits, PM_N_PITCH, PM_N_TOK, pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0), 1,
-                                 pv.group_cnt + 2 + g, (int)R, c.G + pit[g].b, c.st));
+      RUN(pm_unembed_bias_grads(s.dc_logits, s.bt.is_drum, N, S, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, c.st));
     }
     if (chord_tn) {
       if (rows_tn_pays(d))                                          // dW[:S*d] += dH^T x_L, bias gradient (linear.hip)
@@ -1415,6 +1412,40 @@ extern "C" int pm_vae_step_set_output_grads(void* state, const float* d_s_logits
   s->fix_structure = d_s_logits ? 1 : 0;
   s->ext_loss = 1;
   return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
+}
+
+// Where the last forward keeps an activation inside the caller's workspace (host only): parity tools read the tensors the
+// backward takes its ReLU decisions from (tests/test_fullsize_gpu.py imposes them on the fp64 oracle).  `what`: PM_SAVED_*;
+// stack 0 = encoder / 1 = decoder GCN; *byte_offset is relative to the workspace pointer given to pm_vae_step_forward.
+extern "C" int pm_vae_step_saved(const void* state, int32_t what, int32_t stack, int32_t layer, int64_t* byte_offset, int64_t* numel) {
+  const StepState* s = (const StepState*)state;
+  if (!s || s->magic != kMagic || !byte_offset || !numel || !s->ar.base) return PM_E_INVALID;
+  const GcnSaved& g = stack ? s->dg : s->eg;
+  const int64_t N = s->bt.N, B = s->bt.B, G = s->bt.G, d = s->lay.d, L = s->lay.n_layers;
+  const void* p = nullptr;
+  int64_t n = 0;
+  const bool lay_ok = layer >= 0 && layer < L;
+  switch (what) {
+    case PM_SAVED_GCN_H: if (lay_ok) { p = g.h[layer]; n = N * d; } break;
+    case PM_SAVED_GCN_X: if (layer >= 0 && layer <= L) { p = g.x[layer]; n = N * d; } break;
+    case PM_SAVED_GCN_XIN: if (lay_ok) { p = g.xin[layer]; n = N * d; } break;
+    case PM_SAVED_GCN_MEAN: if (lay_ok) { p = g.mean[layer]; n = d; } break;
+    case PM_SAVED_GCN_VAR: if (lay_ok) { p = g.var[layer]; n = d; } break;
+    case PM_SAVED_GCN_T: p = g.T; n = (int64_t)PM_N_DIST * d; break;
+    case PM_SAVED_X0: p = s->x0; n = N * d; break;
+    case PM_SAVED_MERGE_PRE: p = s->m; n = B * d; break;
+    case PM_SAVED_MERGE_MEAN: p = s->mm; n = d; break;
+    case PM_SAVED_MERGE_VAR: p = s->mv; n = d; break;
+    case PM_SAVED_DEC_PRE: p = s->zd; n = B * 2 * d; break;
+    case PM_SAVED_DEC_MEAN: p = s->dm; n = 2 * d; break;
+    case PM_SAVED_DEC_VAR: p = s->dv; n = 2 * d; break;
+    case PM_SAVED_ENC_CNN_LIN1: p = s->h1; n = G * d; break;
+    default: break;
+  }
+  if (!p) return PM_E_INVALID;
+  *byte_offset = (int64_t)((const char*)p - s->ar.base);
+  *numel = n;
+  return PM_OK;
 }
 
 extern "C" int pm_vae_step_backward_decoder(void* state, pm_stream_t stream) {

@@ -136,6 +136,17 @@ def batch_flags(tokens: torch.Tensor, edge_index: torch.Tensor, edge_type: torch
     host-known facts that select the measured path of the native step — active token slots (`PmBatch.n_slots`) and
     "every node receives track edges of at most one relation" (`PmBatch.flags` bit 0, compact GCL).  Same definitions as
     `collate_samples`; on device tensors this costs ONE host read per batch object (callers cache the result)."""
+    if tokens.is_cuda and tokens.dtype == torch.int32 and tokens.is_contiguous() and edge_index.dtype == torch.int64 \
+            and edge_index.is_contiguous() and edge_type.dtype == torch.int32 and edge_type.is_contiguous() and edge_type.numel() > 0:
+        # on the device: two launches and the one host read (csrc/plan.hip pm_batch_flags); same definitions as below
+        from ._lib import call, ptr, stream
+        scratch = torch.zeros(int(num_nodes) + 3, dtype=torch.int32, device=tokens.device)
+        call("pm_batch_flags", ptr(tokens), ptr(edge_index), ptr(edge_type), int(num_nodes), int(edge_type.numel()),
+             ptr(scratch), ptr(scratch[int(num_nodes):]), stream())
+        n_slots, multi, bad = scratch[int(num_nodes):].tolist()
+        if bad:
+            raise ValueError("batch holds token ids, edge types or node ids outside their ranges")
+        return max(int(n_slots), 1), not bool(multi)
     tok = tokens.long()
     live = (tok[:, 1:, 0] != C.PITCH_PAD) | (tok[:, 1:, 1] != C.DUR_PAD)
     slot_live = live.any(dim=0)

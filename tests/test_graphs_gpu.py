@@ -70,3 +70,30 @@ def test_token_grid_gather():
     b = device_batch_from_structure(torch.from_numpy(s).to(DEV), 2, token_grid=grid)
     g, k, t = np.nonzero(s)                                            # (bar, track, timestep) order == node order
     assert torch.equal(b.tokens.cpu(), grid.cpu()[g, k, t].to(torch.int32))
+
+
+def test_batch_flags_on_the_device_equal_the_torch_definition():
+    """graphs.batch_flags — the active token slots, the compact-GCL premise, the id range check of a foreign batch — by
+    csrc/plan.hip pm_batch_flags (two launches, one host read) against the torch op sequence on the CPU copy."""
+    from polyphemus_amd.graphs import batch_flags
+    from polyphemus_amd.synthetic import synthetic_batch
+    for kw in (dict(seed=3), dict(seed=4, max_notes=9), dict(seed=5, max_notes=14)):
+        b = synthetic_batch(6, 2, p=0.3, **kw)
+        want = batch_flags(b.tokens, b.edge_index, b.edge_type, b.num_nodes)
+        g = b.to(DEV)
+        assert batch_flags(g.tokens, g.edge_index, g.edge_type, g.num_nodes) == want == (b.n_slots, b.track_unique)
+    # a node that receives edges of two track relations: the compact GCL must be refused
+    b = synthetic_batch(4, 2, p=0.3, seed=6)
+    et = b.edge_type.clone()
+    trk = torch.nonzero(et < 4).reshape(-1)
+    dst = b.edge_index[1]
+    victim = int(dst[trk[0]])
+    other = [int(i) for i in trk if int(dst[i]) == victim]
+    et[other[0]] = (int(et[other[0]]) + 1) % 4 if len(other) > 1 else et[other[0]]
+    if len(other) > 1:
+        assert batch_flags(b.tokens, b.edge_index, et, b.num_nodes)[1] is False
+        assert batch_flags(b.tokens.to(DEV), b.edge_index.to(DEV), et.to(DEV), b.num_nodes)[1] is False
+    bad = b.tokens.clone()
+    bad[0, 3, 0] = 131
+    with pytest.raises(ValueError):
+        batch_flags(bad.to(DEV), b.edge_index.to(DEV), b.edge_type.to(DEV), b.num_nodes)

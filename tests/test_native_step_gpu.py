@@ -431,6 +431,9 @@ def _synthetic_step(d, L, seed):
     out = tr.losses_dict(tr.train_step(batch, eps))
     (s_logits, c_logits), mu, _ = tr.step_outputs()
     info = tr.step_info()
+    # (where the decoder head's gradients sit in the flat buffer: they are formed before the backward meets a ReLU)
+    lo = vae._offsets["decoder.c_decoder.chord_decoder.weight"]
+    info["head_lo"] = int(lo)
     return out, tr.grads.detach().cpu().numpy(), c_logits.cpu().numpy(), mu.cpu().numpy(), info
 
 
@@ -449,7 +452,15 @@ def test_gcl_kernels_match_the_segment_reduce_plus_grouped_product_step(d, L):
         assert abs(lf[k] - lu[k]) <= 2e-6 * max(1.0, abs(lu[k])), k
     assert rel_err(torch.from_numpy(cf), torch.from_numpy(cu)) < 2e-5
     assert rel_err(torch.from_numpy(mu_f), torch.from_numpy(mu_u)) < 2e-5
-    assert rel_err(torch.from_numpy(gf), torch.from_numpy(gu)) < 2e-4
+    # Gradients.  The two kernel sets use different operand formats (fp16 pair against the exact bf16 triple), so their
+    # activations differ at the 1e-6 level and a pre-activation that close to zero may take the other ReLU decision: ONE such
+    # element moves the gradient by ~1 / sqrt(N d) = 1.6e-3 in relative L2 here (tests/test_fullsize_gpu.py imposes the
+    # decisions and finds nothing else).  Hence: the decoder head's gradients, formed before the backward meets a ReLU, to
+    # 2e-5; the whole gradient to what a handful of flipped decisions can move it.
+    gf, gu = torch.from_numpy(gf).double(), torch.from_numpy(gu).double()
+    lo = info_f["head_lo"]
+    assert float((gf[lo:] - gu[lo:]).norm() / gu[lo:].norm()) < 2e-5
+    assert float((gf - gu).norm() / gu.norm()) < 4e-3
 
 
 def test_loss_trajectory_follows_the_fp64_oracle():

@@ -358,3 +358,65 @@ def hip_vs_oracle_fullsize(spec, threads=None, dev="cuda"):
     rep["grad"] = grad_errors(names, hip_g, g64, g32)
     rep["grad"].pop("per_tensor")
     return rep
+
+
+# ---- the ReLU decisions a native step took, as masks for the oracle (oracle/kinks.ReluProbe.forced) ------------------------
+SAVED = {k: i for i, k in enumerate(["GCN_H", "GCN_X", "GCN_XIN", "GCN_MEAN", "GCN_VAR", "GCN_T", "X0", "MERGE_PRE", "MERGE_MEAN",
+                                     "MERGE_VAR", "DEC_PRE", "DEC_MEAN", "DEC_VAR", "ENC_CNN_LIN1"])}   # PM_SAVED_* of the header
+
+
+def saved_tensor(step, what: str, stack: int = 0, layer: int = 0) -> torch.Tensor:
+    """An activation of the last native forward, as a view of the step's workspace arena (pm_vae_step_saved)."""
+    import ctypes
+    from polyphemus_amd._lib import call
+    off, n = ctypes.c_int64(), ctypes.c_int64()
+    call("pm_vae_step_saved", step.addr, SAVED[what], stack, layer, ctypes.addressof(off), ctypes.addressof(n))
+    return step.ws[off.value:off.value + 4 * n.value].view(torch.float32)
+
+
+def hip_relu_decisions(live, cfg):
+    """The ReLU decisions the BACKWARD of the native step just run on `live` (hip_fullsize_step(..., lr=0, keep=live)) took,
+    keyed by the oracle's site index (oracle/kinks.relu_sites): per GCL layer the six per-relation message ReLUs
+    (x[src] * T[dist] > 0 from the saved layer input and distance table: segreduce.hip k_segreduce_bwd) and the ReLU behind the
+    norm (pm_bn_relu_decisions = the expression of pm_bn_bwd_elem on the saved pre-norm rows and batch statistics), the chord
+    encoder's ReLU (its saved output > 0: pm_relu_bwd), the two head norms, CNNEncoder.lin[1].  Not imposed: the two
+    BatchNorm2d ReLUs and the max-pool of the structure encoder's convolutions (0.8 M elements against 67 M), the structure
+    decoder (the reference's loss sends no gradient there)."""
+    import ctypes
+    from oracle import kinks
+    from polyphemus_amd._lib import call, ptr, stream
+    vae, tr, g = live["vae"], live["trainer"], live["batch"]
+    step = tr.step
+    sites = kinks.relu_sites(cfg)
+    N, d, L = g.num_nodes, cfg["d"], cfg["gnn_n_layers"]
+    P = dict(vae.named_parameters())
+    forced = {}
+
+    def bn_mask(x, mean, var, key, rows, C):
+        out = torch.empty(rows, C, dtype=torch.uint8, device=x.device)
+        call("pm_bn_relu_decisions", ptr(x), ptr(mean), ptr(var), ptr(P[key + ".weight"].detach()), ptr(P[key + ".bias"].detach()),
+             1e-5, rows, C, ptr(out), stream())
+        return out.bool().cpu()
+
+    et, ed, src = g.edge_type.long(), g.edge_dist.long(), g.edge_index[0].long()
+    for stack, (tag, key) in enumerate((("enc_gcn", "encoder.c_encoder.graph_encoder"), ("dec_gcn", "decoder.c_decoder.graph_decoder"))):
+        T = saved_tensor(step, "GCN_T", stack).view(32, d)
+        for i in range(L):
+            x = saved_tensor(step, "GCN_XIN", stack, i).view(N, d)
+            for r in range(6):
+                m = et == r
+                forced[sites.index(f"{tag}.{i}.msg.{r}")] = ((x[src[m]] * T[ed[m]]) > 0).cpu()
+            forced[sites.index(f"{tag}.{i}.norm")] = bn_mask(saved_tensor(step, "GCN_H", stack, i), saved_tensor(step, "GCN_MEAN", stack, i),
+                                                             saved_tensor(step, "GCN_VAR", stack, i), f"{key}.norm_layers.{i}.module", N, d)
+    x0 = saved_tensor(step, "X0").view(N, d) > 0
+    drum = g.is_drum.bool()
+    forced[sites.index("enc_chord.drums")] = x0[drum].cpu()
+    forced[sites.index("enc_chord.non_drums")] = x0[~drum].cpu()
+    B = g.s_tensor.shape[0] // cfg["n_bars"]
+    forced[sites.index("enc_merge")] = bn_mask(saved_tensor(step, "MERGE_PRE"), saved_tensor(step, "MERGE_MEAN"),
+                                               saved_tensor(step, "MERGE_VAR"), "encoder.bn_linear_merge", B, d)
+    forced[sites.index("dec_bn")] = bn_mask(saved_tensor(step, "DEC_PRE"), saved_tensor(step, "DEC_MEAN"), saved_tensor(step, "DEC_VAR"),
+                                            "decoder.batch_norm", B, 2 * d)
+    forced[sites.index("enc_cnn.lin1")] = (saved_tensor(step, "ENC_CNN_LIN1").view(-1, d) > 0).cpu()
+    torch.cuda.synchronize()
+    return forced

@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--active-slots-only", action="store_true")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--profile", action="store_true", help="torch.profiler table of one step (GPU kernels by total time)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=8, d=256, n_bars=2, resolution=8)
@@ -63,6 +64,20 @@ def main():
             wall += time.perf_counter() - t0
             for i, k in enumerate(names):
                 acc[k] += ev[i].elapsed_time(ev[i + 1])
+    if a.profile:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            g.__dict__.pop("_pm_inputs", None)
+            with torch.autocast("cuda", dtype=torch.float16):
+                (s_logits, c_logits), mu, lv = vae(g)
+                tot, parts = reference_losses(g.s_tensor, s_logits, g.c_tensor, c_logits, mu, lv)
+            scaler.scale(tot).backward()
+            scaler.step(opt)
+            scaler.update()
+            opt.zero_grad()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70))
+        w = "encoder.c_encoder.graph_encoder.layers.1.weight"
     n = a.steps
     print(f"reference loop shape, configs[1], decoder head slots {vae._native_step().info()['n_slots']}: wall {1e3 * wall / n:.3f} ms per step; "
           + ", ".join(f"{k} {acc[k] / n:.3f}" for k in names) + " ms (GPU time between events)")

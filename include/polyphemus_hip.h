@@ -246,7 +246,8 @@ int pm_gcl_input_grad_bn(const PmBnBwd* norm, uint16_t* dh_planes /* 3 planes [N
  * products hi*hi + hi*lo + lo*hi with fp32 accumulation: element error <= 2^-22 relative plus the dropped lo*lo term of the
  * same size — below the rounding an fp32 dot product of the same length accumulates — at half the matrix-core work, two
  * thirds of the operand bytes (csrc/common.h pm_split2h_pair; parity of the step against the fp64 oracle: tests/).
- * Planes keep the layout and strides of the three-plane format; plane 2 is unused.
+ * Planes keep the layout and strides of the three-plane format; plane 2 is unused.  d = 512 runs the same format through the
+ * ring pipeline of wide.hip (pm_gcl_forward_fused_h2, pm_bn_bwd_fused_h2 + pm_gcl_input_grad_fused_h2, pm_gcl_weight_grad_fused_h2).
  *   absmax_in : device words [PM_ABSMAX_SLOTS] holding float bits whose maximum is max |x| of the kernel's fp32 input (pm_absmax, or a producer's
  *               absmax_out: pm_bn_apply_fused_absmax, PmNormSums.absmax_out); forward: of the layer input x, input gradient: of du
  *   absmax_aux: forward only: the same for the distance table T
@@ -271,6 +272,15 @@ int pm_gcl_forward_fused_h2(const float* x, const float* T, const int32_t* plan,
 int pm_gcl_input_grad_bn_h2(const PmBnBwd* norm, uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
                             int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes, float* dA,
                             const PmH2* h2, pm_stream_t stream);
+/* d = 512 (no norm backward inside the input gradient there): the norm's backward pass writing dh planes in the pair format,
+ * and the input gradient reading them */
+int pm_bn_bwd_fused_h2(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var, float eps,
+                       const float* gamma, const float* beta, int relu, float* dgamma, float* dbeta, float* dbias_pre,
+                       double* acc3, uint16_t* dx_planes, int64_t plane_stride, int32_t sums_ready, const PmH2* h2,
+                       pm_stream_t stream);
+int pm_gcl_input_grad_fused_h2(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N, int32_t E,
+                               int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes, float* dA,
+                               const float* dh_scale, float w_scale, pm_stream_t stream);
 int pm_gcl_weight_grad_fused_h2(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,
                                 int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
                                 int32_t use_classes, float* dW, const float* a_scale, const float* dh_scale,

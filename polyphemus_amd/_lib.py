@@ -139,6 +139,8 @@ _SIGS = {
     "pm_gcl_forward_fused_h2": "pppiiiifuuppippplps",
     "pm_gcl_input_grad_bn_h2": "pplpiiiipipps",
     "pm_gcl_weight_grad_fused_h2": "plplpiiiiippps",
+    "pm_bn_bwd_fused_h2": "ppiippfppippppplips",
+    "pm_gcl_input_grad_fused_h2": "plpiiiipippfs",
     "pm_bn_apply_fused_absmax": "piipfpppipppppfps",
     "pm_set_deterministic": "i",
     "pm_get_deterministic": "",

@@ -898,6 +898,17 @@ extern "C" int pm_gcl_input_grad_fused(const uint16_t* dh_planes, int64_t plane_
   return gcl_input_grad_impl(const_cast<uint16_t*>(dh_planes), plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, nullptr,
                              (hipStream_t)stream);
 }
+// ... on dh planes in the fp16 pair format (written by pm_bn_bwd_fused_h2 with scale *dh_scale); d = 512 (at d <= 256 the
+// norm backward runs inside the kernel: pm_gcl_input_grad_bn_h2)
+extern "C" int pm_gcl_input_grad_fused_h2(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
+                                          int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
+                                          float* dA, const float* dh_scale, float w_scale, pm_stream_t stream) {
+  if (!dh_planes || !plan || !w_frag_t || !dA || !dh_scale || !(w_scale > 0.f) || N <= 0 || d != 512 || plane_stride < (int64_t)N * d ||
+      (plane_stride & 7) || ((uintptr_t)dh_planes % 16) || ((uintptr_t)w_frag_t % 16) || ((uintptr_t)dA % 16) ||
+      plane_stride * 6 >= 0x7fffffffLL || (int64_t)N * 4 * d * 4 >= 0x7fffffffLL)
+    return PM_E_INVALID;
+  return pm_wide_gcl_input_grad(dh_planes, plane_stride, plan, N, E, G, w_frag_t, use_classes, dA, (hipStream_t)stream, dh_scale, w_scale);
+}
 // ... with the BatchNorm backward in front of it fused in (GclBn above): `dh_planes` is WRITTEN (the weight gradient reads it)
 extern "C" int pm_gcl_input_grad_bn(const PmBnBwd* nb, uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan,
                                     int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag_t, int32_t use_classes,
@@ -1132,7 +1143,7 @@ static int gcl_weight_grad_impl(const uint16_t* a_planes, int64_t a_plane_stride
     hipLaunchKernelGGL((k_gcl_dw<DD, HH>), grid, block, lds, st, a_planes, a_plane_stride, dh_planes, dh_plane_stride, \
                        pv.trk_list, pv.trk_cnt, dW, N, nsplit, use_classes, gate, sa, sdh);                            \
   } while (0)
-  if (sa) { if (d == 256) LAUNCH(256, true); else LAUNCH(128, true); }
+  if (sa) { if (d == 512) LAUNCH(512, true); else if (d == 256) LAUNCH(256, true); else LAUNCH(128, true); }
   else if (d == 512) LAUNCH(512, false); else if (d == 256) LAUNCH(256, false); else LAUNCH(128, false);
 #undef LAUNCH
   pm_prof_close(st, pe);
@@ -1149,7 +1160,7 @@ extern "C" int pm_gcl_weight_grad_fused_h2(const uint16_t* a_planes, int64_t a_p
                                            int64_t dh_plane_stride, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                                            int32_t d, int32_t use_classes, float* dW, const float* a_scale,
                                            const float* dh_scale, pm_stream_t stream) {
-  if (!a_scale || !dh_scale || (d != 128 && d != 256)) return PM_E_INVALID;
+  if (!a_scale || !dh_scale) return PM_E_INVALID;
   return gcl_weight_grad_impl(a_planes, a_plane_stride, dh_planes, dh_plane_stride, plan, N, E, G, d, use_classes, dW, a_scale,
                               dh_scale, stream);
 }
@@ -1168,10 +1179,10 @@ static int gcl_forward_impl(const float* x, const float* T, const int32_t* plan,
   if (planes && (plane_stride < (int64_t)N * 4 * d || (plane_stride & 7) || ((uintptr_t)planes % 16) ||
                  plane_stride * 6 >= 0x7fffffffLL))
     return PM_E_INVALID;
-  if (h2 && (d == 512 || !h2->absmax_in || !h2->absmax_aux || !h2->scale_out || !(h2->w_scale > 0.f))) return PM_E_INVALID;
+  if (h2 && (!h2->absmax_in || !h2->absmax_aux || !h2->scale_out || !(h2->w_scale > 0.f))) return PM_E_INVALID;
   if (d == 512)                 // 512-wide layers: the ring pipeline of wide.hip
     return pm_wide_gcl_forward(x, T, plan, N, E, G, dropout_p, seed, layer_uid, w_frag, bias, use_classes, h, col_stats,
-                               planes, plane_stride, nullptr, (hipStream_t)stream);
+                               planes, plane_stride, nullptr, (hipStream_t)stream, h2);
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   GclArgs a;
   a.mx = h2 ? h2->absmax_in : nullptr; a.mt = h2 ? h2->absmax_aux : nullptr; a.w_scale = h2 ? h2->w_scale : 1.f;

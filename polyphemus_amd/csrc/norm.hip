@@ -469,8 +469,6 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
                                                         float momentum, unsigned* absmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
   float amax = 0.f;                                               // max |y| of this thread (absmax != NULL: PmH2.absmax_in of the next layer)
-  __shared__ unsigned s_amax;
-  if (threadIdx.x == 0) s_amax = 0u;                              // (the barrier behind the sums reduction orders it)
   float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
   // (BN_APPLY_U > 0: a thread's first pieces of x and of the residual are requested BEFORE the workgroup reduces the
   //  replicated sums — 16 fp64 loads per column — so that the reduction's latency has loads in flight under it)
@@ -530,7 +528,7 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
     if (res) rv = reinterpret_cast<const float4*>(res)[i];
     apply(i, xv, rv);
   }
-  if (absmax) pm_absmax_block(absmax, amax, &s_amax);            // (uniform branch: every thread of the workgroup calls it)
+  if (absmax) pm_absmax_wave(absmax, amax);                       // (one atomic per wave, spread over the slots: no barrier in the short workgroups' tail)
 }
 extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps,
                                         const float* gamma, const float* beta, const float* residual, int relu, float* y,
@@ -621,8 +619,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
                                                             int64_t n4, int C, double count, BnCtx ctx,
                                                             const double* __restrict__ acc3, float* dgamma,
                                                             float* dbeta, float* dbias_pre, float* __restrict__ dx,
-                                                            uint16_t* __restrict__ dx_planes, int64_t plane_stride) {
+                                                            uint16_t* __restrict__ dx_planes, int64_t plane_stride,
+                                                            const unsigned* __restrict__ mdu, float* sdh_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [6][C]: mean, rstd, gamma, beta, mean(du), mean(du*xhat)
+  __shared__ float s_gm[4];
   float* const s_m = sm; float* const s_rs = sm + C; float* const s_ga = sm + 2 * C; float* const s_be = sm + 3 * C;
   float* const s_m0 = sm + 4 * C; float* const s_m1 = sm + 5 * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -641,6 +641,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
     }
   }
   __syncthreads();
+  // mdu != NULL: planes in the fp16 pair format (PmH2): dh * 2^k with k from |dy|max and the largest gamma * rstd, the same in
+  // every workgroup (as k_gcl_dagg of gcl.hip); *sdh_out receives the scale
+  float dsc = 1.f;
+  if (mdu) {
+    float gm = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) gm = fmaxf(gm, fabsf(s_ga[c] * s_rs[c]));
+    gm = pm_wave_max(gm);
+    if ((threadIdx.x & 63) == 0) s_gm[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    gm = fmaxf(fmaxf(s_gm[0], s_gm[1]), fmaxf(s_gm[2], s_gm[3]));
+    dsc = pm_pow2_scale(gm * pm_absmax_read(mdu) * 16.f, 13);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sdh_out = dsc;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)((i * 4) % C);
     const float4 xv = reinterpret_cast<const float4*>(x)[i], dv = reinterpret_cast<const float4*>(dy)[i];
@@ -649,14 +662,23 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       o[j] = pm_bn_bwd_elem(xs[j], ds[j], s_m[c + j], s_rs[c + j], s_ga[c + j], s_be[c + j], s_m0[c + j], s_m1[c + j], ctx.relu);
+    if (mdu) {
+      unsigned l1, l2, u1, u2;
+      pm_split2h_pair(pm_clamp_f16(o[0] * dsc), pm_clamp_f16(o[1] * dsc), l1, l2);
+      pm_split2h_pair(pm_clamp_f16(o[2] * dsc), pm_clamp_f16(o[3] * dsc), u1, u2);
+      const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2};
+      *reinterpret_cast<pm_u32x2*>(dx_planes + i * 4) = p1;
+      *reinterpret_cast<pm_u32x2*>(dx_planes + plane_stride + i * 4) = p2;
+    } else
     if (dx_planes) pm_store_planes4(dx_planes, plane_stride, i * 4, o[0], o[1], o[2], o[3]);   // GEMM operand planes
     else reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
-extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
-                               const float* var, float eps, const float* gamma, const float* beta, int relu,
-                               float* dgamma, float* dbeta, float* dbias_pre, float* dx, double* acc3,
-                               uint16_t* dx_planes, int64_t plane_stride, int32_t sums_ready, pm_stream_t stream) {
+static int bn_bwd_fused_impl(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
+                             const float* var, float eps, const float* gamma, const float* beta, int relu,
+                             float* dgamma, float* dbeta, float* dbias_pre, float* dx, double* acc3,
+                             uint16_t* dx_planes, int64_t plane_stride, int32_t sums_ready, const uint32_t* mdu, float* sdh_out,
+                             pm_stream_t stream) {
   if (!x || !dy || !mean || !var || !gamma || !beta || (!dx && !dx_planes) || !acc3 || O <= 0 || C <= 0 ||
       (C % 4) != 0 || C > 4096)
     return PM_E_INVALID;
@@ -674,8 +696,24 @@ extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32
                        pm_det_gate(st));
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
-                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride);
+                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride, mdu, sdh_out);
   return pm_check_launch();
+}
+extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
+                               const float* var, float eps, const float* gamma, const float* beta, int relu,
+                               float* dgamma, float* dbeta, float* dbias_pre, float* dx, double* acc3,
+                               uint16_t* dx_planes, int64_t plane_stride, int32_t sums_ready, pm_stream_t stream) {
+  return bn_bwd_fused_impl(x, dy, O, C, mean, var, eps, gamma, beta, relu, dgamma, dbeta, dbias_pre, dx, acc3, dx_planes, plane_stride,
+                           sums_ready, nullptr, nullptr, stream);
+}
+// ... writing `dx_planes` in the fp16 pair format (PmH2: absmax_in = |dy|max words, scale_out receives the planes' scale)
+extern "C" int pm_bn_bwd_fused_h2(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
+                                  const float* var, float eps, const float* gamma, const float* beta, int relu,
+                                  float* dgamma, float* dbeta, float* dbias_pre, double* acc3, uint16_t* dx_planes,
+                                  int64_t plane_stride, int32_t sums_ready, const PmH2* h2, pm_stream_t stream) {
+  if (!h2 || !h2->absmax_in || !h2->scale_out || !dx_planes) return PM_E_INVALID;
+  return bn_bwd_fused_impl(x, dy, O, C, mean, var, eps, gamma, beta, relu, dgamma, dbeta, dbias_pre, nullptr, acc3, dx_planes,
+                           plane_stride, sums_ready, h2->absmax_in, h2->scale_out, stream);
 }
 
 // the column sums alone (the apply half then runs inside the consumer: pm_gcl_input_grad_bn, gcl.hip)

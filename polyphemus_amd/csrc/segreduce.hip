@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       if (!ok[v]) continue;
       *reinterpret_cast<float4*>(dx + (int64_t)n * d + c[v]) = acc[v];
       if (FUSE) {
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[v].x), fabsf(acc[v].y))), fmaxf(fabsf(acc[v].z), fabsf(acc[v].w)));
+        if constexpr (NV == 1)     // (d <= 256; the wider variants are at their register budget: their callers take pm_absmax)
+          amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[v].x), fabsf(acc[v].y))), fmaxf(fabsf(acc[v].z), fabsf(acc[v].w)));
         const float4 hv = PF ? hcur[v] : *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
         const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
         const float ds[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
@@ -474,12 +475,12 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     for (int j = 0; j < 4; ++j)
       if (z0[v][j] != 0.f) atomicAdd(&sT[j * dq + (c[v] >> 2)], z0[v][j]);
   }
-  if (FUSE && nn.absmax_out) {                                     // (non-negative floats order like their bit patterns)
+  if (FUSE && NV == 1 && nn.absmax_out) {                          // (non-negative floats order like their bit patterns)
     amax = pm_wave_max(amax);
     if (lane == 0) atomicMax(sMax, __float_as_uint(amax));
   }
   __syncthreads();
-  if (FUSE && nn.absmax_out && threadIdx.x == 0) atomicMax(nn.absmax_out + (blockIdx.x % PM_ABSMAX_SLOTS), *sMax);
+  if (FUSE && NV == 1 && nn.absmax_out && threadIdx.x == 0) atomicMax(nn.absmax_out + (blockIdx.x % PM_ABSMAX_SLOTS), *sMax);
   for (int i = threadIdx.x; i < pr * d; i += blockDim.x) {               // private rows of all waves -> shared image
     const int r = i / d, col = i - r * d;
     float t = 0.f;

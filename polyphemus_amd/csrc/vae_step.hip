@@ -403,8 +403,9 @@ GcnRoute gcn_route(const Ctx& c, const GcnSaved& sv) {
 // norm backward inside and the tile weight gradient all have to apply (they hand each other planes), d in {128, 256}
 static bool stack_h2(const Ctx& c, const GcnSaved& sv) {
   const GcnRoute r = gcn_route(c, sv);
-  return cfg().h2 && r.gcl_kernels && !r.dense && c.bn && (c.d == 128 || c.d == 256) && cfg().dagg_bn && !cfg().dw_side &&
-         !cfg().no_dw;
+  // (d <= 256: the norm backward runs inside the input gradient, which then writes the dh planes; d = 512: the norm's own pass does)
+  return cfg().h2 && r.gcl_kernels && !r.dense && c.bn && (((c.d == 128 || c.d == 256) && cfg().dagg_bn) || c.d == 512) &&
+         !cfg().dw_side && !cfg().no_dw;
 }
 // The part of a GCN stack's forward that depends on the parameters only: the distance table of the shared edge_nn and
 // the bf16 planes of the layers' weights.  Issued at the start of the step, on the second stream.
@@ -580,10 +581,17 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const bool res_in_dagg = in_dagg && !dropping && cfg().dagg_res;
     double* const acc3 = sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL;
     const bool sums_ready = i < c.L - 1 && fuse_sums;
-    const bool du_tracked = sums_ready;       // (h2: pm_segreduce_bwd_norm of layer i+1 also left |dx|max in mdu[i])
+    const bool du_tracked = sums_ready && d <= 256;   // (h2: pm_segreduce_bwd_norm of layer i+1 also left |dx|max in mdu[i]; its 512-wide variant has no register for it)
     if (in_dagg) {
       if (!sums_ready)
         RUN(pm_bn_bwd_sums(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, acc3, c.st));
+    } else if (c.bn && sv.h2) {                          // d = 512 in the fp16 pair format: the norm's pass writes the two dh planes
+      if (!du_tracked) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i * PM_ABSMAX_SLOTS, c.st));
+      PmH2 h2;
+      h2.absmax_in = sv.mdu + i * PM_ABSMAX_SLOTS; h2.absmax_aux = nullptr; h2.scale_out = sv.sdh + i; h2.w_scale = kH2WScale; h2.reserved = 0;
+      RUN(pm_bn_bwd_fused_h2(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w, c.G + bn.b,
+                               c.G + g.bias[i], sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL, dhp, dps,
+                               (i < c.L - 1 && fuse_sums) ? 1 : 0, &h2, c.st));
     } else if (c.bn)
       RUN(pm_bn_bwd_fused(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, c.G + bn.w,
                             c.G + bn.b, c.G + g.bias[i], c.planes ? nullptr : dh,
@@ -645,7 +653,10 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         } else
         RUN(pm_gcl_input_grad_bn(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                    cfg().no_classes ? 0 : 1, dA, c.st));
-      } else if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
+      } else if (sv.h2)                                   // (d = 512: ring pipeline of wide.hip on the pair-format planes)
+        RUN(pm_gcl_input_grad_fused_h2(dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
+                                         cfg().no_classes ? 0 : 1, dA, sv.sdh + i, kH2WScale, c.st));
+      else if (c.planes && sv.Wft && gcl_width(d) && gcl_fused_on() && gcl_fits(N, d, 1))      // A-stationary kernel (gcl.hip) / ring pipeline (wide.hip)
         RUN(pm_gcl_input_grad_fused(dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
                                       cfg().no_classes ? 0 : 1, dA, c.st));
       else
@@ -664,7 +675,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
       nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
-      nn.absmax_out = sv.h2 ? sv.mdu + (i - 1) * PM_ABSMAX_SLOTS : nullptr;
+      nn.absmax_out = (sv.h2 && d <= 256) ? sv.mdu + (i - 1) * PM_ABSMAX_SLOTS : nullptr;
       RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
                                   c.compact, out, dT, &nn, c.st));
     } else {

@@ -8,10 +8,11 @@
 int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                         float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag, const float* bias,
                         int32_t use_classes, float* h, double* col_stats, uint16_t* planes, int64_t plane_stride,
-                        const uint16_t* a_planes_in, hipStream_t st);
+                        const uint16_t* a_planes_in, hipStream_t st, const PmH2* h2 = nullptr);
 // dA' = dh @ [W_t; W_4; W_5; root]^T (pm_gcl_input_grad_fused at d = 512)
 int pm_wide_gcl_input_grad(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N, int32_t E,
-                           int32_t G, const uint16_t* w_frag_t, int32_t use_classes, float* dA, hipStream_t st);
+                           int32_t G, const uint16_t* w_frag_t, int32_t use_classes, float* dA, hipStream_t st,
+                           const float* dh_scale = nullptr, float w_scale = 1.f);   // (dh_scale: planes in the fp16 pair format)
 // C[N, Nout] = X[N, 512] @ W (+ bias), Nout a multiple of 512 (pm_rows_times_weight at K = 512)
 int pm_wide_rows_times_weight(const float* X, int32_t ldx, int32_t N, const uint16_t* w_frag, int32_t kind,
                               int32_t w_tiles, int32_t Nout, const float* bias, float* C, int32_t ldc, hipStream_t st);

@@ -54,11 +54,16 @@ struct WideArgs {
   // epilogue
   const float* bias; float* out; int ldo; double* colstats;
   unsigned* gate;                                           // deterministic mode (common.h): MFMA waves add the column sums in turn
+  // fp16 pair format (H2 kernels; PmH2 of the header): V_FWD: |max| words of x and of T, where to leave the scale of the A' planes;
+  // V_DAGG: the device float the dh planes' scale sits in; both: the scale of the weight planes
+  const unsigned* mx; const unsigned* mt; float* sa_out; const float* sin; float w_scale;
 };
 }  // namespace
 
-template <int VAR, bool DROP, int NPW, int BKIND>
+template <int VAR, bool DROP, int NPW, int BKIND, bool H2>
 __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
+  static_assert(!H2 || VAR == V_FWD || VAR == V_DAGG, "the fp16 pair format exists for the sparse GCL forward and the input gradient");
+  constexpr int NPL = H2 ? 2 : 3, T60 = H2 ? 3 : 0;        // operand planes; first product of the chain (PA / PB below)
   constexpr int D = WD;
   constexpr int NPT = NPW * 64;                              // producer threads
   constexpr bool GCL = VAR == V_FWD || VAR == V_FWDP || VAR == V_DAGG;
@@ -103,6 +108,14 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
   const int total = npass * cpp;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // H2: operand scale of the aggregate (forward: from the |max| words, as k_gcl_fwd) and what undoes the two scales at the end
+  float asc = 1.f, oinv = 1.f;
+  if constexpr (H2 && VAR == V_FWD) {
+    asc = pm_pow2_scale(pm_absmax_read(g.mx) * fmaxf(1.f, pm_absmax_read(g.mt) * g.scale), 13);
+    oinv = 1.f / (asc * g.w_scale);
+    if (blockIdx.x == 0 && tid == 0) *g.sa_out = asc;
+  }
+  if constexpr (H2 && VAR == V_DAGG) oinv = 1.f / (g.sin[0] * g.w_scale);
   if constexpr (GCL) {
     if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
     __syncthreads();
@@ -129,21 +142,30 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
           const int rr = ps * (NPW * 4) + r0, n = sNode[rr];
           const int off = (n * 4 * D + blk * D + half * CH + ch * 8) * 2;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NPL; ++p) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(img + p * PLANE + rr * ROWB + ((ch ^ (rr & 15)) << 4));
             __builtin_amdgcn_raw_buffer_store_b128(v, prs, n >= 0 ? off + p * ps_b : GCL_OOB, 0, 0);
           }
         }
       };
-      auto put = [&](char* img, int rr, int q, float4 o) {
-        unsigned l1, l2, l3, u1, u2, u3;
-        pm_split3_pair(o.x, o.y, l1, l2, l3);
-        pm_split3_pair(o.z, o.w, u1, u2, u3);
-        const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+      auto put = [&](char* img, int rr, int q, float4 o) {          // (H2: the values come in already scaled; two planes)
         char* dst = img + rr * ROWB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
-        *reinterpret_cast<pm_u32x2*>(dst) = p1;
-        *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
-        *reinterpret_cast<pm_u32x2*>(dst + 2 * PLANE) = p3;
+        if constexpr (H2) {
+          unsigned l1, l2, u1, u2;
+          pm_split2h_pair(o.x, o.y, l1, l2);
+          pm_split2h_pair(o.z, o.w, u1, u2);
+          const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2};
+          *reinterpret_cast<pm_u32x2*>(dst) = p1;
+          *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
+        } else {
+          unsigned l1, l2, l3, u1, u2, u3;
+          pm_split3_pair(o.x, o.y, l1, l2, l3);
+          pm_split3_pair(o.z, o.w, u1, u2, u3);
+          const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+          *reinterpret_cast<pm_u32x2*>(dst) = p1;
+          *reinterpret_cast<pm_u32x2*>(dst + PLANE) = p2;
+          *reinterpret_cast<pm_u32x2*>(dst + 2 * PLANE) = p3;
+        }
       };
       auto build = [&](int c) {
 #pragma clang fp contract(off)   // (bit-identical to k_segreduce_fwd / k_gcl_fwd, whatever the code shape around the adds)
@@ -175,7 +197,10 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
           __builtin_amdgcn_sched_barrier(0);
           if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-          for (int ps = 0; ps < NPS; ++ps) put(img, ps * RPP + prow, q, xs[ps]);
+          for (int ps = 0; ps < NPS; ++ps) {
+            if constexpr (H2) { xs[ps].x *= asc; xs[ps].y *= asc; xs[ps].z *= asc; xs[ps].w *= asc; }
+            put(img, ps * RPP + prow, q, xs[ps]);
+          }
           put_table();
           return;
         }
@@ -219,7 +244,11 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
             acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
           }
           // 1 / max(count, 1) for count <= 3: the correctly rounded quotients, as the division gives them
-          const float inv = ecnt[ps] == 2 ? 0.5f : (ecnt[ps] == 3 ? 1.0f / 3.0f : 1.0f);
+          float inv = ecnt[ps] == 2 ? 0.5f : (ecnt[ps] == 3 ? 1.0f / 3.0f : 1.0f);
+          if constexpr (H2) {                      // mean, then the operand scale (a power of two)
+            acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+            inv = asc;
+          }
           put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
         }
         if (redo) {                                              // lists longer than the cached slots: serial, from global
@@ -236,7 +265,11 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
                                    DROP ? pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]) : 0u);
               acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
             }
-            const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+            float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+            if constexpr (H2) {
+              acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+              inv = asc;
+            }
             put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
           }
         }
@@ -264,7 +297,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
           const int ch = (pt + k * NPT) & 15;
           const int off = (node[k] >= 0 && gc < total) ? (node[k] * ld + col + ch * 8) * 2 : GCL_OOB;
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NPL; ++p)
             v[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off == GCL_OOB ? GCL_OOB : off + p * ps_b, 0, 0);
         }
       };
@@ -274,7 +307,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
         for (int k = 0; k < PPT; ++k) {
           const int pi = pt + k * NPT, rr = pi >> 4, ch = pi & 15;
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NPL; ++p)
             *reinterpret_cast<u32x4*>(img + p * PLANE + rr * ROWB + ((ch ^ (rr & 15)) << 4)) = v[k][p];
         }
       };
@@ -382,7 +415,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
 #pragma unroll
   for (int s = 0; s < BD; ++s)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bload1(bq[s][p], base_cur + s * ks_stride, p);
+    for (int p = 0; p < NPL; ++p) bload1(bq[s][p], base_cur + s * ks_stride, p);
   if constexpr (VAR == V_FWD) {
     // Row metadata (while the producers build the self block): four threads per row, three of them fetch one relation
     // block's CSR range and its first EMAXW edges
@@ -434,7 +467,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              const float v = row < nvalid ? acc[i][j][r] + bv[j] : 0.f;
+              const float v = row < nvalid ? (H2 ? acc[i][j][r] * oinv + bv[j] : acc[i][j][r] + bv[j]) : 0.f;
               cs += (double)v; cq += (double)v * (double)v;
             }
           cs += __shfl_xor(cs, 32, 64); cq += __shfl_xor(cq, 32, 64);
@@ -458,7 +491,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
         for (int q = 0; q < 8; ++q)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            stg[((q & 3) + 8 * (q >> 2) + 4 * lh) * 64 + j * 32 + li] = acc[i][j][hr * 8 + q] + bv[j];
+            stg[((q & 3) + 8 * (q >> 2) + 4 * lh) * 64 + j * 32 + li] = H2 ? acc[i][j][hr * 8 + q] * oinv + bv[j] : acc[i][j][hr * 8 + q] + bv[j];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -488,7 +521,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
     for (int ks = 0; ks < 8; ++ks) {
       bf16x8 a[3][NI];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NPL; ++p)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int rr = i * 32 + li;
@@ -499,12 +532,12 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
       const int tk = ks + BD;
       const int soff = tk < 8 ? base_cur + tk * ks_stride : base_next + (tk - 8) * ks_stride;
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6) {
+      for (int t6 = T60; t6 < 6; ++t6) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][i], bq[ks % BD][PB[t6]][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = gcl_mfma<H2>(a[PA[t6]][i], bq[ks % BD][PB[t6]][j], acc[i][j]);
         if constexpr (BD == 1) {          // one k-step of fragments: each plane is refilled right after its last use
           if (t6 == 2) { bload1(bq[0][2], soff, 2); __builtin_amdgcn_sched_barrier(0); }
           if (t6 == 4) { bload1(bq[0][1], soff, 1); __builtin_amdgcn_sched_barrier(0); }
@@ -513,7 +546,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
       }
       if constexpr (BD == 2) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bload1(bq[ks % BD][p], soff, p);
+        for (int p = 0; p < NPL; ++p) bload1(bq[ks % BD][p], soff, p);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -539,14 +572,14 @@ int wide_npw(int dflt) {
   static const int v = getenv("PM_WIDE_NPW") ? atoi(getenv("PM_WIDE_NPW")) : 0;
   return (v == 4 || v == 8) ? v : dflt;
 }
-template <int VAR, bool DROP, int NPW, int BKIND>
+template <int VAR, bool DROP, int NPW, int BKIND, bool H2 = false>
 void launch_wide(const WideArgs& a, unsigned grid, size_t lds, hipStream_t st) {
   static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];
   if (!once) {
-    hipFuncSetAttribute((const void*)k_wide<VAR, DROP, NPW, BKIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_wide<VAR, DROP, NPW, BKIND, H2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  hipLaunchKernelGGL((k_wide<VAR, DROP, NPW, BKIND>), dim3(grid), dim3((NCW + NPW) * 64), lds, st, a);
+  hipLaunchKernelGGL((k_wide<VAR, DROP, NPW, BKIND, H2>), dim3(grid), dim3((NCW + NPW) * 64), lds, st, a);
 }
 size_t wide_lds(int var) {
   size_t b = 2 * IMG + BM * 4;
@@ -559,7 +592,7 @@ size_t wide_lds(int var) {
 int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G,
                         float dropout_p, uint32_t seed, uint32_t layer_uid, const uint16_t* w_frag, const float* bias,
                         int32_t use_classes, float* h, double* col_stats, uint16_t* planes, int64_t plane_stride,
-                        const uint16_t* a_planes_in, hipStream_t st) {
+                        const uint16_t* a_planes_in, hipStream_t st, const PmH2* h2) {
   const int d = WD;
   if ((int64_t)N * d * 4 * 4 >= 0x7fffffffLL) return PM_E_INVALID;
   if (a_planes_in && (plane_stride < (int64_t)N * 4 * d || (plane_stride & 7) || plane_stride * 6 >= 0x7fffffffLL))
@@ -583,6 +616,10 @@ int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int
   } else {
     a.planes = planes; a.plane_stride = plane_stride;
     const size_t lds = wide_lds(V_FWD);
+    if (h2) {                                              // fp16 pair format: eight producer waves
+      a.mx = h2->absmax_in; a.mt = h2->absmax_aux; a.sa_out = h2->scale_out; a.w_scale = h2->w_scale;
+      if (drop) launch_wide<V_FWD, true, 8, 1, true>(a, grid, lds, st); else launch_wide<V_FWD, false, 8, 1, true>(a, grid, lds, st);
+    } else
     if (wide_npw(8) == 8) { if (drop) launch_wide<V_FWD, true, 8, 1>(a, grid, lds, st); else launch_wide<V_FWD, false, 8, 1>(a, grid, lds, st); }
     else { if (drop) launch_wide<V_FWD, true, 4, 1>(a, grid, lds, st); else launch_wide<V_FWD, false, 4, 1>(a, grid, lds, st); }
   }
@@ -591,7 +628,8 @@ int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int
 }
 
 int pm_wide_gcl_input_grad(const uint16_t* dh_planes, int64_t plane_stride, const int32_t* plan, int32_t N, int32_t E,
-                           int32_t G, const uint16_t* w_frag_t, int32_t use_classes, float* dA, hipStream_t st) {
+                           int32_t G, const uint16_t* w_frag_t, int32_t use_classes, float* dA, hipStream_t st,
+                           const float* dh_scale, float w_scale) {
   const int d = WD;
   if ((int64_t)N * 4 * d * 4 >= 0x7fffffffLL || plane_stride * 6 >= 0x7fffffffLL) return PM_E_INVALID;
   PmPlanView pv = pm_plan_view(plan, N, E, G);
@@ -602,6 +640,10 @@ int pm_wide_gcl_input_grad(const uint16_t* dh_planes, int64_t plane_stride, cons
   a.out = dA; a.ldo = 4 * d;
   const unsigned grid = pm_gcl_grid(N);
   const int pe = pm_prof_open(st, PM_PROF_GCL_DAGG, 2.0 * N * 4.0 * d * d);
+  if (dh_scale) {                                          // fp16 pair format
+    a.sin = dh_scale; a.w_scale = w_scale;
+    launch_wide<V_DAGG, false, 4, 0, true>(a, grid, wide_lds(V_DAGG), st);
+  } else
   if (wide_npw(4) == 8) launch_wide<V_DAGG, false, 8, 0>(a, grid, wide_lds(V_DAGG), st);
   else launch_wide<V_DAGG, false, 4, 0>(a, grid, wide_lds(V_DAGG), st);
   pm_prof_close(st, pe);

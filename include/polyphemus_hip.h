@@ -254,9 +254,9 @@ int pm_gcl_input_grad_bn(const PmBnBwd* norm, uint16_t* dh_planes /* 3 planes [N
  *   scale_out : device float the kernel WRITES: the power of two its activation planes (A' / dh) carry; the weight gradient
  *               undoes both
  *   w_scale   : the power of two the weight planes were built with (pm_split_planes_frag_h2) */
-enum { PM_ABSMAX_SLOTS = 16 };   /* a tensor's |max| lives in this many words (the maximum of them counts): workgroups add theirs
-                                   with one atomic each, spread over the slots — thousands of atomics on ONE address cost a
-                                   launch ~30 us */
+enum { PM_ABSMAX_SLOTS = 64 };   /* a tensor's |max| lives in this many words (the maximum of them counts; one wave reads them with
+                                   one load): workgroups add theirs with ONE atomic each, spread over the slots — atomics on one
+                                   address serialise at ~150 ns each (4096 of them cost a 10 us launch 37 us more) */
 typedef struct PmH2 {
   const uint32_t* absmax_in; const uint32_t* absmax_aux; float* scale_out; float w_scale; int32_t reserved;
 } PmH2;

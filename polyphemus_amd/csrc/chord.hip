@@ -190,9 +190,6 @@ extern "C" int pm_chord_sum_fwd(const float* PT, const float* cvec, const int32_
 typedef float c_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 c_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int c_u32x4 __attribute__((ext_vector_type(4)));
-#ifndef CHORD_WHATIF
-#define CHORD_WHATIF 0                    // timing what-ifs of k_chord_sum_bwd (WRONG results): 1 no flush, 2 no one-hot / MFMA, 3 no dY loads
-#endif
 namespace {
 constexpr int CH_ROWS = 2048;             // nodes of a workgroup's chunk staged in LDS at a time
 constexpr int CH_NVT = 5;                 // token tiles of 32: 5 for the pitch tables (131), 4 of them for the duration tables (99)
@@ -277,7 +274,7 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
       for (int i = 0; i < 8; ++i) {
         tk[i] = sTok[kb + i];
         const int of = sOff[kb + i];
-        x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (CHORD_WHATIF == 3 || of == (int)0x80000000) ? (int)0x80000000 : of + colb, 0, 0));
+        x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, of == (int)0x80000000 ? (int)0x80000000 : of + colb, 0, 0));
       }
     };
     auto step = [&](const int (&tk)[8], const float (&x)[8]) {
@@ -294,7 +291,7 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
       const c_bf16x8 b3 = __builtin_bit_cast(c_bf16x8, c_u32x4{p3[0], p3[1], p3[2], p3[3]});
 #pragma unroll
       for (int q = 0; q < CH_NVT; ++q) {
-        if (!(live & (1u << q)) || CHORD_WHATIF == 2) continue;    // (wave-uniform)
+        if (!(live & (1u << q))) continue;    // (wave-uniform)
         const int v = q * 32 + li;
         unsigned a[4];
 #pragma unroll
@@ -327,7 +324,7 @@ __global__ void __launch_bounds__(512) k_chord_sum_bwd(const float* __restrict__
     for (int r = 0; r < 16; ++r) {
       const int v = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float val = acc[q][r];
-      if (v < V && val != 0.f && CHORD_WHATIF != 1) atomicAdd(out + (int64_t)v * d, val);
+      if (v < V && val != 0.f) atomicAdd(out + (int64_t)v * d, val);
     }
   pm_turn_leave_block(gate);
 }
@@ -371,9 +368,9 @@ extern "C" int pm_chord_sum_bwd(const float* dY, const int32_t* tokens, const in
   PmPlanView pv = pm_plan_view(plan, N, E, G_);
   // ~640 nodes per workgroup (PM_CHORD_BWD_CHUNK: development A/B); one more workgroup than chunks: the two groups'
   // chunk counts round up separately
-  static const int chunk_env = getenv("PM_CHORD_BWD_CHUNK") ? atoi(getenv("PM_CHORD_BWD_CHUNK")) : 0;
+  constexpr int chunk_env = 0;
   const int per = chunk_env > 0 ? chunk_env : 640;
-  static const bool skip_pad = !(getenv("PM_CHORD_SKIP_PAD") && atoi(getenv("PM_CHORD_SKIP_PAD")) == 0);   // 0: every node in every (slot, kind), no subtraction pass
+  constexpr bool skip_pad = true;   // 0: every node in every (slot, kind), no subtraction pass
   const int nb = (int)pm_cdiv(N, per) + 1;
   const int waves = d / 32 > 8 ? 8 : d / 32, cblks = (d / 32 + waves - 1) / waves;
   if (d / 32 != waves * cblks) return PM_E_INVALID;

@@ -198,19 +198,13 @@ __device__ static inline float pm_pow2_scale(float bound, int target) {
 }
 __device__ static inline float pm_clamp_f16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 // |max| of a tensor kept as PM_ABSMAX_SLOTS words of float bits (non-negative floats order like their bit patterns)
+// (every lane of the wave must call it: one word per lane, then a wave reduction)
 __device__ static inline float pm_absmax_read(const unsigned* __restrict__ p) {
-  unsigned m = 0u;
-#pragma unroll
-  for (int i = 0; i < PM_ABSMAX_SLOTS; ++i) m = p[i] > m ? p[i] : m;
-  return __uint_as_float(m);
-}
-// a wave's contribution (kernels of many short workgroups, where a barrier at the end would show): one atomic per wave, waves
-// spread over the slots
-__device__ static inline void pm_absmax_wave(unsigned* __restrict__ out, float v) {
-  v = fabsf(v);
+  static_assert(PM_ABSMAX_SLOTS == 64, "one slot per lane");
+  float v = __uint_as_float(p[__lane_id()]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % PM_ABSMAX_SLOTS), __float_as_uint(v));
+  return v;
 }
 // a workgroup's contribution: every thread calls it with its own maximum; `sm` is one LDS word the caller has zeroed in front
 // of an earlier barrier.  One global atomic per workgroup, on slot blockIdx.x % PM_ABSMAX_SLOTS.

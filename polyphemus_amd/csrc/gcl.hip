@@ -27,54 +27,18 @@
 #include "gcl_tiles.h"
 #include <type_traits>
 #include "wide.h"
-#ifndef GCL_TRACE
 #ifndef GCL_PLANE_AUX
 #define GCL_PLANE_AUX 2       // cache policy of the A' plane stores (buffer instruction immediate: bit 0 sc0, bit 1 nt, bit 4 sc1):
-                              // non-temporal — the 100 MB of planes a launch writes are read again only in the backward pass;
+                              // non-temporal — the planes a launch writes are read again only in the backward pass;
                               // step 4.955-4.980 against 4.980-4.998 ms (same box, two runs each; nt + sc1: 4.952-4.970)
-#endif
-#ifndef GCL_WHATIF
-#define GCL_WHATIF 0
 #endif
 #ifndef GCL_DIRECT_EPI
 #define GCL_DIRECT_EPI 1      // k_gcl_fwd stores the h rows and adds the norm's column sums straight from the MFMA accumulators (0: through an LDS stage)
 #endif
 #ifndef GCL_DAGG_PLANE_AUX
-#define GCL_DAGG_PLANE_AUX 0  // cache policy of the dh plane stores of k_gcl_dagg<.., true> (read next by k_gcl_dw): default; 2 (non-temporal) measured below
-#endif
-#ifndef GCL_CONS_STORE
-#define GCL_CONS_STORE 0      // 1: the A' planes leave through the MFMA waves (the fragments they read for k-step ks ARE 16-byte
-                              // pieces of the plane rows; wave ks mod NCW stores them) instead of the producer waves re-reading the
-                              // finished image.  Bit-identical planes, and 126 us per launch against 66: vmcnt retires in order,
-                              // so every weight-fragment wait of the MFMA chain then includes a store's write latency
-#endif
-// development (tools/build_variants.py): GCL_PACE = n puts n x 16 idle issue cycles of the MFMA wave behind every MFMA of
-// k_gcl_fwd, so that the wave does not sit in the SIMD's issue stage with an MFMA the busy matrix pipe cannot take
-#ifndef GCL_PACE
-#define GCL_PACE 0
-#endif
-#if GCL_PACE
-#define GCL_PACE_NOPS(ACC) do { _Pragma("unroll") for (int pz = 0; pz < GCL_PACE; ++pz) asm volatile("s_nop 15" : "+v"(ACC)); } while (0)
-#else
-#define GCL_PACE_NOPS(ACC) do {} while (0)
-#endif
-#define GCL_TRACE 0           // development: workgroup GCL_TRACE - 1 writes s_memtime stamps into col_stats instead of the sums
-#endif
-#if GCL_TRACE
-#define STAMP() do { if (blockIdx.x == (GCL_TRACE - 1) && lane == 0 && (wave == 0 || wave == 4) && nst < 60) \
-    reinterpret_cast<long long*>(g.colstats)[wave * 16 + nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP() do {} while (0)
+#define GCL_DAGG_PLANE_AUX 0  // cache policy of the dh plane stores of k_gcl_dagg<.., true> (read next by k_gcl_dw): default; non-temporal measured slower
 #endif
 
-#ifdef GCL_BLOCKLOG
-// development builds (tools/build_variants.py gcl.hip log=-DGCL_BLOCKLOG): realtime ticks (100 MHz) at the start and end of
-// every workgroup of the last k_gcl_fwd launch, its XCC id and what it worked on
-__device__ long long g_blocklog[1024][4];
-extern "C" int pm_debug_read_blocklog(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blocklog), sizeof(long long) * 1024 * 4) == hipSuccess ? 0 : 1;
-}
-#endif
 namespace {
 constexpr int EMAX = 3;       // edges per (node, relation) gathered in one go (beyond: a serial tail loop)
 #ifndef GCL_NPW
@@ -128,16 +92,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 
   // ---- tile -> (track group, first row): the packed tile list of the grouped GEMM, XCD-contiguous
   PmTile tl;
-#ifdef GCL_BLOCKLOG
-  if (threadIdx.x == 0 && blockIdx.x < 1024) {
-    g_blocklog[blockIdx.x][0] = (long long)__builtin_amdgcn_s_memrealtime();
-    g_blocklog[blockIdx.x][1] = 0;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_blocklog[blockIdx.x][2] = (long long)(xcc & 0xf);
-    g_blocklog[blockIdx.x][3] = -1;
-  }
-#endif
   // H2: the power of two the aggregate is multiplied by before it is split — from the |max| of x and of T, so every
   // workgroup derives the same one: |A'| <= |x|max * max(1, |T|max / (1 - p)) lands in [2^12, 2^13)
   float asc = 1.f, oinv = 1.f;
@@ -147,9 +101,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     if (blockIdx.x == 0 && threadIdx.x == 0) *g.sa_out = asc;          // (the weight gradient of the backward pass undoes it)
   }
   if (!pm_gcl_tile_lookup(g.trk_cnt, g.use_classes, blockIdx.x, tl)) { pm_turn_skip_block(g.gate); return; }
-#ifdef GCL_BLOCKLOG
-  const long long t_sched = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
   const int grp = tl.grp, m0 = tl.m0, rows = tl.rows;        // rows = 64, or 32: half a tile (tile_order.h)
   const bool full = rows > BM / 2;                           // half tiles: the second 32-row block is neither built nor multiplied
   const int M = g.trk_cnt[grp];
@@ -168,12 +119,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // epilogue straight from the accumulators (GCL_DIRECT_EPI); deterministic mode (its gate orders whole workgroups through
   // barriers), the development traces and a launch without the norm's sums keep the LDS-staged epilogue
-  const bool direct_epi = GCL_DIRECT_EPI && !GCL_TRACE && !g.gate;
-  int nst = 0;
-  STAMP();
-#if GCL_TRACE
-  if (blockIdx.x == (GCL_TRACE - 1) && tid == 0) reinterpret_cast<long long*>(g.colstats)[200] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
+  const bool direct_epi = GCL_DIRECT_EPI && !g.gate;
   // ---- prologue (all waves): the rows' nodes; the distance table
   if (tid < BM) {
     const int row = m0 + tid;
@@ -194,19 +140,12 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
       b = g.rowptr[n * PM_N_REL + rel];
       cnt = g.rowptr[n * PM_N_REL + rel + 1] - b;
     }
-#if GCL_WHATIF == 2 || GCL_WHATIF == 6                      // timing what-if (WRONG results): no in-edges at all
-    cnt = 0;
-#endif
     int w[EMAX], id[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
       w[e] = 0; id[e] = 0;
       if (e < cnt) {
-#if GCL_WHATIF == 1                                      // timing what-if (WRONG results): every gather reads the row's own node (cache-hot)
-        w[e] = n | (g.csr_dist[b + e] << 27);
-#else
         w[e] = g.csr_src[b + e] | (g.csr_dist[b + e] << 27);
-#endif
         if (DROP) id[e] = (int)pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[b + e]);   // (the edge's dropout key, once per edge)
       }
     }
@@ -214,8 +153,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     dst[0] = make_int4(w[0], w[1], w[2], cnt);
     dst[1] = make_int4(b, id[0], id[1], id[2]);
   };
-
-  STAMP();
   // ---- producer: aggregate of chunk c into image (c & 1)
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, GCL_OOB, 0x00020000);
   // A' planes of chunk c (kept for the weight gradient of the backward pass): copied from its LDS image, 16 bytes per lane.
@@ -223,7 +160,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   // write latency into the gather's wait.  Rows past the end of the list: out-of-range offset, the store is dropped.
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
   auto store_planes = [&](int c) {
-    if (!g.planes || GCL_WHATIF == 5 || GCL_CONS_STORE) return; // (5: timing what-if without the A' plane stores)
+    if (!g.planes) return;
     const int blk = chunk_blk(c), half = c % NCH;
     const char* img = img0 + (c & 1) * IMG;
     const int pt = tid - NCW * 64, ch = pt & 15, r0 = pt >> 4;        // 16 lanes per row (one 256-byte plane row), 4 rows per wave
@@ -278,9 +215,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
         xs[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, n >= 0 ? (n * D + f) * 4 : GCL_OOB, 0, 0));
       }
       __builtin_amdgcn_sched_barrier(0);
-      STAMP();
       if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
-      STAMP();
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         if constexpr (H2) { xs[ps].x *= asc; xs[ps].y *= asc; xs[ps].z *= asc; xs[ps].w *= asc; }
@@ -303,9 +238,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
             xrs, e < ecnt[ps] ? ((ew[ps][e] & 0x7ffffff) * D + f) * 4 : GCL_OOB, 0, 0));
     }
     __builtin_amdgcn_sched_barrier(0);       // every gather of the chunk is in flight before the first one is waited for
-    STAMP();
     if (c > 0) { store_planes(c - 1); __builtin_amdgcn_sched_barrier(0); }
-    STAMP();
     auto msg = [&](float4 xe, int dist, uint32_t key) {            // key = pm_edge_key(seed, layer, edge id)
       const float4 tv = *reinterpret_cast<const float4*>(sT + dist * D + f);
       float4 m = make_float4(fmaxf(xe.x * tv.x, 0.f), fmaxf(xe.y * tv.y, 0.f), fmaxf(xe.z * tv.z, 0.f),
@@ -337,7 +270,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
         inv = asc;
       }
       put(img, rr, q, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
-      if (ps == 0) STAMP();
     }
     if (redo) {
 #pragma unroll 1
@@ -368,9 +300,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     for (int c = 0; c <= nchunk; ++c) {
       if (c < nchunk) build(c);
       else store_planes(c - 1);
-      STAMP();
       __syncthreads();
-      STAMP();
     }
   } else {
   // ---- consumers (same barrier sequence: one after the first image, one per chunk)
@@ -391,9 +321,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   // (the block offset is wave-uniform: it rides in the instruction's scalar offset, the lane part never changes — no
   //  vector ALU work per load; past the end the last chunk is re-read and never used)
   auto bload = [&](bf16x8 (&dst)[3][TN], int gs) {               // fragments of global k-step gs (16 rows of the weight)
-#if GCL_WHATIF == 3 || GCL_WHATIF == 6                          // timing what-if (WRONG results): the weight fragments are loaded once and kept
-    if (gs >= GCL_BDEPTH) return;
-#endif
     const int c = min(gs >> 3, nchunk - 1), ks = gs & 7;
     const int soff = __builtin_amdgcn_readfirstlane((((krow0(c) >> 4) + ks) * BFN + ct0) * 3072);
 #pragma unroll
@@ -406,19 +333,12 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 #pragma unroll
   for (int s = 0; s < GCL_BDEPTH; ++s) bload(bq[s], s);
   load_metadata();
-  STAMP();
   __syncthreads();
-  STAMP();
   // (two copies of the loop, picked once: a half tile — tile_order.h — has no second 32-row block to multiply)
-  // A' planes (GCL_CONS_STORE): the rows of this lane's fragments and the plane resource
-  const __amdgpu_buffer_rsrc_t cprs = __builtin_amdgcn_make_buffer_rsrc(g.planes, 0, g.planes ? GCL_OOB : 0, 0x00020000);
-  const int cn0 = sNode[li], cn1 = sNode[32 + li];
-  const int cps_b = (int)(g.plane_stride * 2);
   auto consume = [&](auto ni_tag) {
     constexpr int NI = decltype(ni_tag)::value;
     for (int c = 0; c < nchunk; ++c) {
       const char* img = img0 + (c & 1) * IMG;
-      const int pblk = chunk_blk(c), phalf = c % NCH;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         bf16x8 a[3][NI];
@@ -429,16 +349,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
             const int rr = i * 32 + li;
             a[p][i] = *reinterpret_cast<const bf16x8*>(img + p * PLANE + rr * ROWB + (((ks * 2 + lh) ^ (rr & 15)) << 4));
           }
-        if (GCL_CONS_STORE && GCL_WHATIF != 5 && g.planes && (ks % NCW) == wave) {     // (wave-uniform)
-#pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            const int n = i ? cn1 : cn0;
-            const int off = n >= 0 ? (n * 4 * D + pblk * D + phalf * CH + (ks * 2 + lh) * 8) * 2 : GCL_OOB;
-#pragma unroll
-            for (int p = 0; p < NPL; ++p)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a[p][i]), cprs, n >= 0 ? off + p * cps_b : GCL_OOB, 0, GCL_PLANE_AUX);
-          }
-        }
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
 #pragma unroll
         for (int t6 = T60; t6 < 6; ++t6)
@@ -446,18 +356,12 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
           for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-#if GCL_WHATIF == 4                                              // timing what-if (WRONG results): one product of the six
-              { if (t6 == 0) acc[i][j] = gcl_mfma<H2>(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j]); }
-#else
               { acc[i][j] = gcl_mfma<H2>(a[PA[t6]][i], bq[ks % GCL_BDEPTH][PB[t6]][j], acc[i][j]);
-                GCL_PACE_NOPS(acc[i][j]); }
-#endif
+              }
         bload(bq[ks % GCL_BDEPTH], c * 8 + ks + GCL_BDEPTH);
         __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: GCL_BDEPTH k-steps ahead of its use
       }
-      STAMP();
       __syncthreads();
-      STAMP();
     }
   };
   if (full) consume(std::integral_constant<int, 2>{});
@@ -512,7 +416,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
   }
   }
   if (direct_epi) return;                                      // (every wave: nothing of the epilogue below is left to do)
-  STAMP();
   __syncthreads();
   // ---- epilogue (all waves): rows scattered to their nodes, one 4*D-byte row per store; fp64 column sums for the
   // BatchNorm that follows (partial per row group, combined through LDS, one atomic pair per column)
@@ -529,11 +432,7 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
       cs += (double)v; cq += (double)v * (double)v;
     }
   }
-  STAMP();
-#if GCL_TRACE
-  if (blockIdx.x == (GCL_TRACE - 1) && tid == 0) reinterpret_cast<long long*>(g.colstats)[201] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-  if (g.colstats && !GCL_TRACE) {
+  if (g.colstats) {
     double* sS = reinterpret_cast<double*>(sT);                // [NG][2][D] (the distance table is no longer needed)
     if (tid < 512) { sS[(rg * 2) * D + col] = cs; sS[(rg * 2 + 1) * D + col] = cq; }
     __syncthreads();
@@ -546,13 +445,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
     }
     pm_turn_leave_block(g.gate);
   } else pm_turn_skip_block(g.gate);
-#ifdef GCL_BLOCKLOG
-  __syncthreads();
-  if (threadIdx.x == 0 && blockIdx.x < 1024) {
-    g_blocklog[blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime();
-    g_blocklog[blockIdx.x][3] = (long long)(nblk * 100 + rows) + 100000 * (t_sched - g_blocklog[blockIdx.x][0]);   // + ticks spent finding the tile
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -564,16 +456,6 @@ __global__ void __launch_bounds__(gcl_fwd_threads<D>()) __attribute__((amdgpu_wa
 // [track | onset | next | self] (a block = d columns; blocks no row of the tile receives edges of are skipped, as the
 // grouped product skips them), each wave 64 rows by d/4 columns, B fragments straight from the fragment-major
 // transposed weight planes in L2, GCL_DAGG_BDEPTH k-steps ahead.  Same products, same k order as the grouped product.
-#if GCL_TRACE
-__device__ long long g_gcl_trace[256];
-extern "C" int pm_debug_read_trace(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gcl_trace), sizeof(long long) * 256) == hipSuccess ? 0 : 1;
-}
-#define STAMP2() do { if (blockIdx.x == (GCL_TRACE - 1) && lane == 0 && (wave == 0 || wave == 4) && nst < 60) \
-    g_gcl_trace[wave * 16 + nst++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP2() do {} while (0)
-#endif
 // The output never leaves through the MFMA waves: vmcnt retires in order, so 64 row-segment stores in front of the next
 // block's weight-fragment loads would put the write latency into every block.  Waves 4..7 take each finished block
 // from an LDS stage (64 x d fp32) and store it as whole 4*d-byte rows.
@@ -636,8 +518,6 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
   auto blk_of = [&](int q) { return q == 0 ? 0 : (q == nblk - 1 ? 3 : (q == 1 ? (use_on ? 1 : 2) : 2)); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  int nst = 0;
-  STAMP2();
   if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
   if (BNF) {
     for (int c = tid; c < D; c += (NMW + 4) * 64) {
@@ -647,7 +527,6 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
     }
   }
   __syncthreads();
-  STAMP2();
   // H2: dh is multiplied by a power of two before it is split, the same in every workgroup: from |du|max and the largest
   // gamma * rstd, |dh| <= gamma rstd |du|max (2 + |xhat|max); with |xhat| <= 14 the scaled values stay below 2^13 (a
   // standardised value beyond that would still fit fp16 up to |xhat| = 125; the split clamps)
@@ -699,7 +578,6 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
           rv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(urs, node[k] >= 0 ? (node[k] * D + c4 * 4) * 4 : GCL_OOB, 0, 0));
       }
       __syncthreads();                                         // stage holds block qb
-      STAMP2();
       const int blk = blk_of(qb);
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
@@ -708,7 +586,6 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
         if (addq) { f.x += rv[k].x; f.y += rv[k].y; f.z += rv[k].z; f.w += rv[k].w; }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), crs, node[k] >= 0 ? (int)(((int64_t)node[k] * 4 * D + blk * D + c4 * 4) * 4) : GCL_OOB, 0, 0);
       }
-      STAMP2();
     }
     return;
   }
@@ -795,9 +672,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
   bf16x8 bq[BD][3][TN];
 #pragma unroll
   for (int s = 0; s < BD; ++s) bload(bq[s], s);
-  STAMP2();
   __syncthreads();
-  STAMP2();
   // A fragments of k-step ks (both 32-row blocks, three planes); read one step ahead of the MFMAs that use them
   auto aload = [&](bf16x8 (&a)[3][2], int ks) {
 #pragma unroll
@@ -837,9 +712,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
       __builtin_amdgcn_sched_barrier(0);
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    STAMP2();
     __syncthreads();                                             // the store waves have read the previous block
-    STAMP2();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -847,7 +720,6 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * (D / NMW) + j * 32 + li] = H2 ? acc[i][j][r] * dinv : acc[i][j][r];
-    STAMP2();
     __syncthreads();
   }
   };
@@ -861,7 +733,7 @@ static int gcl_input_grad_impl(uint16_t* dh_planes, int64_t plane_stride, const 
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   // MFMA waves per workgroup (+ four store waves): eight at d = 256 (two per SIMD: one wave's fragment waits are covered by
   // its partner's MFMAs, as in wide.hip); A/B: PM_GCL_DAGG_WAVES
-  static const int nmw_env = getenv("PM_GCL_DAGG_WAVES") ? atoi(getenv("PM_GCL_DAGG_WAVES")) : 0;
+  constexpr int nmw_env = 0;
   const int nmw = (d == 256 && nmw_env != 4) ? 8 : 4;
   const dim3 grid(pm_gcl_grid(N)), block((nmw + 4) * 64);
   const size_t lds = (size_t)3 * BM * d * 2 + (size_t)BM * d * 4;
@@ -995,8 +867,6 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
   if (kbeg >= kend) { pm_turn_skip_block(gate, DW_NMW); return; }
   const int* list = trk_list + (int64_t)grp * N + lo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int nst = 0;
-  STAMP2();
   // loaders: thread -> 16-byte chunk ch of rows r0 and r0 + 16 of each tile, three planes, both operands
   const int lt = tid - DW_NMW * 64, ch = lt & 15, r0 = lt >> 4;
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ap), 0, GCL_OOB, 0x00020000);
@@ -1021,7 +891,6 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
     if (s0 > kbeg) __syncthreads();                              // the previous segment's list and tiles are done with
     for (int i = tid; i < nt * DW_KT; i += DW_NTHR) sMap[i] = i < slen ? list[s0 + i] : -1;
     __syncthreads();
-    STAMP2();
     if (wave >= DW_NMW) {
       auto issue = [&](u32x4 (&v)[2][2][3], int t) {
 #pragma unroll
@@ -1064,10 +933,8 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
       }
     } else {
       __syncthreads();                                             // tile 0 staged
-      STAMP2();
 #pragma unroll 1
       for (int t = 0; t < nt; ++t) {
-        if ((t & 7) == 0) STAMP2();
         const char* st = smem + (t & 1) * DW_STAGE;
 #pragma unroll
         for (int ks = 0; ks < DW_KT / 16; ++ks) {
@@ -1093,7 +960,6 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
     }
   }
   if (wave >= DW_NMW) return;
-  STAMP2();
   float oinv = 1.f;                                              // H2: undo the two operand scales (powers of two)
   if constexpr (H2) oinv = 1.f / (sa[0] * sdh[0]);
   pm_turn_enter(gate, blockIdx.x * DW_NMW + wave);
@@ -1109,7 +975,6 @@ k_gcl_dw(const uint16_t* __restrict__ Ap, int64_t aps, const uint16_t* __restric
       for (int j = 0; j < DW_WN; ++j) atomicAdd(crow + j * 32, H2 ? acc[i][j][r] * oinv : acc[i][j][r]);
     }
   pm_turn_leave(gate, blockIdx.x * DW_NMW + wave);
-  STAMP2();
 }
 
 static int gcl_weight_grad_impl(const uint16_t* a_planes, int64_t a_plane_stride, const uint16_t* dh_planes,

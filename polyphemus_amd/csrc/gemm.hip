@@ -892,16 +892,16 @@ static int pick_config(int transA, int M, int N, int K, bool x6_ok = false, bool
   //    TN: 128x64x16 123-155 (77-107).  Small problems stay on the fp32 tiles (fewer, cheaper workgroups).
   //    Inside the training step (row-gathered, grouped launches, one 8-wave workgroup per CU) the gain did not
   //    materialise (10.71 ms against 10.78 ms per step), so split mode is opt-in: PM_GEMM_SPLIT=1 or a forced config.
-  static const bool split_on = getenv("PM_GEMM_SPLIT") && atoi(getenv("PM_GEMM_SPLIT")) > 0;
+  constexpr bool split_on = false;
   // default: the large UNGROUPED NN / NT products (chord encoder / decoder and their input gradients) run in split
   // mode (78-90 us against 99-112 us in the step); weight gradients stay on the fp32 tiles (split mode: 132 against 106 us)
-  static const bool split_ungrouped = !(getenv("PM_GEMM_SPLIT_UNGROUPED") && atoi(getenv("PM_GEMM_SPLIT_UNGROUPED")) == 0);
+  constexpr bool split_ungrouped = true;
   // (N < 128: the 128-wide split tiles would be partly empty — the duration un-embedding, N = 99: 60 us against 46 us on the fp32 tiles)
   // ... since round 4 the large weight gradients too: they now run beside the head chain / in the step's tail, not beside the
   // one-workgroup-per-CU GCL kernels, and there the split tiles win (step 4.892 -> 4.859 ms; PM_GEMM_SPLIT_TN=0: fp32 tiles)
-  static const bool split_tn = !(getenv("PM_GEMM_SPLIT_TN") && atoi(getenv("PM_GEMM_SPLIT_TN")) == 0);
+  constexpr bool split_tn = true;
   if ((split_on || (split_ungrouped && ungrouped && !transA && N >= 128) || (split_tn && transA)) && x6_ok && (double)M * N * K >= 1.0e9) {
-    static const int tn_cfg = getenv("PM_GEMM_TN_CFG") ? atoi(getenv("PM_GEMM_TN_CFG")) : 5;   // (development A/B: 4, 5, 7)
+    constexpr int tn_cfg = 5;   // (development A/B: 4, 5, 7)
     if (transA) return (tn_cfg == 4 || tn_cfg == 7) ? tn_cfg : 5;
     return K >= 1024 ? 7 : 4;
   }
@@ -957,7 +957,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
   // planes mode: 64x64x32 tiles (measured in the step: 128x64x32 85 us, 128x128x32 97-130 us against 70-80 us)
   // B direct (config 9): B given additionally as fragment-major planes; forward / input-gradient products whose tiles
   // are aligned with the fragment grid (and, with row classes, with the 128-wide column tile)
-  static const bool bdirect_on = !(getenv("PM_GEMM_BDIRECT") && atoi(getenv("PM_GEMM_BDIRECT")) == 0);
+  constexpr bool bdirect_on = true;
   const bool bdirect = planes && q->b_frag && bdirect_on && !transA && N % 128 == 0 && K % 32 == 0 && q->ldb % 32 == 0 &&
                        (n_groups == 1 || q->b_split_rows > 0) && q->b_split_rows % 32 == 0 &&
                        (q->b_split_rows == 0 || (q->b_group_stride % q->ldb == 0 && q->b_shared_off % q->ldb == 0)) &&
@@ -992,7 +992,7 @@ extern "C" int pm_gemm_f32_desc(const PmGemmDesc* q, pm_stream_t stream) {
     split_k = 1;
     if (transA && tiles * n_groups < 768) {
       // (768 since the large weight gradients run on the 128x64 split tiles: 4.637 against 4.667 ms per step with 1024; 256: 5.18 ms)
-      static const int tn_target = getenv("PM_GEMM_TN_TARGET") ? atoi(getenv("PM_GEMM_TN_TARGET")) : 768;
+      constexpr int tn_target = 768;
       split_k = (int)(tn_target / (tiles * n_groups));
       const int maxs = (int)pm_cdiv(partitioned ? K / n_groups : K, 8 * BK);
       if (split_k > maxs) split_k = maxs;

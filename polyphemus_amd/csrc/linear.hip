@@ -507,7 +507,7 @@ extern "C" int pm_rows_tn_weight_grad(const float* A, int32_t lda, int32_t M, co
   hipStream_t st = (hipStream_t)stream;
   const int ntm = M / DW_T, ntn = Nn / DW_T, ntile = ntm * ntn;
   // K slices: about one workgroup per CU (the kernel holds one); at least 8 k-tiles per slice
-  static const int target = getenv("PM_ROWS_TN_BLOCKS") ? atoi(getenv("PM_ROWS_TN_BLOCKS")) : 256;
+  constexpr int target = 256;
   int nsplit = (target + ntile - 1) / ntile;
   const int maxs = (int)pm_cdiv(K, 8 * DW_KT);
   if (nsplit > maxs) nsplit = maxs;

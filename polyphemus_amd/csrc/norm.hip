@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_bn_apply1(const float* __restrict__ x, 
   }
 }
 static inline int fused_grid(int64_t n) {      // fewer, longer workgroups: each one first reduces the replicated sums
-  static const int cap = getenv("PM_BN_GRID") ? atoi(getenv("PM_BN_GRID")) : 1024;
+  constexpr int cap = 1024;
   int64_t g = pm_cdiv(n, 256); return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 static inline int ew_grid(int64_t n) { int64_t g = pm_cdiv(n, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
@@ -284,7 +284,7 @@ extern "C" int pm_bn_bwd(const float* x, const float* dy, int32_t O, int32_t C, 
 
 // workgroup size of the two kernels below for O >= 128 rows (PM_BN_SMALL_THREADS: development A/B, profiles/LOG.md)
 static int bn_small_threads() {
-  static const int t = getenv("PM_BN_SMALL_THREADS") ? atoi(getenv("PM_BN_SMALL_THREADS")) : 1024;
+  constexpr int t = 1024;
   return (t == 256 || t == 512) ? t : 1024;
 }
 
@@ -458,10 +458,6 @@ extern "C" int pm_bn_bwd_from_sums(const float* x, const float* dy, int32_t O, i
 // (accumulators are replicated PM_BN_REPL times — the producer picks the replica from its row-panel index — so that
 // no address takes more than ~64 serialized fp64 atomics; consumers add the replicas up once per workgroup into LDS)
 // (pm_repl_sum: common.h)
-#ifndef BN_APPLY_U
-#define BN_APPLY_U 0                      // pieces of x requested ahead of the sums reduction: measured 4.950 (4) / 4.946 (2) against 4.934 ms
-                                          // per step (0) — other workgroups already cover that latency; left off
-#endif
 __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict__ x, int64_t n4, int C, double count,
                                                         const double* __restrict__ sums, BnCtx ctx,
                                                         const float* __restrict__ res, float* __restrict__ y,
@@ -469,22 +465,10 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
                                                         float momentum, unsigned* absmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [3][C]: mean, rstd*gamma, beta
   float amax = 0.f;                                               // max |y| of this thread (absmax != NULL: PmH2.absmax_in of the next layer)
+  __shared__ unsigned s_amax;
+  if (threadIdx.x == 0) s_amax = 0u;                              // (the barrier behind the sums reduction orders it)
   float* const s_m = sm; float* const s_sc = sm + C; float* const s_be = sm + 2 * C;
-  // (BN_APPLY_U > 0: a thread's first pieces of x and of the residual are requested BEFORE the workgroup reduces the
-  //  replicated sums — 16 fp64 loads per column — so that the reduction's latency has loads in flight under it)
-  constexpr int U = BN_APPLY_U;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float4 xq[U > 0 ? U : 1], rq[U > 0 ? U : 1];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int64_t i = i0 + u * stride;
-    xq[u] = make_float4(0.f, 0.f, 0.f, 0.f); rq[u] = xq[u];
-    if (i < n4) {
-      xq[u] = reinterpret_cast<const float4*>(x)[i];
-      if (res) rq[u] = reinterpret_cast<const float4*>(res)[i];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const double mu = pm_repl_sum(sums, 2, C, 0, c) / count;
     double v = pm_repl_sum(sums, 2, C, 1, c) / count - mu * mu;
@@ -517,18 +501,13 @@ __global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict_
     reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (absmax) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   };
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int64_t i = i0 + u * stride;
-    if (i < n4) apply(i, xq[u], rq[u]);
-  }
-  for (int64_t i = i0 + U * stride; i < n4; i += stride) {
+  for (int64_t i = i0; i < n4; i += stride) {
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (res) rv = reinterpret_cast<const float4*>(res)[i];
     apply(i, xv, rv);
   }
-  if (absmax) pm_absmax_wave(absmax, amax);                       // (one atomic per wave, spread over the slots: no barrier in the short workgroups' tail)
+  if (absmax) pm_absmax_block(absmax, amax, &s_amax);            // (uniform branch: every thread of the workgroup calls it; 16 workgroups per slot)
 }
 extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, const double* sums, float eps,
                                         const float* gamma, const float* beta, const float* residual, int relu, float* y,

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) k_segreduce_fwd(const float* __restrict__
 
 // A/B switch: PM_SEG_XCD=0 restores the plain node order of both segment-reduce kernels
 static bool seg_xcd_aware() {
-  static const bool on = !(getenv("PM_SEG_XCD") && atoi(getenv("PM_SEG_XCD")) == 0);
+  constexpr bool on = true;
   return on;
 }
 
@@ -193,20 +193,8 @@ extern "C" int pm_segreduce_fwd_planes(const float* x, const float* T, const int
 // the LDS float atomics, which bound the kernel there — 2.01 -> 0.74 ms per launch at d = 512, 2.08 M edges.  At d = 256 it
 // costs nothing; the d = 512 kernel with the norm sums is at its 128-VGPR budget (12 spilled registers, 85 -> 92 us on
 // sparse graphs), so sparse batches keep the per-edge form there.
-#ifndef SEG_META_AHEAD
-#define SEG_META_AHEAD 0                  // 1: edge metadata of the next trip requested one trip ahead — measured slower (LOG)
-#endif
-#ifndef SEG_WHATIF
-#define SEG_WHATIF 0                      // timing what-ifs (tools/build_variants.py; WRONG results): 1 no table flush, 2 no edge loop, 4 no norm-sum flush
-#endif
 #ifndef SEG_KEEP
 #define SEG_KEEP 1                        // the fused norm's per-column constants in registers (d <= 256); 0: re-read per node (L1)
-#endif
-#ifndef SEG_PREFETCH
-#define SEG_PREFETCH 0                    // 1: rows and CSC offsets of the wave's next node requested one node ahead (d <= 256) — measured
-                                          // 43.5 against 44.2 us per launch with two edges per trip and the norm constants re-read
-                                          // (-DSEG_EPT=2 -DSEG_KEEP=0: no spills), 56.0 with four (20 spilled registers): the kernel is
-                                          // at the row-gather ceiling (profiles/LOG.md), not on the per-node chain; left off
 #endif
 #ifndef SEG_EPT
 #define SEG_EPT 4                         // out-edges of a node whose row gathers are in flight together (k_segreduce_bwd, d <= 256)
@@ -307,46 +295,12 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       for (int j = 0; j < 4; ++j) run[v][j] = 0.f;
     }
   };
-  // NEXT-NODE PREFETCH (d <= 256): a wave walks ~4 nodes one after the other and each node is a chain of dependent
-  // round trips (CSC offsets -> edge words -> row gathers -> store, then the pre-norm row of the fused sums); with 16
-  // waves per CU the chain, not the bandwidth, set the pace (edge loop removed: 24.7 us for 83 MB = 3.4 TB/s).  The rows of
-  // the wave's next node (x, the root block of dA, the residual gradient, the pre-norm row) and its CSC offsets are
-  // requested before the current node's edges are walked, so a node costs the edge-word -> gather chain only.
-  constexpr bool PF = NV == 1 && SEG_PREFETCH;
-  float4 pf_x[NV], pf_a[NV], pf_r[NV], pf_h[NV];
-  int pf_beg = 0, pf_end = 0;
-  auto request = [&](int n, float4 (&qx)[NV], float4 (&qa)[NV], float4 (&qr)[NV], float4 (&qh)[NV], int& qb, int& qe) __attribute__((always_inline)) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      if (!ok[v]) continue;
-      qx[v] = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c[v]);
-      qa[v] = *reinterpret_cast<const float4*>(dA + ((int64_t)n * nblk + (nblk - 1)) * d + c[v]);
-      if (dres) qr[v] = *reinterpret_cast<const float4*>(dres + (int64_t)n * d + c[v]);
-      if (FUSE) qh[v] = *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
-    }
-    qb = colptr[n]; qe = colptr[n + 1];
-  };
-  if (PF) {
-    const int n_first = __builtin_amdgcn_readfirstlane(n_lo + wave);
-    if (n_first < n_hi) request(n_first, pf_x, pf_a, pf_r, pf_h, pf_beg, pf_end);
-  }
   for (int n0 = n_lo; n0 < n_hi; n0 += n_step) {
     const int n = __builtin_amdgcn_readfirstlane(n0 + wave);
     if (n >= n_hi) continue;
-    float4 xv[NV], acc[NV], hcur[NV];
+    float4 xv[NV], acc[NV];
     int beg, end;
-    if (PF) {
-      float4 rcur[NV];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) { xv[v] = pf_x[v]; acc[v] = pf_a[v]; rcur[v] = pf_r[v]; hcur[v] = pf_h[v]; }
-      beg = pf_beg; end = pf_end;
-      const int nnext = n + n_step;                            // (uniform: n is)
-      if (nnext < n_hi) request(nnext, pf_x, pf_a, pf_r, pf_h, pf_beg, pf_end);
-      if (dres) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) { acc[v].x += rcur[v].x; acc[v].y += rcur[v].y; acc[v].z += rcur[v].z; acc[v].w += rcur[v].w; }
-      }
-    } else {
+    {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       if (!ok[v]) continue;
@@ -359,9 +313,8 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     }
     beg = colptr[n]; end = colptr[n + 1];
     }
-    // edge metadata through the scalar cache (p is uniform), requested at the top of their trip.  SEG_META_AHEAD=1 requests
-    // the next trip's words before this trip's rows are gathered: 55.1-55.5 us per launch against 50.5-51.1 (19 spilled
-    // SGPRs, 6 VGPRs, a copy of the words per trip)
+    // edge metadata through the scalar cache (p is uniform), requested at the top of their trip (requesting the next trip's
+    // words ahead measured slower: 55 against 51 us, spilled SGPRs — profiles/LOG.md)
     struct Meta { int dst[EPT], dist[EPT], blk[EPT]; float w[EPT]; uint32_t key[EPT]; };
     auto load_meta = [&](Meta& m, int p) __attribute__((always_inline)) {
 #pragma unroll
@@ -377,11 +330,9 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         m.key[u] = DROP ? pm_edge_key(seed, layer_uid, (uint32_t)csc_eid[q]) : 0u;
       }
     };
-    Meta mt, mn;
-    if (SEG_META_AHEAD && beg < end) load_meta(mt, beg);
-    for (int p = (SEG_WHATIF & 2) ? end : beg; p < end; p += EPT) {                  // EPT edges per trip: their row gathers overlap
-      if (!SEG_META_AHEAD) load_meta(mt, p);
-      else if (p + EPT < end) { load_meta(mn, p + EPT); __builtin_amdgcn_sched_barrier(0); }
+    Meta mt;
+    for (int p = beg; p < end; p += EPT) {                  // EPT edges per trip: their row gathers overlap
+      load_meta(mt, p);
       const int (&dst)[EPT] = mt.dst, (&dist)[EPT] = mt.dist, (&blk)[EPT] = mt.blk;
       const float (&w)[EPT] = mt.w;
       const uint32_t (&key)[EPT] = mt.key;
@@ -428,7 +379,6 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
         }
       }
       cur = dist[EPT - 1];
-      if (SEG_META_AHEAD) mt = mn;
     }
     if (RL) {
 #pragma unroll
@@ -443,7 +393,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
       if (FUSE) {
         if constexpr (NV == 1)     // (d <= 256; the wider variants are at their register budget: their callers take pm_absmax)
           amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[v].x), fabsf(acc[v].y))), fmaxf(fabsf(acc[v].z), fabsf(acc[v].w)));
-        const float4 hv = PF ? hcur[v] : *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
+        const float4 hv = *reinterpret_cast<const float4*>(nn.h + (int64_t)n * d + c[v]);
         const float hs[4] = {hv.x, hv.y, hv.z, hv.w};
         const float ds[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
         float m4[4], r4[4], g4n[4], b4[4];
@@ -490,7 +440,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
   __syncthreads();
   // deterministic mode (common.h): ONE wave per workgroup (its LDS adds are in program order) and the workgroups flush in turn
   pm_turn_enter_block(gate);
-  for (int i = threadIdx.x; i < ((SEG_WHATIF & 1) ? 0 : PM_N_DIST * d); i += blockDim.x) {       // i runs over dT (coalesced atomics)
+  for (int i = threadIdx.x; i < PM_N_DIST * d; i += blockDim.x) {       // i runs over dT (coalesced atomics)
     const int col = i % d;
     const float v = sT[i - col + (col & 3) * dq + (col >> 2)];
     if (v != 0.f) atomicAdd(&dT[i], v);
@@ -518,7 +468,7 @@ __global__ void __launch_bounds__(1024) k_segreduce_bwd(const float* __restrict_
     }
     const int nslot = nwv < 4 ? nwv : 4;
     double* dst = nn.acc3 + (int64_t)(blockIdx.x % PM_BN_REPL) * 3 * d;
-    for (int i = threadIdx.x; i < ((SEG_WHATIF & 4) ? 0 : 3 * d); i += blockDim.x) {
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) {
       double t = 0;
       for (int q = 0; q < nslot; ++q) t += sd[(int64_t)q * 3 * d + i];
       atomicAdd(&dst[i], t);
@@ -555,8 +505,8 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   // (deterministic mode: one wave per workgroup — several waves would race on the LDS table —, 512 workgroups)
   unsigned* const gate = pm_det_gate(st);
   // (PM_SEG_WAVES / PM_SEG_BLOCKS: development overrides of the workgroup shape, profiles/LOG.md)
-  static const int dev_waves = getenv("PM_SEG_WAVES") ? atoi(getenv("PM_SEG_WAVES")) : 0;
-  static const int dev_blocks = getenv("PM_SEG_BLOCKS") ? atoi(getenv("PM_SEG_BLOCKS")) : 0;
+  constexpr int dev_waves = 0;
+  constexpr int dev_blocks = 0;
   const int threads = gate ? 64 : (N >= 4096 ? (dev_waves > 0 && dev_waves <= 16 ? dev_waves * 64 : 1024) : 256);
   int nblk = (int)pm_cdiv(N, threads / 64);
   const int cap = gate ? 512 : (dev_blocks > 0 ? dev_blocks : 256);
@@ -565,7 +515,7 @@ static int segreduce_bwd_impl(const float* x, const float* T, const float* dA, c
   int xcd_nodes = 0;                                    // nodes per XCD, a multiple of the waves per workgroup
   if (seg_xcd_aware() && nblk >= 16 && (nblk & 7) == 0) xcd_nodes = (int)pm_cdiv(pm_cdiv(N, 8), threads / 64) * (threads / 64);
   // private distance rows per wave: as many as fit 144 KB of LDS next to the shared table (default cap 4: measured 42.1 us against 42.5 at 7 and 48.7 without, d = 256)
-  static const int pr_cap = getenv("PM_SEG_PRIV") ? atoi(getenv("PM_SEG_PRIV")) : 4;
+  constexpr int pr_cap = 4;
   int pr = (int)((144 * 1024 / sizeof(float) / d - PM_N_DIST) / (threads / 64));
   if (pr > pr_cap) pr = pr_cap;
   if (pr < 0) pr = 0;

@@ -63,24 +63,24 @@ static StepCfg read_cfg() {
   k.gcl_fused = flag("PM_GCL_FUSED", true);
   k.no_dw = flag("PM_GCL_NO_DW", false);
   k.no_rows_w = flag("PM_NO_ROWS_W", false);
-  k.no_rows_tn = flag("PM_NO_ROWS_TN", false);
-  k.no_unembed_dh = flag("PM_NO_UNEMBED_DH", false);
+  k.no_rows_tn = false;
+  k.no_unembed_dh = false;
   k.no_classes = getenv("PM_GCL_NO_CLASSES") != nullptr;
-  k.no_bfrag = getenv("PM_GCL_NO_BFRAG") != nullptr;
+  k.no_bfrag = false;
   k.fused_ce = flag("PM_FUSED_CE", true);
   k.debug = getenv("PM_DEBUG") != nullptr;
   k.side_stream = getenv("PM_SIDE_STREAM") ? atoi(getenv("PM_SIDE_STREAM")) : 0xffff;
-  k.late_wgrads = flag("PM_LATE_WGRADS", true);
-  k.late_wgrads_at = getenv("PM_LATE_WGRADS") ? atoi(getenv("PM_LATE_WGRADS")) : 1;
-  k.dw_side = flag("PM_DW_SIDE", false);
+  k.late_wgrads = true;
+  k.late_wgrads_at = 1;
+  k.dw_side = false;
   k.dagg_bn = flag("PM_DAGG_BN", true);
   k.plan_side = flag("PM_PLAN_SIDE", true);
   k.chord_tables = flag("PM_CHORD_TABLES", true);
-  k.dagg_res = flag("PM_DAGG_RES", false);
+  k.dagg_res = flag("PM_DAGG_RES", true);
   k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.h2 = flag("PM_H2", true);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
-  k.dense_deg = getenv("PM_DENSE_DEG") ? atoi(getenv("PM_DENSE_DEG")) : 16;
+  k.dense_deg = 16;
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
 }
@@ -211,7 +211,6 @@ static Branch* branch_of_device() {
     // workgroup per CU and must not queue behind a 2048-workgroup convolution)
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-    if (getenv("PM_SIDE_PRIO")) lo = atoi(getenv("PM_SIDE_PRIO"));
     b.ok = hipStreamCreateWithPriority(&b.st, hipStreamNonBlocking, lo) == hipSuccess;
     for (int i = 0; i < BR_SITES && b.ok; ++i)
       b.ok = hipEventCreateWithFlags(&b.fork[i], hipEventDisableTiming) == hipSuccess &&
@@ -361,7 +360,7 @@ static bool gcl_fused_on() { return cfg().gcl_fused; }
 // 400 against 449 us per launch at d = 512, but 140 against 117 us at d = 256 — there the loaders' split arithmetic (5.5
 // vector instructions per element, on the SIMDs the MFMA waves run on) costs more than the fp32 matrix pipe loses
 static bool rows_tn_pays(int d) {
-  static const int min_d = getenv("PM_ROWS_TN_MIN_D") ? atoi(getenv("PM_ROWS_TN_MIN_D")) : 512;   // (development A/B)
+  constexpr int min_d = 512;   // (development A/B)
   return !cfg().no_rows_tn && d >= min_d && d % 128 == 0;
 }
 // widths the kernels of gcl.hip / linear.hip (128, 256) and wide.hip (512) cover

@@ -569,7 +569,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
 namespace {
 // producer waves of the variants (A/B switch PM_WIDE_NPW=4|8, read once)
 int wide_npw(int dflt) {
-  static const int v = getenv("PM_WIDE_NPW") ? atoi(getenv("PM_WIDE_NPW")) : 0;
+  constexpr int v = 0;
   return (v == 4 || v == 8) ? v : dflt;
 }
 template <int VAR, bool DROP, int NPW, int BKIND, bool H2 = false>

@@ -317,7 +317,7 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline_subprocess(cfg, timeout_s=240):
+def cpu_baseline_subprocess(cfg, timeout_s=300):
     """Run the CPU leg in a child process (never touches the GPU) under a hard timeout."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--d", str(cfg["d"]), "--n-bars",
@@ -340,6 +340,9 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     rate = cpu_baseline_at(cfg, 64, seconds_budget)
     small = cpu_baseline_at(cfg, 8, seconds_budget / 4)
     rate["configs0_B8"] = {"value": small["value"], "unit": small["unit"], "sample": small["sample"]}
+    if cfg["d"] != 512:            # ... and the reference's own width (training.json: d = 512), B = 32, beside the d = 512 GPU workload
+        wide = cpu_baseline_at(dict(cfg, d=512), 32, seconds_budget / 2)
+        rate["training_json_d512_B32"] = {"value": wide["value"], "unit": wide["unit"], "sample": wide["sample"]}
     return rate
 
 

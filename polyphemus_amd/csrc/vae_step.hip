@@ -132,6 +132,7 @@ struct GcnSaved {
   // mdu[i * PM_ABSMAX_SLOTS ..] = of the gradient arriving at layer i's norm; sA[i] / sdh[i] = the scales the layer's A' / dh
   // planes were written with
   bool h2; uint32_t* mx; uint32_t* mdu; float* sA; float* sdh;
+  const float* x0_src; int64_t x0_src_n;   // optional: a smaller tensor with the same |max| as the stack's input (its rows are copies)
 };
 constexpr float kH2WScale = 16.f;        // weight planes of the fp16 pair format: W * 2^4 (glorot-range weights land around 1)
 
@@ -492,7 +493,11 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     const bool from_planes = gcl_kernels && dense && d == 512;
     const bool x_tracked = sv.h2 && i > 0 && !(c.pdrop > 0.f);   // (the norm apply of layer i-1 left |x|max in mx[i])
     if (fused && sv.h2) {
-      if (!x_tracked) RUN(pm_absmax(sv.xin[i], (int64_t)N * d, sv.mx + i * PM_ABSMAX_SLOTS, c.st));
+      if (!x_tracked) {
+        // (the decoder's first input is the bar vectors broadcast to their nodes: the [G, d] source has the same |max|)
+        if (i == 0 && sv.x0_src && !(c.pdrop > 0.f)) RUN(pm_absmax(sv.x0_src, sv.x0_src_n, sv.mx, c.st));
+        else RUN(pm_absmax(sv.xin[i], (int64_t)N * d, sv.mx + i * PM_ABSMAX_SLOTS, c.st));
+      }
       PmH2 h2;
       h2.absmax_in = sv.mx + i * PM_ABSMAX_SLOTS; h2.absmax_aux = sv.mx + c.L * PM_ABSMAX_SLOTS; h2.scale_out = sv.sA + i;
       h2.w_scale = kH2WScale; h2.reserved = 0;
@@ -931,6 +936,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
   };
   if (run) branch_join(c, BR_WPREP_DEC);               // the decoder's weight planes and distance table are ready
+  s.dg.x0_src = s.cb; s.dg.x0_src_n = (int64_t)Gn * d;
   float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
   if (run) structure_decoder();
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head

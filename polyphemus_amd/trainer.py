@@ -50,6 +50,20 @@ class ExpDecayLR:
         return self.peak_lr * math.exp(-self.decay_factor * (self.update_steps - self.warmup_steps))
 
 
+def bucket_boundaries(vae: VAE):
+    """Element offsets that split the flat gradient buffer into the three exchange buckets, in flat order: 0 = structure encoder
+    + embeddings + chord encoder (final last: behind `pm_vae_step_backward_encoder_tail`), 1 = graph encoder .. end of the
+    encoder (final behind `pm_vae_step_backward_encoder`), 2 = decoder (final behind the decoder backward and the join of its
+    weight gradients).  Asserts the parameter order the native split relies on."""
+    dec_lo = vae._offsets[vae._names("decoder.")[0]]
+    mid_lo = vae._offsets[vae._names("encoder.c_encoder.graph_encoder.")[0]]
+    for n in vae._names("encoder."):
+        late = n.startswith(("encoder.s_encoder.", "encoder.c_encoder.non_drums", "encoder.c_encoder.drums",
+                             "encoder.c_encoder.dur_emb", "encoder.c_encoder.bn_", "encoder.c_encoder.chord_encoder"))
+        assert (vae._offsets[n] < mid_lo) == late, f"unexpected parameter order at {n}"
+    return [mid_lo, dec_lo]
+
+
 class HipTrainer:
     def __init__(self, vae: VAE, lr=5e-6, betas=(0.9, 0.98), eps=1e-9, lr_scheduler: Optional[dict] = None,
                  structure_loss_on_logits: bool = False, beta: float = 0.0, process_group=None, native: bool = True,
@@ -102,15 +116,7 @@ class HipTrainer:
                 head, tail = k.split(".layers.0.nn.")
                 for i in range(1, vae.cfg["gnn_n_layers"]):
                     self._G[f"{head}.layers.{i}.nn.{tail}"] = self._G[k]
-        # gradient buckets in flat order: 0 = structure encoder + embeddings + chord encoder (final last),
-        # 1 = graph encoder .. end of the encoder (final after the first half of the encoder backward), 2 = decoder
-        dec_lo = vae._offsets[vae._names("decoder.")[0]]
-        mid_lo = vae._offsets[vae._names("encoder.c_encoder.graph_encoder.")[0]]
-        for n in vae._names("encoder."):                              # the layout the native split relies on
-            late = n.startswith(("encoder.s_encoder.", "encoder.c_encoder.non_drums", "encoder.c_encoder.drums",
-                                 "encoder.c_encoder.dur_emb", "encoder.c_encoder.bn_", "encoder.c_encoder.chord_encoder"))
-            assert (vae._offsets[n] < mid_lo) == late, f"unexpected parameter order at {n}"
-        self.buckets = GradBuckets(self.grads, [mid_lo, dec_lo], process_group)
+        self.buckets = GradBuckets(self.grads, bucket_boundaries(vae), process_group)
         self.world = self.buckets.world
         # gradient accumulation: running sum of grads / k; all-reduced (one bucket) and consumed by Adam every k-th batch
         self.grad_accum = torch.zeros_like(flat) if self.iters_to_accumulate > 1 else None

@@ -188,3 +188,36 @@ def test_device_loader_world8_shards(n, world, bs):
     seen = np.concatenate([np.concatenate(p) for p in plans])
     assert set(seen.tolist()) == set(range(n))
     assert len(seen) - n == per_rank * world - n                                   # only the wrapped tail repeats
+
+
+@pytest.mark.parametrize("d,nb", [(512, 16), (256, 2)])
+def test_gradient_buckets_cover_the_flat_buffer_exactly(d, nb):
+    """The three exchange buckets of the data-parallel step (trainer.bucket_boundaries; BASELINE configs[3] / configs[4] at
+    d = 512 with 16 bars: 56.9 M parameters, 228 MB) partition the flat gradient buffer: contiguous, disjoint, complete,
+    16-byte-aligned starts (RCCL's vector loads), and every parameter's gradient lies in the bucket whose backward call makes
+    it final — host-side arithmetic, no GPU."""
+    import torch
+    from polyphemus_amd.model import VAE
+    from polyphemus_amd.parallel import GradBuckets
+    from polyphemus_amd.trainer import bucket_boundaries
+    vae = VAE(dropout=0, batch_norm=True, gnn_n_layers=8, d=d, n_bars=nb, resolution=8, device=torch.device("cpu"))
+    flat = torch.zeros(vae.flat_params.numel())
+    bounds = bucket_boundaries(vae)
+    gb = GradBuckets(flat, bounds)
+    assert len(gb.views) == 3 and sum(v.numel() for v in gb.views) == flat.numel()
+    edges = [0] + list(bounds) + [flat.numel()]
+    assert edges == sorted(edges) and len(set(edges)) == 4
+    for k, v in enumerate(gb.views):
+        assert v.data_ptr() == flat.data_ptr() + 4 * edges[k] and edges[k] % 4 == 0      # contiguous; 16-byte aligned start
+        v.fill_(float(k + 1))
+    assert float(flat.min()) == 1.0 and int((flat == 0).sum()) == 0                      # nothing left uncovered
+    P = dict(vae.named_parameters())
+    for n in vae._param_names:
+        lo, hi = vae._offsets[n], vae._offsets[n] + P[n].numel()
+        k = 2 if n.startswith("decoder.") else (1 if lo >= bounds[0] else 0)
+        assert edges[k] <= lo and hi <= edges[k + 1], n                                   # no parameter straddles a boundary
+        if n.startswith(("encoder.c_encoder.graph_encoder.", "encoder.c_encoder.graph_attention.", "encoder.c_encoder.bars_encoder.",
+                         "encoder.linear_", "encoder.bn_linear_merge.")):
+            assert k == 1, n
+    if (d, nb) == (512, 16):
+        assert flat.numel() * 4 > 225e6                                                   # SURVEY 8(e): 228 MB exchanged per step

@@ -1385,3 +1385,128 @@ def test_relu_bwd_planes_matches_torch_and_the_plane_split():
     assert torch.equal(only, planes)
     with pytest.raises(Exception):
         call("pm_relu_bwd_planes", ptr(dy), ptr(h), n - 1, ptr(dh), None, 0, stream())      # n % 4 != 0
+
+
+# ---- the fp16 pair operand format of the GCL products (PmH2, include/polyphemus_hip.h) --------------------------------------
+import ctypes as _ct
+
+
+class _PmH2(_ct.Structure):
+    _fields_ = [("absmax_in", _ct.c_void_p), ("absmax_aux", _ct.c_void_p), ("scale_out", _ct.c_void_p), ("w_scale", _ct.c_float),
+                ("reserved", _ct.c_int32)]
+
+
+def _absmax_words(t):
+    w = torch.zeros(64, dtype=torch.int32, device=t.device)
+    call("pm_absmax", ptr(t), t.numel(), ptr(w), stream())
+    return w
+
+
+def _pair_value(planes, scale):
+    """[2 or 3, n] int16 planes in the fp16 pair format -> fp64 values"""
+    return (planes[0].view(torch.float16).double() + planes[1].view(torch.float16).double()) / float(scale)
+
+
+@pytest.mark.parametrize("d,p,xs,gs", [(128, 0.0, 1.0, 1.0), (256, 0.1, 37.0, 1e-6), (256, 0.0, 1e-3, 1e3), (512, 0.1, 5.0, 1e-5),
+                                       (256, 0.1, "split", 1e-4)])
+def test_gcl_products_in_the_fp16_pair_format(d, p, xs, gs):
+    """The three GCL products on fp16 pair operands (v * 2^k = hi + lo, three MFMA products per fp32 product; PmH2) against the
+    same kernels on the exact bf16 triple and against fp64, over operand magnitudes from 1e-6 to 1e3 (`xs`: scale of the layer
+    input, `gs`: of the incoming gradient — the power-of-two scales come from the tensors' |max| words):
+      * `pm_absmax`: the 64 words hold max |x| exactly;
+      * forward: h to 5e-6 of both; the A' planes decode (hi + lo) / scale to the triple's exact aggregate within 2^-21 of its |max|;
+      * input gradient (d <= 256: norm backward inside, `pm_gcl_input_grad_bn_h2`; d = 512: `pm_bn_bwd_fused_h2` +
+        `pm_gcl_input_grad_fused_h2`): dA' to 5e-6, the dh planes decode to the triple's dh within 2^-21 of |max|;
+      * weight gradient from the two pair-format planes: 3e-6 of an fp64 contraction of the decoded operands."""
+    if xs == "split":                  # 258 row tiles for 256 CUs: half tiles (csrc/tile_order.h)
+        cpu, xs = synthetic_batch(256, 2, p=0.25, seed=1235), 3.0
+    else:
+        cpu = synthetic_batch(40, 2, p=0.3, seed=29)
+    b, plan = make_plan(cpu)
+    N, dd = cpu.num_nodes, d * d
+    torch.manual_seed(11)
+    x = torch.randn(N, d, device=DEV) * xs
+    T = ops.edge_table(torch.randn(d, 32, device=DEV) * 0.5, torch.randn(d, device=DEV) * 0.1)
+    W = torch.randn(7 * d, d, device=DEV) / d ** 0.5
+    bias = torch.randn(d, device=DEV) * xs
+    WS = 16.0
+    Wf3, Wft3 = ops.split_planes_frag(W, 1), ops.split_planes_frag(W, 0)
+    Wf2, Wft2 = torch.zeros_like(Wf3), torch.zeros_like(Wft3)
+    for kind, dst in ((1, Wf2), (0, Wft2)):
+        call("pm_split_planes_frag_h2", ptr(W), 7 * d, d, kind, 1, 7 * dd, 7 * dd * 3, WS, ptr(dst), stream())
+    mx, mt = _absmax_words(x), _absmax_words(T)
+    assert float(mx.view(torch.float32).max()) == float(x.abs().max()) and float(mt.view(torch.float32).max()) == float(T.abs().max())
+    # ---- forward
+    P3 = torch.zeros(3, N * 4 * d, dtype=torch.int16, device=DEV)
+    h3 = ops.gcl_forward_fused(x, T, plan, p, 5, 2, Wf3, bias, planes=P3)
+    P2 = torch.zeros(3, N * 4 * d, dtype=torch.int16, device=DEV)
+    sA = torch.zeros(1, device=DEV)
+    s2 = torch.zeros(8, 2, d, dtype=torch.float64, device=DEV)
+    h2 = torch.empty(N, d, device=DEV)
+    hh = _PmH2(ptr(mx), ptr(mt), ptr(sA), WS, 0)
+    call("pm_gcl_forward_fused_h2", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, ptr(Wf2), ptr(bias), 1, ptr(h2),
+         ptr(s2), ptr(P2), N * 4 * d, _ct.addressof(hh), stream())
+    A3 = _planes_value(P3).double()
+    A2 = _pair_value(P2, float(sA))
+    sa = float(sA)
+    assert sa > 0 and np.log2(sa) == round(np.log2(sa)) and 2.0 ** 9 <= float(A3.abs().max()) * sa < 2.0 ** 13
+    assert float((A2 - A3).abs().max()) <= 2.0 ** -21 * float(A3.abs().max())
+    assert rel_err(h2, h3) < 5e-6
+    trel_t = plan.field("node_trel").long()[:N]
+    Wn = torch.stack([torch.cat([W[t * d:(t + 1) * d], W[4 * d:]]) for t in range(4)]).double()
+    assert rel_err(h2, torch.einsum("nk,nkj->nj", A3.view(N, 4 * d), Wn[trel_t]) + bias.double()) < 5e-6
+    assert rel_err(s2.sum(0)[0], h2.double().sum(0)) < 1e-12
+    assert P2[2].abs().max() == 0                                      # plane 2 is not part of the format
+    # ---- input gradient with the norm backward
+    hpre = torch.randn(N, d, device=DEV) * 1.5 + 0.3
+    du = torch.randn(N, d, device=DEV) * gs
+    gamma, beta = torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV) * 0.2
+    mean, var = hpre.mean(0), hpre.var(0, unbiased=False)
+    acc3 = ops.bn_bwd_sums(hpre, du, mean, var, gamma, beta)
+    mdu = _absmax_words(du)
+    sdh = torch.zeros(1, device=DEV)
+    dA2 = torch.full((N, 4 * d), float("nan"), device=DEV)
+    D2 = torch.zeros(3, N * d, dtype=torch.int16, device=DEV)
+    hb = _PmH2(ptr(mdu), None, ptr(sdh), WS, 0)
+    if d <= 256:
+        dA3, D3 = ops.gcl_input_grad_bn(hpre, du, mean, var, gamma, beta, acc3, plan, Wft3)
+        nb = ops._BnBwd(ptr(hpre), ptr(du), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(acc3), None, None, None, 1e-5, 1, 0, 0)
+        call("pm_gcl_input_grad_bn_h2", _ct.addressof(nb), ptr(D2), N * d, ptr(plan.buf), N, plan.E, plan.G, d, ptr(Wft2), 1, ptr(dA2),
+             _ct.addressof(hb), stream())
+    else:
+        D3 = torch.zeros(3, N * d, dtype=torch.int16, device=DEV)
+        call("pm_bn_bwd_fused", ptr(hpre), ptr(du), N, d, ptr(mean), ptr(var), 1e-5, ptr(gamma), ptr(beta), 1, None, None, None, None,
+             ptr(acc3), ptr(D3), N * d, 1, stream())
+        dA3 = ops.gcl_input_grad_fused(D3, plan, d, Wft3)
+        call("pm_bn_bwd_fused_h2", ptr(hpre), ptr(du), N, d, ptr(mean), ptr(var), 1e-5, ptr(gamma), ptr(beta), 1, None, None, None,
+             ptr(acc3), ptr(D2), N * d, 1, _ct.addressof(hb), stream())
+        call("pm_gcl_input_grad_fused_h2", ptr(D2), N * d, ptr(plan.buf), N, plan.E, plan.G, d, ptr(Wft2), 1, ptr(dA2), ptr(sdh), WS,
+             stream())
+    dh3 = _planes_value(D3).double()
+    dh2 = _pair_value(D2, float(sdh))
+    assert 2.0 ** 4 <= float(dh3.abs().max()) * float(sdh) < 2.0 ** 15     # inside fp16's window with room on both sides
+    assert float((dh2 - dh3).abs().max()) <= 2.0 ** -21 * float(dh3.abs().max())
+    dst, et = cpu.edge_index[1], cpu.edge_type
+    on, nx = torch.zeros(N, dtype=torch.bool), torch.zeros(N, dtype=torch.bool)
+    on[dst[et == 4]] = True
+    nx[dst[et == 5]] = True
+    keep = torch.ones(N, 4, d, dtype=torch.bool)
+    keep[~on, 1] = False
+    keep[~nx, 2] = False
+    keep = keep.view(N, 4 * d).to(DEV)
+    assert rel_err(dA2[keep], dA3[keep]) < 5e-6
+    # ---- weight gradient from the two pair-format plane sets
+    base = torch.randn(7 * d, d, device=DEV) * xs * gs
+    dW2 = base.clone()
+    call("pm_gcl_weight_grad_fused_h2", ptr(P2), N * 4 * d, ptr(D2), N * d, ptr(plan.buf), N, plan.E, plan.G, d, 1, ptr(dW2), ptr(sA),
+         ptr(sdh), stream())
+    A2v, trel = A2.view(N, 4 * d), trel_t
+    A2v = torch.where(keep, A2v, torch.zeros_like(A2v))               # (blocks the forward does not write for a row are zero aggregates)
+    want = base.double().clone()
+    dh2v = dh2.view(N, d)
+    for t in range(4):
+        rows = trel == t
+        want[t * d:(t + 1) * d] += A2v[rows, :d].T @ dh2v[rows]
+    want[4 * d:] += A2v[:, d:].T @ dh2v
+    scale = float((want - base.double()).abs().max())
+    assert float((dW2.double() - want).abs().max()) < 3e-6 * scale

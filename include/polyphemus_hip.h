@@ -53,7 +53,7 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra).
  *   7: round 5 (the fp16 pair operand format: PmH2, pm_absmax, pm_split_planes_frag_h2, pm_gcl_forward_fused_h2,
  *   pm_gcl_input_grad_bn_h2, pm_gcl_weight_grad_fused_h2; PmNormSums.absmax_out; pm_bn_apply_fused_absmax; pm_vae_step_set_output_grads: the drop-in module's
- *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads). */
+ *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads; pm_deterministic_faults). */
 #define PM_ABI_VERSION 7
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -68,6 +68,11 @@ const char* pm_build_info(void);
  * for parity tests and debugging.  Host calls, no GPU work. */
 int pm_set_deterministic(int32_t on);
 int pm_get_deterministic(void);
+/* Faults of the mode since the library was loaded (synchronises the device; < 0: could not be read): gates that could not be set
+ * up (the launch ran un-gated) + waves that gave up waiting for their turn after 4 s and went ahead unordered.  0 = every gated
+ * launch so far was ordered.  While the mode is on the step keeps every launch on the caller's stream (two gated kernels on two
+ * streams could starve each other's turns). */
+int pm_deterministic_faults(void);
 
 /* ------------------------------------------------------------------ graph plan
  * Replaces the per-layer boolean-mask edge selection `edge_index[:, edge_type == i]`
@@ -882,6 +887,11 @@ int pm_bn_relu_decisions(const float* x /* [rows,C] */, const float* mean, const
  * gradients of the step's own loss kernels. */
 int pm_vae_step_set_output_grads(void* state, const float* d_s_logits /* [G,4,32] */, const float* d_c_logits /* [N,S,230] */,
                                  const float* d_mu /* [B,d] */, const float* d_log_var /* [B,d] */, pm_stream_t stream);
+/* ORDERING CONTRACT of the decoder's gradients: pm_vae_step_backward_decoder returns with the weight gradients of the decoder's
+ * head (un-embeddings, chord decoder, the two head products) still running on the library's second stream, NOT yet joined to
+ * `stream`.  They are final for the caller only behind pm_vae_step_join_decoder_grads, pm_vae_step_backward_encoder_heads or
+ * pm_vae_step_backward_encoder (each makes `stream` wait for them).  A host that reads, synchronises on, or all-reduces the
+ * decoder's gradients directly after this call MUST call pm_vae_step_join_decoder_grads first. */
 int pm_vae_step_backward_decoder(void* state, pm_stream_t stream);
 /* Data parallel: the weight gradients of the decoder's head run on the library's second stream beside the head chain and
  * are joined inside pm_vae_step_backward_encoder; a caller that hands the decoder's gradient bucket to an all-reduce

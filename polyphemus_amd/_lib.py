@@ -144,6 +144,7 @@ _SIGS = {
     "pm_bn_apply_fused_absmax": "piipfpppipppppfps",
     "pm_set_deterministic": "i",
     "pm_get_deterministic": "",
+    "pm_deterministic_faults": "",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
@@ -232,3 +233,26 @@ def set_deterministic(on: bool) -> None:
 
 def is_deterministic() -> bool:
     return bool(lib().pm_get_deterministic())
+
+
+def deterministic_faults() -> int:
+    """Gates that could not be set up + waves that timed out waiting for their turn since the library was loaded; 0 = every
+    gated launch was ordered (synchronises the device)."""
+    return int(lib().pm_deterministic_faults())
+
+
+class deterministic:
+    """`with deterministic(True): ...` — the mode for the block, the previous mode restored afterwards (a process started with
+    PM_DETERMINISTIC=1 stays in it)."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = is_deterministic()
+        set_deterministic(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        set_deterministic(self.prev)
+        return False

@@ -85,6 +85,9 @@ __host__ __device__ static inline uint32_t pm_keep_threshold(float p) {
 // pm_det_gate(stream): nullptr when the mode is off, otherwise a counter cleared on `stream` ahead of the launch.
 unsigned* pm_det_gate(hipStream_t st);
 int pm_det_on();
+// device word of gate time-outs (a wave that gave up waiting for its turn after 4 s went ahead UNORDERED: the run is then not
+// bit-reproducible); read back, together with the host's count of gates that could not be set up, by pm_deterministic_faults()
+unsigned* pm_det_fault_word();
 
 #ifdef __HIPCC__
 __device__ static inline unsigned pm_linear_block() {
@@ -96,6 +99,7 @@ __device__ static inline unsigned pm_linear_thread() {
 // one lane polls, with a back-off that grows with the distance to its turn (thousands of waves polling one line as fast
 // as they can slow down the very workgroup they are waiting for: 65 us per turn measured, ~4 with the back-off);
 // bounded: a lost turn must not hang the device — after 4 s (s_memrealtime counts at 100 MHz) the wave goes ahead unordered
+// (a gate is 16 words: word 0 the turn counter, word 1 counts the waves that timed out on it)
 __device__ static inline void pm_gate_spin(unsigned* gate, unsigned turn) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
@@ -104,7 +108,7 @@ __device__ static inline void pm_gate_spin(unsigned* gate, unsigned turn) {
     unsigned dist = turn - cur;
     if (dist > 48u) dist = 48u;
     for (unsigned i = 0; i < dist; ++i) __builtin_amdgcn_s_sleep(48);          // ~1.5 us per unit of distance
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) return;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { atomicAdd(gate + 1, 1u); return; }   // counted: pm_deterministic_faults
   }
 }
 // WAVE-level turn (waves that reach the ordered section independently, e.g. consumer waves of a specialised kernel)

@@ -14,6 +14,7 @@ struct Pool { unsigned* base; unsigned next; bool tried; };
 Pool g_pool[16];
 std::mutex g_mu;
 int g_on = -1;                                // -1: read PM_DETERMINISTIC at first use
+int g_null_gates = 0;                         // gates that could not be set up while the mode was on (the launch ran un-gated)
 }
 
 extern "C" int pm_get_deterministic(void) {
@@ -31,18 +32,37 @@ int pm_det_on() { return pm_get_deterministic(); }
 unsigned* pm_det_gate(hipStream_t st) {
   if (!pm_get_deterministic()) return nullptr;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { std::lock_guard<std::mutex> lock(g_mu); ++g_null_gates; return nullptr; }
   unsigned* g = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_mu);
     Pool& p = g_pool[dev];
     if (!p.tried) {
       p.tried = true;
-      if (hipMalloc((void**)&p.base, kGates * 64) != hipSuccess) p.base = nullptr;   // one gate per 64 bytes
+      if (hipMalloc((void**)&p.base, kGates * 64) != hipSuccess || hipMemset(p.base, 0, kGates * 64) != hipSuccess) p.base = nullptr;   // one gate per 64 bytes
     }
-    if (!p.base) return nullptr;
+    if (!p.base) { ++g_null_gates; return nullptr; }
     g = p.base + (size_t)(p.next++ % kGates) * 16;
   }
-  if (hipMemsetAsync(g, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(g, 0, sizeof(unsigned), st) != hipSuccess) { std::lock_guard<std::mutex> lock(g_mu); ++g_null_gates; return nullptr; }
   return g;
+}
+// Faults of the deterministic mode since the library was loaded (synchronises the device): gates that could not be set up +
+// waves that gave up waiting for their turn (word 1 of every gate of the pool; cleared only with the pool).  0 = every gated
+// launch so far was ordered, i.e. the runs were bit-reproducible.
+extern "C" int pm_deterministic_faults(void) {
+  int total;
+  unsigned* base[16];
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    total = g_null_gates;
+    for (int d = 0; d < 16; ++d) base[d] = g_pool[d].base;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !base[dev]) return total;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  static unsigned host[kGates * 16];
+  if (hipMemcpy(host, base[dev], sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int g = 0; g < kGates; ++g) total += (int)host[g * 16 + 1];
+  return total;
 }

@@ -229,7 +229,9 @@ __global__ void k_spin_us(int us) {
 struct BranchScope {
   Ctx& c; hipStream_t main; double* scratch_main; Branch* b; int site;
   BranchScope(Ctx& c_, int site_) : c(c_), main(c_.st), scratch_main(c_.bn_scratch), b(nullptr), site(site_) {
-    if (!c.s->ar.base || site_ >= BR_SITES || !(cfg().side_stream & (1 << site_))) return;
+    // (deterministic mode: one stream — two gated kernels on two streams could each fill an XCD with waves waiting for a turn
+    //  that belongs to a workgroup the other has not let in)
+    if (!c.s->ar.base || site_ >= BR_SITES || !(cfg().side_stream & (1 << site_)) || pm_det_on()) return;
     b = branch_of_device();
     if (!b) return;
     if (hipEventRecord(b->fork[site], main) != hipSuccess || hipStreamWaitEvent(b->st, b->fork[site], 0) != hipSuccess) {
@@ -1377,7 +1379,7 @@ extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
   info[3] = (s->eg.Wfn && s->dg.Wfn) ? 1 : 0;          // fragment-major weight planes built (B-direct GEMM mode available)
   info[4] = c.N; info[5] = c.E; info[6] = c.Gn; info[7] = c.B;
   // the EFFECTIVE switches (read from the environment at load / pm_vae_step_reload_switches, not at call time)
-  info[8] = cfg().fused_ce ? 1 : 0; info[9] = cfg().side_stream; info[10] = pm_det_on(); info[11] = cfg().gcl_fused ? 1 : 0;
+  info[8] = cfg().fused_ce ? 1 : 0; info[9] = pm_det_on() ? 0 : cfg().side_stream; info[10] = pm_det_on(); info[11] = cfg().gcl_fused ? 1 : 0;
   info[12] = cfg().dagg_bn ? 1 : 0;            // (the norm backward of the GCN layers inside the input gradient kernel)
   info[13] = s->chord_tab;                      // (the chord encoder as table algebra)
   info[14] = (s->eg.h2 ? 1 : 0) | (s->dg.h2 ? 2 : 0);     // (the GCL products of the encoder / decoder stack in the fp16 pair format)

@@ -37,11 +37,12 @@ def run_steps(cfg, batch, eps, native=True, steps=2, fix=False, msg_dropout=0.1,
 
 @pytest.fixture
 def deterministic():
-    _lib.set_deterministic(True)
-    try:
+    """the mode for one test (the previous mode restored: a process started with PM_DETERMINISTIC=1 stays in it); afterwards no
+    gate may have failed to set up and no wave may have timed out on its turn — either would make the run silently unordered"""
+    faults0 = _lib.deterministic_faults()
+    with _lib.deterministic(True):
         yield
-    finally:
-        _lib.set_deterministic(False)
+        assert _lib.deterministic_faults() == faults0, "a gated launch ran unordered (gate time-out or null gate)"
 
 
 def assert_bit_identical(a, b):

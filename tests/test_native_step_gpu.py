@@ -518,7 +518,9 @@ def test_loss_trajectory_follows_the_fp64_oracle():
     print("kld trajectory  HIP:", [round(h["kld"], 3) for h in hip], " fp64 oracle:", [round(o["kld"], 3) for o in ora])
     assert max(o["kld"] for o in ora) > 10.0 * ora[0]["kld"], [o["kld"] for o in ora]         # the oracle's own transient
     # (the sixth step of this transient moves with the rounding of the step: 316 .. 329 over this round's kernel sets, oracle 343)
-    assert max(h["kld"] for h in hip) > 8.0 * hip[0]["kld"], [h["kld"] for h in hip]
+    # ... and the HIP path's transient is the oracle's: its peak within 15 % of the oracle's peak (measured -4 .. -8 %: the two
+    # trajectories separate slowly, see above)
+    assert 0.85 < max(h["kld"] for h in hip) / max(o["kld"] for o in ora) < 1.15, ([h["kld"] for h in hip], [o["kld"] for o in ora])
     # (while the trajectories have not separated, the KLDs agree in order of magnitude at every step)
     for i in range(6):
         assert 0.2 < hip[i]["kld"] / ora[i]["kld"] < 5.0, (i, hip[i]["kld"], ora[i]["kld"])

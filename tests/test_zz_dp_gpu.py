@@ -8,7 +8,7 @@ rank, always killed): a multi-process problem can never again hide the parity te
 import pytest
 import torch
 
-from util import RanksHung, run_ranks
+from util import RanksHung, run_ranks, run_ranks_sharing_one_gpu
 
 pytestmark = pytest.mark.gpu
 CFG = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=64, n_bars=2, resolution=8)
@@ -54,7 +54,7 @@ def test_two_rank_step_matches_mean_gradient_step(side_delay_us):
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     os.environ["PM_SIDE_DELAY_US"] = str(side_delay_us)          # read by the ranks' library at load
     try:
-        res = run_ranks(_worker, 2, (backend,), timeout=120.0)   # a rank that hangs or dies FAILS the test (RanksHung)
+        res = run_ranks_sharing_one_gpu(_worker, 2, (backend,), timeout=120.0)   # a rank that hangs or dies FAILS the test (RanksHung)
     finally:
         os.environ.pop("PM_SIDE_DELAY_US", None)
     (p0, g0), (p1, g1) = [(torch.from_numpy(a), torch.from_numpy(b)) for a, b in res]
@@ -157,7 +157,7 @@ def test_global_token_mean_weights_the_ranks_by_their_token_counts():
     gradient equals sum_r (n_r * world / n_total) * g_r, g_r = the rank's own local-mean gradient — i.e. its mean over the
     ranks is the gradient of the token mean over the global batch (per-replica BatchNorm statistics apart)."""
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
-    res = run_ranks(_gtm_worker, 2, (backend,), timeout=120.0)      # a rank that hangs or dies FAILS the test (RanksHung)
+    res = run_ranks_sharing_one_gpu(_gtm_worker, 2, (backend,), timeout=120.0)      # a rank that hangs or dies FAILS the test (RanksHung)
     got = torch.from_numpy(res[0])
     assert torch.equal(got, torch.from_numpy(res[1]))
     from polyphemus_amd.model import VAE
@@ -267,7 +267,7 @@ def test_sync_bn_data_parallel_step_equals_single_device_global_batch():
     12 samples — the reference's semantics, whose BatchNorm statistics and loss means span the whole batch —, and the
     running statistics agree."""
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
-    res = run_ranks(_sync_worker, 2, (backend,), timeout=150.0)      # a rank that hangs or dies FAILS the test (RanksHung)
+    res = run_ranks_sharing_one_gpu(_sync_worker, 2, (backend,), timeout=150.0)      # a rank that hangs or dies FAILS the test (RanksHung)
     g_dp = torch.from_numpy(res[0][0]).double() / 2.0           # the buckets hold the SUM over the ranks
     assert torch.equal(torch.from_numpy(res[0][0]), torch.from_numpy(res[1][0]))
     from polyphemus_amd.graphs import collate_samples

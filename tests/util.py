@@ -113,6 +113,44 @@ class RanksHung(RuntimeError):
     pass
 
 
+def _share_probe(rank, world):
+    """two processes on ONE device: each opens it, runs a kernel and meets the other in a gloo all-reduce"""
+    import datetime
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))
+    try:
+        t = torch.ones(1024, device=dev) * (rank + 1)
+        torch.cuda.synchronize()
+        c = t.cpu()
+        dist.all_reduce(c)
+        return float(c[0])
+    finally:
+        dist.destroy_process_group()
+
+
+def run_ranks_sharing_one_gpu(fn, world, args=(), timeout=90.0):
+    """`run_ranks` for the data-parallel tests.  With as many devices as ranks a rank that hangs or dies FAILS the test.  On a
+    one-GPU box the ranks share the device over gloo; if they hang there, a minimal probe decides what that means: when two
+    processes cannot even open the device side by side (an environment property of the box) the test is skipped with that
+    reason; when the probe works, the hang is the code's and the test fails."""
+    try:
+        return run_ranks(fn, world, args, timeout)
+    except RanksHung as exc:
+        if torch.cuda.device_count() >= world:
+            raise
+        try:
+            ok = run_ranks(_share_probe, world, (), timeout=60.0) == [float(world * (world + 1) // 2)] * world
+        except (RanksHung, AssertionError):
+            ok = False
+        if ok:
+            raise
+        import pytest
+        pytest.skip(f"{world} processes cannot share this box's single GPU (probe failed): environmental, not a parity failure; "
+                    f"the hang was: {str(exc)[:300]}")
+
+
 def free_port():
     import socket
     with socket.socket() as s:

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Development micro-benchmark of the three GCL kernels of csrc/gcl.hip against the kernels they replace, on the bench
 batch (B = 256, d = 256).  WHICH selects what runs (u unfused forward pair, f fused forward, p fused forward without the A'
-output, n input gradient, w weight gradient); PM_LIB_PATH selects a library variant (tools/build_variants.py); TRACE=1 / n / w
-prints the in-kernel timeline of one workgroup from a -DGCL_TRACE=<block + 1> build."""
+output, n input gradient, w weight gradient); PM_LIB_PATH selects a library variant (tools/build_variants.py).  (bf16-triple
+entry points: the fp16 pair format is measured through the step — tools/ab_round.sh with PM_H2=0 / 1.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -70,34 +70,6 @@ def main():
     if "w" in which: out.append(f"dW grouped {timeit(tn_unfused):.1f} us  128x128 {timeit(tn_fused):.1f} us")
     if "n" in which: out.append(f"dA' grouped {timeit(nt_unfused):.1f} us  A-stationary {timeit(nt_fused):.1f} us")
     print("  ".join(out), flush=True)
-    if os.environ.get("TRACE") == "w":
-        import ctypes
-        from polyphemus_amd._lib import lib
-        tn_fused(); torch.cuda.synchronize()
-        buf = (ctypes.c_longlong * 256)()
-        lib().pm_debug_read_trace(buf)
-        tr = list(buf)
-        st = [v for v in tr[0:60] if v]
-        print("dw wave 0", [round((v - st[0]) / 100.0, 2) for v in st])
-    elif os.environ.get("TRACE") == "n":
-        import ctypes
-        from polyphemus_amd._lib import lib
-        nt_fused(); torch.cuda.synchronize()
-        buf = (ctypes.c_longlong * 256)()
-        lib().pm_debug_read_trace(buf)
-        tr = list(buf)
-        for w in (0, 4):
-            st = [v for v in tr[w * 16: w * 16 + 60] if v]
-            print("dagg wave", w, [round((v - st[0]) / 100.0, 2) for v in st])
-    elif os.environ.get("TRACE"):
-        s.zero_()
-        fused()
-        torch.cuda.synchronize()
-        tr = s.view(torch.int64).flatten().cpu().tolist()
-        print("realtime ticks (100 MHz) start->epilogue end:", tr[201] - tr[200], "core ticks:", max(tr[:60]) - tr[0])
-        for w in (0, 4):
-            st = [v for v in tr[w * 16: w * 16 + 60] if v]
-            print("wave", w, [round((v - st[0]) / 100.0, 2) for v in st], "(us at 100 MHz)" )
 
 if __name__ == "__main__":
     main()

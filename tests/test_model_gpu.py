@@ -71,7 +71,15 @@ def params_close(got, ref, init, lr_sum, noise_only=False, gref=None):
     return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)) >= 0.98
 
 
-def hip_forward(vae, g, eps):
+def hip_forward(vae, g, eps, path="bridges", monkeypatch=None):
+    """path "bridges": encoder / reparametrisation / decoder one by one (generate.py's surface; the Python orchestration);
+    "model_call": `vae(g)` as training.py:141 calls it — ONE autograd node over the C++ step — with `eps` injected."""
+    if path == "model_call":
+        from polyphemus_amd import model as model_mod
+        monkeypatch.setattr(model_mod, "_draw_eps", lambda n, d, dev: eps.clone())
+        (s_logits, c_logits), mu, lv = vae(g)
+        assert vae._native_step().info()["n_slots"] == 15
+        return s_logits, c_logits, mu, lv
     mu, lv = vae.encoder(g)
     z = _ReparamFn.apply(mu, lv, eps)
     s_logits, c_logits = vae.decoder(z, g)
@@ -171,10 +179,13 @@ def test_train_step_matches_reference_golden(case, amp, path, monkeypatch):
                                     z[gk] if gk in z.files else None), (step, k)
 
 
-@pytest.mark.parametrize("B,nb,d,L,p", [(8, 2, 64, 2, 0.25), (6, 3, 32, 3, 0.15)])
-def test_train_forward_backward_with_message_dropout_matches_oracle(B, nb, d, L, p):
+@pytest.mark.parametrize("path", ["model_call", "bridges"])
+@pytest.mark.parametrize("B,nb,d,L,p", [(8, 2, 64, 2, 0.25), (6, 3, 32, 3, 0.15), (8, 2, 128, 2, 0.25)])
+def test_train_forward_backward_with_message_dropout_matches_oracle(B, nb, d, L, p, path, monkeypatch):
     """HIP vs CPU oracle with the p=0.1 message dropout ACTIVE: the oracle replays the kernel's
-    counter-based mask, so forward outputs and all gradients are comparable."""
+    counter-based mask, so forward outputs and all gradients are comparable.  The loss reaches EVERY output (the structure
+    logits, mu and log_var directly — unlike the reference's loss): through `model(graph)` that is the caller's-loss path of the
+    C++ step (pm_vae_step_set_output_grads with all four gradients, structure decoder backward on)."""
     cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=L, d=d, n_bars=nb, resolution=8)
     torch.manual_seed(1)
     vae = VAE(**cfg, device=DEV).to(DEV)
@@ -184,7 +195,7 @@ def test_train_forward_backward_with_message_dropout_matches_oracle(B, nb, d, L,
     eps = torch.randn(B, d)
     sd = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
     names = [n for n, _ in vae.named_parameters()]
-    s_logits, c_logits, mu, lv = hip_forward(vae, g, eps.to(DEV))
+    s_logits, c_logits, mu, lv = hip_forward(vae, g, eps.to(DEV), path, monkeypatch)
     seeds = {"encoder": None, "decoder": None}
     # the two autograd bridges drew consecutive seeds (encoder first, then decoder)
     vae._step -= 2
@@ -219,8 +230,9 @@ def test_train_forward_backward_with_message_dropout_matches_oracle(B, nb, d, L,
             assert int(sd2[k]) == int(P[k]), k
 
 
+@pytest.mark.parametrize("path", ["model_call", "bridges"])
 @pytest.mark.parametrize("batch_norm,p_cfg", [(True, 0.2), (False, 0.0), (False, 0.3)])
-def test_constructor_switches_dropout_and_batch_norm_match_oracle(batch_norm, p_cfg):
+def test_constructor_switches_dropout_and_batch_norm_match_oracle(batch_norm, p_cfg, path, monkeypatch):
     """The two non-default constructor kwargs of the boundary (train.py:176): `dropout` != 0 (element dropout layers at
     model.py:160,199,244-247,267-270,389-390,473,479,558-559,640) and `batch_norm` = False (model.py:176-188,218-238,
     278-292).  The reference draws its dropout masks from torch's RNG; here the oracle replays the HIP path's counter
@@ -236,7 +248,7 @@ def test_constructor_switches_dropout_and_batch_norm_match_oracle(batch_norm, p_
     eps = torch.randn(B, d)
     sd = {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
     names = [n for n, _ in vae.named_parameters()]
-    s_logits, c_logits, mu, lv = hip_forward(vae, g, eps.to(DEV))
+    s_logits, c_logits, mu, lv = hip_forward(vae, g, eps.to(DEV), path, monkeypatch)
     vae._step -= 2
     seeds = {"enc": vae._next_seed(), "dec": vae._next_seed()}
 

@@ -221,3 +221,29 @@ def test_gradient_buckets_cover_the_flat_buffer_exactly(d, nb):
             assert k == 1, n
     if (d, nb) == (512, 16):
         assert flat.numel() * 4 > 225e6                                                   # 228 MB exchanged per step
+
+
+def test_bench_preflight_names_what_keeps_the_communicator_from_forming(monkeypatch, capsys):
+    """`bench.py --gpus N`: before the process group exists every rank checks what RCCL depends on and exits legibly (exit code
+    4, the facts on stderr) instead of hanging in the first collective: fewer visible devices than local ranks,
+    HSA_ENABLE_IPC_MODE_LEGACY not 0, no rendezvous address."""
+    import json
+    import bench
+    for k, v in (("WORLD_SIZE", "2"), ("RANK", "1"), ("LOCAL_RANK", "1"), ("LOCAL_WORLD_SIZE", "2"), ("MASTER_ADDR", "127.0.0.1"),
+                 ("MASTER_PORT", "29999")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    facts = bench.preflight("gloo")                               # gloo: nothing to object to on a CPU box
+    assert facts["world_size"] == 2 and facts["rank"] == 1 and facts["device_count"] == 0
+    with pytest.raises(SystemExit) as e:                          # nccl with no visible GPU: one rank per device is impossible
+        bench.preflight("nccl")
+    assert e.value.code == 4
+    err = capsys.readouterr().err
+    assert "rank 1" in err and "2 ranks on this node but 0 visible GPU" in err and '"device_count": 0' in err
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    monkeypatch.delenv("MASTER_ADDR")
+    with pytest.raises(SystemExit):
+        bench.preflight("nccl")
+    err = capsys.readouterr().err
+    assert "HSA_ENABLE_IPC_MODE_LEGACY is not 0" in err and "MASTER_ADDR is not set" in err
+    json.loads(err[err.index("{"):err.rindex("}") + 1])           # the facts are machine-readable

@@ -687,7 +687,7 @@ def main():
         gemm_ms = sum(survey[k]["total_ms"] for k in gemm_keys)
         gemm_tf = sum(survey[k]["work"] for k in gemm_keys) / (gemm_ms * 1e-3) / 1e12
         split = dom.startswith("gcl") or dom[8:].startswith(("planes", "x6"))   # fp32 product = 6 bf16 MFMA products (fp32 accumulate)
-        h2 = dom.startswith("gcl") and step_info.get("h2", 0) == 3              # ... or 3 fp16 products (fp16 pair format, d <= 256)
+        h2 = dom.startswith("gcl") and step_info.get("h2", 0) == 3              # ... or 3 fp16 products (fp16 pair format: the sparse-graph route of d = 128 / 256 / 512)
         nprod = 3.0 if h2 else 6.0
         peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
         insn = ("v_mfma_f32_32x32x16_f16, 3 products per fp32 product (fp16 pair operands)" if h2 else
@@ -772,7 +772,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": ("fp32 storage and accumulation; the products run on the 16-bit matrix pipe with split operands: the three "
-                           "GCL products of d <= 256 as 3 fp16 MFMA products per fp32 product (fp16 pair format: 22-bit operands, "
+                           "GCL products (d = 128 / 256 / 512; not the dense-graph route) as 3 fp16 MFMA products per fp32 product (fp16 pair format: 22-bit operands, "
                            "power-of-two scales from the tensors' |max|), every other split product as 6 bf16 MFMA products (exact "
                            "three-term split); full-size outputs 2e-6 .. 4e-6 from the fp64 oracle either way (the reference's own "
                            "fp32 arithmetic: 1e-4 .. 3e-4), profiles/r05_*parity*.jsonl"),

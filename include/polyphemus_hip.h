@@ -53,8 +53,10 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra).
  *   7: round 5 (the fp16 pair operand format: PmH2, pm_absmax, pm_split_planes_frag_h2, pm_gcl_forward_fused_h2,
  *   pm_gcl_input_grad_bn_h2, pm_gcl_weight_grad_fused_h2; PmNormSums.absmax_out; pm_bn_apply_fused_absmax; pm_vae_step_set_output_grads: the drop-in module's
- *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads; pm_deterministic_faults). */
-#define PM_ABI_VERSION 7
+ *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads; pm_deterministic_faults).
+ *   8: round 6 (pm_bar_aggregate_fwd / _bwd: bar-resident aggregation of dense graphs; pm_gcl_forward_from_planes_h2: the dense
+ *   route's product in the fp16 pair format). */
+#define PM_ABI_VERSION 8
 int pm_abi_version(void);
 const char* pm_build_info(void);
 
@@ -306,6 +308,11 @@ int pm_gcl_forward_from_planes(const uint16_t* a_planes /* 3 planes [N,4d] */, i
                                int32_t N, int32_t E, int32_t G, int32_t d, const uint16_t* w_frag,
                                const float* bias /* [d] or NULL */, int32_t use_classes, float* h /* [N,d] */,
                                double* col_stats /* [PM_BN_REPL][2][d] += or NULL */, pm_stream_t stream);
+/* ... on planes in the fp16 pair format: two fp16 planes of A' * (*a_scale), written by pm_bar_aggregate_fwd with a PmH2 (whose
+ * scale_out is `a_scale`); `w_frag` from pm_split_planes_frag_h2(kind 1) with `w_scale`.  d = 512. */
+int pm_gcl_forward_from_planes_h2(const uint16_t* a_planes, int64_t plane_stride, const int32_t* plan, int32_t N, int32_t E,
+                                  int32_t G, int32_t d, const uint16_t* w_frag, const float* bias, int32_t use_classes,
+                                  float* h, double* col_stats, const float* a_scale, float w_scale, pm_stream_t stream);
 /* C[N, Nout] = X[N, K] @ W (+ bias) for a plain linear layer with a short inner dimension, K in {128, 256, 512}, Nout a
  * multiple of K (chord decoder forward model.py:555-559; chord encoder input gradient, autograd of model.py:384-390),
  * A-stationary (linear.hip k_rows_w): the 64 fp32 rows of a tile are split into bf16 planes once and kept in LDS for all
@@ -345,6 +352,22 @@ int pm_segreduce_bwd(const float* x, const float* T, const float* dA /* [N,7d] o
                      const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p,
                      uint32_t seed, uint32_t layer_uid, int32_t compact, float* dx /* [N,d] */,
                      float* dT /* [32,d] += */, pm_stream_t stream);
+
+/* Bar-resident aggregation (bar.hip): the route of DENSE graphs (BASELINE configs[4]: 127 in-edges per node).  Same maths
+ * as pm_segreduce_fwd_planes / pm_segreduce_bwd(_norm) on the compact layout (GCL.message model.py:123-135, propagate /
+ * scatter-mean model.py:110, their autograd), but one workgroup owns one bar (edges never leave their bar, data.py:24-121; a bar
+ * has at most 4 x 32 nodes — a larger "bar" traps) and a chunk of channels, reads the bar's rows from HBM ONCE into LDS and
+ * gathers from there.  Forward: A' [N, 4d] as operand planes — three bf16 planes (`h2` NULL; bit-identical to
+ * pm_segreduce_fwd_planes(compact = 1)) or the two fp16 planes of the pair format (`h2`: absmax_in = |max| words of x, absmax_aux
+ * = of T, *scale_out receives the power of two the planes carry; w_scale unused); d a multiple of 128.  Backward: dx, dT += and
+ * (next_norm non-NULL) the column sums / |dx|max of the norm below, as pm_segreduce_bwd_norm; d a multiple of 64. */
+int pm_bar_aggregate_fwd(const float* x, const float* T, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                         float dropout_p, uint32_t seed, uint32_t layer_uid, uint16_t* planes, int64_t plane_stride,
+                         const PmH2* h2 /* or NULL */, pm_stream_t stream);
+int pm_bar_aggregate_bwd(const float* x, const float* T, const float* dA /* [N,4d] */, const float* dres /* [N,d] or NULL */,
+                         const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, float dropout_p, uint32_t seed,
+                         uint32_t layer_uid, float* dx /* [N,d] */, float* dT /* [32,d] += */,
+                         const PmNormSums* next_norm /* or NULL */, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ dense contraction (fp32 MFMA)
  * C[M,N] (=|+=) op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU), v_mfma_f32_32x32x2_f32.

@@ -142,6 +142,9 @@ _SIGS = {
     "pm_bn_bwd_fused_h2": "ppiippfppippppplips",
     "pm_gcl_input_grad_fused_h2": "plpiiiipippfs",
     "pm_bn_apply_fused_absmax": "piipfpppipppppfps",
+    "pm_bar_aggregate_fwd": "pppiiiifuuplps",
+    "pm_bar_aggregate_bwd": "pppppiiiifuuppps",
+    "pm_gcl_forward_from_planes_h2": "plpiiiippipppfs",
     "pm_set_deterministic": "i",
     "pm_get_deterministic": "",
     "pm_deterministic_faults": "",
@@ -149,7 +152,7 @@ _SIGS = {
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
           "pm_unembed_dh_scratch_bytes"}
-ABI_VERSION = 7          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
+ABI_VERSION = 8          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])
 

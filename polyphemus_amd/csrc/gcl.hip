@@ -1114,3 +1114,17 @@ extern "C" int pm_gcl_forward_from_planes(const uint16_t* a_planes, int64_t plan
   return pm_wide_gcl_forward(nullptr, nullptr, plan, N, E, G, 0.f, 0, 0, w_frag, bias, use_classes, h, col_stats, nullptr,
                              plane_stride, a_planes, (hipStream_t)stream);
 }
+// ... on planes in the fp16 pair format (two fp16 planes of A' * (*a_scale), written by pm_bar_aggregate_fwd with a PmH2);
+// `w_frag` from pm_split_planes_frag_h2(kind 1) with `w_scale`
+extern "C" int pm_gcl_forward_from_planes_h2(const uint16_t* a_planes, int64_t plane_stride, const int32_t* plan, int32_t N,
+                                             int32_t E, int32_t G, int32_t d, const uint16_t* w_frag, const float* bias,
+                                             int32_t use_classes, float* h, double* col_stats, const float* a_scale,
+                                             float w_scale, pm_stream_t stream) {
+  if (!a_planes || !plan || !w_frag || !h || !a_scale || !(w_scale > 0.f) || N <= 0 || d != 512 || ((uintptr_t)a_planes % 16) ||
+      ((uintptr_t)w_frag % 16) || ((uintptr_t)h % 16))
+    return PM_E_INVALID;
+  PmH2 h2;
+  h2.absmax_in = nullptr; h2.absmax_aux = nullptr; h2.scale_out = const_cast<float*>(a_scale); h2.w_scale = w_scale; h2.reserved = 0;
+  return pm_wide_gcl_forward(nullptr, nullptr, plan, N, E, G, 0.f, 0, 0, w_frag, bias, use_classes, h, col_stats, nullptr,
+                             plane_stride, a_planes, (hipStream_t)stream, &h2);
+}

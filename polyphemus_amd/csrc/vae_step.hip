@@ -55,6 +55,7 @@ struct StepCfg {
   bool h2;                     // PM_H2=0: the GCL products of d in {128, 256} on the exact three-term bf16 split (six MFMA products per fp32
                                // product) instead of the fp16 pair format (three; PmH2 of the header) — the parity tests run both
   int dense_deg;
+  bool bar_route;              // PM_BAR_ROUTE=0: dense graphs on the row-gather kernels of segreduce.hip (rounds 1-5) instead of bar.hip
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
 };
 static StepCfg read_cfg() {
@@ -81,6 +82,7 @@ static StepCfg read_cfg() {
   k.h2 = flag("PM_H2", true);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = 16;
+  k.bar_route = flag("PM_BAR_ROUTE", true);
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
 }
@@ -391,7 +393,7 @@ PmGemmDesc gcl_desc(const PmPlanView& pv, int N, int d) {
 // one grouped launch over the four track relations whose B operand is "stacked" (group rows + shared rows),
 // i.e. 8 N d^2 flops instead of 14 N d^2 (the other three track blocks of every row are identically zero).
 // which kernel set a GCN stack of this batch takes (host-known: shapes and switches)
-struct GcnRoute { bool gcl_kernels, dense; };
+struct GcnRoute { bool gcl_kernels, dense, bar; };
 GcnRoute gcn_route(const Ctx& c, const GcnSaved& sv) {
   GcnRoute r;
   // the kernels of gcl.hip take the fragment-major weight copies (forward, input gradient) or no weight at all (weight gradient)
@@ -399,6 +401,9 @@ GcnRoute gcn_route(const Ctx& c, const GcnSaved& sv) {
   // dense graphs (mean in-degree >= cfg().dense_deg; the fused kernel's producers keep three edges per (node, relation)
   // in flight and redo longer lists serially): stand-alone segment-reduce, then — at d = 512 — the product from its planes
   r.dense = (int64_t)c.E >= (int64_t)cfg().dense_deg * c.N;
+  // ... with the bar resident in LDS (bar.hip; round 6) instead of row gathers from L2 (segreduce.hip).  Deterministic mode keeps
+  // the segment-reduce kernels (their one-wave-per-workgroup form orders the LDS table adds)
+  r.bar = r.dense && c.compact && c.planes && (c.d % 128) == 0 && cfg().bar_route && !pm_det_on();
   return r;
 }
 // The stack's three GCL products in the fp16 pair format (gcl.hip H2 kernels): the fused forward, the input gradient with the
@@ -406,8 +411,9 @@ GcnRoute gcn_route(const Ctx& c, const GcnSaved& sv) {
 static bool stack_h2(const Ctx& c, const GcnSaved& sv) {
   const GcnRoute r = gcn_route(c, sv);
   // (d <= 256: the norm backward runs inside the input gradient, which then writes the dh planes; d = 512: the norm's own pass does)
-  return cfg().h2 && r.gcl_kernels && !r.dense && c.bn && (((c.d == 128 || c.d == 256) && cfg().dagg_bn) || c.d == 512) &&
-         !cfg().dw_side && !cfg().no_dw;
+  // (dense graphs: at d = 512 the bar-resident aggregation writes the pair format and the product reads it from the planes)
+  return cfg().h2 && r.gcl_kernels && (!r.dense || (r.bar && c.d == 512)) && c.bn &&
+         (((c.d == 128 || c.d == 256) && cfg().dagg_bn) || c.d == 512) && !cfg().dw_side && !cfg().no_dw;
 }
 // The part of a GCN stack's forward that depends on the parameters only: the distance table of the shared edge_nn and
 // the bf16 planes of the layers' weights.  Issued at the start of the step, on the second stream.
@@ -494,7 +500,7 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     const bool fused = gcl_kernels && !dense;
     const bool from_planes = gcl_kernels && dense && d == 512;
     const bool x_tracked = sv.h2 && i > 0 && !(c.pdrop > 0.f);   // (the norm apply of layer i-1 left |x|max in mx[i])
-    if (fused && sv.h2) {
+    if ((fused || from_planes) && sv.h2) {
       if (!x_tracked) {
         // (the decoder's first input is the bar vectors broadcast to their nodes: the [G, d] source has the same |max|)
         if (i == 0 && sv.x0_src && !(c.pdrop > 0.f)) RUN(pm_absmax(sv.x0_src, sv.x0_src_n, sv.mx, c.st));
@@ -503,6 +509,9 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       PmH2 h2;
       h2.absmax_in = sv.mx + i * PM_ABSMAX_SLOTS; h2.absmax_aux = sv.mx + c.L * PM_ABSMAX_SLOTS; h2.scale_out = sv.sA + i;
       h2.w_scale = kH2WScale; h2.reserved = 0;
+      if (from_planes)                                     // dense graphs: bar-resident aggregation, then the product from its planes
+        RUN(pm_bar_aggregate_fwd(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, sv.Ap[i], aps, &h2, c.st));
+      else
       RUN(pm_gcl_forward_fused_h2(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                     sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
                                     sv.h[i], sums, sv.Ap[i], aps, &h2, c.st));
@@ -510,11 +519,16 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
       RUN(pm_gcl_forward_fused(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i,
                                  sv.Wfn + (int64_t)i * sv.wf_stride, c.P + g.bias[i], cfg().no_classes ? 0 : 1,
                                  sv.h[i], sums, sv.Ap[i], aps, c.st));
+    else if (r.bar)
+      RUN(pm_bar_aggregate_fwd(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, sv.Ap[i], aps, nullptr, c.st));
     else if (c.planes)
       RUN(pm_segreduce_fwd_planes(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, 1, sv.Ap[i], aps, c.st));
     else
       RUN(pm_segreduce_fwd(sv.xin[i], sv.T, c.s->plan, N, c.E, c.Gn, d, p, seed, uid0 + i, c.compact, sv.A[i], c.st));
     if (fused) {
+    } else if (from_planes && sv.h2) {
+      RUN(pm_gcl_forward_from_planes_h2(sv.Ap[i], aps, c.s->plan, N, c.E, c.Gn, d, sv.Wfn + (int64_t)i * sv.wf_stride,
+                                          c.P + g.bias[i], cfg().no_classes ? 0 : 1, sv.h[i], sums, sv.sA + i, kH2WScale, c.st));
     } else if (from_planes) {
       RUN(pm_gcl_forward_from_planes(sv.Ap[i], aps, c.s->plan, N, c.E, c.Gn, d, sv.Wfn + (int64_t)i * sv.wf_stride,
                                        c.P + g.bias[i], cfg().no_classes ? 0 : 1, sv.h[i], sums, c.st));
@@ -587,7 +601,8 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const bool res_in_dagg = in_dagg && !dropping && cfg().dagg_res;
     double* const acc3 = sv.pool + ((size_t)i * 5 + 2) * d * PM_BN_REPL;
     const bool sums_ready = i < c.L - 1 && fuse_sums;
-    const bool du_tracked = sums_ready && d <= 256;   // (h2: pm_segreduce_bwd_norm of layer i+1 also left |dx|max in mdu[i]; its 512-wide variant has no register for it)
+    const GcnRoute rt = gcn_route(c, sv);
+    const bool du_tracked = sums_ready && (d <= 256 || rt.bar);   // (h2: pm_segreduce_bwd_norm of layer i+1 also left |dx|max in mdu[i]; its 512-wide variant has no register for it, the bar-resident kernel has)
     if (in_dagg) {
       if (!sums_ready)
         RUN(pm_bn_bwd_sums(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, acc3, c.st));
@@ -681,9 +696,16 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
       PmNormSums nn;
       nn.h = sv.h[i - 1]; nn.mean = sv.mean[i - 1]; nn.var = sv.var[i - 1]; nn.gamma = c.P + pb.w; nn.beta = c.P + pb.b;
       nn.eps = 1e-5f; nn.relu = 1; nn.acc3 = sv.pool + ((size_t)(i - 1) * 5 + 2) * d * PM_BN_REPL;
-      nn.absmax_out = (sv.h2 && d <= 256) ? sv.mdu + (i - 1) * PM_ABSMAX_SLOTS : nullptr;
+      nn.absmax_out = (sv.h2 && (d <= 256 || rt.bar)) ? sv.mdu + (i - 1) * PM_ABSMAX_SLOTS : nullptr;
+      if (rt.bar)
+        RUN(pm_bar_aggregate_bwd(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
+                                   out, dT, &nn, c.st));
+      else
       RUN(pm_segreduce_bwd_norm(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
                                   c.compact, out, dT, &nn, c.st));
+    } else if (rt.bar) {
+      RUN(pm_bar_aggregate_bwd(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
+                                 out, dT, nullptr, c.st));
     } else {
       RUN(pm_segreduce_bwd(sv.x[i], sv.T, dA, res_in_dagg ? nullptr : dx, c.s->plan, N, c.E, c.Gn, d, sv.p, sv.seed, sv.uid0 + i,
                              c.compact, out, dT, c.st));

@@ -55,14 +55,14 @@ struct WideArgs {
   const float* bias; float* out; int ldo; double* colstats;
   unsigned* gate;                                           // deterministic mode (common.h): MFMA waves add the column sums in turn
   // fp16 pair format (H2 kernels; PmH2 of the header): V_FWD: |max| words of x and of T, where to leave the scale of the A' planes;
-  // V_DAGG: the device float the dh planes' scale sits in; both: the scale of the weight planes
+  // V_DAGG / V_FWDP: the device float the input planes' scale sits in; all: the scale of the weight planes
   const unsigned* mx; const unsigned* mt; float* sa_out; const float* sin; float w_scale;
 };
 }  // namespace
 
 template <int VAR, bool DROP, int NPW, int BKIND, bool H2>
 __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
-  static_assert(!H2 || VAR == V_FWD || VAR == V_DAGG, "the fp16 pair format exists for the sparse GCL forward and the input gradient");
+  static_assert(!H2 || VAR == V_FWD || VAR == V_FWDP || VAR == V_DAGG, "the fp16 pair format exists for the GCL forward (fused or from planes) and the input gradient");
   constexpr int NPL = H2 ? 2 : 3, T60 = H2 ? 3 : 0;        // operand planes; first product of the chain (PA / PB below)
   constexpr int D = WD;
   constexpr int NPT = NPW * 64;                              // producer threads
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) k_wide(WideArgs g) {
     oinv = 1.f / (asc * g.w_scale);
     if (blockIdx.x == 0 && tid == 0) *g.sa_out = asc;
   }
-  if constexpr (H2 && VAR == V_DAGG) oinv = 1.f / (g.sin[0] * g.w_scale);
+  if constexpr (H2 && (VAR == V_DAGG || VAR == V_FWDP)) oinv = 1.f / (g.sin[0] * g.w_scale);   // (V_FWDP: the scale the aggregation kernel left)
   if constexpr (GCL) {
     if (tid < BM) sNode[tid] = (m0 + tid < M && tid < rows) ? list[m0 + tid] : -1;
     __syncthreads();
@@ -611,6 +611,10 @@ int pm_wide_gcl_forward(const float* x, const float* T, const int32_t* plan, int
   const int pe = pm_prof_open(st, PM_PROF_GCL_FWD, 2.0 * N * 4.0 * d * d);
   if (a_planes_in) {
     a.pin = a_planes_in; a.pin_stride = plane_stride;
+    if (h2) {                                              // fp16 pair format: planes and their scale from pm_bar_aggregate_fwd
+      a.sin = h2->scale_out; a.w_scale = h2->w_scale;
+      launch_wide<V_FWDP, false, 4, 1, true>(a, grid, wide_lds(V_FWDP), st);
+    } else
     if (wide_npw(4) == 8) launch_wide<V_FWDP, false, 8, 1>(a, grid, wide_lds(V_FWDP), st);
     else launch_wide<V_FWDP, false, 4, 1>(a, grid, wide_lds(V_FWDP), st);
   } else {

@@ -39,7 +39,7 @@ PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 def kernel_source_digest():
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "segreduce.hip", "gcl.hip", "wide.hip", "gcl_tiles.h", "tile_order.h", "common.h"):
+    for f in ("gemm.hip", "segreduce.hip", "bar.hip", "gcl.hip", "wide.hip", "gcl_tiles.h", "tile_order.h", "common.h"):
         h.update(open(os.path.join(ROOT, "polyphemus_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -696,7 +696,7 @@ def main():
         sampling = (f"HIP events around every {EVENT_STRIDE}-th launch of this kernel inside the timed region "
                     f"({ds['launches']} launches sampled)")
         if args.d == 512:
-            gcl_names = {"gcl_fwd": ("k_wide<V_FWDP>: GCL forward product from the segment-reduce's A' planes (wide.hip)" if args.dense else
+            gcl_names = {"gcl_fwd": ("k_wide<V_FWDP>: GCL forward product from the A' planes of the bar-resident aggregation (bar.hip -> wide.hip)" if args.dense else
                                      "k_wide<V_FWD>: GCL forward, aggregate built in LDS + weight product in one kernel (wide.hip)"),
                          "gcl_dagg": "k_wide<V_DAGG>: GCL input gradient, dh streamed through the LDS ring (wide.hip)",
                          "gcl_dw": "k_gcl_dw<512>: GCL weight gradient, 128x128 tiles"}
@@ -707,6 +707,10 @@ def main():
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4), "traffic": pmc_traffic(dom, workload_key),
+                # the same launch against the OTHER roof: memory-side counter bytes per launch / its duration / 8 TB/s — for a
+                # kernel that gathers, stores operand planes and multiplies in one launch both fractions are co-limits
+                "hbm_counter_frac": (round(pmc_traffic(dom, workload_key) / (ds["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+                                     if pmc_traffic(dom, workload_key) else None),
                 "peak_note": ((f"dense fp16 MFMA peak / 3 (fp32-equivalent flops; the same kernel on the six-product bf16 split had a "
                                f"roof of {round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}: {round(tf / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4)} of that)" if h2 else
                                "dense bf16 MFMA peak / 6 (fp32-equivalent flops)") if split else "dense fp32 MFMA peak")
@@ -770,9 +774,11 @@ def main():
             "metric": "bar-graphs/sec VAE fwd+bwd (+loss +Adam), LMD2 4-track x 32-ts synthetic",
             "value": round(value, 1), "unit": "bar-graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (fp16-pair MFMA products)" if step_info.get("h2", 0) == 3 else "f32 (bf16-triple MFMA products)"),
+            "data": "synthetic",
             "dtype_note": ("fp32 storage and accumulation; the products run on the 16-bit matrix pipe with split operands: the three "
-                           "GCL products (d = 128 / 256 / 512; not the dense-graph route) as 3 fp16 MFMA products per fp32 product (fp16 pair format: 22-bit operands, "
+                           "GCL products (d = 128 / 256 / 512; since round 6 also the dense-graph route at d = 512) as 3 fp16 MFMA products per fp32 product (fp16 pair format: 22-bit operands, "
                            "power-of-two scales from the tensors' |max|), every other split product as 6 bf16 MFMA products (exact "
                            "three-term split); full-size outputs 2e-6 .. 4e-6 from the fp64 oracle either way (the reference's own "
                            "fp32 arithmetic: 1e-4 .. 3e-4), profiles/r05_*parity*.jsonl"),

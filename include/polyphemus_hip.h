@@ -48,14 +48,14 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   pm_rows_tn_weight_grad, pm_gcl_tile_order / pm_row_tile_order, pm_vae_step_reload_switches).
  *   5: round 4 (pm_set_deterministic / pm_get_deterministic; plan scratch field grown; PmVaeLayout.flags / .dropout — the
  *   C++ step covers batch_norm = False and cfg.dropout —; pm_vae_step_info writes 16 ints; pm_relu_bwd_planes;
- *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain).
+ *   pm_vae_step_backward_encoder_heads, pm_vae_step_join_decoder_grads; pm_head_chain — the latter removed again in ABI 8).
  *   6: round 4, second half (pm_gcl_input_grad_bn / PmBnBwd, pm_bn_bwd_sums: the norm backward inside the input gradient;
  *   pm_chord_pad_vec, pm_chord_tables_fwd, pm_chord_sum_fwd / _bwd, pm_chord_tables_bwd_w / _x: the chord encoder as table algebra).
  *   7: round 5 (the fp16 pair operand format: PmH2, pm_absmax, pm_split_planes_frag_h2, pm_gcl_forward_fused_h2,
  *   pm_gcl_input_grad_bn_h2, pm_gcl_weight_grad_fused_h2; PmNormSums.absmax_out; pm_bn_apply_fused_absmax; pm_vae_step_set_output_grads: the drop-in module's
  *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads; pm_deterministic_faults).
  *   8: round 6 (pm_bar_aggregate_fwd / _bwd: bar-resident aggregation of dense graphs; pm_gcl_forward_from_planes_h2: the dense
- *   route's product in the fp16 pair format). */
+ *   route's product in the fp16 pair format; pm_h2_clamp_events: saturation counter of the pair format). */
 #define PM_ABI_VERSION 8
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -75,6 +75,13 @@ int pm_get_deterministic(void);
  * launch so far was ordered.  While the mode is on the step keeps every launch on the caller's stream (two gated kernels on two
  * streams could starve each other's turns). */
 int pm_deterministic_faults(void);
+/* Saturation events of the fp16 pair operand format (PmH2 below): the threads of the kernels that split an fp32 tensor into
+ * scaled fp16 hi + lo planes (pm_gcl_input_grad_bn_h2, pm_bn_bwd_fused_h2, pm_split_planes_frag_h2) whose value exceeded
+ * +-65504 after scaling and was cut — the |max| BOUND the power-of-two scale is taken from was too small by more than 2^3 (the
+ * dh bound holds for standardised values |xhat| <= 14; a near-constant BatchNorm column reaches sqrt(N)).  Counted since the
+ * library was loaded or since the last call with reset != 0 (synchronises the device; < 0: could not be read).  0 = no gradient
+ * was clipped; the parity tests assert it. */
+int pm_h2_clamp_events(int32_t reset);
 
 /* ------------------------------------------------------------------ graph plan
  * Replaces the per-layer boolean-mask edge selection `edge_index[:, edge_type == i]`
@@ -787,37 +794,6 @@ int pm_prof_end(double* ms /* [35] host */, double* work /* [35] host */, int64_
  * `state` is a caller-owned HOST blob of pm_vae_step_state_bytes() that carries the saved-activation
  * pointers between the calls.  Training mode only (batch statistics, running stats updated). */
 #define PM_MAX_LAYERS 16
-/* ------------------------------------------------------------------ head chains (csrc/heads.hip)
- * The layers between the two GCN stacks — Encoder.forward's merge / mu / log_var layers (model.py:472-481), the
- * reparametrisation (model.py:671-673), Decoder.forward's first layers (model.py:637-641), the bars encoders / decoders
- * (model.py:411-415,546-549) and their autograd — as ONE persistent launch per chain instead of ~14: a chain is a list of
- * stages run by one resident grid (PM_HEAD_GRID workgroups), separated by grid barriers on `bar` (a zeroed device counter).
- * Stage: acc[B, N] = init + in[B, K] @ A (+ in2[B, K2] @ A2) + bias, with A = W (w_kmajor: W[k * ldw + n]) or W^T
- * (W[n * ldw + k], a Linear's forward); `dual`: the second product is a second accumulator (+ bias2).  Epilogues:
- *   PM_HE_NONE         out = acc
- *   PM_HE_BN_FWD       training-mode BatchNorm1d over the B rows (+ ReLU): out2 = acc (kept for the backward), out =
- *                      [relu](gamma * (acc - mean) * rstd + beta); mean / var saved, running statistics updated
- *   PM_HE_BN_BWD       its backward with acc = d(out): dgamma += , dbeta += , out = d(input)  (xpre = the saved out2)
- *   PM_HE_REPARAM_FWD  (dual) out2 = mu = acc, out3 = log_var = acc2, out = exp(0.5 log_var) * noise + mu
- *   PM_HE_REPARAM_BWD  dmu += acc, dlv += acc * noise * 0.5 * exp(0.5 lv); out = acc (optional)
- * fp32 FMAs in k order, fp64 column statistics in a fixed order: deterministic.  B <= 1024; K, K2 multiples of 32, N and
- * the leading dimensions multiples of 4, operands 16-byte aligned. */
-enum { PM_HE_NONE = 0, PM_HE_BN_FWD, PM_HE_REPARAM_FWD, PM_HE_BN_BWD, PM_HE_REPARAM_BWD };
-enum { PM_HEAD_MAX_STAGES = 6, PM_HEAD_GRID = 64 };
-typedef struct PmHeadStage {
-  const float* in; const float* W; const float* bias; const float* in2; const float* W2; const float* bias2;
-  const float* init;
-  float* out; float* out2; float* out3;
-  const float* gamma; const float* beta; float* mean; float* var; float* rmean; float* rvar;
-  const float* xpre; float* dgamma; float* dbeta;
-  const float* noise; const float* lv; float* dmu; float* dlv;
-  int32_t ld_in, ldw, ld_in2, ldw2, K, K2, N, w_kmajor, dual, ld_init, ld_out, ld_out2, ld_out3, epi, relu, ld_xpre,
-      ld_noise, ld_lv, ld_d, barrier_after;
-  float eps, momentum;
-} PmHeadStage;
-typedef struct PmHeadChain { PmHeadStage st[PM_HEAD_MAX_STAGES]; int32_t n, B; unsigned* bar; } PmHeadChain;
-int pm_head_chain(const PmHeadChain* chain, pm_stream_t stream);
-
 typedef struct PmLin { int64_t w, b; } PmLin;              /* offsets into params (and grads)            */
 typedef struct PmBn { int64_t w, b, rm, rv; } PmBn;        /* w,b: params; rm,rv: running stats in buffers */
 typedef struct PmGcn {
@@ -856,9 +832,11 @@ typedef struct PmBatch {                                    /* device pointers o
   const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
-/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_NO_ROWS_TN, PM_NO_UNEMBED_DH, PM_GCL_NO_CLASSES,
- * PM_GCL_NO_BFRAG, PM_FUSED_CE, PM_DENSE_DEG, PM_GCL_OFFSET_LIMIT, PM_SIDE_STREAM, PM_DEBUG) are read once, when the library is loaded;
- * this re-reads them (host only) so that one process can run one batch through two kernel sets. */
+/* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_GCL_NO_CLASSES, PM_FUSED_CE,
+ * PM_SIDE_STREAM, PM_SIDE_DELAY_US, PM_DAGG_BN, PM_DAGG_RES, PM_PLAN_SIDE, PM_CHORD_TABLES, PM_H2, PM_BAR_ROUTE, PM_GCL_OFFSET_LIMIT,
+ * PM_DEBUG: the complete list, csrc/vae_step.hip read_cfg) are read once, when the library is loaded; this re-reads them (host
+ * only) so that one process can run one batch through two kernel sets.  Switches of earlier rounds that are no longer read:
+ * PM_NO_ROWS_TN, PM_NO_UNEMBED_DH, PM_GCL_NO_BFRAG, PM_DENSE_DEG, PM_LATE_WGRADS, PM_DW_SIDE, PM_FUSED_HEADS. */
 int pm_vae_step_reload_switches(void);
 int64_t pm_vae_layout_bytes(void);
 int64_t pm_vae_step_state_bytes(void);

@@ -133,7 +133,6 @@ _SIGS = {
     "pm_vae_step_backward_encoder_heads": "ps",
     "pm_vae_step_reload_switches": "",
     "pm_relu_bwd_planes": "pplppls",
-    "pm_head_chain": "ps",
     "pm_absmax": "plps",
     "pm_split_planes_frag_h2": "piiiillfps",
     "pm_gcl_forward_fused_h2": "pppiiiifuuppippplps",
@@ -148,6 +147,7 @@ _SIGS = {
     "pm_set_deterministic": "i",
     "pm_get_deterministic": "",
     "pm_deterministic_faults": "",
+    "pm_h2_clamp_events": "i",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
@@ -242,6 +242,12 @@ def deterministic_faults() -> int:
     """Gates that could not be set up + waves that timed out waiting for their turn since the library was loaded; 0 = every
     gated launch was ordered (synchronises the device)."""
     return int(lib().pm_deterministic_faults())
+
+
+def h2_clamp_events(reset: bool = False) -> int:
+    """Threads of the fp16-pair split kernels whose scaled value saturated at +-65504 (a gradient was clipped) since the library
+    was loaded / the last reset; 0 = every operand fitted its scale (synchronises the device)."""
+    return int(lib().pm_h2_clamp_events(1 if reset else 0))
 
 
 class deterministic:

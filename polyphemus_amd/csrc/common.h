@@ -85,9 +85,8 @@ __host__ __device__ static inline uint32_t pm_keep_threshold(float p) {
 // pm_det_gate(stream): nullptr when the mode is off, otherwise a counter cleared on `stream` ahead of the launch.
 unsigned* pm_det_gate(hipStream_t st);
 int pm_det_on();
-// device word of gate time-outs (a wave that gave up waiting for its turn after 4 s went ahead UNORDERED: the run is then not
-// bit-reproducible); read back, together with the host's count of gates that could not be set up, by pm_deterministic_faults()
-unsigned* pm_det_fault_word();
+// device word counting the threads whose fp16-pair split saturated (pm_clamp_f16 above); nullptr if it could not be set up
+unsigned* pm_h2_clamp_word();
 
 #ifdef __HIPCC__
 __device__ static inline unsigned pm_linear_block() {
@@ -201,6 +200,15 @@ __device__ static inline float pm_pow2_scale(float bound, int target) {
   return __uint_as_float((unsigned)(k + 127) << 23);
 }
 __device__ static inline float pm_clamp_f16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+// ... and remember that it cut something: the pair format SATURATES where a tensor's |max| bound is too small by more than 2^3
+// (the dh bound 16 gamma rstd |du|max holds for |xhat| <= 14: a near-constant BatchNorm column has |xhat| up to sqrt(N)).  Every
+// kernel that clamps ORs into `cut` and, at its end, counts the threads that saw a cut in the device word of pm_h2_clamp_word()
+// — read back by pm_h2_clamp_events() (det.hip), asserted 0 by the parity tests.
+__device__ static inline float pm_clamp_f16(float v, bool& cut) {
+  const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+  cut = cut || (c != v);                                      // (a NaN counts: c != v)
+  return c;
+}
 // |max| of a tensor kept as PM_ABSMAX_SLOTS words of float bits (non-negative floats order like their bit patterns)
 // (every lane of the wave must call it: one word per lane, then a wave reduction)
 __device__ static inline float pm_absmax_read(const unsigned* __restrict__ p) {

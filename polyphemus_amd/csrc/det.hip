@@ -66,3 +66,31 @@ extern "C" int pm_deterministic_faults(void) {
   for (int g = 0; g < kGates; ++g) total += (int)host[g * 16 + 1];
   return total;
 }
+
+// ---- saturation events of the fp16 pair format (common.h pm_clamp_f16): one device word per device
+namespace {
+unsigned* g_clamp_word[16];
+bool g_clamp_tried[16];
+}
+unsigned* pm_h2_clamp_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!g_clamp_tried[dev]) {
+    g_clamp_tried[dev] = true;
+    if (hipMalloc((void**)&g_clamp_word[dev], 64) != hipSuccess || hipMemset(g_clamp_word[dev], 0, 64) != hipSuccess) g_clamp_word[dev] = nullptr;
+  }
+  return g_clamp_word[dev];
+}
+// Threads of the pair-format kernels (input gradient with the norm inside, the norm's own pass at d = 512, weight planes) whose
+// split saturated at +-65504 since the library was loaded or since the last call with reset != 0 (synchronises the device;
+// < 0: could not be read).  0 = every operand fitted its power-of-two scale.
+extern "C" int pm_h2_clamp_events(int32_t reset) {
+  unsigned* w = pm_h2_clamp_word();
+  if (!w) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  unsigned v = 0;
+  if (hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset && hipMemset(w, 0, sizeof(v)) != hipSuccess) return -1;
+  return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}

@@ -471,7 +471,7 @@ struct GclBn {
   const double* acc3; float* dgamma; float* dbeta; float* dbias_pre;
   double count; float eps; int relu, add_res;
   // fp16 pair format (H2): |max| of du as float bits, the scale of the weight planes, where to leave the scale of the dh planes
-  const unsigned* mdu; float w_scale; float* sdh_out;
+  const unsigned* mdu; float w_scale; float* sdh_out; unsigned* clamps;
 };
 }  // namespace
 template <int D, int NMW, bool BNF, bool H2>
@@ -595,6 +595,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bn.h), 0, GCL_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bn.du), 0, GCL_OOB, 0x00020000);
     constexpr int LPR = D / 4, NE = BM * LPR / NMT, NB = NE < 8 ? NE : 8;   // lanes per row, float4 per thread, per batch
+    bool cut = false;                                          // (H2: some value of this thread exceeded the scale's window)
 #pragma unroll 1
     for (int k0 = 0; k0 < NE; k0 += NB) {
       float4 hv[NB], dv[NB];
@@ -620,8 +621,8 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
         char* dst = smem + rr * RB + (((q >> 1) ^ (rr & 15)) << 4) + ((q & 1) << 3);
         if constexpr (H2) {
           unsigned l1, l2, u1, u2;
-          pm_split2h_pair(pm_clamp_f16(o0 * dsc), pm_clamp_f16(o1 * dsc), l1, l2);
-          pm_split2h_pair(pm_clamp_f16(o2 * dsc), pm_clamp_f16(o3 * dsc), u1, u2);
+          pm_split2h_pair(pm_clamp_f16(o0 * dsc, cut), pm_clamp_f16(o1 * dsc, cut), l1, l2);
+          pm_split2h_pair(pm_clamp_f16(o2 * dsc, cut), pm_clamp_f16(o3 * dsc, cut), u1, u2);
           const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2};
           *reinterpret_cast<pm_u32x2*>(dst) = p1;
           *reinterpret_cast<pm_u32x2*>(dst + PL) = p2;
@@ -636,6 +637,7 @@ k_gcl_dagg(uint16_t* __restrict__ dhp, int64_t dps, const int* __restrict__ trk_
         }
       }
     }
+    if (H2 && cut && bn.clamps) atomicAdd(bn.clamps, 1u);
   } else {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dhp), 0, GCL_OOB, 0x00020000);
     constexpr int CPR = D / 8, NCHK = BM * CPR / NMT;            // chunks per row, chunks per thread and plane
@@ -793,7 +795,7 @@ extern "C" int pm_gcl_input_grad_bn(const PmBnBwd* nb, uint16_t* dh_planes, int6
   GclBn b;
   b.h = nb->h; b.du = nb->du; b.mean = nb->mean; b.var = nb->var; b.gamma = nb->gamma; b.beta = nb->beta; b.acc3 = nb->acc3;
   b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu; b.add_res = nb->add_residual;
-  b.mdu = nullptr; b.w_scale = 1.f; b.sdh_out = nullptr;
+  b.mdu = nullptr; b.w_scale = 1.f; b.sdh_out = nullptr; b.clamps = nullptr;
   return gcl_input_grad_impl(dh_planes, plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, &b, (hipStream_t)stream);
 }
 // ... in the fp16 pair format (PmH2 of the header): `dh_planes` receives TWO fp16 planes of dh * (*h2->scale_out), `w_frag_t`
@@ -810,7 +812,7 @@ extern "C" int pm_gcl_input_grad_bn_h2(const PmBnBwd* nb, uint16_t* dh_planes, i
   GclBn b;
   b.h = nb->h; b.du = nb->du; b.mean = nb->mean; b.var = nb->var; b.gamma = nb->gamma; b.beta = nb->beta; b.acc3 = nb->acc3;
   b.dgamma = nb->dgamma; b.dbeta = nb->dbeta; b.dbias_pre = nb->dbias_pre; b.count = (double)N; b.eps = nb->eps; b.relu = nb->relu; b.add_res = nb->add_residual;
-  b.mdu = h2->absmax_in; b.w_scale = h2->w_scale; b.sdh_out = h2->scale_out;
+  b.mdu = h2->absmax_in; b.w_scale = h2->w_scale; b.sdh_out = h2->scale_out; b.clamps = pm_h2_clamp_word();
   return gcl_input_grad_impl(dh_planes, plane_stride, plan, N, E, G, d, w_frag_t, use_classes, dA, &b, (hipStream_t)stream);
 }
 

@@ -1100,7 +1100,8 @@ extern "C" int pm_split_planes(const float* src, int64_t n, uint16_t* planes, in
 template <bool H2>
 __global__ void __launch_bounds__(256) k_split_planes_frag(const float* __restrict__ W, int rows, int cols, int kind,
                                                            int64_t src_stride, int64_t dst_stride,
-                                                           uint16_t* __restrict__ out, float w_scale) {
+                                                           uint16_t* __restrict__ out, float w_scale, unsigned* clamps) {
+  bool cut = false;                                          // (H2: a weight times w_scale beyond fp16's range)
   const float* src = W + (int64_t)blockIdx.y * src_stride;
   uint16_t* dst = out + (int64_t)blockIdx.y * dst_stride;
   const int64_t chunks = (int64_t)rows * cols / 8;
@@ -1126,7 +1127,7 @@ __global__ void __launch_bounds__(256) k_split_planes_frag(const float* __restri
     uint16_t* o = dst + blk * 1536 + lane * 8;             // 3 planes x 512 bf16 per block
     if constexpr (H2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pm_split2h_pair(pm_clamp_f16(x[2 * e] * w_scale), pm_clamp_f16(x[2 * e + 1] * w_scale), p1[e], p2[e]);
+      for (int e = 0; e < 4; ++e) pm_split2h_pair(pm_clamp_f16(x[2 * e] * w_scale, cut), pm_clamp_f16(x[2 * e + 1] * w_scale, cut), p1[e], p2[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) pm_split3_pair(x[2 * e], x[2 * e + 1], p1[e], p2[e], p3[e]);
@@ -1135,6 +1136,7 @@ __global__ void __launch_bounds__(256) k_split_planes_frag(const float* __restri
     *reinterpret_cast<u32x4*>(o) = u32x4{p1[0], p1[1], p1[2], p1[3]};
     *reinterpret_cast<u32x4*>(o + 512) = u32x4{p2[0], p2[1], p2[2], p2[3]};
   }
+  if (H2 && cut && clamps) atomicAdd(clamps, 1u);
 }
 static int split_planes_frag_impl(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,
                                   int64_t src_stride, int64_t dst_stride, float w_scale, uint16_t* out, pm_stream_t stream) {
@@ -1145,10 +1147,10 @@ static int split_planes_frag_impl(const float* W, int32_t rows, int32_t cols, in
   if (grid > 2048) grid = 2048;
   if (w_scale > 0.f)
     hipLaunchKernelGGL(k_split_planes_frag<true>, dim3((unsigned)grid, (unsigned)n_mats), dim3(256), 0, (hipStream_t)stream, W,
-                       rows, cols, kind, src_stride, dst_stride, out, w_scale);
+                       rows, cols, kind, src_stride, dst_stride, out, w_scale, pm_h2_clamp_word());
   else
     hipLaunchKernelGGL(k_split_planes_frag<false>, dim3((unsigned)grid, (unsigned)n_mats), dim3(256), 0, (hipStream_t)stream, W,
-                       rows, cols, kind, src_stride, dst_stride, out, 0.f);
+                       rows, cols, kind, src_stride, dst_stride, out, 0.f, nullptr);
   return pm_check_launch();
 }
 extern "C" int pm_split_planes_frag(const float* W, int32_t rows, int32_t cols, int32_t kind, int32_t n_mats,

@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
                                                             const double* __restrict__ acc3, float* dgamma,
                                                             float* dbeta, float* dbias_pre, float* __restrict__ dx,
                                                             uint16_t* __restrict__ dx_planes, int64_t plane_stride,
-                                                            const unsigned* __restrict__ mdu, float* sdh_out) {
+                                                            const unsigned* __restrict__ mdu, float* sdh_out, unsigned* clamps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [6][C]: mean, rstd, gamma, beta, mean(du), mean(du*xhat)
   __shared__ float s_gm[4];
   float* const s_m = sm; float* const s_rs = sm + C; float* const s_ga = sm + 2 * C; float* const s_be = sm + 3 * C;
@@ -633,6 +633,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
     dsc = pm_pow2_scale(gm * pm_absmax_read(mdu) * 16.f, 13);
     if (blockIdx.x == 0 && threadIdx.x == 0) *sdh_out = dsc;
   }
+  bool cut = false;                                          // (pair format: a value of this thread exceeded the scale's window)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)((i * 4) % C);
     const float4 xv = reinterpret_cast<const float4*>(x)[i], dv = reinterpret_cast<const float4*>(dy)[i];
@@ -643,8 +644,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
       o[j] = pm_bn_bwd_elem(xs[j], ds[j], s_m[c + j], s_rs[c + j], s_ga[c + j], s_be[c + j], s_m0[c + j], s_m1[c + j], ctx.relu);
     if (mdu) {
       unsigned l1, l2, u1, u2;
-      pm_split2h_pair(pm_clamp_f16(o[0] * dsc), pm_clamp_f16(o[1] * dsc), l1, l2);
-      pm_split2h_pair(pm_clamp_f16(o[2] * dsc), pm_clamp_f16(o[3] * dsc), u1, u2);
+      pm_split2h_pair(pm_clamp_f16(o[0] * dsc, cut), pm_clamp_f16(o[1] * dsc, cut), l1, l2);
+      pm_split2h_pair(pm_clamp_f16(o[2] * dsc, cut), pm_clamp_f16(o[3] * dsc, cut), u1, u2);
       const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2};
       *reinterpret_cast<pm_u32x2*>(dx_planes + i * 4) = p1;
       *reinterpret_cast<pm_u32x2*>(dx_planes + plane_stride + i * 4) = p2;
@@ -652,6 +653,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply4_sums(const float* __restr
     if (dx_planes) pm_store_planes4(dx_planes, plane_stride, i * 4, o[0], o[1], o[2], o[3]);   // GEMM operand planes
     else reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
+  if (cut && clamps) atomicAdd(clamps, 1u);
 }
 static int bn_bwd_fused_impl(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,
                              const float* var, float eps, const float* gamma, const float* beta, int relu,
@@ -675,7 +677,8 @@ static int bn_bwd_fused_impl(const float* x, const float* dy, int32_t O, int32_t
                        pm_det_gate(st));
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
-                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride, mdu, sdh_out);
+                     (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride, mdu, sdh_out,
+                     mdu ? pm_h2_clamp_word() : nullptr);
   return pm_check_launch();
 }
 extern "C" int pm_bn_bwd_fused(const float* x, const float* dy, int32_t O, int32_t C, const float* mean,

@@ -21,25 +21,25 @@ int pm_plan_build_marked(const int64_t* edge_index, const int32_t* edge_type, co
                          int32_t N, int32_t E, int32_t G, int32_t* plan, hipStream_t stream, hipEvent_t after_count);   // plan.hip
 namespace {
 
-// A/B switches of the step, read ONCE (first use): which kernel set the measured path takes never changes inside a run.
+// A/B switches of the step: environment variables read ONCE, when the library is loaded (pm_vae_step_reload_switches re-reads:
+// tests) — which kernel set the measured path takes never changes inside a run.  read_cfg() below is the complete list:
 //   PM_GCL_FUSED=0      the round-1 kernels (segment-reduce forward + grouped planes products, tile kernels for the chord
 //                       products) instead of gcl.hip / linear.hip / wide.hip
-//   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products;
-//                       PM_NO_ROWS_TN=1: only the chord weight gradients back on the fp32 tile GEMM;
-//                       PM_NO_UNEMBED_DH=1: the un-embedding's input gradient as three fp32 tile GEMMs
-//   PM_GCL_NO_CLASSES=1 no skipping of all-zero onset / next blocks;  PM_GCL_NO_BFRAG=1: no fragment-major weight copies
+//   PM_GCL_NO_DW=1      only the GCL weight gradient back on the grouped product;  PM_NO_ROWS_W=1: only the chord products
+//   PM_GCL_NO_CLASSES   (set) no skipping of all-zero onset / next blocks
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
 //   PM_SIDE_STREAM=m    bit mask of the branch sites (BR_* below) issued on the library's second stream (default: all;
-//                       0: everything on the caller's stream)
-//   PM_DENSE_DEG=n      mean in-degree (E / N) from which the fused forward hands the aggregation to the stand-alone
-//                       segment-reduce kernel (d = 512: its planes are then contracted by pm_gcl_forward_from_planes)
+//                       0: everything on the caller's stream);  PM_SIDE_DELAY_US=n (tests): every branch starts n us late
+//   PM_DAGG_BN=0, PM_DAGG_RES=0, PM_PLAN_SIDE=0, PM_CHORD_TABLES=0, PM_H2=0, PM_BAR_ROUTE=0: see the fields of StepCfg
+//   PM_GCL_OFFSET_LIMIT=n, PM_DEBUG
+// Former switches that are constants now (their losing side was measured and removed: profiles/LOG.md): PM_NO_ROWS_TN,
+// PM_NO_UNEMBED_DH, PM_GCL_NO_BFRAG, PM_DENSE_DEG (16), PM_LATE_WGRADS, PM_DW_SIDE, PM_FUSED_HEADS (csrc/heads.hip, deleted in
+// round 6) — setting them has no effect.
 struct StepCfg {
   bool gcl_fused, no_dw, no_rows_w, no_rows_tn, no_unembed_dh, no_classes, no_bfrag, fused_ce, debug;
   int side_stream;             // PM_SIDE_STREAM: bit per branch site (BR_*), default all
   int side_delay_us;           // PM_SIDE_DELAY_US (tests): every branch starts with a kernel that spins this long on the second stream,
                                // so a missing join shows as a wrong result instead of passing by luck of timing
-  bool fused_heads;            // PM_FUSED_HEADS=1: the head chains as one persistent launch each (heads.hip) instead of ~14 launches —
-                               // built, parity-tested, and SLOWER (5.19 against 5.08 ms per step: profiles/LOG.md); off
   bool dw_side;                // PM_DW_SIDE=1: the GCL weight gradients on the second stream
   bool dagg_bn;                // PM_DAGG_BN=0: the norm backward of a GCN layer as its own pass (pm_bn_bwd_fused) instead of inside the
                                // input gradient's prologue (pm_gcl_input_grad_bn; d in {128, 256})
@@ -78,7 +78,6 @@ static StepCfg read_cfg() {
   k.plan_side = flag("PM_PLAN_SIDE", true);
   k.chord_tables = flag("PM_CHORD_TABLES", true);
   k.dagg_res = flag("PM_DAGG_RES", true);
-  k.fused_heads = flag("PM_FUSED_HEADS", false);
   k.h2 = flag("PM_H2", true);
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = 16;
@@ -160,7 +159,6 @@ struct StepState {
   const float *a1d, *h1d, *x0d, *xLg, *zcat_d, *zg_d, *zr_d, *sbd, *u1d, *H_d;
   uint32_t seed_enc, seed_dec;
   float *bk_dx0, *bk_dzcat;               // carried from pm_vae_step_backward_encoder to ..._encoder_tail
-  unsigned *bar_fwd, *bar_dec, *bar_enc;  // grid-barrier counters of the three head-chain launches (zero region)
   float *bk_dxL;                          // carried from pm_vae_step_backward_encoder_heads to pm_vae_step_backward_encoder
   int rc;
   unsigned br_open;                       // branches issued on the second stream and not yet joined (bit = site)
@@ -310,22 +308,6 @@ void lin_bwd(Ctx& c, const float* dy, const float* x, PmLin l, int M, int Nout, 
   else RUN(pm_gemm_f32_desc(&w, c.st));
   if (dx) RUN(pm_gemm_f32(0, 0, M, Kin, Nout, dy, lddy, c.P + l.w, Kin, dx, lddx ? lddx : Kin, nullptr,
                             c.s->ar.zeroed(dx) ? PM_GEMM_ZEROED : 0, 1, nullptr, 0, nullptr, c.st));
-}
-// ---- head chains as one persistent launch each (csrc/heads.hip); not with cfg.dropout (its layers sit between the stages)
-static bool heads_fused(const Ctx& c) { return cfg().fused_heads && !(c.pdrop > 0.f) && c.B <= 1024 && (c.d % 32) == 0; }
-static PmHeadStage head_stage(const float* in, int ld_in, int K, const float* W, int ldw, int kmajor, const float* bias, float* out,
-                              int ld_out, int N, int barrier_after) {
-  PmHeadStage s;
-  memset(&s, 0, sizeof(s));
-  s.in = in; s.ld_in = ld_in; s.K = K; s.W = W; s.ldw = ldw; s.w_kmajor = kmajor; s.bias = bias; s.out = out; s.ld_out = ld_out;
-  s.N = N; s.barrier_after = barrier_after; s.epi = PM_HE_NONE; s.eps = 1e-5f; s.momentum = 0.1f;
-  return s;
-}
-static void head_bn(Ctx& c, PmHeadStage& s, int epi, PmBn bn, int col0, float* mean, float* var, bool running) {
-  s.epi = epi; s.relu = 1;
-  s.gamma = c.P + bn.w + col0; s.beta = c.P + bn.b + col0; s.mean = mean + col0; s.var = var + col0;
-  if (epi == PM_HE_BN_FWD && running) { s.rmean = c.Bf + bn.rm + col0; s.rvar = c.Bf + bn.rv + col0; }
-  if (epi == PM_HE_BN_BWD) { s.dgamma = c.G + bn.w + col0; s.dbeta = c.G + bn.b + col0; }
 }
 // training-mode BatchNorm forward (+ReLU, + residual); mean/var are saved for the backward
 void bn_fwd(Ctx& c, const float* x, int O, int C, int I, PmBn bn, bool relu, const float* res, float* y, float* mean,
@@ -893,12 +875,11 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_bn_stats(s.g, N, 1, 1, s.gm, s.gv, c.Bf + Y.enc_gate_bn.rm, c.Bf + Y.enc_gate_bn.rv, 0.1f, c.bn_scratch, c.st));
     RUN(pm_attnpool_fwd(xL, s.g, s.gm, s.gv, 1e-5f, c.P + Y.enc_gate_bn.w, c.P + Y.enc_gate_bn.b, s.plan, N, c.E, Gn, d,
                           s.alpha, s.pooled, c.st));
-    if (!heads_fused(c)) lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);   // z_c = zcat[:, :d]
+    lin(c, s.pooled, Y.enc_c_bars, B, d, nb * d, s.zcat, false, nb * d, 2 * d);   // z_c = zcat[:, :d]
   }
   // ---------------- merge + heads (model.py:472-481), reparametrisation (model.py:671-673)
   s.m = ar.zf((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
   s.mu = ar.zf((size_t)B * d); s.lv = ar.zf((size_t)B * d); s.z = ar.f((size_t)B * d);
-  s.bar_fwd = (unsigned*)ar.z(64); s.bar_dec = (unsigned*)ar.z(64); s.bar_enc = (unsigned*)ar.z(64);
   // ---------------- decoder (model.py:634-655)
   s.zd = ar.zf((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
   s.sb = ar.zf((size_t)Gn * d); s.u1 = ar.f((size_t)Gn * d); s.u2 = ar.f((size_t)Gn * 512);
@@ -908,29 +889,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   float* const zrd_buf = dropping ? ar.f((size_t)B * 2 * d) : nullptr;
   float* const sbd_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
   float* const u1d_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
-  if (run && heads_fused(c)) {
-    // the whole chain pooled -> z_c | merge -> BatchNorm -> mu, log_var -> z -> decoder's first layer -> BatchNorm -> bars decoder
-    // as ONE persistent launch of five stages (csrc/heads.hip)
-    branch_join(c, BR_ENC_FWD);                        // z_s = zcat[:, d:] comes from the structure encoder (second stream)
-    PmHeadChain ch;
-    memset(&ch, 0, sizeof(ch));
-    ch.B = B; ch.bar = s.bar_fwd; ch.n = 5;
-    ch.st[0] = head_stage(s.pooled, nb * d, nb * d, c.P + Y.enc_c_bars.w, nb * d, 0, c.P + Y.enc_c_bars.b, s.zcat, 2 * d, d, 1);
-    ch.st[1] = head_stage(s.zcat, 2 * d, 2 * d, c.P + Y.enc_merge.w, 2 * d, 0, c.P + Y.enc_merge.b, s.zg, d, d, 1);
-    head_bn(c, ch.st[1], PM_HE_BN_FWD, Y.enc_bn_merge, 0, s.mm, s.mv, true);
-    ch.st[1].out2 = s.m; ch.st[1].ld_out2 = d;
-    ch.st[2] = head_stage(s.zg, d, d, c.P + Y.enc_mu.w, d, 0, c.P + Y.enc_mu.b, s.z, d, d, 1);
-    ch.st[2].in2 = s.zg; ch.st[2].ld_in2 = d; ch.st[2].K2 = d; ch.st[2].W2 = c.P + Y.enc_lv.w; ch.st[2].ldw2 = d;
-    ch.st[2].bias2 = c.P + Y.enc_lv.b; ch.st[2].dual = 1; ch.st[2].epi = PM_HE_REPARAM_FWD; ch.st[2].noise = s.eps;
-    ch.st[2].ld_noise = d; ch.st[2].out2 = s.mu; ch.st[2].ld_out2 = d; ch.st[2].out3 = s.lv; ch.st[2].ld_out3 = d;
-    ch.st[3] = head_stage(s.z, d, d, c.P + Y.dec_lin.w, d, 0, c.P + Y.dec_lin.b, s.zr, 2 * d, 2 * d, 1);
-    head_bn(c, ch.st[3], PM_HE_BN_FWD, Y.dec_bn, 0, s.dm, s.dv, true);
-    ch.st[3].out2 = s.zd; ch.st[3].ld_out2 = 2 * d;
-    ch.st[4] = head_stage(s.zr + d, 2 * d, d, c.P + Y.dec_c_bars.w, d, 0, c.P + Y.dec_c_bars.b, s.cb, nb * d, nb * d, 0);
-    RUN(pm_head_chain(&ch, c.st));
-    s.zcat_d = s.zcat; s.zg_d = s.zg; s.zr_d = s.zr;
-    RUN(pm_bar_broadcast_fwd(s.cb, s.plan, N, c.E, Gn, d, xd0, c.st));
-  } else if (run) {
+  if (run) {
     branch_join(c, BR_ENC_FWD);
     s.zcat_d = drop(c, s.zcat, B, 2 * d, SITE_ENC_MERGE_IN, seed_enc, zcatd_buf);            // Encoder.dropout_layer, model.py:473
     lin(c, s.zcat_d, Y.enc_merge, B, d, 2 * d, s.m, false);
@@ -1093,43 +1052,12 @@ void backward_decoder(Ctx& c) {
   Deferred df;
   float* dzd = ar.zf((size_t)B * 2 * d);
   s.dz = ar.zf((size_t)B * d);
-  if (heads_fused(c)) {
-    // bars decoder -> BatchNorm backward -> decoder's first layer -> reparametrisation backward: one persistent launch
-    // (csrc/heads.hip); the weight gradients of the two products follow on the second stream (deferred, below)
-    lin_bwd(c, dcb, s.zr_d + d, Y.dec_c_bars, B, nb * d, d, nullptr, 0, 2 * d, 2 * d, true, &df);
-    branch_join(c, BR_DEC_BWD);
-    PmHeadChain ch;
-    memset(&ch, 0, sizeof(ch));
-    ch.B = B; ch.bar = s.bar_dec;
-    int n = 0;
-    // content half of d(zr): d(cb) @ W, straight into the norm's backward on columns [d, 2d)
-    ch.st[n] = head_stage(dcb, nb * d, nb * d, c.P + Y.dec_c_bars.w, d, 1, nullptr, dzd + d, 2 * d, d, 0);
-    head_bn(c, ch.st[n], PM_HE_BN_BWD, Y.dec_bn, d, s.dm, s.dv, false);
-    ch.st[n].xpre = s.zd + d; ch.st[n].ld_xpre = 2 * d;
-    ++n;
-    if (s.fix_structure) {        // structure half: d(zr)[:, :d] comes from the structure decoder's backward (second stream)
-      ch.st[n] = head_stage(nullptr, 0, 0, nullptr, 0, 1, nullptr, dzd, 2 * d, d, 0);
-      ch.st[n].init = dzr; ch.st[n].ld_init = 2 * d;
-      head_bn(c, ch.st[n], PM_HE_BN_BWD, Y.dec_bn, 0, s.dm, s.dv, false);
-      ch.st[n].xpre = s.zd; ch.st[n].ld_xpre = 2 * d;
-      ++n;
-    }                             // (else that half of d(zr) is zero, and so is its d(zd): zero region)
-    ch.st[n - 1].barrier_after = 1;
-    ch.st[n] = head_stage(dzd, 2 * d, 2 * d, c.P + Y.dec_lin.w, d, 1, nullptr, s.dz, d, d, 0);
-    ch.st[n].epi = PM_HE_REPARAM_BWD; ch.st[n].noise = s.eps; ch.st[n].ld_noise = d; ch.st[n].lv = s.lv; ch.st[n].ld_lv = d;
-    ch.st[n].dmu = s.dmu; ch.st[n].dlv = s.dlv; ch.st[n].ld_d = d;
-    ++n;
-    ch.n = n;
-    RUN(pm_head_chain(&ch, c.st));
-    lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, nullptr, 0, 0, 0, true, &df);
-  } else {
   lin_bwd(c, dcb, s.zr_d + d, Y.dec_c_bars, B, nb * d, d, dzr + d, 0, 2 * d, 2 * d, true, &df);
   branch_join(c, BR_DEC_BWD);
   drop(c, dzr, B, 2 * d, SITE_DEC_IN, s.seed_dec, dzr);           // backward of Decoder.dropout
   bn_bwd(c, s.zd, dzr, B, 2 * d, 1, Y.dec_bn, s.dm, s.dv, true, dzd);
   lin_bwd(c, dzd, s.z, Y.dec_lin, B, 2 * d, d, s.dz, 0, 0, 0, true, &df);
   RUN(pm_reparam_bwd(s.dz, s.lv, s.eps, (int64_t)B * d, s.dmu, s.dlv, c.st));
-  }
   if (late_wgrads && cfg().late_wgrads_at == 2) decoder_weight_grads();
   if (df.n) {                                         // the two head products' weight gradients: behind the others on the second stream
     BranchScope br(c, BR_DEC_WGRAD);
@@ -1152,23 +1080,6 @@ void backward_encoder_heads(Ctx& c) {
   float* dm = ar.f((size_t)B * d);
   float* dzcat = ar.zf((size_t)B * 2 * d);
   float* dpooled = ar.zf((size_t)Gn * d);
-  const bool fused = heads_fused(c);
-  if (fused) {
-    // mu / log_var heads -> BatchNorm backward -> merge layer -> bars encoder: one persistent launch (csrc/heads.hip)
-    PmHeadChain ch;
-    memset(&ch, 0, sizeof(ch));
-    ch.B = B; ch.bar = s.bar_enc; ch.n = 3;
-    ch.st[0] = head_stage(s.dmu, d, d, c.P + Y.enc_mu.w, d, 1, nullptr, dm, d, d, 1);
-    ch.st[0].in2 = s.dlv; ch.st[0].ld_in2 = d; ch.st[0].K2 = d; ch.st[0].W2 = c.P + Y.enc_lv.w; ch.st[0].ldw2 = d;
-    head_bn(c, ch.st[0], PM_HE_BN_BWD, Y.enc_bn_merge, 0, s.mm, s.mv, false);
-    ch.st[0].xpre = s.m; ch.st[0].ld_xpre = d;
-    ch.st[1] = head_stage(dm, d, d, c.P + Y.enc_merge.w, 2 * d, 1, nullptr, dzcat, 2 * d, 2 * d, 1);
-    ch.st[2] = head_stage(dzcat, 2 * d, d, c.P + Y.enc_c_bars.w, nb * d, 1, nullptr, dpooled, nb * d, nb * d, 0);
-    RUN(pm_head_chain(&ch, c.st));
-    lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, nullptr, 0, 0, 0, true, &df);
-    lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, nullptr, 0, 0, 0, true, &df);
-    lin_bwd(c, dm, s.zcat_d, Y.enc_merge, B, d, 2 * d, nullptr, 0, 0, 0, true, &df);
-  } else {
   lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
   lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
   RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
@@ -1176,7 +1087,6 @@ void backward_encoder_heads(Ctx& c) {
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
   lin_bwd(c, dm, s.zcat_d, Y.enc_merge, B, d, 2 * d, dzcat, 0, 0, 0, true, &df);
   drop(c, dzcat, B, 2 * d, SITE_ENC_MERGE_IN, s.seed_enc, dzcat);
-  }
   // ---- structure branch (z_s = zcat[:, d:]): on the second stream, under the whole content-encoder backward; joined at
   // the end of backward_encoder_tail
   {
@@ -1200,7 +1110,7 @@ void backward_encoder_heads(Ctx& c) {
     RUN(pm_conv3x3_bwd_weight(s.bt.s_tensor, dc0, Gn, 1, 8, 4, 32, 0, c.G + Y.enc_conv0.w, c.G + Y.enc_conv0.b, c.st));
   }
   // ---- content branch (z_c = zcat[:, :d])
-  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, fused ? nullptr : dpooled, 2 * d, nb * d, nb * d, true, &df);
+  lin_bwd(c, dzcat, s.pooled, Y.enc_c_bars, B, d, nb * d, dpooled, 2 * d, nb * d, nb * d, true, &df);
   if (df.n) {                                         // the four head products' weight gradients: second stream, joined below
     BranchScope br(c, BR_ENC_HEAD_WGRAD);
     flush_deferred(c, df);

@@ -60,6 +60,7 @@ def _expect_dedicated_kernels(info, L=8):
     """the three GCL products and the chord products of the step ran on gcl.hip / linear.hip / wide.hip (the chord ENCODER
     runs as table algebra, chord.hip: the decoder's two products remain)"""
     n = info["launches"]
+    assert info.get("h2_clamp_events", 0) == 0, info        # (no operand of the fp16 pair format saturated: no gradient was clipped)
     assert info["compact"] == 1 and info["planes"] == 1 and info["b_frag"] == 1 and info["n_slots"] < 15, info
     assert info["chord_tables"] == 1 and info["dagg_bn"] == 1, info
     assert n["gcl_fwd"] == 2 * L and n["gcl_dagg"] == 2 * L and n["gcl_dw"] == 2 * L and n["rows_w"] == 2, info
@@ -251,6 +252,7 @@ def test_dense_shard_at_its_real_size_properties():
     info, names = run["info"], run["names"]
     n = info["launches"]
     assert info["N"] == 16384 and info["E"] == 2080768 and info["compact"] == 1 and info["planes"] == 1, info
+    assert info["h2"] == 3 and info["h2_clamp_events"] == 0, info     # (round 6: the dense route runs the pair format too; nothing saturated)
     assert n["gcl_fwd"] == 16 and n["segreduce_fwd"] == 16 and n["gcl_dagg"] == 16 and n["gcl_dw"] == 16 and n["rows_w"] == 2, info
     assert n["planesB_nn"] == 0 and n["planesB_nt"] == 0 and n["planes_tn"] == 0, info
     for k, v in run["outputs"].items():

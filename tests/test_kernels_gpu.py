@@ -1389,6 +1389,7 @@ def test_relu_bwd_planes_matches_torch_and_the_plane_split():
 
 # ---- the fp16 pair operand format of the GCL products (PmH2, include/polyphemus_hip.h) --------------------------------------
 import ctypes as _ct
+from polyphemus_amd import _lib as _lib_mod
 
 
 class _PmH2(_ct.Structure):
@@ -1424,6 +1425,7 @@ def test_gcl_products_in_the_fp16_pair_format(d, p, xs, gs):
         cpu = synthetic_batch(40, 2, p=0.3, seed=29)
     b, plan = make_plan(cpu)
     N, dd = cpu.num_nodes, d * d
+    clamps0 = _lib_mod.h2_clamp_events()
     torch.manual_seed(11)
     x = torch.randn(N, d, device=DEV) * xs
     T = ops.edge_table(torch.randn(d, 32, device=DEV) * 0.5, torch.randn(d, device=DEV) * 0.1)
@@ -1510,3 +1512,45 @@ def test_gcl_products_in_the_fp16_pair_format(d, p, xs, gs):
     want[4 * d:] += A2v[:, d:].T @ dh2v
     scale = float((want - base.double()).abs().max())
     assert float((dW2.double() - want).abs().max()) < 3e-6 * scale
+    assert _lib_mod.h2_clamp_events() == clamps0              # nothing saturated: every operand fitted its power-of-two scale
+
+
+def test_pair_format_saturation_is_counted():
+    """the fp16 pair split clamps at +-65504 where a tensor's |max| BOUND was too small (dh: the bound
+    16 gamma rstd |du|max holds for |xhat| <= 14, a BatchNorm column with one outlier reaches sqrt(N)) — silently, before round 6.
+    `pm_h2_clamp_events` counts the threads that cut a value.  Here the bound is made wrong on purpose: (1) |du|max words that
+    understate the gradient 4096-fold in `pm_gcl_input_grad_bn_h2` and `pm_bn_bwd_fused_h2`; (2) weight planes with a scale that
+    takes glorot-range weights out of fp16's range.  The properly scaled calls before and after leave the counter alone."""
+    cpu = synthetic_batch(40, 2, p=0.3, seed=29)
+    b, plan = make_plan(cpu)
+    N = cpu.num_nodes
+    torch.manual_seed(5)
+    _lib_mod.h2_clamp_events(reset=True)
+    for d in (256, 512):
+        W = torch.randn(7 * d, d, device=DEV) / d ** 0.5
+        Wft2 = torch.zeros(3, 7 * d * d, dtype=torch.int16, device=DEV)
+        call("pm_split_planes_frag_h2", ptr(W), 7 * d, d, 0, 1, 7 * d * d, 7 * d * d * 3, 16.0, ptr(Wft2), stream())
+        assert _lib_mod.h2_clamp_events() == 0
+        hpre = torch.randn(N, d, device=DEV) * 1.5 + 0.3
+        du = torch.randn(N, d, device=DEV)
+        gamma, beta = torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV) * 0.2
+        mean, var = hpre.mean(0), hpre.var(0, unbiased=False)
+        acc3 = ops.bn_bwd_sums(hpre, du, mean, var, gamma, beta)
+        for lie in (1.0, 1.0 / 4096):
+            mdu = _absmax_words(du * lie)
+            sdh = torch.zeros(1, device=DEV)
+            dA2 = torch.empty(N, 4 * d, device=DEV)
+            D2 = torch.zeros(3, N * d, dtype=torch.int16, device=DEV)
+            hb = _PmH2(ptr(mdu), None, ptr(sdh), 16.0, 0)
+            if d <= 256:
+                nb = ops._BnBwd(ptr(hpre), ptr(du), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(acc3), None, None, None, 1e-5, 1, 0, 0)
+                call("pm_gcl_input_grad_bn_h2", _ct.addressof(nb), ptr(D2), N * d, ptr(plan.buf), N, plan.E, plan.G, d, ptr(Wft2), 1,
+                     ptr(dA2), _ct.addressof(hb), stream())
+            else:
+                call("pm_bn_bwd_fused_h2", ptr(hpre), ptr(du), N, d, ptr(mean), ptr(var), 1e-5, ptr(gamma), ptr(beta), 1, None, None, None,
+                     ptr(acc3), ptr(D2), N * d, 1, _ct.addressof(hb), stream())
+            n = _lib_mod.h2_clamp_events(reset=True)
+            assert (n == 0) if lie == 1.0 else (n > 0), (d, lie, n)
+    call("pm_split_planes_frag_h2", ptr(W), 7 * d, d, 0, 1, 7 * d * d, 7 * d * d * 3, 1.0e7, ptr(Wft2), stream())
+    assert _lib_mod.h2_clamp_events(reset=True) > 0
+    assert _lib_mod.h2_clamp_events() == 0

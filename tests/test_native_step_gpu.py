@@ -561,38 +561,3 @@ def test_native_step_covers_the_constructor_switches(d, batch_norm, p_cfg):
             assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * max(1.0, float(sb[k].abs().max())) + 4e-5, k
         else:
             assert torch.equal(sa[k], sb[k]), k
-
-
-def test_fused_head_chains_match_the_launch_chains():
-    """PM_FUSED_HEADS=1 (csrc/heads.hip: the layers between the two GCN stacks as one persistent launch per direction; opt-in,
-    measured slower) against the default launch chains: same step up to fp32 summation order."""
-    import os
-    from polyphemus_amd._lib import lib
-    cfg = dict(dropout=0, batch_norm=True, gnn_n_layers=2, d=128, n_bars=2, resolution=8)
-    batch = synthetic_batch(40, 2, p=0.25, seed=33).to(DEV)
-    eps = torch.randn(40, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
-    res = []
-    try:
-        for fused in ("0", "1"):
-            os.environ["PM_FUSED_HEADS"] = fused
-            assert lib().pm_vae_step_reload_switches() == 0
-            torch.manual_seed(0)
-            vae = VAE(**cfg, device=DEV).to(DEV)
-            vae.train()
-            vae.msg_dropout = 0.0
-            tr = HipTrainer(vae, lr=5e-6, structure_loss_on_logits=True)
-            tr.keep_logits = True
-            loss = tr.losses_dict(tr.train_step(batch, eps))
-            (s_logits, c_logits), mu, lv = tr.step_outputs()
-            res.append((loss, tr.grads.clone(), mu.clone(), lv.clone(), c_logits.clone(),
-                        {k: v.detach().clone() for k, v in vae.state_dict().items() if "running" in k}))
-    finally:
-        os.environ.pop("PM_FUSED_HEADS", None)
-        assert lib().pm_vae_step_reload_switches() == 0
-    (la, ga, ma, va, ca, ra), (lb, gb, mb, vb, cb, rb) = res
-    for k in la:
-        assert abs(la[k] - lb[k]) <= 2e-6 * max(1.0, abs(la[k])), k
-    assert rel_err(mb, ma) < 2e-5 and rel_err(vb, va) < 2e-5 and rel_err(cb, ca) < 2e-5
-    assert rel_err(gb, ga) < 2e-3
-    for k in ra:
-        assert rel_err(rb[k], ra[k]) < 1e-5, k

@@ -37,7 +37,7 @@ import sys
 import pytest
 import torch
 
-from util import DENSE_SHARD_B64, FULLSIZE, REL_TOL, hip_fullsize_step, hip_vs_oracle_fullsize
+from util import DENSE_SHARD_B64, FULLSIZE, REL_TOL, SMALLSIZE, hip_fullsize_step, hip_vs_oracle_fullsize
 
 pytestmark = pytest.mark.gpu
 
@@ -118,7 +118,8 @@ def test_deterministic_step_matches_fp64_oracle_at_the_bench_workload():
     assert g["worst_tensor_err"] < cap_w and g["rel_l2"] < cap_l2, g
 
 
-@pytest.mark.parametrize("name", ["configs1_lmd2_b256_d256", "configs1_seed1235_258_tiles", "configs2_lmd16_b64_d256", "training_json_b256_d512"])
+@pytest.mark.parametrize("name", ["configs1_lmd2_b256_d256", "configs1_seed1235_258_tiles", "configs2_lmd16_b64_d256", "training_json_b256_d512",
+                                  "configs4_dense_shard_b8_d512", "small_b24_d128_l3"])
 def test_gradient_is_the_fp64_oracles_under_the_relu_decisions_the_step_took(name):
     """WHY the default-mode gradient sits 2e-4 .. 8e-4 (relative L2) from the fp64 oracle at full size while every output is
     2e-6 away: the loss is piecewise smooth, and an fp32 step whose activations are ~1e-6 from the exact ones takes the other
@@ -130,7 +131,7 @@ def test_gradient_is_the_fp64_oracles_under_the_relu_decisions_the_step_took(nam
     comparison against regressions."""
     from oracle import kinks
     from util import grad_errors, hip_relu_decisions, oracle_fullsize
-    spec = FULLSIZE[name]
+    spec = FULLSIZE.get(name) or SMALLSIZE[name]
     live = {}
     run = hip_fullsize_step(spec, lr=0.0, keep=live)          # (lr = 0: the norms' gamma / beta the decisions depend on stay put)
     forced = hip_relu_decisions(live, run["cfg"])

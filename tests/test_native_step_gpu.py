@@ -517,10 +517,12 @@ def test_loss_trajectory_follows_the_fp64_oracle():
         assert abs(hip[i]["kld"] - ora[i]["kld"]) <= 1e-3 * max(1.0, abs(ora[i]["kld"])), (i, hip[i]["kld"], ora[i]["kld"])
     print("kld trajectory  HIP:", [round(h["kld"], 3) for h in hip], " fp64 oracle:", [round(o["kld"], 3) for o in ora])
     assert max(o["kld"] for o in ora) > 10.0 * ora[0]["kld"], [o["kld"] for o in ora]         # the oracle's own transient
-    # (the sixth step of this transient moves with the rounding of the step: 316 .. 329 over this round's kernel sets, oracle 343)
-    # ... and the HIP path's transient is the oracle's: its peak within 15 % of the oracle's peak (measured -4 .. -8 %: the two
-    # trajectories separate slowly, see above)
-    assert 0.85 < max(h["kld"] for h in hip) / max(o["kld"] for o in ora) < 1.15, ([h["kld"] for h in hip], [o["kld"] for o in ora])
+    # The transient multiplies the KLD ~6x per step at its end, and with it every rounding difference: the SIXTH step moves from
+    # run to run of one binary with the order of the step's float atomics — 341 .. 399 in eleven runs of the round-5 and round-6
+    # libraries on one box (oracle 343; profiles/LOG.md, round 6), the fifth 62.5 .. 64.8 (oracle 63.7).  So: the fifth step within
+    # 4 % of the oracle's, the peak inside the band that spread allows (a 15 % band here failed one run in four, both rounds).
+    assert abs(hip[4]["kld"] / ora[4]["kld"] - 1.0) < 0.04, (hip[4]["kld"], ora[4]["kld"])
+    assert 0.75 < max(h["kld"] for h in hip) / max(o["kld"] for o in ora) < 1.35, ([h["kld"] for h in hip], [o["kld"] for o in ora])
     # (while the trajectories have not separated, the KLDs agree in order of magnitude at every step)
     for i in range(6):
         assert 0.2 < hip[i]["kld"] / ora[i]["kld"] < 5.0, (i, hip[i]["kld"], ora[i]["kld"])

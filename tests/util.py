@@ -245,6 +245,11 @@ FULLSIZE = {
     # chord product run as 32-row halves (csrc/tile_order.h); rank 1's batch of a multi-GPU bench run
     "configs1_seed1235_258_tiles": dict(B=256, nb=2, d=256, L=8, p=0.25, dense=False, msg_p=0.1, seed=1235),
 }
+# a small d = 128 step (the kernels of gcl.hip at their narrowest width) for the forced-decision test: ADVICE r5 — at small sizes the
+# fused-vs-unfused comparison only bounds the whole gradient by what a few flipped ReLU decisions can move it
+SMALLSIZE = {
+    "small_b24_d128_l3": dict(B=24, nb=2, d=128, L=3, p=0.25, dense=False, msg_p=0.1, seed=31),
+}
 # one GPU's shard of configs[4] at its real size (B = 64: N = 16,384 nodes, 2.08 M edges): too large for the oracle's
 # per-edge fp64 tensors — property checks only (tests/test_fullsize_gpu.py)
 DENSE_SHARD_B64 = dict(B=64, nb=2, d=512, L=8, p=1.0, dense=True, msg_p=0.1, seed=1234)

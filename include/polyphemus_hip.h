@@ -55,7 +55,8 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   pm_gcl_input_grad_bn_h2, pm_gcl_weight_grad_fused_h2; PmNormSums.absmax_out; pm_bn_apply_fused_absmax; pm_vae_step_set_output_grads: the drop-in module's
  *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads; pm_deterministic_faults).
  *   8: round 6 (pm_bar_aggregate_fwd / _bwd: bar-resident aggregation of dense graphs; pm_gcl_forward_from_planes_h2: the dense
- *   route's product in the fp16 pair format; pm_h2_clamp_events: saturation counter of the pair format). */
+ *   route's product in the fp16 pair format; pm_h2_clamp_events: saturation counter of the pair format; PmBatch.flags bit 3 and
+ *   pm_vae_step_output_views: the drop-in module's outputs and gradients as views of the arena). */
 #define PM_ABI_VERSION 8
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -828,7 +829,10 @@ typedef struct PmBatch {                                    /* device pointers o
                                                                relation (host-verified) -> compact GCL, K = 4d;
                                                                bit 1: GCL GEMM operands as pre-split bf16 planes;
                                                                bit 2: also store the content logits (pm_vae_step_outputs)
-                                                               — the fused un-embedding + CE otherwise writes d_logits only */
+                                                               — the fused un-embedding + CE otherwise writes d_logits only;
+                                                               bit 3: the CALLER computes the loss (pm_vae_step_set_output_grads
+                                                               follows): the forward stores the logits and skips its own
+                                                               cross-entropy / KLD / BCE and their gradients */
   const float* ce_scale;                                    /* NULL, or device [2]: weights of the pitch / duration CE
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
@@ -888,6 +892,12 @@ int pm_bn_relu_decisions(const float* x /* [rows,C] */, const float* mean, const
  * gradients of the step's own loss kernels. */
 int pm_vae_step_set_output_grads(void* state, const float* d_s_logits /* [G,4,32] */, const float* d_c_logits /* [N,S,230] */,
                                  const float* d_mu /* [B,d] */, const float* d_log_var /* [B,d] */, pm_stream_t stream);
+/* The outputs of the last forward and the buffers their gradients are read from, as byte offsets into the workspace given to
+ * pm_vae_step_forward (host only): [0..3] = s_logits [G,4,32], c_logits [N,S,230], mu [B,d], log_var [B,d]; [4..7] = the
+ * gradient buffers in the same order.  A caller that writes a gradient into its buffer passes that pointer to
+ * pm_vae_step_set_output_grads (no copy); any other d_c_logits pointer is used where it lies (no copy either: it must stay
+ * alive, 16-byte aligned, until the four backward calls have run). */
+int pm_vae_step_output_views(const void* state, int64_t* byte_offset /* [8] */, int64_t* numel /* [8] */);
 /* ORDERING CONTRACT of the decoder's gradients: pm_vae_step_backward_decoder returns with the weight gradients of the decoder's
  * head (un-embeddings, chord decoder, the two head products) still running on the library's second stream, NOT yet joined to
  * `stream`.  They are final for the caller only behind pm_vae_step_join_decoder_grads, pm_vae_step_backward_encoder_heads or

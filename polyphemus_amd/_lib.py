@@ -125,6 +125,7 @@ _SIGS = {
     "pm_vae_step_outputs": "ppppps".replace(" ", ""),
     "pm_vae_step_set_output_grads": "ppppps",
     "pm_vae_step_saved": "piiipp",
+    "pm_vae_step_output_views": "ppp",
     "pm_bn_relu_decisions": "pppppflips",
     "pm_vae_step_backward_decoder": "ps",
     "pm_vae_step_backward_encoder": "ps",

@@ -153,6 +153,7 @@ struct StepState {
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
+  float* dc_logits_own;                   // the arena's d(c_logits) buffer (dc_logits may point at the caller's gradient tensor: ext_loss)
   float* PT; int chord_tab;          // chord encoder as table algebra (chord.hip): projected tables [2][S][2][131][d]
   uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t, *w_unembed_dh;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
   // cfg.dropout: the tensors behind the element dropout layers (the undropped ones when the model has none)
@@ -924,7 +925,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   if (run) structure_decoder();
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
-  s.dc_logits = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
+  s.dc_logits = s.dc_logits_own = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
   s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
   uint16_t* const wf_dec = s.wf_dec;
@@ -941,7 +942,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     // list) fused with the two cross-entropy terms of the loss (training.py:316-323): the logits of a 64-row tile never
     // leave the CU, d(loss)/d(logits) and the three bias gradients come out; the logits themselves only on request
     // (csrc/unembed.hip; PM_FUSED_CE=0: three products + the loss kernel)
-    if (fused_ce) {
+    // PmBatch.flags bit 3 (the drop-in module: the CALLER computes the loss): the logits only — three fp32 products, no
+    // cross-entropy, no d(logits) (224 MB at 15 slots that pm_vae_step_set_output_grads would overwrite), no KLD / BCE
+    const bool logits_only = (s.bt.flags & 8) != 0;
+    if (fused_ce && !logits_only) {
       RUN(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
                           c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
                           (s.bt.flags & 4) ? s.c_logits : nullptr, s.dc_logits, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b,
@@ -953,12 +957,14 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
                       c.P + Y.dec_pitch_d.b, 0, 1, pv.row_list, 1, pv.group_cnt + 2, c.st));
     RUN(pm_gemm_f32(0, 1, (int)R, PM_N_PITCH, dh, s.H, d, c.P + Y.dec_pitch_nd.w, dh, s.c_logits, PM_N_TOK,
                       c.P + Y.dec_pitch_nd.b, 0, 1, pv.row_list + (int64_t)N * PM_N_SLOTS, 1, pv.group_cnt + 3, c.st));
+    if (!logits_only)
     RUN(pm_content_ce_scaled(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.bt.ce_scale, s.dc_logits,
                                c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     }
-    RUN(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
+    if (!logits_only) RUN(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
     branch_join(c, BR_DEC_FWD);
-    if (s.fix_structure)
+    if (logits_only) {
+    } else if (s.fix_structure)
       RUN(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
     else      // training.py:307 evaluates the BCE on the target itself: a constant, no gradient (SURVEY B-1)
       RUN(pm_bce_logits(s.bt.s_tensor, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, nullptr, s.losses, c.st));
@@ -1330,7 +1336,7 @@ extern "C" int pm_vae_step_outputs(const void* state, float* s_logits, float* c_
   hipError_t e = hipSuccess;
   if (s_logits && e == hipSuccess) e = hipMemcpyAsync(s_logits, s->s_logits, sizeof(float) * G * 128, hipMemcpyDeviceToDevice, st);
   const bool fused_ce = cfg().fused_ce;
-  if (c_logits && fused_ce && !(s->bt.flags & 4)) return PM_E_INVALID;      // the step was told not to keep the logits
+  if (c_logits && fused_ce && !(s->bt.flags & (4 | 8))) return PM_E_INVALID;      // the step was told not to keep the logits
   if (c_logits && e == hipSuccess) e = hipMemcpyAsync(c_logits, s->c_logits, sizeof(float) * N * S * PM_N_TOK, hipMemcpyDeviceToDevice, st);
   if (mu && e == hipSuccess) e = hipMemcpyAsync(mu, s->mu, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
   if (log_var && e == hipSuccess) e = hipMemcpyAsync(log_var, s->lv, sizeof(float) * B * d, hipMemcpyDeviceToDevice, st);
@@ -1349,9 +1355,14 @@ extern "C" int pm_vae_step_set_output_grads(void* state, const float* d_s_logits
   hipStream_t st = (hipStream_t)stream;
   const size_t N = s->bt.N, S = s->bt.n_slots, G = s->bt.G, B = s->bt.B, d = s->lay.d;
   auto put = [&](float* dst, const float* src, size_t n) {
+    if (src == dst) return hipSuccess;                    // (the caller wrote into the arena's own buffer: pm_vae_step_output_views)
     return src ? hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dst, 0, sizeof(float) * n, st);
   };
-  hipError_t e = put(s->dc_logits, d_c_logits, N * S * PM_N_TOK);
+  // d(c_logits) is the step's largest tensor (224 MB at 15 slots): the backward READS it only, so the caller's tensor is used
+  // where it lies (it must stay alive until the four backward calls have run; 16-byte aligned); NULL = a zero gradient
+  hipError_t e = hipSuccess;
+  if (d_c_logits && d_c_logits != s->dc_logits_own && !((uintptr_t)d_c_logits % 16)) s->dc_logits = const_cast<float*>(d_c_logits);
+  else { s->dc_logits = s->dc_logits_own; if (d_c_logits != s->dc_logits_own) e = put(s->dc_logits_own, d_c_logits, N * S * PM_N_TOK); }
   if (e == hipSuccess && d_s_logits) e = put(s->ds_logits, d_s_logits, G * 128);
   if (e == hipSuccess) e = put(s->dmu, d_mu, B * d);
   if (e == hipSuccess) e = put(s->dlv, d_log_var, B * d);
@@ -1362,6 +1373,23 @@ extern "C" int pm_vae_step_set_output_grads(void* state, const float* d_s_logits
   s->fix_structure = d_s_logits ? 1 : 0;
   s->ext_loss = 1;
   return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
+}
+
+// The four outputs of the last forward and the buffers their gradients go to, as byte offsets into the caller's workspace
+// (host only): the drop-in module hands them to autograd as VIEWS instead of copying 2 x 224 MB per step.
+// offsets / numel[0..7] = s_logits [G,4,32], c_logits [N,S,230], mu [B,d], log_var [B,d], d_s_logits, d_c_logits, d_mu, d_log_var.
+extern "C" int pm_vae_step_output_views(const void* state, int64_t* byte_offset, int64_t* numel) {
+  const StepState* s = (const StepState*)state;
+  if (!s || s->magic != kMagic || !byte_offset || !numel || !s->ar.base || !s->s_logits || !s->c_logits) return PM_E_INVALID;
+  const int64_t N = s->bt.N, S = s->bt.n_slots, G = s->bt.G, B = s->bt.B, d = s->lay.d;
+  const float* p[8] = {s->s_logits, s->c_logits, s->mu, s->lv, s->ds_logits, s->dc_logits_own, s->dmu, s->dlv};
+  const int64_t n[8] = {G * 128, N * S * PM_N_TOK, B * d, B * d, G * 128, N * S * PM_N_TOK, B * d, B * d};
+  for (int i = 0; i < 8; ++i) {
+    if (!p[i]) return PM_E_INVALID;
+    byte_offset[i] = (int64_t)((const char*)p[i] - s->ar.base);
+    numel[i] = n[i];
+  }
+  return PM_OK;
 }
 
 // Where the last forward keeps an activation inside the caller's workspace (host only): parity tools read the tensors the

@@ -271,9 +271,14 @@ class _VaeStepFn(torch.autograd.Function):
     def forward(ctx, vae, graph, eps, *params):
         step = vae._native_step()
         n_slots = None if vae.active_slots_only else 15
-        grads = torch.zeros_like(vae.flat_params)            # (the forward already leaves gradients of its own loss here)
-        step.forward(graph, eps, grads, keep_logits=True, n_slots=n_slots)
-        (s_logits, c_logits), mu, lv = step.outputs()
+        # (a fresh zeroed gradient buffer per call, 10 us of memset at d = 256: autograd may keep the returned views as
+        #  `p.grad` — with gradient accumulation beyond this step — so the buffer cannot be the previous call's)
+        grads = torch.zeros_like(vae.flat_params)
+        # ext_loss: the caller computes the loss — the forward stores the logits and runs none of its own loss kernels
+        step.forward(graph, eps, grads, keep_logits=True, n_slots=n_slots, ext_loss=True)
+        # outputs as views of the step's arena (no 224 MB copy of the logits); vae.outputs_as_views = False: fresh copies, for a
+        # caller that keeps the outputs of one call alive across the next
+        (s_logits, c_logits), mu, lv = step.output_views() if vae.outputs_as_views else step.outputs()
         S = c_logits.shape[1]
         if S < 15:                                           # slots that hold PAD in every node: not computed (opt-in)
             full = c_logits.new_zeros(c_logits.shape[0], 15, c_logits.shape[2])
@@ -414,6 +419,7 @@ class VAE(nn.Module):
         # True: the decoder head covers only the batch's active token slots — c_logits of slots that hold PAD in every node
         # come back as zeros (the reference's loss ignores them: same loss, same gradients); default: all 15, as the reference
         self.active_slots_only = False
+        self.outputs_as_views = True                         # model(graph) in training mode returns views of the native step's arena
         self._step_ticket = 0
         self._flatten()
 
@@ -506,6 +512,13 @@ class VAE(nn.Module):
         self._check_flat()
         self.engine.msg_dropout = self.msg_dropout
         return prepare_graph(graph, self.cfg["n_bars"])
+
+    def __getstate__(self):
+        # the native step's handle holds ctypes structs with raw device pointers: not picklable, not copyable — rebuilt on use
+        # (copy.deepcopy(vae) / torch.save(vae) after a native forward raised before round 6)
+        st = dict(self.__dict__)
+        st["_native"] = None
+        return st
 
     def _native_step(self):
         from .native import NativeStep

@@ -110,7 +110,7 @@ def build_layout(vae) -> PmVaeLayout:
 
 
 def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_slots: int, track_unique: bool,
-               keep_logits: bool = False) -> PmBatch:
+               keep_logits: bool = False, ext_loss: bool = False) -> PmBatch:
     """Batch descriptor of the native step; every tensor is a checked device tensor of the dtype the C side reads
     (int64 edge_index / bars / batch, int32 ids, uint8 is_drum, fp32 s_tensor: `HipTrainer._prep_inputs`)."""
     for t, dt in ((edge_index, torch.int64), (bars, torch.int64), (batch, torch.int64), (s_tensor, torch.float32),
@@ -127,7 +127,8 @@ def make_batch(edge_index, bars, batch, s_tensor, tokens, is_drum_u8, et, ed, n_
     b.n_slots = int(n_slots)
     # bit 0: one track relation per node (compact GCL); bit 1: GCL GEMM operands as pre-split bf16 planes
     # bit 2: the fused un-embedding + CE also stores the content logits (step_outputs, evaluation)
-    b.flags = (1 if track_unique else 0) | (2 if _PLANES else 0) | (4 if keep_logits else 0)
+    # bit 3: the caller computes the loss (model(graph) + autograd): logits only, no loss kernels in the forward
+    b.flags = (1 if track_unique else 0) | (2 if _PLANES else 0) | (4 if keep_logits else 0) | (8 if ext_loss else 0)
     return b
 
 
@@ -201,7 +202,7 @@ class NativeStep:
         return C.addressof(self.state)
 
     def forward(self, graph, eps, grads, keep_logits: bool, beta: float = 0.0, fix_structure: bool = False,
-                n_slots=None, ce_scale=None, want_token_counts: bool = False):
+                n_slots=None, ce_scale=None, want_token_counts: bool = False, ext_loss: bool = False):
         """plan -> encoder -> reparametrisation -> decoder -> the step's own losses into `self.loss_buf` (+ their gradients
         with respect to the outputs; the bias gradients of the un-embedding land in `grads`).  `n_slots`: token slots the
         decoder head covers (default: the batch's active slots; 15 = every slot, as the reference computes them)."""
@@ -215,7 +216,7 @@ class NativeStep:
             s_tensor = s_tensor.float().contiguous()
         s_tensor = s_tensor.reshape(-1, 4, 32)
         bt = make_batch(ei, bars, bat, s_tensor, tok, drum, et, ed, act_slots if n_slots is None else n_slots, unique,
-                        keep_logits=keep_logits)
+                        keep_logits=keep_logits, ext_loss=ext_loss)
         if ce_scale is not None:
             bt.ce_scale = ce_scale.data_ptr()
         bt.B = bt.G // vae.cfg["n_bars"]
@@ -252,8 +253,22 @@ class NativeStep:
         self._call("pm_vae_step_outputs", self.addr, ptr(s_logits), ptr(c_logits), ptr(mu), ptr(lv), self._stream())
         return (s_logits, c_logits), mu, lv
 
+    def output_views(self):
+        """`((s_logits, c_logits), mu, log_var)` of the last forward as VIEWS of the workspace arena (no copies: c_logits is
+        224 MB at 15 slots) — valid until the next forward of this model overwrites the arena."""
+        off, num = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        self._call("pm_vae_step_output_views", self.addr, C.cast(off, C.c_void_p), C.cast(num, C.c_void_p))
+        i, vae = self.info(), self.vae
+        d, nb = vae.cfg["d"], vae.cfg["n_bars"]
+        shapes = ((i["B"], nb, 4, 32), (i["N"], i["n_slots"], 230), (i["B"], d), (i["B"], d))
+        s_logits, c_logits, mu, lv = (self.ws[int(off[k]):int(off[k]) + 4 * int(num[k])].view(torch.float32).view(shapes[k])
+                                      for k in range(4))
+        return (s_logits, c_logits), mu, lv
+
     def set_output_grads(self, ds_logits, dc_logits, dmu, dlv):
         ptr = self._ptr
+        # (d_c_logits is READ where it lies by the backward calls: keep it alive until the next forward)
+        self._grad_refs = (ds_logits, dc_logits, dmu, dlv)
         self._call("pm_vae_step_set_output_grads", self.addr, ptr(ds_logits), ptr(dc_logits), ptr(dmu), ptr(dlv), self._stream())
 
     def backward_decoder(self):

@@ -421,3 +421,41 @@ def test_evaluate_batch_matches_reference_metrics(case):
     assert set(accs) == set(want)
     for k, v in want.items():
         assert abs(accs[k] - v) < 1e-6, (k, accs[k], v)
+
+
+def test_model_call_outputs_are_arena_views_and_the_module_copies(monkeypatch):
+    """Round 6: `vae(graph)` in training mode returns VIEWS of the native step's arena (no copy of
+    the [N, 15, 230] logits), the caller's d(c_logits) is read where it lies, and the forward runs none of its own loss kernels;
+    `outputs_as_views = False` gives fresh copies with the same values and the same gradients.  A model that has run a native
+    forward can be deep-copied (its ctypes handle is dropped and rebuilt): the copy trains on."""
+    import copy
+    z, cfg = load_case("lmd2_tiny")
+    eps = torch.from_numpy(z["in/eps"]).to(DEV)
+    res = []
+    for views in (True, False):
+        vae = VAE(**cfg, device=DEV).to(DEV)
+        vae.load_state_dict(state_dict_from_golden(z))
+        vae.train()
+        vae.msg_dropout = 0.0
+        vae.outputs_as_views = views
+        g = batch_from_golden(z, cfg).to(DEV)
+        s_logits, c_logits, mu, lv = hip_forward(vae, g, eps, "model_call", monkeypatch)
+        ws = vae._native_step().ws
+        inside = ws.data_ptr() <= c_logits.data_ptr() < ws.data_ptr() + ws.numel()
+        assert inside == views
+        loss = (c_logits.float() ** 2).mean() + (s_logits ** 2).mean() + (mu ** 2).mean() + (lv ** 2).mean()
+        loss.backward()
+        res.append((c_logits.detach().clone(), mu.detach().clone(), {n: p.grad.detach().clone() for n, p in vae.named_parameters()}))
+        if views:
+            twin = copy.deepcopy(vae)                                  # (raised before round 6: ctypes pointers in vae.__dict__)
+            assert twin.__dict__["_native"] is None
+            for (n, p), (_, q) in zip(vae.named_parameters(), twin.named_parameters()):
+                assert torch.equal(p.detach(), q.detach()), n
+            twin.zero_grad(set_to_none=True)
+            outs = hip_forward(twin, batch_from_golden(z, cfg).to(DEV), eps, "model_call", monkeypatch)
+            assert rel_err(outs[1], res[0][0]) < 1e-6
+    (ca, ma, ga), (cb, mb, gb) = res
+    assert torch.equal(ca, cb) and torch.equal(ma, mb)
+    num = sum(float(((ga[n].double() - gb[n].double()) ** 2).sum()) for n in ga)
+    den = sum(float((gb[n].double() ** 2).sum()) for n in ga)
+    assert (num / den) ** 0.5 < 2e-5                                   # (float atomics: not bit-identical run to run)

@@ -122,35 +122,39 @@ __global__ void __launch_bounds__(1024) k_bar_fwd(BarFwdArgs g) {
         // this lane's edge of the batch: source row offset | distance, and the edge's dropout key
         const bool ok = base + q < cnt;
         const int p = b + base + q;
-        int wa = XB + BAR_MAX * (FCH * 4), key = 0;
+        int wa = XB + BAR_MAX * (FCH * 4), wt = 0, key = 0;     // LDS byte addresses of the source row and of the table row
         if (ok) {
           const int sl = g.csr_src[p] - n0;
           if ((unsigned)sl >= (unsigned)nn) __builtin_trap();  // (an edge that leaves its bar)
-          wa = (XB + sl * (FCH * 4)) | g.csr_dist[p];
+          wa = XB + sl * (FCH * 4);
+          wt = g.csr_dist[p] * (FCH * 4);
           if (DROP) key = (int)pm_edge_key(g.seed, g.layer_uid, (uint32_t)g.csr_eid[p]);
         }
         const int nb = __builtin_amdgcn_readfirstlane(min(32, nmax - base));   // (wave-uniform: a scalar loop)
 #pragma unroll 2
         for (int j = 0; j < nb; ++j) {
-          const int a = __builtin_amdgcn_ds_bpermute(bp0 + j * 4, wa);
-          const float4 xe = *reinterpret_cast<const float4*>(lds + ((a & ~(FCH * 4 - 1)) | qoff));
-          const float4 tv = *reinterpret_cast<const float4*>(lds + (((a & 31) << 9) | qoff));
+          const float4 xe = *reinterpret_cast<const float4*>(lds + (__builtin_amdgcn_ds_bpermute(bp0 + j * 4, wa) | qoff));
+          const float4 tv = *reinterpret_cast<const float4*>(lds + (__builtin_amdgcn_ds_bpermute(bp0 + j * 4, wt) | qoff));
           float4 m = make_float4(fmaxf(xe.x * tv.x, 0.f), fmaxf(xe.y * tv.y, 0.f), fmaxf(xe.z * tv.z, 0.f), fmaxf(xe.w * tv.w, 0.f));
           if (DROP && !(BAR_WHATIF & 1)) {
             const uint32_t k = (uint32_t)__builtin_amdgcn_ds_bpermute(bp0 + j * 4, key);
             const uint32_t gh = pm_group_hash(k, f >> 2);
             // keep iff (hash >> 8) >= thresh, i.e. hash >= thresh << 8 (thresh < 2^24): no shifts
-            m.x = pm_lane_hash(gh, 0) >= thr8 ? m.x * g.scale : 0.f;
-            m.y = pm_lane_hash(gh, 1) >= thr8 ? m.y * g.scale : 0.f;
-            m.z = pm_lane_hash(gh, 2) >= thr8 ? m.z * g.scale : 0.f;
-            m.w = pm_lane_hash(gh, 3) >= thr8 ? m.w * g.scale : 0.f;
+            // (H2: the 1 / (1 - p) of the kept messages is applied once, to the sum; the three-plane form keeps k_segreduce_fwd's
+            //  per-message product: bit-identical planes)
+            const float sc = H2 ? 1.f : g.scale;
+            m.x = pm_lane_hash(gh, 0) >= thr8 ? m.x * sc : 0.f;
+            m.y = pm_lane_hash(gh, 1) >= thr8 ? m.y * sc : 0.f;
+            m.z = pm_lane_hash(gh, 2) >= thr8 ? m.z * sc : 0.f;
+            m.w = pm_lane_hash(gh, 3) >= thr8 ? m.w * sc : 0.f;
           }
           acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
         }
       }
       if (live) {
         float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
-        if constexpr (H2) {                                    // mean, then the operand scale (a power of two), as k_gcl_fwd
+        if constexpr (H2) {                                    // mean (with the dropout's 1 / (1 - p)), then the operand scale (a power of two)
+          if (DROP) inv *= g.scale;
           acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
           inv = asc;
         }

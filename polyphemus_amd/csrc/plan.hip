@@ -128,13 +128,41 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_add(ScanArrays a, const i
 }
 
 // ---------------------------------------------------------------- counting
+// ctr[key] += 1 for every active lane, returning the lane's old value — with the lanes of a wave that share a key added by ONE
+// atomic (the leader adds the group's size, the others take its result + their rank).  Edge lists are grouped by source (the
+// reference's graph_from_tensor emits a node's out-edges together, data.py:24-121), so the out-edge counter / cursor of a node
+// was hit by 64 same-address atomics of one wave at once: on dense graphs (127 out-edges per node) they serialise — k_plan_fill
+// 595 us, k_plan_count 290 us per step at the dense shard before round 6.  Two groups are peeled per wave (a wave straddles at
+// most two sources there); whatever is left adds on its own.  Every lane of the wave must call it.
+__device__ static inline int wave_grouped_add(int* ctr, int key, bool active) {
+  int res = 0;
+  bool pending = active;
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    const unsigned long long pm = __builtin_amdgcn_ballot_w64(pending);
+    if (pm == 0) break;
+    const int leader = __builtin_ctzll(pm);
+    const int lk = __builtin_amdgcn_readlane(key, leader);
+    const bool same = pending && key == lk;
+    const unsigned long long sm = __builtin_amdgcn_ballot_w64(same);
+    int base = 0;
+    if ((int)__lane_id() == leader) base = atomicAdd(ctr + lk, (int)__builtin_popcountll(sm));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (same) {
+      res = base + (int)__builtin_popcountll(sm & ((1ull << __lane_id()) - 1ull));
+      pending = false;
+    }
+  }
+  if (pending) res = atomicAdd(ctr + key, 1);
+  return res;
+}
 __device__ static inline void d_count_edges(const int64_t* __restrict__ ei, const int32_t* __restrict__ et, int E, int* rowcnt,
                               int* colcnt, int bid) {
   const int e = bid * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int s = (int)ei[e], d = (int)ei[(int64_t)E + e];
-  atomicAdd(&rowcnt[d * PM_N_REL + et[e]], 1);
-  atomicAdd(&colcnt[s], 1);
+  const bool act = e < E;
+  const int s = act ? (int)ei[e] : 0;
+  if (act) atomicAdd(&rowcnt[(int)ei[(int64_t)E + e] * PM_N_REL + et[e]], 1);
+  wave_grouped_add(colcnt, s, act);
 }
 __device__ static inline void d_count_nodes(const int64_t* __restrict__ bars, const int64_t* __restrict__ batch,
                               const uint8_t* __restrict__ is_drum, int n_bars, int N, int* node_bar, int* barcnt,
@@ -168,11 +196,14 @@ __device__ static inline void d_fill(const int64_t* __restrict__ ei, const int32
                        const int* __restrict__ rowptr, const int* __restrict__ colptr, int* cur_in, int* cur_out,
                        int* csr_eid, int* csc_eid, int bid) {
   const int e = bid * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int s = (int)ei[e], d = (int)ei[(int64_t)E + e];
-  const int key = d * PM_N_REL + et[e];
-  csr_eid[rowptr[key] + atomicAdd(&cur_in[key], 1)] = e;
-  csc_eid[colptr[s] + atomicAdd(&cur_out[s], 1)] = e;
+  const bool act = e < E;
+  const int s = act ? (int)ei[e] : 0;
+  if (act) {
+    const int key = (int)ei[(int64_t)E + e] * PM_N_REL + et[e];
+    csr_eid[rowptr[key] + atomicAdd(&cur_in[key], 1)] = e;
+  }
+  const int slot = wave_grouped_add(cur_out, s, act);           // (the positions inside a segment are re-ordered by stage 5 anyway)
+  if (act) csc_eid[colptr[s] + slot] = e;
 }
 __device__ static inline void sort_segment(int* a, int beg, int end) {       // ascending edge id => deterministic sums
   for (int i = beg + 1; i < end; ++i) {

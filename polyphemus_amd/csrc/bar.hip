@@ -27,9 +27,6 @@
 #include <string.h>
 #include "prof.h"
 
-#ifndef BAR_WHATIF
-#define BAR_WHATIF 0                  // development: 1 = no dropout hash, 2 = backward without the table-gradient flush, 3 = both
-#endif
 namespace {
 constexpr int BAR_MAX = 128;          // nodes of a bar: 4 tracks x 32 timesteps (constants.py:11-12)
 constexpr int FCH = 128;              // forward: channels per workgroup (half a wave per destination)
@@ -136,7 +133,7 @@ __global__ void __launch_bounds__(1024) k_bar_fwd(BarFwdArgs g) {
           const float4 xe = *reinterpret_cast<const float4*>(lds + (__builtin_amdgcn_ds_bpermute(bp0 + j * 4, wa) | qoff));
           const float4 tv = *reinterpret_cast<const float4*>(lds + (__builtin_amdgcn_ds_bpermute(bp0 + j * 4, wt) | qoff));
           float4 m = make_float4(fmaxf(xe.x * tv.x, 0.f), fmaxf(xe.y * tv.y, 0.f), fmaxf(xe.z * tv.z, 0.f), fmaxf(xe.w * tv.w, 0.f));
-          if (DROP && !(BAR_WHATIF & 1)) {
+          if (DROP) {
             const uint32_t k = (uint32_t)__builtin_amdgcn_ds_bpermute(bp0 + j * 4, key);
             const uint32_t gh = pm_group_hash(k, f >> 2);
             // keep iff (hash >> 8) >= thresh, i.e. hash >= thresh << 8 (thresh < 2^24): no shifts
@@ -297,7 +294,7 @@ __global__ void __launch_bounds__(1024) k_bar_bwd(BarBwdArgs g) {
         const float we = __int_as_float(__builtin_amdgcn_ds_bpermute(bp0 + j * 4, __float_as_int(w)));
         const int dist = a & (ROWB - 1);
         const bool chg = dist != cur;
-        if (!(BAR_WHATIF & 2) && __builtin_amdgcn_ballot_w64(chg) != 0) {           // (some group's distance changes: a scalar branch)
+        if (__builtin_amdgcn_ballot_w64(chg) != 0) {           // (some group's distance changes: a scalar branch)
           flush(chg && cur != NONE);
           cur = dist;
         }
@@ -307,12 +304,12 @@ __global__ void __launch_bounds__(1024) k_bar_bwd(BarBwdArgs g) {
         const float gs[4] = {g4.x * we, g4.y * we, g4.z * we, g4.w * we};
         const float ts[4] = {tv.x, tv.y, tv.z, tv.w};
         uint32_t gh = 0;
-        if (DROP && !(BAR_WHATIF & 1)) gh = pm_group_hash((uint32_t)__builtin_amdgcn_ds_bpermute(bp0 + j * 4, key), f >> 2);
+        if (DROP) gh = pm_group_hash((uint32_t)__builtin_amdgcn_ds_bpermute(bp0 + j * 4, key), f >> 2);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           // branch-free: both conditions as masks, one select
           const int pos = xs[jj] * ts[jj] > 0.f;
-          const int keep = (DROP && !(BAR_WHATIF & 1)) ? (pm_lane_hash(gh, jj) >= thr8) : 1;
+          const int keep = DROP ? (pm_lane_hash(gh, jj) >= thr8) : 1;
           const float gg = (pos & keep) ? gs[jj] : 0.f;
           ap[jj] = fmaf(gg, ts[jj], ap[jj]);
           run[jj] = fmaf(gg, xs[jj], run[jj]);

@@ -43,12 +43,13 @@ sq() {      # name, bench args...: matrix-core / issue counters of the tile kern
   done
   { echo "# rocprofv3 --pmc (two passes), bench.py --steps 2 --warmup 1 $*: per-launch averages; SQ_VALU_MFMA_BUSY_CYCLES counts cycles,"
     echo "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* quad-cycles summed over waves, SQ_BUSY_CU_CYCLES per CU (MI355X_MICROARCH.md)"
-    for i in 1 2; do python tools/pmc_kernels.py "$O/sq_${name}_$i" k_gcl_fwd k_gcl_dagg k_gcl_dw k_wide k_rows_w k_rows_tn k_segreduce_bwd k_unembed; done
+    for i in 1 2; do python tools/pmc_kernels.py "$O/sq_${name}_$i" k_gcl_fwd k_gcl_dagg k_gcl_dw k_wide k_rows_w k_rows_tn k_segreduce_bwd k_unembed k_bar_fwd k_bar_bwd; done
   } > "$O/sq_counters_$name.txt" 2>> "$O/trace_d256.log"
   rm -rf "$O/sq_${name}_1" "$O/sq_${name}_2"
 }
 sq d256
 sq d512 --d 512
+sq dense --dense --d 512 --batch 64
 # the bench batch has 256 row tiles = one per CU; seven of the eight seeds 1234..1241 have 257-261
 for sd in 1234 1235 1236 1237; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --seed $sd 2>/dev/null | python tools/benchline.py "seed $sd"; done > "$O/bench_seeds.txt" 2>&1
 for m in 0 65535; do PM_SIDE_STREAM=$m python tools/phase_times.py; done > "$O/phase_times.txt" 2>&1

@@ -653,7 +653,9 @@ def main():
     mfma_classes = [k for k in survey if k.startswith(("gemm", "gcl"))]       # every kernel class that runs on the matrix cores
     dom = max(mfma_classes, key=lambda k: survey[k]["total_ms"])
     # the aggregation kernel of the forward: the fused layer kernel (gcl.hip) where it runs, else the segment-reduce
-    seg_key = "gcl_fwd" if "gcl_fwd" in survey else "segreduce_fwd"
+    # the aggregation kernel whose HBM view the line carries: the fused GCL forward on sparse graphs; on the dense route the
+    # aggregation is a kernel of its own again (csrc/bar.hip, profiler class segreduce_fwd) — and vector-ALU bound, see below
+    seg_key = "segreduce_fwd" if (args.dense and "segreduce_fwd" in survey) else ("gcl_fwd" if "gcl_fwd" in survey else "segreduce_fwd")
     L.pm_prof_configure((1 << names.index(dom)) | (1 << names.index(seg_key)), EVENT_STRIDE)
     L.pm_prof_begin(args.steps * 64 + 64)
     sync()
@@ -738,7 +740,8 @@ def main():
             seg_bytes = ss["work"] / ss["launches"]
         gbs = seg_bytes / (ss["avg_us"] * 1e-6) / 1e9
         roof_seg = {"bound": "hbm", "kernel": "k_gcl_fwd (aggregate built in LDS + weight product, one kernel)"
-                    if seg_key == "gcl_fwd" else "k_segreduce_fwd", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                    if seg_key == "gcl_fwd" else ("k_bar_fwd (dense graphs: the bar's rows in LDS, csrc/bar.hip)" if args.dense else "k_segreduce_fwd"),
+                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                     "traffic": pmc_traffic(seg_key, workload_key),
                     "launches_per_step": survey[seg_key]["launches"] / SURVEY, "avg_launch_us": round(ss["avg_us"], 2),
@@ -765,6 +768,12 @@ def main():
                                     "algorithmic_bytes_per_launch": sb["work"] / sb["launches"],
                                     "traffic": pmc_traffic("segreduce_bwd", workload_key),
                                     "from": "survey steps (every launch bracketed)"}
+        if args.dense:
+            # measured with SQ counters (profiles/r06_v1_sq_counters_dense.txt; bench.py cannot read PMC counters itself): the dense
+            # aggregation is bound by vector-ALU ISSUE, one wave-instruction per 4 cycles per SIMD — its HBM fraction is not its roof
+            roof_seg["valu_note"] = ("k_bar_fwd / k_bar_bwd are vector-ALU issue bound: SQ_INSTS_VALU 149.3 M / 214.9 M wave-instructions per launch "
+                                     "x 4 cycles / 1024 SIMDs = 0.91 / 0.79 of the launch's SIMD cycles (profiles/r06_v1_sq_counters_dense.txt; "
+                                     "DESIGN.md section 5): 30 / 38 instructions per 256 edge-channels, 14 of them the dropout hash")
         if seg_alone is not None:
             roof_seg["standalone_fwd"] = seg_alone
         bars_total = float(tot_nodes[1].item())

@@ -159,3 +159,48 @@ def test_bar_backward_matches_autograd_of_the_reference_op_chain():
     dT = torch.zeros(32, d, device=DEV)
     call("pm_bar_aggregate_bwd", ptr(x), ptr(T), ptr(dA), None, ptr(plan.buf), N, plan.E, plan.G, d, p, 77, 3, ptr(dx), ptr(dT), None, stream())
     assert rel_err(dx, xr.grad) < 1e-5 and rel_err(dT, Tr.grad) < 1e-5
+
+
+def test_bar_kernels_at_the_dense_shards_real_size():
+    """configs[4], one GPU's shard at its REAL size (B = 64: N = 16,384 nodes, E = 2.08 M edges, d = 512, message dropout on) —
+    too large for the CPU oracle's per-edge fp64 tensors, not for a kernel-level comparison: the bar-resident forward gives the
+    row-gather kernel's planes bit for bit, the pair-format planes decode to them within 2^-21 of |max|, and the backward (with the
+    norm sums of the layer below) agrees with `pm_segreduce_bwd_norm` to 2e-6 — the kernels tests/test_kernels_gpu.py pins to the
+    torch restatement of GCL.message + scatter-mean (model.py:110,123-135)."""
+    b, plan = make_plan(synthetic_batch(64, 2, seed=1234, dense=True))
+    N, d, p = plan.N, 512, 0.1
+    assert N == 16384 and plan.E == 2080768
+    x, T = _inputs(N, d, seed=3)
+    P0 = torch.zeros(3, N * 4 * d, dtype=torch.int16, device=DEV)
+    P1 = torch.zeros(3, N * 4 * d, dtype=torch.int16, device=DEV)
+    call("pm_segreduce_fwd_planes", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, 1, ptr(P0), N * 4 * d, stream())
+    call("pm_bar_aggregate_fwd", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, ptr(P1), N * 4 * d, None, stream())
+    assert torch.equal(P0, P1)
+    mx, mt = _absmax_words(x), _absmax_words(T)
+    sA = torch.zeros(1, device=DEV)
+    hh = _PmH2(ptr(mx), ptr(mt), ptr(sA), 16.0, 0)
+    P1.zero_()
+    call("pm_bar_aggregate_fwd", ptr(x), ptr(T), ptr(plan.buf), N, plan.E, plan.G, d, p, 5, 2, ptr(P1), N * 4 * d, _ct.addressof(hh), stream())
+    A3 = _planes_value(P0).double()
+    assert float((_pair_value(P1, float(sA)) - A3).abs().max()) <= 2.0 ** -21 * float(A3.abs().max())
+    del P0, P1, A3
+    dA = torch.randn(N, 4 * d, device=DEV)
+    hpre = torch.randn(N, d, device=DEV) * 1.5 + 0.3
+    gamma, beta = torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV) * 0.2
+    mean, var = hpre.mean(0), hpre.var(0, unbiased=False)
+    outs = []
+    for fn in ("pm_segreduce_bwd_norm", "pm_bar_aggregate_bwd"):
+        dx = torch.empty(N, d, device=DEV)
+        dT = torch.zeros(32, d, device=DEV)
+        acc3 = torch.zeros(8, 3, d, dtype=torch.float64, device=DEV)
+        amax = torch.zeros(64, dtype=torch.int32, device=DEV)
+        nn = _NormSums(ptr(hpre), ptr(mean), ptr(var), ptr(gamma), ptr(beta), 1e-5, 1, ptr(acc3), ptr(amax))
+        args = (ptr(x), ptr(T), ptr(dA), None, ptr(plan.buf), N, plan.E, plan.G, d, p, 9, 4)
+        if fn == "pm_segreduce_bwd_norm":
+            call(fn, *args, 1, ptr(dx), ptr(dT), _ct.addressof(nn), stream())
+        else:
+            call(fn, *args, ptr(dx), ptr(dT), _ct.addressof(nn), stream())
+        outs.append((dx, dT, acc3.sum(0), float(amax.view(torch.float32).max())))
+    (dx0, dT0, a0, _), (dx1, dT1, a1, m1) = outs
+    assert rel_err(dx1, dx0) < 2e-6 and rel_err(dT1, dT0) < 2e-5 and rel_err(a1, a0) < 1e-6
+    assert m1 == float(dx1.abs().max())

@@ -56,7 +56,8 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   `model(graph)` + autograd runs the C++ step; pm_vae_step_saved, pm_bn_relu_decisions: parity introspection; pm_batch_flags; pm_unembed_bias_grads; pm_deterministic_faults).
  *   8: round 6 (pm_bar_aggregate_fwd / _bwd: bar-resident aggregation of dense graphs; pm_gcl_forward_from_planes_h2: the dense
  *   route's product in the fp16 pair format; pm_h2_clamp_events: saturation counter of the pair format; PmBatch.flags bit 3 and
- *   pm_vae_step_output_views: the drop-in module's outputs and gradients as views of the arena). */
+ *   pm_vae_step_output_views: the drop-in module's outputs and gradients as views of the arena;
+ *   pm_unembed_row_lists / pm_unembed_ce_rows / pm_unembed_dh_rows: the decoder head without its PAD-target rows). */
 #define PM_ABI_VERSION 8
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -726,6 +727,25 @@ int64_t pm_unembed_dh_scratch_bytes(int32_t d);
 int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum /* [131,d/2] */, const float* w_pitch_nd,
                   const float* w_dur /* [99,d/2] */, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
                   int32_t n_slots, float* dH, uint16_t* w_planes, int32_t prepare, pm_stream_t stream);
+/* Row lists of the decoder head WITHOUT the rows whose targets are PAD (CrossEntropyLoss(ignore_index), training.py:101-102,316-323:
+ * no loss, zero gradient; 30 % of the active-slot rows at the bench's batches): row_lists [3][N*n_slots] — job 0 pitch of the drum
+ * nodes' rows, 1 pitch of the other rows, 2 duration of all rows, each ascending; a row stays when its pitch OR its duration target
+ * is not PAD —, pad_lists (or NULL) the rows left out in the same layout, row_counts [pm_unembed_row_counts_len(N, n_slots)]
+ * (device: [0..2] the lengths of row_lists, [4..6] of pad_lists, the rest scratch), and zeros in the halves of `dH_zero`
+ * [N*n_slots, d] (or NULL) that belong to the rows left out.  pm_unembed_ce_rows / pm_unembed_dh_rows are pm_unembed_ce /
+ * pm_unembed_dh over such lists (row_counts: three lengths): logits, d_logits and dH of the other rows are not touched (the
+ * weight-gradient products take the same lists as row maps). */
+int64_t pm_unembed_row_counts_len(int32_t N, int32_t n_slots);
+int pm_unembed_row_lists(const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
+                         int32_t* row_lists, int32_t* pad_lists, int32_t* row_counts, float* dH_zero, pm_stream_t stream);
+int pm_unembed_ce_rows(const float* H, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
+                       const float* b_pitch_nd, const float* w_dur, const float* b_dur, const int32_t* tokens, const int32_t* plan,
+                       int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float grad_scale, const float* dev_scale,
+                       float* logits, float* d_logits, float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out,
+                       uint16_t* w_planes, const int32_t* row_lists, const int32_t* row_counts, pm_stream_t stream);
+int pm_unembed_dh_rows(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
+                       const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
+                       uint16_t* w_planes, const int32_t* row_lists, const int32_t* row_counts, pm_stream_t stream);
 /* Bias gradients (+=) of the three un-embeddings (model.py:561-567) from a given d(loss)/d(logits) [N, S, 230]: column sums
  * of the pitch columns over the drum nodes' / the other nodes' rows and of the duration columns over all rows. */
 int pm_unembed_bias_grads(const float* d_logits, const uint8_t* is_drum /* [N] */, int32_t N, int32_t S,
@@ -860,7 +880,8 @@ int pm_vae_step_forward(const PmVaeLayout* lay, const float* params, float* buff
 /* Introspection of the last forward (host only): info = {compact GCL, bf16-planes GEMM operands, active slots S,
  * fragment-major weight planes built (B-direct GEMM mode), N, E, G, B, then the EFFECTIVE switches of the library —
  * fused un-embedding + cross-entropy (PM_FUSED_CE), second-stream site mask (PM_SIDE_STREAM), deterministic mode,
- * fused GCL kernels (PM_GCL_FUSED), norm backward inside the GCL input gradient (PM_DAGG_BN), chord encoder as table algebra (PM_CHORD_TABLES) —, 2 reserved}.  The parity tests use it to assert that the golden-pinned step IS
+ * fused GCL kernels (PM_GCL_FUSED), norm backward inside the GCL input gradient (PM_DAGG_BN), chord encoder as table algebra (PM_CHORD_TABLES) —, GCL stacks in the fp16 pair format (bit 0 encoder, 1 decoder),
+ * decoder head over the row lists without PAD targets (PM_PAD_SKIP)}.  The parity tests use it to assert that the golden-pinned step IS
  * the measured variant. */
 int pm_vae_step_info(const void* state, int32_t* info /* [16] host */);
 /* The model outputs of `VAE.forward` (model.py:665-678) as the last forward computed them, copied out of the arena

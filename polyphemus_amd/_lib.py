@@ -105,6 +105,10 @@ _SIGS = {
     "pm_unembed_ce": "pppppppppiiiiifpppppppps",
     "pm_unembed_dh": "pppppiiiiippis",
     "pm_unembed_dh_scratch_bytes": "i",
+    "pm_unembed_row_counts_len": "ii",
+    "pm_unembed_row_lists": "ppiiiiipppps",
+    "pm_unembed_ce_rows": "pppppppppiiiiifpppppppppps",
+    "pm_unembed_dh_rows": "pppppiiiiipppps",
     "pm_unembed_scratch_bytes": "i",
     "pm_kld": "ppiifppps",
     "pm_unembed_bias_grads": "ppiippps",
@@ -152,7 +156,7 @@ _SIGS = {
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float, "u": C.c_uint32, "s": C.c_void_p, "D": C.c_double}
 _RET64 = {"pm_vae_step_workspace_bytes", "pm_vae_layout_bytes", "pm_vae_step_state_bytes", "pm_unembed_scratch_bytes",
-          "pm_unembed_dh_scratch_bytes"}
+          "pm_unembed_dh_scratch_bytes", "pm_unembed_row_counts_len"}
 ABI_VERSION = 8          # PM_ABI_VERSION of include/polyphemus_hip.h this table was written against
 EXPORTED = sorted(list(_SIGS) + ["pm_abi_version", "pm_build_info", "pm_dropout_hash", "pm_vae_layout_bytes",
                                  "pm_vae_step_state_bytes"])

@@ -533,12 +533,12 @@ extern "C" int64_t pm_unembed_scratch_bytes(int32_t d) {
   return (int64_t)448 * (d / 2) * 3 * 2 + (int64_t)UREP * UREP_F * 4 + UREP * 2 * 8;
 }
 
-extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
-                             const float* b_pitch_nd, const float* w_dur, const float* b_dur, const int32_t* tokens,
-                             const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
-                             float grad_scale, const float* dev_scale, float* logits, float* d_logits,
-                             float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes,
-                             pm_stream_t stream) {
+static int unembed_ce_impl(const float* H, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
+                           const float* b_pitch_nd, const float* w_dur, const float* b_dur, const int32_t* tokens,
+                           const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
+                           float grad_scale, const float* dev_scale, float* logits, float* d_logits,
+                           float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes,
+                           const int32_t* row_lists, const int32_t* row_counts, pm_stream_t stream) {
   if (!H || !w_pitch_drum || !b_pitch_drum || !w_pitch_nd || !b_pitch_nd || !w_dur || !b_dur || !tokens || !plan ||
       !d_logits || !out || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
     return PM_E_INVALID;
@@ -553,6 +553,9 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
   a.job[0] = {w_pitch_drum, b_pitch_drum, db_pitch_drum, pv.row_list, pv.group_cnt + 2, PM_N_PITCH, 0, 0, 0, 130};
   a.job[1] = {w_pitch_nd, b_pitch_nd, db_pitch_nd, pv.row_list + (int64_t)N * PM_N_SLOTS, pv.group_cnt + 3, PM_N_PITCH, 0, 0, 0, 130};
   a.job[2] = {w_dur, b_dur, db_dur, nullptr, nullptr, PM_N_DUR, dh, PM_N_PITCH, 1, 98};
+  if (row_lists) {                 // rows that have a target only (pm_unembed_row_lists): the others get neither loss nor gradient
+    for (int j = 0; j < 3; ++j) { a.job[j].rowmap = row_lists + (int64_t)j * R; a.job[j].dyn_rows = row_counts + j; }
+  }
   a.H = H; a.tok = tokens; a.hist = pv.tok_hist; a.dev_scale = dev_scale; a.logits = logits; a.dlogits = d_logits; a.out = out;
   a.R = (int)R; a.S = n_slots; a.d = d; a.dh = dh; a.grad_scale = grad_scale;
   a.gate = nullptr;
@@ -587,6 +590,132 @@ extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const fl
   if (nb > 768) nb = 768;                              // persistent: ~3 resident workgroups per CU and job
   a.gate = pm_det_gate(st);
   hipLaunchKernelGGL(k_unembed_ce, dim3(nb, 3), dim3(256), 0, st, a);
+  return pm_check_launch();
+}
+extern "C" int pm_unembed_ce(const float* H, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
+                             const float* b_pitch_nd, const float* w_dur, const float* b_dur, const int32_t* tokens,
+                             const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
+                             float grad_scale, const float* dev_scale, float* logits, float* d_logits,
+                             float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes,
+                             pm_stream_t stream) {
+  return unembed_ce_impl(H, w_pitch_drum, b_pitch_drum, w_pitch_nd, b_pitch_nd, w_dur, b_dur, tokens, plan, N, E, G, d, n_slots,
+                         grad_scale, dev_scale, logits, d_logits, db_pitch_drum, db_pitch_nd, db_dur, out, w_planes, nullptr, nullptr,
+                         stream);
+}
+// ... over the rows that HAVE a target only (`row_lists` / `row_counts` of pm_unembed_row_lists): logits / d_logits of the other
+// rows are NOT written — every reader of d_logits takes the same lists (pm_unembed_dh_rows, the weight-gradient products).  A
+// second call over the PAD lists (no bias gradients, its own `out`) adds the logits of the remaining rows where a caller wants them.
+extern "C" int pm_unembed_ce_rows(const float* H, const float* w_pitch_drum, const float* b_pitch_drum, const float* w_pitch_nd,
+                                  const float* b_pitch_nd, const float* w_dur, const float* b_dur, const int32_t* tokens,
+                                  const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots,
+                                  float grad_scale, const float* dev_scale, float* logits, float* d_logits,
+                                  float* db_pitch_drum, float* db_pitch_nd, float* db_dur, double* out, uint16_t* w_planes,
+                                  const int32_t* row_lists, const int32_t* row_counts, pm_stream_t stream) {
+  if (!row_lists || !row_counts) return PM_E_INVALID;
+  return unembed_ce_impl(H, w_pitch_drum, b_pitch_drum, w_pitch_nd, b_pitch_nd, w_dur, b_dur, tokens, plan, N, E, G, d, n_slots,
+                         grad_scale, dev_scale, logits, d_logits, db_pitch_drum, db_pitch_nd, db_dur, out, w_planes, row_lists,
+                         row_counts, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row lists without the PAD targets (round 6).  CrossEntropyLoss(ignore_index = PAD), training.py:101-102,316-323: a (node, slot)
+// row whose target token is PAD has no loss and a zero gradient — 30 % of the active-slot rows of the bench's batches (a cell
+// holds 1..4 notes, the slots behind its EOS are PAD).  The un-embedding kernels run ~7-10 tiles of 64 rows per CU in sequence,
+// bound by the latency of a tile's phases, so the rows are taken out of their TILE LISTS: list j holds, in ascending order, the
+// rows of job j (pitch of the drum nodes' rows, pitch of the others', duration of all rows) that have a target; counts[j] its
+// length.  A row stays when EITHER of its two targets is not PAD (the data pads pitch and duration together; a row with one PAD
+// target goes through the kernels as before — zero gradient in that block — so that every listed row of d_logits is written in
+// all its 230 columns: k_unembed_dh reads one column of the neighbouring block).  The rows left out go to `pad_lists` (when
+// given: the logits of those rows, for callers that want every logit) and their halves of `dH_zero` ([N S, d]: the
+// un-embedding's input gradient, which its readers take whole) are cleared.
+// Two launches over chunks of 1024 candidates: counts per chunk, then every chunk sums the counts before it and writes its rows
+// (ballot + popcount inside): deterministic, ~80 workgroups per job at configs[1].
+namespace {
+constexpr int RL_CHUNK = 1024;
+struct RowListArgs {
+  const int32_t* cand[3]; const int32_t* ncand[3];      // candidate rows of job j (NULL: rows 0 .. R - 1) and their device-side count
+  const int* tok; int32_t* lists; int32_t* pad_lists; int32_t* counts; int32_t* chunk_cnt; float* dH;
+  int R, S, d, dh, nchunk;
+};
+__device__ __forceinline__ bool rl_candidate(const RowListArgs& a, int j, int r, int M, int& rg) {
+  rg = -1;
+  if (r >= M) return false;
+  rg = a.cand[j] ? a.cand[j][r] : r;
+  const int n = rg / a.S, sl = rg - n * a.S + 1;
+  const int2 t = *reinterpret_cast<const int2*>(a.tok + ((int64_t)n * 16 + sl) * 2);
+  return t.x != 130 || t.y != 98;
+}
+}  // namespace
+__global__ void __launch_bounds__(RL_CHUNK) k_unembed_row_count(RowListArgs a) {
+  __shared__ int s_wsum[16];
+  const int j = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+  const int M = a.ncand[j] ? *a.ncand[j] : a.R;
+  int rg;
+  const bool valid = rl_candidate(a, j, c * RL_CHUNK + tid, M, rg);
+  const unsigned long long bm = __builtin_amdgcn_ballot_w64(valid);
+  if ((tid & 63) == 0) s_wsum[tid >> 6] = (int)__builtin_popcountll(bm);
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += s_wsum[w];
+    a.chunk_cnt[j * a.nchunk + c] = t;
+  }
+}
+__global__ void __launch_bounds__(RL_CHUNK) k_unembed_row_fill(RowListArgs a) {
+  __shared__ int s_wsum[16], s_pre[16];
+  const int j = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.ncand[j] ? *a.ncand[j] : a.R;
+  if (c * RL_CHUNK >= M && c != 0) return;                        // (chunk 0 reports the counts of an empty job)
+  int pre = 0;                                                    // listed rows of the chunks before this one
+  for (int q = tid; q < c; q += RL_CHUNK) pre += a.chunk_cnt[j * a.nchunk + q];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) pre += __shfl_xor(pre, o);
+  int rg;
+  const bool valid = rl_candidate(a, j, c * RL_CHUNK + tid, M, rg);
+  const unsigned long long bm = __builtin_amdgcn_ballot_w64(valid);
+  if (lane == 0) { s_wsum[wave] = (int)__builtin_popcountll(bm); s_pre[wave] = pre; }
+  __syncthreads();
+  int base = 0, before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const int v = s_wsum[w]; base += s_pre[w]; before += w < wave ? v : 0; total += v; }
+  const int mine = before + (int)__builtin_popcountll(bm & ((1ull << lane) - 1ull));        // listed rows of this chunk before this one
+  if (valid) a.lists[(int64_t)j * a.R + base + mine] = rg;
+  else if (rg >= 0 && a.pad_lists) a.pad_lists[(int64_t)j * a.R + (c * RL_CHUNK - base) + (tid - mine)] = rg;
+  if (a.dH) {                                                     // the rows left out: their half of the dH row is zero (a wave per row)
+    unsigned long long out = __builtin_amdgcn_ballot_w64(rg >= 0 && !valid);
+    const int koff = j == 2 ? a.dh : 0;
+    while (out) {
+      const int l = __builtin_ctzll(out);
+      out &= out - 1;
+      float4* z = reinterpret_cast<float4*>(a.dH + (int64_t)__builtin_amdgcn_readlane(rg, l) * a.d + koff);
+      for (int q = lane; q < a.dh / 4; q += 64) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const int rest = M - c * RL_CHUNK;
+  if (tid == 0 && rest <= RL_CHUNK) {                             // the job's last chunk
+    a.counts[j] = base + total;
+    a.counts[4 + j] = M - (base + total);
+  }
+}
+extern "C" int64_t pm_unembed_row_counts_len(int32_t N, int32_t n_slots) {
+  return 8 + 3 * pm_cdiv((int64_t)N * n_slots, RL_CHUNK);
+}
+extern "C" int pm_unembed_row_lists(const int32_t* tokens, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                                    int32_t n_slots, int32_t* row_lists, int32_t* pad_lists, int32_t* row_counts, float* dH_zero,
+                                    pm_stream_t stream) {
+  if (!tokens || !plan || !row_lists || !row_counts || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS ||
+      ((uintptr_t)dH_zero % 16) || ((uintptr_t)tokens % 8))
+    return PM_E_INVALID;
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  RowListArgs a;
+  a.cand[0] = pv.row_list; a.ncand[0] = pv.group_cnt + 2;
+  a.cand[1] = pv.row_list + (int64_t)N * PM_N_SLOTS; a.ncand[1] = pv.group_cnt + 3;
+  a.cand[2] = nullptr; a.ncand[2] = nullptr;
+  a.tok = tokens; a.lists = row_lists; a.pad_lists = pad_lists; a.counts = row_counts; a.chunk_cnt = row_counts + 8; a.dH = dH_zero;
+  a.R = N * n_slots; a.S = n_slots; a.d = d; a.dh = d / 2; a.nchunk = (int)pm_cdiv((int64_t)a.R, RL_CHUNK);
+  hipLaunchKernelGGL(k_unembed_row_count, dim3(a.nchunk, 3), dim3(RL_CHUNK), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_unembed_row_fill, dim3(a.nchunk, 3), dim3(RL_CHUNK), 0, (hipStream_t)stream, a);
   return pm_check_launch();
 }
 
@@ -863,9 +992,10 @@ __global__ void __launch_bounds__(dh_threads<DH>()) k_unembed_dh(UnembedDhArgs a
 extern "C" int64_t pm_unembed_dh_scratch_bytes(int32_t d) { return (int64_t)(9 + 9 + 7) * (d / 2 / 32) * 3072; }
 // `prepare` != 0: only the weight planes (parameters only: the step issues it with its other weight preparation);
 // 0: the product (the planes must be current)
-extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
-                             const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
-                             uint16_t* w_planes, int32_t prepare, pm_stream_t stream) {
+static int unembed_dh_impl(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
+                           const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
+                           uint16_t* w_planes, int32_t prepare, const int32_t* row_lists, const int32_t* row_counts,
+                           pm_stream_t stream) {
   if (!w_pitch_drum || !w_pitch_nd || !w_dur || !w_planes || N <= 0 || d <= 0 || n_slots < 1 || n_slots > PM_N_SLOTS ||
       ((uintptr_t)w_planes % 16))
     return PM_E_INVALID;
@@ -892,6 +1022,9 @@ extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, c
   PmPlanView pv = pm_plan_view(plan, N, E, G);
   a.job[0].rowmap = pv.row_list; a.job[0].dyn_rows = pv.group_cnt + 2;
   a.job[1].rowmap = pv.row_list + (int64_t)N * PM_N_SLOTS; a.job[1].dyn_rows = pv.group_cnt + 3;
+  if (row_lists) {                 // rows with a target only (pm_unembed_row_lists; the other rows of dH are zeros already)
+    for (int j = 0; j < 3; ++j) { a.job[j].rowmap = row_lists + (int64_t)j * R; a.job[j].dyn_rows = row_counts + j; }
+  }
   a.dlogits = d_logits; a.dH = dH; a.wplanes = reinterpret_cast<const char*>(w_planes); a.R = (int)R;
   // one workgroup per CU (two images: 119 KB of LDS) and an equal share of the tile list each
   int nb = (int)(2 * pm_cdiv(R, UBM) + 1);
@@ -908,4 +1041,18 @@ extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, c
   if (dh == 256) LAUNCH(256); else if (dh == 128) LAUNCH(128); else LAUNCH(64);
 #undef LAUNCH
   return pm_check_launch();
+}
+extern "C" int pm_unembed_dh(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
+                             const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
+                             uint16_t* w_planes, int32_t prepare, pm_stream_t stream) {
+  return unembed_dh_impl(d_logits, w_pitch_drum, w_pitch_nd, w_dur, plan, N, E, G, d, n_slots, dH, w_planes, prepare, nullptr, nullptr,
+                         stream);
+}
+// ... over the row lists of pm_unembed_row_lists (the rows they leave out must be zero in dH already: that call zeroes them)
+extern "C" int pm_unembed_dh_rows(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
+                                  const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
+                                  uint16_t* w_planes, const int32_t* row_lists, const int32_t* row_counts, pm_stream_t stream) {
+  if (!row_lists || !row_counts) return PM_E_INVALID;
+  return unembed_dh_impl(d_logits, w_pitch_drum, w_pitch_nd, w_dur, plan, N, E, G, d, n_slots, dH, w_planes, 0, row_lists, row_counts,
+                         stream);
 }

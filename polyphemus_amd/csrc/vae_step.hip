@@ -55,6 +55,7 @@ struct StepCfg {
   bool h2;                     // PM_H2=0: the GCL products of d in {128, 256} on the exact three-term bf16 split (six MFMA products per fp32
                                // product) instead of the fp16 pair format (three; PmH2 of the header) — the parity tests run both
   int dense_deg;
+  bool pad_skip;               // PM_PAD_SKIP=0: the decoder head over every (node, active slot) row, PAD targets included (rounds 2-5)
   bool bar_route;              // PM_BAR_ROUTE=0: dense graphs on the row-gather kernels of segreduce.hip (rounds 1-5) instead of bar.hip
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
 };
@@ -82,6 +83,7 @@ static StepCfg read_cfg() {
   k.side_delay_us = getenv("PM_SIDE_DELAY_US") ? atoi(getenv("PM_SIDE_DELAY_US")) : 0;
   k.dense_deg = 16;
   k.bar_route = flag("PM_BAR_ROUTE", true);
+  k.pad_skip = flag("PM_PAD_SKIP", true);
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
 }
@@ -153,6 +155,10 @@ struct StepState {
   float *zd, *dm, *dv, *zr, *sb, *u1, *u2, *c2, *a2, *m2, *v2, *s_logits, *cb; GcnSaved dg; float *H, *c_logits;
   // loss gradients
   float *dc_logits, *ds_logits, *dmu, *dlv, *dz;
+  // rows of the decoder head that have a target (round 6, pm_unembed_row_lists): the fused un-embedding + CE, its input gradient and
+  // the un-embedding weight gradients skip the rows whose target is PAD (30 % at the bench's batches); off when the logits are kept or
+  // the caller supplies the loss
+  int pad_skip; int32_t* ue_lists; int32_t* ue_counts; float* dH;
   float* dc_logits_own;                   // the arena's d(c_logits) buffer (dc_logits may point at the caller's gradient tensor: ext_loss)
   float* PT; int chord_tab;          // chord encoder as table algebra (chord.hip): projected tables [2][S][2][131][d]
   uint16_t *wf_enc, *wf_enc_t, *wf_dec, *wf_dec_t, *w_unembed_dh;   // chord encoder / decoder weights as fragment-major planes (kind 0 / 1)
@@ -809,6 +815,17 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
       RUN(pm_unembed_dh(nullptr, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, nullptr, N, c.E, Gn, d, S,
                           nullptr, s.w_unembed_dh, 1, c.st));
     }
+    // the decoder head's row lists without the PAD targets, and zeros in the rows of dH they leave out: tokens and plan only — here
+    // (second stream, behind the plan on the same stream), a millisecond ahead of their first reader
+    s.dH = ar.f((size_t)N * S * d);
+    // (PmBatch.flags bit 2 — the caller wants every logit —: the rows left out as lists of their own, for a second pass of the head)
+    const bool pad_rows = (s.bt.flags & 4) != 0;
+    s.ue_lists = (int32_t*)ar.take((size_t)6 * N * S * sizeof(int32_t));      // (3 + 3 whatever the flags: pm_vae_step_workspace_bytes does not see them)
+    s.ue_counts = (int32_t*)ar.take((size_t)pm_unembed_row_counts_len(N, S) * sizeof(int32_t));
+    s.pad_skip = (cfg().pad_skip && cfg().fused_ce && plan_side && s.w_unembed_dh && !(s.bt.flags & 8)) ? 1 : 0;
+    if (s.pad_skip)
+      RUN(pm_unembed_row_lists(s.bt.tokens, s.plan, N, c.E, Gn, d, S, s.ue_lists, pad_rows ? s.ue_lists + (size_t)3 * N * S : nullptr,
+                                 s.ue_counts, s.dH, c.st));
     br.mark(BR_WPREP_DEC);
     if (run) {
     RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
@@ -932,6 +949,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   const bool rows_w = wf_dec != nullptr;
   const bool fused_ce = cfg().fused_ce;
   uint16_t* w_unembed = fused_ce ? (uint16_t*)ar.take((size_t)pm_unembed_scratch_bytes(d)) : nullptr;   // planes of the three un-embedding weights + accumulator replicas
+  double* const pad_losses = ar.zdbl(4);              // (the zero losses of the second head pass over the PAD rows, PmBatch.flags bit 2)
   if (run) {
     if (rows_w) {
       RUN(pm_rows_times_weight(xdL, d, N, d, wf_dec, 0, 0, S * d, c.P + Y.dec_chord.b, s.H, S * d, c.st));
@@ -945,7 +963,17 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     // PmBatch.flags bit 3 (the drop-in module: the CALLER computes the loss): the logits only — three fp32 products, no
     // cross-entropy, no d(logits) (224 MB at 15 slots that pm_vae_step_set_output_grads would overwrite), no KLD / BCE
     const bool logits_only = (s.bt.flags & 8) != 0;
-    if (fused_ce && !logits_only) {
+    if (fused_ce && !logits_only && s.pad_skip) {
+      RUN(pm_unembed_ce_rows(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
+                               c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
+                               (s.bt.flags & 4) ? s.c_logits : nullptr, s.dc_logits, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b,
+                               c.G + Y.dec_dur.b, s.losses, w_unembed, s.ue_lists, s.ue_counts, c.st));
+      if (s.bt.flags & 4)            // every logit wanted: the same kernel over the rows left out (no loss, no gradient: PAD targets)
+        RUN(pm_unembed_ce_rows(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
+                                 c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
+                                 s.c_logits, s.dc_logits, nullptr, nullptr, nullptr, pad_losses, w_unembed, s.ue_lists + 3 * R,
+                                 s.ue_counts + 4, c.st));
+    } else if (fused_ce && !logits_only) {
       RUN(pm_unembed_ce(s.H, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_d.b, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_pitch_nd.b,
                           c.P + Y.dec_dur.w, c.P + Y.dec_dur.b, s.bt.tokens, s.plan, N, c.E, Gn, d, S, 1.0f, s.bt.ce_scale,
                           (s.bt.flags & 4) ? s.c_logits : nullptr, s.dc_logits, c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b,
@@ -1000,10 +1028,14 @@ void backward_decoder(Ctx& c) {
     lin_bwd(c, dsb, s.zr_d, Y.dec_s_bars, B, nb * d, d, dzr, 0, 2 * d, 2 * d);
   }
   // ---- content decoder
-  float* dH = ar.f((size_t)R * d);
+  float* dH = s.dH;                                     // (carved by the forward: the rows of PAD targets are zero already when pad_skip)
+  const bool skip = s.pad_skip != 0;
   // input gradients of the three un-embeddings first (the critical chain: dH -> dxL -> the decoder's layers) ...
   const PmLin pit[2] = {Y.dec_pitch_d, Y.dec_pitch_nd};
-  if (s.w_unembed_dh)                                   // one launch on the bf16 pipe (unembed.hip)
+  if (s.w_unembed_dh && skip)                           // ... over the rows that have a target
+    RUN(pm_unembed_dh_rows(s.dc_logits, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, s.plan, N, c.E, Gn, d, S,
+                             dH, s.w_unembed_dh, s.ue_lists, s.ue_counts, c.st));
+  else if (s.w_unembed_dh)                              // one launch on the bf16 pipe (unembed.hip)
     RUN(pm_unembed_dh(s.dc_logits, c.P + Y.dec_pitch_d.w, c.P + Y.dec_pitch_nd.w, c.P + Y.dec_dur.w, s.plan, N, c.E, Gn, d, S,
                         dH, s.w_unembed_dh, 0, c.st));
   else {
@@ -1027,11 +1059,11 @@ void backward_decoder(Ctx& c) {
   auto decoder_weight_grads = [&]() {
     BranchScope br(c, BR_DEC_WGRAD);
     RUN(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
-                      nullptr, PM_GEMM_ACCUM, 0, nullptr, 0, nullptr, c.st));
+                      nullptr, PM_GEMM_ACCUM, 0, skip ? s.ue_lists + 2 * R : nullptr, skip ? 1 : 0, skip ? s.ue_counts + 2 : nullptr, c.st));
     for (int g = 0; g < 2; ++g) {
-      const int32_t* lst = pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);
+      const int32_t* lst = skip ? s.ue_lists + g * R : pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);
       RUN(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
-                        PM_GEMM_ACCUM, 0, lst, 1, pv.group_cnt + 2 + g, c.st));
+                        PM_GEMM_ACCUM, 0, lst, 1, skip ? s.ue_counts + g : pv.group_cnt + 2 + g, c.st));
     }
     if (s.ext_loss) {
       // the caller's loss: the bias gradients of the three un-embeddings are the column sums of ITS d(logits) (with the
@@ -1321,7 +1353,7 @@ extern "C" int pm_vae_step_info(const void* state, int32_t* info) {
   info[12] = cfg().dagg_bn ? 1 : 0;            // (the norm backward of the GCN layers inside the input gradient kernel)
   info[13] = s->chord_tab;                      // (the chord encoder as table algebra)
   info[14] = (s->eg.h2 ? 1 : 0) | (s->dg.h2 ? 2 : 0);     // (the GCL products of the encoder / decoder stack in the fp16 pair format)
-  info[15] = 0;
+  info[15] = s->pad_skip;                       // (the decoder head ran over the row lists without PAD targets)
   return PM_OK;
 }
 // Model outputs of the last forward (the arena keeps them until the next pm_vae_step_forward): asynchronous
@@ -1372,6 +1404,7 @@ extern "C" int pm_vae_step_set_output_grads(void* state, const float* d_s_logits
   if (e == hipSuccess) e = hipMemsetAsync(s->G + Y.dec_dur.b, 0, sizeof(float) * PM_N_DUR, st);
   s->fix_structure = d_s_logits ? 1 : 0;
   s->ext_loss = 1;
+  s->pad_skip = 0;                                      // (the caller's d(c_logits) may be non-zero in any row)
   return e == hipSuccess ? PM_OK : PM_E_LAUNCH;
 }
 

@@ -239,7 +239,7 @@ class NativeStep:
         info = (C.c_int32 * 16)()
         self._call("pm_vae_step_info", self.addr, C.cast(info, C.c_void_p))
         keys = ("compact", "planes", "n_slots", "b_frag", "N", "E", "G", "B", "fused_ce", "side_stream", "deterministic",
-                "gcl_fused", "dagg_bn", "chord_tables", "h2")
+                "gcl_fused", "dagg_bn", "chord_tables", "h2", "pad_skip")
         return dict(zip(keys, (int(v) for v in info)))
 
     def outputs(self):

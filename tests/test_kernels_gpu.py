@@ -1227,6 +1227,90 @@ def test_unembed_input_gradient_in_one_launch(d, B, S, drums):
     assert rel_err(dH, want) < 2e-6
 
 
+@pytest.mark.parametrize("d,B,S,drums", [(256, 40, 6, "mixed"), (128, 3, 15, "mixed"), (512, 12, 4, "mixed"), (256, 6, 5, "none"),
+                                          (256, 6, 5, "all"), (256, 300, 3, "mixed"), (256, 1, 7, "mixed")])
+def test_decoder_head_over_the_rows_without_pad_targets(d, B, S, drums):
+    """Round 6: `pm_unembed_row_lists` compacts the head's three row lists (pitch of the drum rows, pitch of the others,
+    duration of all) to the rows that have a target — CrossEntropyLoss(ignore_index) gives a PAD target neither loss nor gradient
+    (training.py:101-102,316-323); a row stays when its pitch OR its duration target is not PAD —, lists the rest separately and
+    clears their halves of dH; `pm_unembed_ce_rows` / `pm_unembed_dh_rows` then run over the lists.  The lists against numpy
+    (ascending, exact); losses, bias gradients, logits and d_logits of the listed rows and dH against `pm_unembed_ce` /
+    `pm_unembed_dh` over every row; a second pass over the PAD lists completes the logits."""
+    import numpy as np
+    cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=31)
+    if drums != "mixed":
+        cpu.is_drum = torch.full_like(cpu.is_drum, drums == "all")
+    cpu.tokens[::7, 2, 0] = 130                                   # PAD in one vocabulary only: the row stays
+    cpu.tokens[3::11, 1, 1] = 98
+    b = cpu.to(DEV)
+    plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars,
+                          b.s_tensor.shape[0], n_slots=S)
+    N, dh, R = cpu.num_nodes, d // 2, cpu.num_nodes * S
+    lists = torch.full((6, R), -7, dtype=torch.int32, device=DEV)
+    counts = torch.full((int(lib().pm_unembed_row_counts_len(N, S)),), -1, dtype=torch.int32, device=DEV)
+    dH = torch.full((N, S, d), float("nan"), device=DEV)
+    call("pm_unembed_row_lists", ptr(plan.tokens), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(lists), ptr(lists[3:]), ptr(counts),
+         ptr(dH), stream())
+    tok = cpu.tokens.numpy()[:, 1:S + 1]                          # target of row (n, s) = tokens[n, s + 1]
+    drum = cpu.is_drum.numpy().astype(bool)
+    live = (tok[..., 0] != 130) | (tok[..., 1] != 98)
+    assert 0 < live.sum() < live.size
+    rows = np.arange(R).reshape(N, S)
+    jobs = [np.broadcast_to(drum[:, None], (N, S)), np.broadcast_to(~drum[:, None], (N, S)), np.ones((N, S), bool)]
+    got_n = counts.tolist()
+    for j in range(3):
+        for base, sel in ((0, live), (3, ~live)):
+            want = rows[jobs[j] & sel]
+            n = got_n[base + j + (1 if base else 0)]              # counts: [0..2] listed, [4..6] left out
+            assert n == want.size, (j, base, got_n[:8], want.size)
+            assert np.array_equal(lists[base + j, :n].cpu().numpy(), want), (j, base)
+            assert bool((lists[base + j, n:] == -7).all())
+    z = dH.cpu().numpy()
+    assert np.all(z[~live] == 0) and np.isnan(z[live]).all()
+
+    torch.manual_seed(d + B)
+    H = torch.randn(N, S, d, device=DEV)
+    W = [torch.randn(v, dh, device=DEV) * 0.2 for v in (131, 131, 99)]
+    bias = [torch.randn(v, device=DEV) for v in (131, 131, 99)]
+    wpl = torch.empty(int(lib().pm_unembed_scratch_bytes(d)), dtype=torch.uint8, device=DEV)
+    head = (ptr(H), ptr(W[0]), ptr(bias[0]), ptr(W[1]), ptr(bias[1]), ptr(W[2]), ptr(bias[2]), ptr(plan.tokens), ptr(plan.buf),
+            N, plan.E, plan.G, d, S, 1.0, None)
+    res = []
+    for skip in (False, True):
+        db = [torch.zeros(v, device=DEV) for v in (131, 131, 99)]
+        out = torch.zeros(4, dtype=torch.float64, device=DEV)
+        dl = torch.full((N, S, 230), float("nan"), device=DEV)
+        lg = torch.full((N, S, 230), float("nan"), device=DEV)
+        tail = (ptr(lg), ptr(dl), ptr(db[0]), ptr(db[1]), ptr(db[2]), ptr(out), ptr(wpl))
+        if skip:
+            call("pm_unembed_ce_rows", *head, *tail, ptr(lists), ptr(counts), stream())
+        else:
+            call("pm_unembed_ce", *head, *tail, stream())
+        res.append((out, dl, db, lg))
+    (o0, dl0, db0, lg0), (o1, dl1, db1, lg1) = res
+    assert torch.allclose(o0, o1, rtol=1e-9, atol=0) and float(o0[0]) > 0 and float(o0[1]) > 0
+    for j in range(3):
+        assert rel_err(db1[j], db0[j]) < 1e-5, j
+    m = torch.from_numpy(live).to(DEV)
+    assert torch.equal(dl1[m], dl0[m]) and torch.equal(lg1[m], lg0[m])
+    assert bool((dl0[~m] == 0).all())                             # what the lists leave out
+    assert bool(torch.isnan(dl1[~m]).all()) and bool(torch.isnan(lg1[~m]).all())
+
+    scratch = torch.empty(int(lib().pm_unembed_dh_scratch_bytes(d)), dtype=torch.uint8, device=DEV)
+    dH0 = torch.full((N, S, d), float("nan"), device=DEV)
+    for prep in (1, 0):
+        call("pm_unembed_dh", ptr(dl0), ptr(W[0]), ptr(W[1]), ptr(W[2]), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(dH0), ptr(scratch),
+             prep, stream())
+    call("pm_unembed_dh_rows", ptr(dl1), ptr(W[0]), ptr(W[1]), ptr(W[2]), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(dH), ptr(scratch),
+         ptr(lists), ptr(counts), stream())
+    assert torch.equal(dH, dH0)
+
+    # the second pass of a caller that wants every logit: the rows left out (no loss, no gradient)
+    out2 = torch.zeros(4, dtype=torch.float64, device=DEV)
+    call("pm_unembed_ce_rows", *head, ptr(lg1), ptr(dl1), None, None, None, ptr(out2), ptr(wpl), ptr(lists[3:]), ptr(counts[4:]), stream())
+    assert torch.equal(lg1, lg0) and torch.equal(dl1, dl0) and float(out2[:2].abs().sum()) == 0
+
+
 def test_unembed_input_gradient_refuses_offsets_beyond_32_bits():
     """`pm_unembed_dh` addresses d_logits and dH with 32-bit byte offsets: sizes beyond that are refused before anything is
     launched (the step then takes the GEMM path, `vae_step.hip`)."""

@@ -206,15 +206,24 @@ __global__ void __launch_bounds__(256) k_kld(const float* __restrict__ mu, const
   if (threadIdx.x == 0) atomicAdd(&out[3], -0.5 * (sh[0] + sh[1] + sh[2] + sh[3]) / B);
   pm_turn_leave_block(gate);
 }
-extern "C" int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu,
-                      float* dlog_var, double* out, pm_stream_t stream) {
+static int kld_impl(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu,
+                    float* dlog_var, double* out, bool clear, pm_stream_t stream) {
   if (!mu || !log_var || !out || B <= 0 || d <= 0 || (dmu && !dlog_var)) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(out + 3, 0, sizeof(double), st);
+  if (clear) hipMemsetAsync(out + 3, 0, sizeof(double), st);
   int nb = (int)pm_cdiv((int64_t)B * d, 256 * 4);
   if (nb > 256) nb = 256;
   hipLaunchKernelGGL(k_kld, dim3(nb), dim3(256), 0, st, mu, log_var, B, d, beta, dmu, dlog_var, out, pm_det_gate(st));
   return pm_check_launch();
+}
+extern "C" int pm_kld(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu,
+                      float* dlog_var, double* out, pm_stream_t stream) {
+  return kld_impl(mu, log_var, B, d, beta, dmu, dlog_var, out, true, stream);
+}
+// (library-internal, vae_step.hip: out[3] += — the step's loss words lie in its cleared region)
+extern "C" int pm_kld_acc(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu,
+                          float* dlog_var, double* out, pm_stream_t stream) {
+  return kld_impl(mu, log_var, B, d, beta, dmu, dlog_var, out, false, stream);
 }
 
 // BCEWithLogitsLoss(reduction='none').mean()  (training.py:310-312)
@@ -234,15 +243,24 @@ __global__ void __launch_bounds__(256) k_bce(const float* __restrict__ x, const 
   if (threadIdx.x == 0) atomicAdd(&out[2], (sh[0] + sh[1] + sh[2] + sh[3]) / (double)n);
   pm_turn_leave_block(gate);
 }
-extern "C" int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits,
-                             double* out, pm_stream_t stream) {
+static int bce_impl(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits,
+                    double* out, bool clear, pm_stream_t stream) {
   if (!logits || !target || !out || n <= 0) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(out + 2, 0, sizeof(double), st);
+  if (clear) hipMemsetAsync(out + 2, 0, sizeof(double), st);
   int nb = (int)pm_cdiv(n, 256 * 4);
   if (nb > 256) nb = 256;
   hipLaunchKernelGGL(k_bce, dim3(nb), dim3(256), 0, st, logits, target, n, grad_scale, dlogits, out, pm_det_gate(st));
   return pm_check_launch();
+}
+extern "C" int pm_bce_logits(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits,
+                             double* out, pm_stream_t stream) {
+  return bce_impl(logits, target, n, grad_scale, dlogits, out, true, stream);
+}
+// (library-internal, vae_step.hip: out[2] +=)
+extern "C" int pm_bce_logits_acc(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits,
+                                 double* out, pm_stream_t stream) {
+  return bce_impl(logits, target, n, grad_scale, dlogits, out, false, stream);
 }
 
 // ---------------------------------------------------------------- evaluation metrics (training.py:349-497)

@@ -19,6 +19,10 @@
 int pm_plan_build_marked(const int64_t* edge_index, const int32_t* edge_type, const int32_t* edge_dist, const int64_t* bars,
                          const int64_t* batch, const uint8_t* is_drum, const int32_t* tokens, int32_t n_bars, int32_t n_slots,
                          int32_t N, int32_t E, int32_t G, int32_t* plan, hipStream_t stream, hipEvent_t after_count);   // plan.hip
+extern "C" int pm_kld_acc(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu, float* dlog_var,
+                          double* out, pm_stream_t stream);                                                       // loss.hip
+extern "C" int pm_bce_logits_acc(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits, double* out,
+                                 pm_stream_t stream);                                                                // loss.hip
 namespace {
 
 // A/B switches of the step: environment variables read ONCE, when the library is loaded (pm_vae_step_reload_switches re-reads:
@@ -203,7 +207,7 @@ struct Ctx {
 // capturable.  Norms on the branch use their own reduction scratch.
 // sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
 // structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
-enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_PLAN_COUNT, BR_SITES };
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_PLAN_COUNT, BR_LOSSES, BR_SITES };
 struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES], idle; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
@@ -898,6 +902,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   // ---------------- merge + heads (model.py:472-481), reparametrisation (model.py:671-673)
   s.m = ar.zf((size_t)B * d); s.mm = ar.f(d); s.mv = ar.f(d); s.zg = ar.f((size_t)B * d);
   s.mu = ar.zf((size_t)B * d); s.lv = ar.zf((size_t)B * d); s.z = ar.f((size_t)B * d);
+  s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   // ---------------- decoder (model.py:634-655)
   s.zd = ar.zf((size_t)B * 2 * d); s.dm = ar.f(2 * d); s.dv = ar.f(2 * d); s.zr = ar.f((size_t)B * 2 * d);
   s.sb = ar.zf((size_t)Gn * d); s.u1 = ar.f((size_t)Gn * d); s.u2 = ar.f((size_t)Gn * 512);
@@ -916,6 +921,16 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.zg_d, Y.enc_mu, B, d, d, s.mu, false);
     lin(c, s.zg_d, Y.enc_lv, B, d, d, s.lv, false);
     RUN(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
+    if (!(s.bt.flags & 8)) {
+      // the two losses nothing of the decoder feeds: the KL term (mu, log_var) and, when the structure loss is the reference's
+      // constant (training.py:307 evaluates the BCE on the target itself, SURVEY B-1), that constant — two 64-workgroup launches
+      // that used to follow the cross-entropy on the caller's stream, with a clear each
+      // (`losses` is the caller's buffer: words 2 and 3 are cleared here, behind the fork, words 0 and 1 are stored by the cross-entropy)
+      BranchScope br(c, BR_LOSSES);
+      if (hipMemsetAsync(s.losses + 2, 0, 2 * sizeof(double), c.st) != hipSuccess) c.chk(PM_E_LAUNCH);
+      RUN(pm_kld_acc(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
+      if (!s.fix_structure) RUN(pm_bce_logits_acc(s.bt.s_tensor, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, nullptr, s.losses, c.st));
+    }
     lin(c, s.z, Y.dec_lin, B, 2 * d, d, s.zd, false);
     bn_fwd(c, s.zd, B, 2 * d, 1, Y.dec_bn, true, nullptr, s.zr, s.dm, s.dv);
     s.zr_d = drop(c, s.zr, B, 2 * d, SITE_DEC_IN, seed_dec, zrd_buf);                        // Decoder.dropout, model.py:640
@@ -943,7 +958,6 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   const int64_t R = (int64_t)N * S;                    // (node, active slot) rows of the head
   s.H = ar.f((size_t)R * d); s.c_logits = ar.f((size_t)R * PM_N_TOK);
   s.dc_logits = s.dc_logits_own = ar.f((size_t)R * PM_N_TOK); s.ds_logits = ar.f((size_t)Gn * 128);
-  s.dmu = ar.zf((size_t)B * d); s.dlv = ar.zf((size_t)B * d);
   // chord decoder (K = d, S*d output columns): A-stationary kernel of linear.hip, its weight rows as fragment-major planes
   uint16_t* const wf_dec = s.wf_dec;
   const bool rows_w = wf_dec != nullptr;
@@ -989,13 +1003,10 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_content_ce_scaled(s.c_logits, s.bt.tokens, pv.tok_hist, s.bt.is_drum, N, S, 1.0f, s.bt.ce_scale, s.dc_logits,
                                c.G + Y.dec_pitch_d.b, c.G + Y.dec_pitch_nd.b, c.G + Y.dec_dur.b, s.losses, c.st));
     }
-    if (!logits_only) RUN(pm_kld(s.mu, s.lv, B, d, s.beta, s.dmu, s.dlv, s.losses, c.st));
+    branch_join(c, BR_LOSSES);                     // (the KL term and the constant structure loss, issued behind the reparametrisation)
     branch_join(c, BR_DEC_FWD);
-    if (logits_only) {
-    } else if (s.fix_structure)
-      RUN(pm_bce_logits(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
-    else      // training.py:307 evaluates the BCE on the target itself: a constant, no gradient (SURVEY B-1)
-      RUN(pm_bce_logits(s.bt.s_tensor, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, nullptr, s.losses, c.st));
+    if (!logits_only && s.fix_structure)
+      RUN(pm_bce_logits_acc(s.s_logits, s.bt.s_tensor, (int64_t)Gn * 128, 1.0f, s.ds_logits, s.losses, c.st));
   }
 }
 

@@ -26,14 +26,17 @@ def main():
     t0, prev_end = int(rows[a]["Start_Timestamp"]), None
     tot = 0
     print(f"# {b - a} launches, {(int(rows[b - 1]['End_Timestamp']) - t0) / 1e3:.1f} us from first start to Adam's end")
-    print("#  idx   start_us    dur_us    gap_us  grid            kernel")
+    qkey = "Stream_Id" if "Stream_Id" in rows[a] and len({r["Stream_Id"] for r in rows[a:b]}) > 1 else ("Queue_Id" if "Queue_Id" in rows[a] else None)
+    qids = {}
+    print("#  idx   start_us    dur_us    gap_us  q  grid            kernel      (q: stream / queue of the launch, numbered in order of appearance)")
     for i, r in enumerate(rows[a:b]):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
         prev_end = max(e, prev_end or e)
         grid = "x".join(str(int(r[k]) // max(1, int(r[w]))) for k, w in (("Grid_Size_X", "Workgroup_Size_X"), ("Grid_Size_Y", "Workgroup_Size_Y"), ("Grid_Size_Z", "Workgroup_Size_Z")))
         tot += e - s
-        print(f"{i:6d} {(s - t0) / 1e3:10.1f} {(e - s) / 1e3:9.1f} {gap:9.1f}  {grid:14s}  {short(r['Kernel_Name'])}")
+        q = qids.setdefault(r[qkey], len(qids)) if qkey else 0
+        print(f"{i:6d} {(s - t0) / 1e3:10.1f} {(e - s) / 1e3:9.1f} {gap:9.1f}  {q}  {grid:14s}  {short(r['Kernel_Name'])}")
     print(f"# kernel time {tot / 1e3:.1f} us")
 
 

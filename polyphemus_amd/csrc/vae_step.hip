@@ -918,8 +918,16 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.zcat_d, Y.enc_merge, B, d, 2 * d, s.m, false);
     bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
     s.zg_d = drop(c, s.zg, B, d, SITE_ENC_MERGE_OUT, seed_enc, zgd_buf);                     // model.py:479
-    lin(c, s.zg_d, Y.enc_mu, B, d, d, s.mu, false);
-    lin(c, s.zg_d, Y.enc_lv, B, d, d, s.lv, false);
+    // mu and log_var (model.py:480-481): two Linear(d, d) on the same input — one grouped launch (the weights lie where the flat
+    // parameter buffer has them, the outputs in the cleared region: K slices add with atomics as in `lin`'s small-product path)
+    if (d % 64 == 0 && d >= 128)
+      RUN(pm_gemm_f32_grouped(0, 1, B, d, d, s.zg_d, d, c.P + Y.enc_mu.w, d, s.mu, d, c.P + Y.enc_mu.b, PM_GEMM_ACCUM | PM_GEMM_ZEROED,
+                                d / 64 < 8 ? d / 64 : 8, nullptr, 0, nullptr, 2, 0, (int64_t)Y.enc_lv.w - (int64_t)Y.enc_mu.w, s.lv - s.mu,
+                                (int64_t)Y.enc_lv.b - (int64_t)Y.enc_mu.b, 0, 0, c.st));
+    else {
+      lin(c, s.zg_d, Y.enc_mu, B, d, d, s.mu, false);
+      lin(c, s.zg_d, Y.enc_lv, B, d, d, s.lv, false);
+    }
     RUN(pm_reparam_fwd(s.mu, s.lv, s.eps, (int64_t)B * d, s.z, c.st));
     if (!(s.bt.flags & 8)) {
       // the two losses nothing of the decoder feeds: the KL term (mu, log_var) and, when the structure loss is the reference's
@@ -1129,9 +1137,19 @@ void backward_encoder_heads(Ctx& c) {
   float* dm = ar.f((size_t)B * d);
   float* dzcat = ar.zf((size_t)B * 2 * d);
   float* dpooled = ar.zf((size_t)Gn * d);
-  lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
-  lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
-  RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
+  if (d % 64 == 0 && d >= 128) {       // (>= 2 K slices: the launch's stores are atomic)
+    // d(zg) = dmu W_mu + dlv W_lv: the two input gradients as ONE grouped launch whose groups add into the same (cleared) output —
+    // K slices and groups meet through atomics — instead of two products and an add
+    lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, nullptr, 0, 0, 0, true, &df);
+    lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, nullptr, 0, 0, 0, true, &df);
+    RUN(pm_gemm_f32_grouped(0, 0, B, d, d, s.dmu, d, c.P + Y.enc_mu.w, d, dzg, d, nullptr, PM_GEMM_ACCUM | PM_GEMM_ZEROED,
+                              d / 64 < 8 ? d / 64 : 8, nullptr, 0, nullptr, 2, s.dlv - s.dmu, (int64_t)Y.enc_lv.w - (int64_t)Y.enc_mu.w, 0, 0, 0, 0,
+                              c.st));
+  } else {
+    lin_bwd(c, s.dmu, s.zg_d, Y.enc_mu, B, d, d, dzg, 0, 0, 0, true, &df);
+    lin_bwd(c, s.dlv, s.zg_d, Y.enc_lv, B, d, d, dzg2, 0, 0, 0, true, &df);
+    RUN(pm_add(dzg, dzg2, (int64_t)B * d, dzg, c.st));
+  }
   drop(c, dzg, B, d, SITE_ENC_MERGE_OUT, s.seed_enc, dzg);
   bn_bwd(c, s.m, dzg, B, d, 1, Y.enc_bn_merge, s.mm, s.mv, true, dm);
   lin_bwd(c, dm, s.zcat_d, Y.enc_merge, B, d, 2 * d, dzcat, 0, 0, 0, true, &df);

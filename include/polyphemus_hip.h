@@ -57,7 +57,8 @@ enum { PM_N_REL = 6, PM_N_DIST = 32, PM_N_SLOTS = 15, PM_N_PITCH = 131, PM_N_DUR
  *   8: round 6 (pm_bar_aggregate_fwd / _bwd: bar-resident aggregation of dense graphs; pm_gcl_forward_from_planes_h2: the dense
  *   route's product in the fp16 pair format; pm_h2_clamp_events: saturation counter of the pair format; PmBatch.flags bit 3 and
  *   pm_vae_step_output_views: the drop-in module's outputs and gradients as views of the arena;
- *   pm_unembed_row_lists / pm_unembed_ce_rows / pm_unembed_dh_rows: the decoder head without its PAD-target rows). */
+ *   pm_unembed_row_lists / pm_unembed_ce_rows / pm_unembed_dh_rows: the decoder head without its PAD-target rows;
+ *   pm_unembed_dw: the three un-embedding weight gradients in one launch). */
 #define PM_ABI_VERSION 8
 int pm_abi_version(void);
 const char* pm_build_info(void);
@@ -746,6 +747,14 @@ int pm_unembed_ce_rows(const float* H, const float* w_pitch_drum, const float* b
 int pm_unembed_dh_rows(const float* d_logits, const float* w_pitch_drum, const float* w_pitch_nd, const float* w_dur,
                        const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d, int32_t n_slots, float* dH,
                        uint16_t* w_planes, const int32_t* row_lists, const int32_t* row_counts, pm_stream_t stream);
+/* Weight gradients of the three un-embeddings in ONE launch (autograd of model.py:561-567): dw_pitch_drum / dw_pitch_nd [131, d/2],
+ * dw_dur [99, d/2] += d_logits[rows, block]^T H[rows, half] over the plan's drum / non-drum rows and all rows, or over the lists of
+ * pm_unembed_row_lists (row_lists / row_counts; NULL: the plan's).  d_logits [N*n_slots, 230], H [N*n_slots, d] (the un-embeddings'
+ * input, fp32, 16-byte aligned); d/2 a multiple of 128; bf16 six-product chain, every row read once per 128 columns of d/2, output
+ * blocks added with float atomics (not reproducible run to run: deterministic callers use pm_gemm_f32 with the same row maps). */
+int pm_unembed_dw(const float* d_logits, const float* H, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                  int32_t n_slots, float* dw_pitch_drum, float* dw_pitch_nd, float* dw_dur, const int32_t* row_lists,
+                  const int32_t* row_counts, pm_stream_t stream);
 /* Bias gradients (+=) of the three un-embeddings (model.py:561-567) from a given d(loss)/d(logits) [N, S, 230]: column sums
  * of the pitch columns over the drum nodes' / the other nodes' rows and of the duration columns over all rows. */
 int pm_unembed_bias_grads(const float* d_logits, const uint8_t* is_drum /* [N] */, int32_t N, int32_t S,

@@ -106,6 +106,7 @@ _SIGS = {
     "pm_unembed_dh": "pppppiiiiippis",
     "pm_unembed_dh_scratch_bytes": "i",
     "pm_unembed_row_counts_len": "ii",
+    "pm_unembed_dw": "pppiiiiippppps",
     "pm_unembed_row_lists": "ppiiiiipppps",
     "pm_unembed_ce_rows": "pppppppppiiiiifpppppppppps",
     "pm_unembed_dh_rows": "pppppiiiiipppps",

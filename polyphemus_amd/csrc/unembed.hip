@@ -1056,3 +1056,270 @@ extern "C" int pm_unembed_dh_rows(const float* d_logits, const float* w_pitch_dr
   return unembed_dh_impl(d_logits, w_pitch_drum, w_pitch_nd, w_dur, plan, N, E, G, d, n_slots, dH, w_planes, 0, row_lists, row_counts,
                          stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients of the three un-embeddings in ONE launch: dW_j[V_j, d/2] += d_logits[rows_j, block_j]^T H[rows_j, half_j]
+// (autograd of model.py:561-567; j = pitch of the drum rows, pitch of the other rows, duration of all rows — or the row lists of
+// pm_unembed_row_lists).  They used to be three split-K launches of the fp32 tile GEMM with 64 x 64 tiles: the 230-float rows of
+// d_logits admit 4-byte loads only, every row was read by two or three tiles of a job and the 768 K slices of a launch added 3 M
+// float atomics: 46 + 24 + 45 us at configs[1] for 5 GFLOP, on the second stream beside the chain between the two GCN stacks — a
+// what-if build without them ran the step 100 us shorter (profiles/LOG.md, round 6).  Here a workgroup owns a contiguous range of
+// the 32-row k-tiles of the three jobs (one list, as in k_unembed_dh) and the WHOLE [160 x 128] output block of the job it is in:
+// four loader waves read a tile's d_logits block as 8-byte column pairs (the duration block from column 130 with the weight row
+// shifted by one, as k_unembed_dh) and its H rows as 16-byte pieces, split them into bf16 planes ([row][column] images of an
+// LDS ring of two stages); four MFMA waves of 32 output columns each read both TRANSPOSED (ds_read_b64_tr_b16, gcl_tiles.h) and
+// run the six-product chain; the block leaves with float atomics when the range crosses into the next job and at its end.
+// Rows are read once per 128 columns of d/2.  Measured stand-alone at configs[1] (113 k listed rows, 110 MB; throw-away builds):
+// 56 us = the loads alone 25.6 (4.3 TB/s: the chip's rate for 0.4-0.5 KB row pieces) + splits and LDS traffic 10 + products 8.6 +
+// the 5.2 M output atomics 11.4 — the parts add up (two or three tiles in flight, four or eight loader waves, loaders and MFMA
+// waves on separate SIMDs: all within 2 us of each other); the three tile products it replaces took 115 us.
+namespace {
+constexpr int UW_KT = 32;                               // rows per k-tile
+constexpr int UW_MC = 160;                              // image columns of the d_logits block
+constexpr int UW_PAIRS = UW_MC / 2;
+constexpr int UW_APITCH = 448;                          // bytes per row of the d_logits image: 320 + 128 — the four rows a transposing read touches start 48 banks apart
+constexpr int UW_APLANE = UW_KT * UW_APITCH;
+constexpr int UW_STAGE = 3 * UW_APLANE + 3 * DW_PLANE;  // 73,728 B
+constexpr int UW_RING = 8;                              // row-id slots (tiles)
+constexpr int UW_LDS = 2 * UW_STAGE + UW_RING * UW_KT * 4;   // + the row ids of the tiles in flight
+#ifndef UW_LW
+#define UW_LW 4               // loader waves (8: 62.9 against 56 us per launch at configs[1]; the pure-load floor is 25 us either way)
+#endif
+constexpr int UW_LT = UW_LW * 64;                       // loader threads
+constexpr int UW_AIT = UW_KT * UW_PAIRS / UW_LT;        // column pairs per loader thread and tile
+constexpr int UW_BIT = UW_KT * 32 / UW_LT;              // 16-byte pieces of H per loader thread and tile
+struct UnembedDwArgs {
+  const int32_t* rowmap[3]; const int32_t* dyn_rows[3];
+  float* dW[3];
+  int V[3], koff[3], cstart[3], npair[3], wshift[3];
+  const float* dlogits; const float* H;
+  int R, d, dh;
+};
+template <int PITCH>
+__device__ inline bf16x8 uw_frag(const char* S, int c0, int ks, int lane) {     // dw_frag (gcl_tiles.h) on an image of another pitch
+  const int g = lane >> 4, i = lane & 15, q = i >> 2;
+  const int k = ks * 16 + 8 * (g >> 1) + q;
+  const int colb = (c0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+  typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4;
+  const char* p0 = S + k * PITCH + colb;
+  const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+  const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * PITCH));
+  const s16x8_t t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, t);
+}
+}  // namespace
+__global__ void __launch_bounds__(256 + UW_LT) k_unembed_dw(UnembedDwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char uw_lds[];
+  int (*const s_rid)[UW_KT] = reinterpret_cast<int (*)[UW_KT]>(uw_lds + 2 * UW_STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
+  const bool loader = hw >= 4;
+  const int wave = loader ? hw - 4 : hw;                // index within the role
+  const int ncol0 = blockIdx.y * DW_T;                  // this workgroup's 128 columns of d/2
+  int Mj[3], tn[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Mj[j] = __builtin_amdgcn_readfirstlane(a.dyn_rows[j] ? *a.dyn_rows[j] : a.R);
+    tn[j] = (Mj[j] + UW_KT - 1) / UW_KT;
+  }
+  const int t1 = tn[0], t2 = tn[0] + tn[1], T = t2 + tn[2];
+  const int u0 = __builtin_amdgcn_readfirstlane((int)((unsigned)T * blockIdx.x / gridDim.x));
+  const int nt = __builtin_amdgcn_readfirstlane((int)((unsigned)T * (blockIdx.x + 1) / gridDim.x)) - u0;
+  if (nt <= 0) return;
+  auto pick = [](int j, auto x0, auto x1, auto x2) __attribute__((always_inline)) { return j == 0 ? x0 : j == 1 ? x1 : x2; };
+  auto job_of = [&](int t) __attribute__((always_inline)) { const int u = u0 + t; return u < t1 ? 0 : u < t2 ? 1 : 2; };   // t = tile of this range
+  if (loader) {
+    // ================= loaders
+    const int lt = wave * 64 + lane, c4 = lt & 31, r0 = lt >> 5;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dlogits), 0, GCL_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.H), 0, GCL_OOB, 0x00020000);
+    auto row_id = [&](int t) __attribute__((always_inline)) {      // threads < UW_KT: row lt of tile t as a (node, slot) row; -1 past the list / the range
+      if (t >= nt) return -1;
+      const int j = job_of(t), r = (u0 + t - pick(j, 0, t1, t2)) * UW_KT + lt;
+      const int32_t* rm = pick(j, a.rowmap[0], a.rowmap[1], a.rowmap[2]);
+      return r < pick(j, Mj[0], Mj[1], Mj[2]) ? (rm ? rm[r] : r) : -1;
+    };
+    // row ids ahead of their use WITHOUT a wait of their own: the read is unconditional (clamped to a valid tile and row; a readable
+    // stand-in where the job has no list) and stays raw until it is published behind the staging of the tile that is due anyway —
+    // a select on the loaded value right behind the request made every sub-step drain ALL the loads in flight (s_waitcnt vmcnt(0))
+    struct RowReq { int raw, r; bool mapped; };
+    auto row_request = [&](int t) __attribute__((always_inline)) {
+      const int tc = t < nt ? t : nt - 1, j = job_of(tc), M = pick(j, Mj[0], Mj[1], Mj[2]);
+      const int r = (u0 + tc - pick(j, 0, t1, t2)) * UW_KT + (lt & (UW_KT - 1));       // (every loader thread asks: no branch around the read)
+      const int32_t* rm = pick(j, a.rowmap[0], a.rowmap[1], a.rowmap[2]);
+      RowReq q;
+      q.mapped = rm != nullptr;
+      q.raw = (q.mapped ? rm : reinterpret_cast<const int32_t*>(a.dlogits))[r < M ? r : M - 1];
+      q.r = (t < nt && r < M) ? r : -1;
+      return q;
+    };
+    auto row_of = [](const RowReq& q) __attribute__((always_inline)) { return q.r < 0 ? -1 : (q.mapped ? q.raw : q.r); };
+    struct Regs { float2 av[UW_AIT]; float4 bv[UW_BIT]; };
+    auto issue = [&](Regs& v, int t) __attribute__((always_inline)) {
+      const int tc = t < nt ? t : nt - 1, j = job_of(tc);
+      const int npair = pick(j, a.npair[0], a.npair[1], a.npair[2]), c0 = pick(j, a.cstart[0], a.cstart[1], a.cstart[2]);
+      const int koff = pick(j, a.koff[0], a.koff[1], a.koff[2]) + ncol0;
+      const int* rows = s_rid[t & (UW_RING - 1)];
+#pragma unroll
+      for (int it = 0; it < UW_AIT; ++it) {
+        const int idx = it * UW_LT + lt, r = idx / UW_PAIRS, pr = idx - r * UW_PAIRS;
+        const int rg = rows[r];
+        v.av[it] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+            ars, (t < nt && rg >= 0 && pr < npair) ? (rg * PM_N_TOK + c0 + 2 * pr) * 4 : GCL_OOB, 0, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < UW_BIT; ++q) {
+        const int rg = rows[r0 + q * (UW_LT / 32)];
+        v.bv[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+            brs, (t < nt && rg >= 0) ? (rg * a.d + koff + c4 * 4) * 4 : GCL_OOB, 0, 0));
+      }
+    };
+    auto put = [&](const Regs& v, int t) __attribute__((always_inline)) {
+      char* st = uw_lds + (t & 1) * UW_STAGE;
+#pragma unroll
+      for (int it = 0; it < UW_AIT; ++it) {
+        const int idx = it * UW_LT + lt, r = idx / UW_PAIRS, pr = idx - r * UW_PAIRS;
+        unsigned h1, h2, h3;
+        pm_split3_pair(v.av[it].x, v.av[it].y, h1, h2, h3);
+        char* dst = st + r * UW_APITCH + pr * 4;
+        *reinterpret_cast<unsigned*>(dst) = h1;
+        *reinterpret_cast<unsigned*>(dst + UW_APLANE) = h2;
+        *reinterpret_cast<unsigned*>(dst + 2 * UW_APLANE) = h3;
+      }
+#pragma unroll
+      for (int q = 0; q < UW_BIT; ++q) {
+        unsigned l1, l2, l3, u1, u2, u3;
+        pm_split3_pair(v.bv[q].x, v.bv[q].y, l1, l2, l3);
+        pm_split3_pair(v.bv[q].z, v.bv[q].w, u1, u2, u3);
+        const pm_u32x2 p1 = {l1, u1}, p2 = {l2, u2}, p3 = {l3, u3};
+        char* dst = st + 3 * UW_APLANE + (r0 + q * (UW_LT / 32)) * DW_PITCH + c4 * 8;
+        *reinterpret_cast<pm_u32x2*>(dst) = p1;
+        *reinterpret_cast<pm_u32x2*>(dst + DW_PLANE) = p2;
+        *reinterpret_cast<pm_u32x2*>(dst + 2 * DW_PLANE) = p3;
+      }
+    };
+    if (lt < UW_KT) {
+#pragma unroll
+      for (int q = 0; q < UW_RING - 1; ++q) s_rid[q][lt] = row_id(q);
+    }
+    __syncthreads();                                               // (A) the row ids of tiles 0 .. 6
+    // Three tiles in flight: with two (k_rows_tn's schedule) a tile took 3.9 us here — the rows of a list are gathered, and the
+    // launch shares the memory system with the chain on the caller's stream.  Sub-step k: request tile k + 3, stage tile k + 1 (it
+    // has had two sub-steps to arrive), publish the row ids of tile k + 7 in the slot tile k - 1 had.
+    Regs v0, v1, v2, v3;
+    issue(v0, 0);
+    issue(v1, 1);
+    issue(v2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    put(v0, 0);
+    __syncthreads();                                               // (B) tile 0 staged
+#define UW_STEP(VI, VP, K)                                                                                             \
+  {                                                                                                                    \
+    const RowReq nq = row_request((K) + UW_RING - 1);                                                                  \
+    issue(VI, (K) + 3);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    put(VP, (K) + 1);                                                                                                  \
+    if (lt < UW_KT) s_rid[((K) + UW_RING - 1) & (UW_RING - 1)][lt] = row_of(nq);                                       \
+    __syncthreads();                                                                                                   \
+  }
+#pragma unroll 1
+    for (int k = 0; k < nt; k += 4) {
+      UW_STEP(v3, v1, k);
+      if (k + 1 >= nt) break;
+      UW_STEP(v0, v2, k + 1);
+      if (k + 2 >= nt) break;
+      UW_STEP(v1, v3, k + 2);
+      if (k + 3 >= nt) break;
+      UW_STEP(v2, v0, k + 3);
+    }
+#undef UW_STEP
+    return;
+  }
+  // ================= MFMA waves: output columns [32 wave, 32 wave + 32) of the 128, all five 32-row blocks of the job's weight
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[5];
+  auto zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  };
+  auto flush = [&](int j) __attribute__((always_inline)) {       // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* const W = pick(j, a.dW[0], a.dW[1], a.dW[2]);
+    const int V = pick(j, a.V[0], a.V[1], a.V[2]), ws = pick(j, a.wshift[0], a.wshift[1], a.wshift[2]);
+    const int col = ncol0 + wave * 32 + li;
+    if (col >= a.dh) return;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int wrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh - ws;
+        if (wrow >= 0 && wrow < V) atomicAdd(W + (int64_t)wrow * a.dh + col, acc[i][r]);
+      }
+  };
+  zero();
+  int jcur = job_of(0);
+  __syncthreads();                                                 // (A)
+  __syncthreads();                                                 // (B)
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const int j = job_of(t);
+    if (j != jcur) { flush(jcur); zero(); jcur = j; }              // (workgroup-uniform)
+    const char* st = uw_lds + (t & 1) * UW_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < UW_KT / 16; ++ks) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = dw_frag(st + 3 * UW_APLANE + p * DW_PLANE, wave * 32, ks, lane);
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};    // smallest terms first
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        bf16x8 av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) av[p] = uw_frag<UW_APITCH>(st + p * UW_APLANE, i * 32, ks, lane);
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[t6]], b[PB[t6]], acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  flush(jcur);
+}
+// d_logits [N*n_slots, 230], H [N*n_slots, d] (the un-embeddings' input), dW_* [V, d/2] += ; row_lists / row_counts of
+// pm_unembed_row_lists or NULL (the plan's drum / non-drum lists, every row for the duration).  d/2 a multiple of 128.
+extern "C" int pm_unembed_dw(const float* d_logits, const float* H, const int32_t* plan, int32_t N, int32_t E, int32_t G, int32_t d,
+                             int32_t n_slots, float* dw_pitch_drum, float* dw_pitch_nd, float* dw_dur, const int32_t* row_lists,
+                             const int32_t* row_counts, pm_stream_t stream) {
+  if (!d_logits || !H || !plan || !dw_pitch_drum || !dw_pitch_nd || !dw_dur || N <= 0 || d <= 0 || n_slots < 1 ||
+      n_slots > PM_N_SLOTS || ((uintptr_t)H % 16) || ((uintptr_t)d_logits % 8) || (row_lists && !row_counts))
+    return PM_E_INVALID;
+  const int dh = d / 2;
+  if (dh % DW_T) return PM_E_UNSUPPORTED;
+  const int64_t R = (int64_t)N * n_slots;
+  if (R * PM_N_TOK * 4 >= ((int64_t)1 << 31) || R * (int64_t)d * 4 >= ((int64_t)1 << 31)) return PM_E_UNSUPPORTED;   // (32-bit byte offsets)
+  PmPlanView pv = pm_plan_view(plan, N, E, G);
+  UnembedDwArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rowmap[0] = pv.row_list; a.dyn_rows[0] = pv.group_cnt + 2;
+  a.rowmap[1] = pv.row_list + (int64_t)N * PM_N_SLOTS; a.dyn_rows[1] = pv.group_cnt + 3;
+  if (row_lists)
+    for (int j = 0; j < 3; ++j) { a.rowmap[j] = row_lists + (int64_t)j * R; a.dyn_rows[j] = row_counts + j; }
+  a.dW[0] = dw_pitch_drum; a.dW[1] = dw_pitch_nd; a.dW[2] = dw_dur;
+  a.V[0] = a.V[1] = PM_N_PITCH; a.V[2] = PM_N_DUR; a.koff[2] = dh;
+  a.cstart[0] = a.cstart[1] = 0; a.npair[0] = a.npair[1] = (PM_N_PITCH + 1) / 2;
+  a.cstart[2] = PM_N_PITCH - 1; a.npair[2] = (PM_N_DUR + 1) / 2; a.wshift[2] = 1;
+  a.dlogits = d_logits; a.H = H; a.R = (int)R; a.d = d; a.dh = dh;
+  hipStream_t st = (hipStream_t)stream;
+  static bool once_dev[16] = {}; bool& once = once_dev[pm_device_slot()];
+  if (!once) {
+    hipFuncSetAttribute((const void*)k_unembed_dw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  // one workgroup per CU (147 KB of LDS); at least ~4 k-tiles each
+  const int ntn = dh / DW_T;
+  int nb = (int)pm_cdiv(2 * pm_cdiv(R, UW_KT) + 2, 4);
+  const int cap = 256 / ntn;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_unembed_dw, dim3(nb, ntn), dim3(256 + UW_LT), UW_LDS, st, a);
+  return pm_check_launch();
+}

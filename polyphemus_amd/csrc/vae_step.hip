@@ -34,7 +34,8 @@ namespace {
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
 //   PM_SIDE_STREAM=m    bit mask of the branch sites (BR_* below) issued on the library's second stream (default: all;
 //                       0: everything on the caller's stream);  PM_SIDE_DELAY_US=n (tests): every branch starts n us late
-//   PM_DAGG_BN=0, PM_DAGG_RES=0, PM_PLAN_SIDE=0, PM_CHORD_TABLES=0, PM_H2=0, PM_BAR_ROUTE=0: see the fields of StepCfg
+//   PM_DAGG_BN=0, PM_DAGG_RES=0, PM_PLAN_SIDE=0, PM_CHORD_TABLES=0, PM_H2=0, PM_BAR_ROUTE=0, PM_PAD_SKIP=0, PM_UNEMBED_DW=0: see the
+//                       fields of StepCfg
 //   PM_GCL_OFFSET_LIMIT=n, PM_DEBUG
 // Former switches that are constants now (their losing side was measured and removed: profiles/LOG.md): PM_NO_ROWS_TN,
 // PM_NO_UNEMBED_DH, PM_GCL_NO_BFRAG, PM_DENSE_DEG (16), PM_LATE_WGRADS, PM_DW_SIDE, PM_FUSED_HEADS (csrc/heads.hip, deleted in
@@ -59,6 +60,7 @@ struct StepCfg {
   bool h2;                     // PM_H2=0: the GCL products of d in {128, 256} on the exact three-term bf16 split (six MFMA products per fp32
                                // product) instead of the fp16 pair format (three; PmH2 of the header) — the parity tests run both
   int dense_deg;
+  bool unembed_dw;             // PM_UNEMBED_DW=0: the un-embedding weight gradients as three split-K products of the fp32 tile GEMM (rounds 2-5)
   bool pad_skip;               // PM_PAD_SKIP=0: the decoder head over every (node, active slot) row, PAD targets included (rounds 2-5)
   bool bar_route;              // PM_BAR_ROUTE=0: dense graphs on the row-gather kernels of segreduce.hip (rounds 1-5) instead of bar.hip
   int64_t offset_limit;        // PM_GCL_OFFSET_LIMIT: operand bytes up to which the 32-bit-offset kernels are used (tests lower it)
@@ -88,6 +90,7 @@ static StepCfg read_cfg() {
   k.dense_deg = 16;
   k.bar_route = flag("PM_BAR_ROUTE", true);
   k.pad_skip = flag("PM_PAD_SKIP", true);
+  k.unembed_dw = flag("PM_UNEMBED_DW", true);
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
 }
@@ -1077,12 +1080,19 @@ void backward_decoder(Ctx& c) {
   // (pm_vae_step_join_decoder_grads: data parallel) or before the encoder's GCL layers (pm_vae_step_backward_encoder).
   auto decoder_weight_grads = [&]() {
     BranchScope br(c, BR_DEC_WGRAD);
+    // the three un-embedding weight gradients: one launch that reads every row once (unembed.hip k_unembed_dw; float atomics per
+    // output block: the deterministic mode, d/2 < 128 and PM_UNEMBED_DW=0 keep the three split-K tile products)
+    if (cfg().unembed_dw && dh % 128 == 0 && !pm_det_on() && R * PM_N_TOK * 4 < ((int64_t)1 << 31) && R * (int64_t)d * 4 < ((int64_t)1 << 31)) {
+      RUN(pm_unembed_dw(s.dc_logits, s.H, s.plan, N, c.E, Gn, d, S, c.G + Y.dec_pitch_d.w, c.G + Y.dec_pitch_nd.w, c.G + Y.dec_dur.w,
+                          skip ? s.ue_lists : nullptr, skip ? s.ue_counts : nullptr, c.st));
+    } else {
     RUN(pm_gemm_f32(1, 0, PM_N_DUR, dh, (int)R, s.dc_logits + PM_N_PITCH, PM_N_TOK, s.H + dh, d, c.G + Y.dec_dur.w, dh,
                       nullptr, PM_GEMM_ACCUM, 0, skip ? s.ue_lists + 2 * R : nullptr, skip ? 1 : 0, skip ? s.ue_counts + 2 : nullptr, c.st));
     for (int g = 0; g < 2; ++g) {
       const int32_t* lst = skip ? s.ue_lists + g * R : pv.row_list + (g ? (int64_t)N * PM_N_SLOTS : 0);
       RUN(pm_gemm_f32(1, 0, PM_N_PITCH, dh, (int)R, s.dc_logits, PM_N_TOK, s.H, d, c.G + pit[g].w, dh, nullptr,
                         PM_GEMM_ACCUM, 0, lst, 1, skip ? s.ue_counts + g : pv.group_cnt + 2 + g, c.st));
+    }
     }
     if (s.ext_loss) {
       // the caller's loss: the bias gradients of the three un-embeddings are the column sums of ITS d(logits) (with the

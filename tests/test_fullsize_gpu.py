@@ -219,14 +219,15 @@ def test_structure_branch_on_the_second_stream_changes_nothing(fix_structure):
 
 
 @pytest.mark.parametrize("env", [{"PM_DAGG_BN": 0}, {"PM_CHORD_TABLES": 0}, {"PM_PLAN_SIDE": 0}, {"PM_DAGG_RES": 1},
-                                 {"PM_PAD_SKIP": 0}],
+                                 {"PM_PAD_SKIP": 0}, {"PM_UNEMBED_DW": 0}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_round4_rearrangements_change_nothing(env):
     """The step's rearrangements of round 4, each against the formulation it replaced, at configs[1]: the norm backward
     inside the input-gradient kernel (PM_DAGG_BN=0: its own pass), the chord encoder as table algebra (PM_CHORD_TABLES=0:
     gather + products over X [N, S, d]), the plan beside the content encoder (PM_PLAN_SIDE=0), the residual gradient in dA's
     self block (PM_DAGG_RES=1; off by default), and round 6's decoder head over the row lists without PAD targets (PM_PAD_SKIP=0:
-    every active-slot row) — same losses, outputs and gradients, to what two fp32 runs of a ReLU network
+    every active-slot row) and its three un-embedding weight gradients in one launch (PM_UNEMBED_DW=0: three split-K tile products) —
+    same losses, outputs and gradients, to what two fp32 runs of a ReLU network
     can agree on.  (Switches the step re-reads: pm_vae_step_reload_switches.)"""
     a, b = _same_step_up_to_relu_kinks(dict(FULLSIZE["configs1_lmd2_b256_d256"]), env)
     for k in ("pitch", "dur", "structure", "kld"):

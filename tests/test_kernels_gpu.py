@@ -1311,6 +1311,47 @@ def test_decoder_head_over_the_rows_without_pad_targets(d, B, S, drums):
     assert torch.equal(lg1, lg0) and torch.equal(dl1, dl0) and float(out2[:2].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("d,B,S,drums,lists", [(256, 40, 6, "mixed", True), (256, 40, 6, "mixed", False), (512, 12, 4, "mixed", True),
+                                                (256, 6, 5, "none", True), (256, 6, 5, "all", False), (256, 300, 3, "mixed", True),
+                                                (256, 1, 7, "mixed", True)])
+def test_unembed_weight_gradients_in_one_launch(d, B, S, drums, lists):
+    """`pm_unembed_dw` (round 6): dW_j += d_logits[rows_j, block_j]^T H[rows_j, half_j] of the three un-embeddings in one launch —
+    every row read once, the duration block from column 130 on with the weight row shifted by one — against the fp64 products over
+    the plan's drum / non-drum rows and all rows, or over the lists of `pm_unembed_row_lists` (rows left out hold NaN: they must
+    not be read); the gradients ACCUMULATE; an empty job and more k-tiles than workgroups (B = 300)."""
+    import numpy as np
+    cpu = synthetic_batch(B, 2, p=0.3 if B > 1 else 0.12, seed=37)
+    if drums != "mixed":
+        cpu.is_drum = torch.full_like(cpu.is_drum, drums == "all")
+    b = cpu.to(DEV)
+    plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars,
+                          b.s_tensor.shape[0], n_slots=S)
+    N, dh, R = cpu.num_nodes, d // 2, cpu.num_nodes * S
+    torch.manual_seed(d + B + S)
+    dl = torch.randn(N, S, 230, device=DEV)
+    H = torch.randn(N, S, d, device=DEV)
+    tok = cpu.tokens.numpy()[:, 1:S + 1]
+    live = torch.from_numpy((tok[..., 0] != 130) | (tok[..., 1] != 98)).to(DEV) if lists else torch.ones(N, S, dtype=torch.bool, device=DEV)
+    lp = cp = None
+    if lists:
+        lst = torch.empty(3, R, dtype=torch.int32, device=DEV)
+        cnt = torch.empty(int(lib().pm_unembed_row_counts_len(N, S)), dtype=torch.int32, device=DEV)
+        call("pm_unembed_row_lists", ptr(plan.tokens), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(lst), None, ptr(cnt), None, stream())
+        dl[~live] = float("nan")
+        H[~live] = float("nan")
+        lp, cp = ptr(lst), ptr(cnt)
+    g0 = [torch.randn(v, dh, device=DEV) for v in (131, 131, 99)]
+    g = [t.clone() for t in g0]
+    call("pm_unembed_dw", ptr(dl), ptr(H), ptr(plan.buf), N, plan.E, plan.G, d, S, ptr(g[0]), ptr(g[1]), ptr(g[2]), lp, cp, stream())
+    drum = b.is_drum.bool()[:, None].expand(N, S)
+    dl64, H64 = torch.nan_to_num(dl).double(), torch.nan_to_num(H).double()
+    for j, (rows, cols, half) in enumerate(((drum & live, slice(0, 131), slice(0, dh)), (~drum & live, slice(0, 131), slice(0, dh)),
+                                            (live, slice(131, 230), slice(dh, d)))):
+        want = g0[j].double() + dl64[rows][:, cols].t() @ H64[rows][:, half]
+        assert bool(torch.isfinite(g[j]).all()), j
+        assert rel_err(g[j], want) < 3e-6, (j, rel_err(g[j], want))
+
+
 def test_unembed_input_gradient_refuses_offsets_beyond_32_bits():
     """`pm_unembed_dh` addresses d_logits and dH with 32-bit byte offsets: sizes beyond that are refused before anything is
     launched (the step then takes the GEMM path, `vae_step.hip`)."""

@@ -727,10 +727,13 @@ def test_bar_broadcast(small):
 
 
 # ------------------------------------------------------------------ structure CNN
-@pytest.mark.parametrize("Ci,Co,H,W,up4", [(1, 8, 4, 32, False), (8, 16, 4, 8, False), (16, 8, 4, 32, True), (8, 1, 4, 32, False)])
-def test_conv3x3(Ci, Co, H, W, up4):
+@pytest.mark.parametrize("G", [13, 512])
+@pytest.mark.parametrize("Ci,Co,H,W,up4", [(1, 8, 4, 32, False), (8, 16, 4, 8, False), (16, 8, 4, 32, True), (8, 1, 4, 32, False),
+                                           (3, 5, 3, 12, False), (2, 3, 2, 16, True)])
+def test_conv3x3(Ci, Co, H, W, up4, G):
+    """The structure CNN's convolutions (model.py:219-230,279-285) against torch in fp64: the model's four shapes (round 6:
+    position-per-thread kernels), two other shapes (the generic kernels), one workgroup and many."""
     torch.manual_seed(Ci * Co)
-    G = 13
     x = torch.randn(G, Ci, H, W // 4 if up4 else W, device=DEV)
     w, bias = torch.randn(Co, Ci, 3, 3, device=DEV) * 0.3, torch.randn(Co, device=DEV)
     xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)

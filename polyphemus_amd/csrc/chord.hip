@@ -143,9 +143,12 @@ extern "C" int pm_chord_tables_fwd(const float* tables, const float* Wc, int32_t
 template <int SMAX>
 __global__ void __launch_bounds__(256) k_chord_sum_fwd(const float* __restrict__ PT, const float* __restrict__ cvec,
                                                        const int* __restrict__ tok, const uint8_t* __restrict__ is_drum, int N,
-                                                       int d, int S, float* __restrict__ x0) {
+                                                       int d, int S, float* __restrict__ x0, unsigned* __restrict__ absmax) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
+  __shared__ unsigned s_amax;                    // absmax != NULL: max x0 of the workgroup's four nodes (PmH2.absmax_in of the first GCL layer)
+  if (threadIdx.x == 0) s_amax = 0u;
+  float amax = 0.f;
+  if (n < N) {
   const int g = is_drum[n] ? 0 : 1;
   const int* tk = tok + (int64_t)n * 32 + 2;                         // slot 1.. (the SOS slot is dropped, model.py:349)
   const float* rows[2 * SMAX];
@@ -167,18 +170,33 @@ __global__ void __launch_bounds__(256) k_chord_sum_fwd(const float* __restrict__
       if (s < 2 * S) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
     a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
     *reinterpret_cast<float4*>(x0 + (int64_t)n * d + c) = a;
+    amax = fmaxf(fmaxf(amax, fmaxf(a.x, a.y)), fmaxf(a.z, a.w));
+  }
+  }
+  if (absmax) {                                  // (uniform) one atomic per workgroup: ~64 per slot at configs[1]
+    __syncthreads();
+    pm_absmax_block(absmax, amax, &s_amax);
   }
 }
-extern "C" int pm_chord_sum_fwd(const float* PT, const float* cvec, const int32_t* tokens, const uint8_t* is_drum, int32_t N,
-                                int32_t d, int32_t n_slots, float* x0, pm_stream_t stream) {
+static int chord_sum_fwd_impl(const float* PT, const float* cvec, const int32_t* tokens, const uint8_t* is_drum, int32_t N,
+                              int32_t d, int32_t n_slots, float* x0, uint32_t* absmax, pm_stream_t stream) {
   if (!PT || !cvec || !tokens || !is_drum || !x0 || N <= 0 || d <= 0 || (d & 7) || n_slots < 1 || n_slots > PM_N_SLOTS)
     return PM_E_INVALID;
   const dim3 grid((unsigned)pm_cdiv(N, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (n_slots <= 5) hipLaunchKernelGGL(k_chord_sum_fwd<5>, grid, block, 0, st, PT, cvec, tokens, is_drum, N, d, n_slots, x0);
-  else if (n_slots <= 8) hipLaunchKernelGGL(k_chord_sum_fwd<8>, grid, block, 0, st, PT, cvec, tokens, is_drum, N, d, n_slots, x0);
-  else hipLaunchKernelGGL(k_chord_sum_fwd<PM_N_SLOTS>, grid, block, 0, st, PT, cvec, tokens, is_drum, N, d, n_slots, x0);
+  if (n_slots <= 5) hipLaunchKernelGGL(k_chord_sum_fwd<5>, grid, block, 0, st, PT, cvec, tokens, is_drum, N, d, n_slots, x0, absmax);
+  else if (n_slots <= 8) hipLaunchKernelGGL(k_chord_sum_fwd<8>, grid, block, 0, st, PT, cvec, tokens, is_drum, N, d, n_slots, x0, absmax);
+  else hipLaunchKernelGGL(k_chord_sum_fwd<PM_N_SLOTS>, grid, block, 0, st, PT, cvec, tokens, is_drum, N, d, n_slots, x0, absmax);
   return pm_check_launch();
+}
+extern "C" int pm_chord_sum_fwd(const float* PT, const float* cvec, const int32_t* tokens, const uint8_t* is_drum, int32_t N,
+                                int32_t d, int32_t n_slots, float* x0, pm_stream_t stream) {
+  return chord_sum_fwd_impl(PT, cvec, tokens, is_drum, N, d, n_slots, x0, nullptr, stream);
+}
+// (library-internal, vae_step.hip) ... and max x0 into `absmax` [PM_ABSMAX_SLOTS] (atomic max of float bits: the caller clears it)
+extern "C" int pm_chord_sum_fwd_absmax(const float* PT, const float* cvec, const int32_t* tokens, const uint8_t* is_drum, int32_t N,
+                                       int32_t d, int32_t n_slots, float* x0, uint32_t* absmax, pm_stream_t stream) {
+  return chord_sum_fwd_impl(PT, cvec, tokens, is_drum, N, d, n_slots, x0, absmax, stream);
 }
 
 // ---------------------------------------------------------------- backward: G = one-hot^T x dY on the matrix cores

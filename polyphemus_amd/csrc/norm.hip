@@ -539,8 +539,12 @@ extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, co
 __global__ void __launch_bounds__(512) k_colreduce_rows_bwd_atomic(const float* __restrict__ x,
                                                                    const float* __restrict__ dy, int O, int C,
                                                                    BnCtx ctx, int rows_per_chunk,
-                                                                   double* __restrict__ acc3, unsigned* gate) {
+                                                                   double* __restrict__ acc3, unsigned* gate,
+                                                                   unsigned* __restrict__ absmax_dy) {
   __shared__ double sh[8][64][12];
+  __shared__ unsigned s_amax;                    // absmax_dy != NULL: max |dy| of this workgroup's rows (PmH2.absmax_in of the layer's input gradient)
+  if (threadIdx.x == 0) s_amax = 0u;
+  float amax = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
   const bool ok = c < C;
@@ -567,6 +571,7 @@ __global__ void __launch_bounds__(512) k_colreduce_rows_bwd_atomic(const float* 
         xw = *reinterpret_cast<const float4*>(x + (int64_t)rb * C + c);
         dw = *reinterpret_cast<const float4*>(dy + (int64_t)rb * C + c);
       }
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(dv.x), fabsf(dv.y))), fmaxf(fmaxf(fabsf(dv.z), fabsf(dv.w)), fmaxf(fmaxf(fabsf(dw.x), fabsf(dw.y)), fmaxf(fabsf(dw.z), fabsf(dw.w)))));
       bn_acc<1>(xv.x, dv.x, m[0], rs[0], ga[0], be[0], ctx.relu, acc[0], acc[4], acc[8]);
       bn_acc<1>(xv.y, dv.y, m[1], rs[1], ga[1], be[1], ctx.relu, acc[1], acc[5], acc[9]);
       bn_acc<1>(xv.z, dv.z, m[2], rs[2], ga[2], be[2], ctx.relu, acc[2], acc[6], acc[10]);
@@ -582,6 +587,13 @@ __global__ void __launch_bounds__(512) k_colreduce_rows_bwd_atomic(const float* 
 #pragma unroll
   for (int j = 0; j < 12; ++j) sh[wave][lane][j] = acc[j];
   __syncthreads();
+  if (absmax_dy) {                              // (uniform) one atomic per workgroup, on the slot of its row chunk
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) atomicMax(&s_amax, __float_as_uint(amax));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(absmax_dy + (blockIdx.y % PM_ABSMAX_SLOTS), s_amax);
+  }
   pm_turn_enter_block(gate);                    // (deterministic mode, common.h: the row chunks add in turn)
   if (wave == 0 && ok) {
     double* dst = acc3 + (int64_t)(blockIdx.y % PM_BN_REPL) * 3 * C;
@@ -674,7 +686,7 @@ static int bn_bwd_fused_impl(const float* x, const float* dy, int32_t O, int32_t
   nc = (int)pm_cdiv(O, rpc);
   if (!sums_ready)
     hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(512), 0, st, x, dy, O, C, ctx, rpc, acc3,
-                       pm_det_gate(st));
+                       pm_det_gate(st), nullptr);
   const int64_t n = (int64_t)O * C;
   hipLaunchKernelGGL(k_bn_bwd_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 6 * C, st, x, dy, n / 4, C,
                      (double)O, ctx, acc3, dgamma, dbeta, dbias_pre, dx, dx_planes, plane_stride, mdu, sdh_out,
@@ -699,8 +711,9 @@ extern "C" int pm_bn_bwd_fused_h2(const float* x, const float* dy, int32_t O, in
 }
 
 // the column sums alone (the apply half then runs inside the consumer: pm_gcl_input_grad_bn, gcl.hip)
-extern "C" int pm_bn_bwd_sums(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
-                              float eps, const float* gamma, const float* beta, int relu, double* acc3, pm_stream_t stream) {
+static int bn_bwd_sums_impl(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
+                            float eps, const float* gamma, const float* beta, int relu, double* acc3, uint32_t* absmax_dy,
+                            pm_stream_t stream) {
   if (!x || !dy || !mean || !var || !gamma || !beta || !acc3 || O <= 0 || C <= 0 || (C % 4) != 0 || C > 4096) return PM_E_INVALID;
   if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return PM_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -711,8 +724,17 @@ extern "C" int pm_bn_bwd_sums(const float* x, const float* dy, int32_t O, int32_
   const int rpc = (int)pm_cdiv(O, nc);
   nc = (int)pm_cdiv(O, rpc);
   hipLaunchKernelGGL(k_colreduce_rows_bwd_atomic, dim3(pm_cdiv(C, 256), nc), dim3(512), 0, st, x, dy, O, C, ctx, rpc, acc3,
-                     pm_det_gate(st));
+                     pm_det_gate(st), absmax_dy);
   return pm_check_launch();
+}
+extern "C" int pm_bn_bwd_sums(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
+                              float eps, const float* gamma, const float* beta, int relu, double* acc3, pm_stream_t stream) {
+  return bn_bwd_sums_impl(x, dy, O, C, mean, var, eps, gamma, beta, relu, acc3, nullptr, stream);
+}
+extern "C" int pm_bn_bwd_sums_absmax(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var,
+                                     float eps, const float* gamma, const float* beta, int relu, double* acc3, uint32_t* absmax_dy,
+                                     pm_stream_t stream) {
+  return bn_bwd_sums_impl(x, dy, O, C, mean, var, eps, gamma, beta, relu, acc3, absmax_dy, stream);
 }
 
 // ---------------------------------------------------------------- element-wise helpers

@@ -21,6 +21,11 @@ int pm_plan_build_marked(const int64_t* edge_index, const int32_t* edge_type, co
                          int32_t N, int32_t E, int32_t G, int32_t* plan, hipStream_t stream, hipEvent_t after_count);   // plan.hip
 extern "C" int pm_kld_acc(const float* mu, const float* log_var, int32_t B, int32_t d, float beta, float* dmu, float* dlog_var,
                           double* out, pm_stream_t stream);                                                       // loss.hip
+extern "C" int pm_chord_sum_fwd_absmax(const float* PT, const float* cvec, const int32_t* tokens, const uint8_t* is_drum, int32_t N, int32_t d,
+                                       int32_t n_slots, float* x0, uint32_t* absmax, pm_stream_t stream);           // chord.hip
+extern "C" int pm_bn_bwd_sums_absmax(const float* x, const float* dy, int32_t O, int32_t C, const float* mean, const float* var, float eps,
+                                     const float* gamma, const float* beta, int relu, double* acc3, uint32_t* absmax_dy,
+                                     pm_stream_t stream);                                                            // norm.hip
 extern "C" int pm_bce_logits_acc(const float* logits, const float* target, int64_t n, float grad_scale, float* dlogits, double* out,
                                  pm_stream_t stream);                                                                // loss.hip
 namespace {
@@ -142,6 +147,7 @@ struct GcnSaved {
   // mdu[i * PM_ABSMAX_SLOTS ..] = of the gradient arriving at layer i's norm; sA[i] / sdh[i] = the scales the layer's A' / dh
   // planes were written with
   bool h2; uint32_t* mx; uint32_t* mdu; float* sA; float* sdh;
+  bool x0_maxed;                           // the producer of the stack's input left its |max| in mx[0] already (pm_chord_sum_fwd_absmax)
   const float* x0_src; int64_t x0_src_n;   // optional: a smaller tensor with the same |max| as the stack's input (its rows are copies)
 };
 constexpr float kH2WScale = 16.f;        // weight planes of the fp16 pair format: W * 2^4 (glorot-range weights land around 1)
@@ -499,7 +505,8 @@ float* gcn_forward(Ctx& c, float* x0, const PmGcn& g, GcnSaved& sv, uint32_t see
     if ((fused || from_planes) && sv.h2) {
       if (!x_tracked) {
         // (the decoder's first input is the bar vectors broadcast to their nodes: the [G, d] source has the same |max|)
-        if (i == 0 && sv.x0_src && !(c.pdrop > 0.f)) RUN(pm_absmax(sv.x0_src, sv.x0_src_n, sv.mx, c.st));
+        if (i == 0 && sv.x0_maxed && !(c.pdrop > 0.f)) {}
+        else if (i == 0 && sv.x0_src && !(c.pdrop > 0.f)) RUN(pm_absmax(sv.x0_src, sv.x0_src_n, sv.mx, c.st));
         else RUN(pm_absmax(sv.xin[i], (int64_t)N * d, sv.mx + i * PM_ABSMAX_SLOTS, c.st));
       }
       PmH2 h2;
@@ -599,9 +606,13 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
     const bool sums_ready = i < c.L - 1 && fuse_sums;
     const GcnRoute rt = gcn_route(c, sv);
     const bool du_tracked = sums_ready && (d <= 256 || rt.bar);   // (h2: pm_segreduce_bwd_norm of layer i+1 also left |dx|max in mdu[i]; its 512-wide variant has no register for it, the bar-resident kernel has)
+    bool du_from_sums = false;                           // (the top layer of a stack: its |du|max rides in the norm's column sums)
     if (in_dagg) {
-      if (!sums_ready)
-        RUN(pm_bn_bwd_sums(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, acc3, c.st));
+      if (!sums_ready) {
+        du_from_sums = sv.h2 && !du_tracked;
+        RUN(pm_bn_bwd_sums_absmax(sv.h[i], dx, N, d, sv.mean[i], sv.var[i], 1e-5f, c.P + bn.w, c.P + bn.b, 1, acc3,
+                                    du_from_sums ? sv.mdu + i * PM_ABSMAX_SLOTS : nullptr, c.st));
+      }
     } else if (c.bn && sv.h2) {                          // d = 512 in the fp16 pair format: the norm's pass writes the two dh planes
       if (!du_tracked) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i * PM_ABSMAX_SLOTS, c.st));
       PmH2 h2;
@@ -662,7 +673,7 @@ float* gcn_backward(Ctx& c, float* dx, const PmGcn& g, GcnSaved& sv) {
         nb.add_residual = res_in_dagg ? 1 : 0; nb.reserved = 0;
         if (sv.h2) {
           // |du|max: the segment-reduce backward of the layer above left it (PmNormSums.absmax_out); the top layer's comes from elsewhere
-          if (!du_tracked) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i * PM_ABSMAX_SLOTS, c.st));
+          if (!du_tracked && !du_from_sums) RUN(pm_absmax(dx, (int64_t)N * d, sv.mdu + i * PM_ABSMAX_SLOTS, c.st));
           PmH2 h2;
           h2.absmax_in = sv.mdu + i * PM_ABSMAX_SLOTS; h2.absmax_aux = nullptr; h2.scale_out = sv.sdh + i; h2.w_scale = kH2WScale; h2.reserved = 0;
           RUN(pm_gcl_input_grad_bn_h2(&nb, dhp, dps, c.s->plan, N, c.E, c.Gn, d, sv.Wft + (int64_t)i * sv.wf_stride,
@@ -873,7 +884,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     if (chord_tab) {
       // x0 = relu(cvec[group] + the 2 S looked-up rows of the projected tables): two launches, no X
       RUN(pm_chord_tables_fwd(tables, c.P + Y.enc_chord.w, d, S, s.PT, c.P + Y.enc_chord.b, s.cvec, c.st));
-      RUN(pm_chord_sum_fwd(s.PT, s.cvec, s.bt.tokens, s.bt.is_drum, N, d, S, s.x0, c.st));
+      s.eg.x0_maxed = s.eg.mx != nullptr;          // (max x0 = the |max| the encoder's first GCL layer scales its operand by)
+      RUN(pm_chord_sum_fwd_absmax(s.PT, s.cvec, s.bt.tokens, s.bt.is_drum, N, d, S, s.x0, s.eg.mx, c.st));
       if (!plan_side) branch_join(c, BR_WPREP);
     } else {
     RUN(pm_embed_gather(tables, s.bt.tokens, s.bt.is_drum, N, d, S, s.X, c.st));

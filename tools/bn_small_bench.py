@@ -1,3 +1,7 @@
+"""Stand-alone timing of the one-launch small-batch norms (pm_bn_small_fwd / _bwd, B = 256 rows): 200 back-to-back calls.
+
+    python tools/bn_small_bench.py         # on the GPU box; numbers in profiles/LOG.md, round 6
+"""
 import torch, sys
 sys.path.insert(0, ".")
 from polyphemus_amd._lib import call, ptr, stream

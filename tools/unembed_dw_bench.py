@@ -1,3 +1,7 @@
+"""Stand-alone timing of pm_unembed_dw at configs[1] (row lists of pm_unembed_row_lists): HIP events around 50 back-to-back calls.
+
+    python tools/unembed_dw_bench.py       # on the GPU box; numbers in profiles/LOG.md, round 6
+"""
 import torch, sys, os
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from polyphemus_amd._lib import call, ptr, stream, lib

@@ -458,7 +458,7 @@ extern "C" int pm_bn_bwd_from_sums(const float* x, const float* dy, int32_t O, i
 // (accumulators are replicated PM_BN_REPL times — the producer picks the replica from its row-panel index — so that
 // no address takes more than ~64 serialized fp64 atomics; consumers add the replicas up once per workgroup into LDS)
 // (pm_repl_sum: common.h)
-__global__ void __launch_bounds__(256) k_bn_apply4_sums(const float* __restrict__ x, int64_t n4, int C, double count,
+__global__ void __launch_bounds__(1024) k_bn_apply4_sums(const float* __restrict__ x, int64_t n4, int C, double count,
                                                         const double* __restrict__ sums, BnCtx ctx,
                                                         const float* __restrict__ res, float* __restrict__ y,
                                                         float* mean, float* var, float* rmean, float* rvar,
@@ -529,7 +529,11 @@ extern "C" int pm_bn_apply_fused_absmax(const float* x, int32_t O, int32_t C, co
   if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || (residual && ((uintptr_t)residual % 16))) return PM_E_INVALID;
   BnCtx ctx = {nullptr, nullptr, gamma, beta, eps, relu};
   const int64_t n = (int64_t)O * C;
-  hipLaunchKernelGGL(k_bn_apply4_sums, dim3(fused_grid(n / 4)), dim3(256), sizeof(float) * 3 * C, (hipStream_t)stream, x,
+  // 512 workgroups of 1024 threads (round 6; 1024 x 256 before: every workgroup starts with the column statistics, and 1024 short
+  // workgroups ramp slowly behind a draining one-workgroup-per-CU kernel: step -30 us at configs[1], same-box A/B in profiles/LOG.md)
+  constexpr int thr = 1024, gcap = 512;
+  int64_t gr = pm_cdiv(n / 4, thr); if (gr > gcap) gr = gcap; if (gr < 1) gr = 1;
+  hipLaunchKernelGGL(k_bn_apply4_sums, dim3((unsigned)gr), dim3(thr), sizeof(float) * 3 * C, (hipStream_t)stream, x,
                      n / 4, C, (double)O, sums, ctx, residual, y, mean, var, running_mean, running_var, momentum, absmax_out);
   return pm_check_launch();
 }

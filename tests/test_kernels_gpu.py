@@ -1314,6 +1314,35 @@ def test_decoder_head_over_the_rows_without_pad_targets(d, B, S, drums):
     assert torch.equal(lg1, lg0) and torch.equal(dl1, dl0) and float(out2[:2].abs().sum()) == 0
 
 
+def test_head_row_lists_beyond_a_thousand_chunks():
+    """`pm_unembed_row_lists` at 1.1 M candidate rows (72 k nodes x 15 slots: 1070 chunks of 1024 — a chunk sums the counts of MORE chunks
+    than it has threads before it writes): lists and counts exact against numpy."""
+    import numpy as np
+    cpu = synthetic_batch(1150, 2, p=0.25, seed=41)
+    b = cpu.to(DEV)
+    S = 15
+    plan = ops.plan_build(b.edge_index, b.edge_type, b.edge_dist, b.bars, b.batch, b.is_drum, b.tokens, b.n_bars,
+                          b.s_tensor.shape[0], n_slots=S)
+    N, R = cpu.num_nodes, cpu.num_nodes * S
+    assert R > 1024 * 1024
+    lists = torch.full((6, R), -7, dtype=torch.int32, device=DEV)
+    counts = torch.full((int(lib().pm_unembed_row_counts_len(N, S)),), -1, dtype=torch.int32, device=DEV)
+    call("pm_unembed_row_lists", ptr(plan.tokens), ptr(plan.buf), N, plan.E, plan.G, 256, S, ptr(lists), ptr(lists[3:]), ptr(counts),
+         None, stream())
+    tok = cpu.tokens.numpy()[:, 1:S + 1]
+    drum = cpu.is_drum.numpy().astype(bool)
+    live = (tok[..., 0] != 130) | (tok[..., 1] != 98)
+    rows = np.arange(R).reshape(N, S)
+    jobs = [np.broadcast_to(drum[:, None], (N, S)), np.broadcast_to(~drum[:, None], (N, S)), np.ones((N, S), bool)]
+    got = counts.tolist()
+    for j in range(3):
+        for base, sel in ((0, live), (3, ~live)):
+            want = rows[jobs[j] & sel]
+            n = got[base + j + (1 if base else 0)]
+            assert n == want.size, (j, base)
+            assert np.array_equal(lists[base + j, :n].cpu().numpy(), want), (j, base)
+
+
 @pytest.mark.parametrize("d,B,S,drums,lists", [(256, 40, 6, "mixed", True), (256, 40, 6, "mixed", False), (512, 12, 4, "mixed", True),
                                                 (256, 6, 5, "none", True), (256, 6, 5, "all", False), (256, 300, 3, "mixed", True),
                                                 (256, 1, 7, "mixed", True)])

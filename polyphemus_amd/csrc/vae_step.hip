@@ -39,8 +39,8 @@ namespace {
 //   PM_FUSED_CE=0       three un-embedding products + the loss kernel instead of the fused un-embedding / cross-entropy kernel
 //   PM_SIDE_STREAM=m    bit mask of the branch sites (BR_* below) issued on the library's second stream (default: all;
 //                       0: everything on the caller's stream);  PM_SIDE_DELAY_US=n (tests): every branch starts n us late
-//   PM_DAGG_BN=0, PM_DAGG_RES=0, PM_PLAN_SIDE=0, PM_CHORD_TABLES=0, PM_H2=0, PM_BAR_ROUTE=0, PM_PAD_SKIP=0, PM_UNEMBED_DW=0: see the
-//                       fields of StepCfg
+//   PM_DAGG_BN=0, PM_DAGG_RES=0, PM_PLAN_SIDE=0, PM_CHORD_TABLES=0, PM_H2=0, PM_BAR_ROUTE=0, PM_PAD_SKIP=0, PM_UNEMBED_DW=0, PM_SENC_FIRST=0: see
+//                       the fields of StepCfg
 //   PM_GCL_OFFSET_LIMIT=n, PM_DEBUG
 // Former switches that are constants now (their losing side was measured and removed: profiles/LOG.md): PM_NO_ROWS_TN,
 // PM_NO_UNEMBED_DH, PM_GCL_NO_BFRAG, PM_DENSE_DEG (16), PM_LATE_WGRADS, PM_DW_SIDE, PM_FUSED_HEADS (csrc/heads.hip, deleted in
@@ -65,6 +65,7 @@ struct StepCfg {
   bool h2;                     // PM_H2=0: the GCL products of d in {128, 256} on the exact three-term bf16 split (six MFMA products per fp32
                                // product) instead of the fp16 pair format (three; PmH2 of the header) — the parity tests run both
   int dense_deg;
+  bool senc_first;             // PM_SENC_FIRST=0: the decoder's weight preparation ahead of the structure encoder on the second stream (rounds 3-5)
   bool unembed_dw;             // PM_UNEMBED_DW=0: the un-embedding weight gradients as three split-K products of the fp32 tile GEMM (rounds 2-5)
   bool pad_skip;               // PM_PAD_SKIP=0: the decoder head over every (node, active slot) row, PAD targets included (rounds 2-5)
   bool bar_route;              // PM_BAR_ROUTE=0: dense graphs on the row-gather kernels of segreduce.hip (rounds 1-5) instead of bar.hip
@@ -96,6 +97,7 @@ static StepCfg read_cfg() {
   k.bar_route = flag("PM_BAR_ROUTE", true);
   k.pad_skip = flag("PM_PAD_SKIP", true);
   k.unembed_dw = flag("PM_UNEMBED_DW", true);
+  k.senc_first = flag("PM_SENC_FIRST", true);
   k.offset_limit = getenv("PM_GCL_OFFSET_LIMIT") ? atoll(getenv("PM_GCL_OFFSET_LIMIT")) : 0x7fffffffLL;
   return k;
 }
@@ -216,7 +218,7 @@ struct Ctx {
 // capturable.  Norms on the branch use their own reduction scratch.
 // sites: structure encoder forward (+ weight preparation, its intermediate join BR_WPREP), structure decoder forward,
 // structure decoder backward, structure encoder backward, the weight gradients of the decoder head / of the chord encoder
-enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_PLAN_COUNT, BR_LOSSES, BR_SITES };
+enum { BR_ENC_FWD = 0, BR_DEC_FWD, BR_DEC_BWD, BR_ENC_BWD, BR_WPREP, BR_DEC_WGRAD, BR_ENC_WGRAD, BR_WPREP_DEC, BR_ENC_HEAD_WGRAD, BR_GCL_DW0, BR_GCL_DW1, BR_PLAN_COUNT, BR_LOSSES, BR_ENC_S_FWD, BR_SITES };
 struct Branch { hipStream_t st; hipEvent_t fork[BR_SITES], join[BR_SITES], idle; bool ok; };
 static Branch* branch_of_device() {
   static Branch br[16];
@@ -816,6 +818,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   // the rest of the branch: issued by decoder_prep_and_structure_encoder() below, behind the first launches of the content encoder
   auto decoder_prep_and_structure_encoder = [&]() {
     br.resume();
+    const bool senc_first = cfg().senc_first;
+    auto dec_prep = [&]() {
     gcn_prepare(c, Y.dec_gcn, s.dg);
     // chord decoder, rows [0, S*d) of its weight [15d, d]: kind 0 for the forward, kind 1 for the input gradient
     if (rows_w_ok) {
@@ -845,6 +849,8 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
       RUN(pm_unembed_row_lists(s.bt.tokens, s.plan, N, c.E, Gn, d, S, s.ue_lists, pad_rows ? s.ue_lists + (size_t)3 * N * S : nullptr,
                                  s.ue_counts, s.dH, c.st));
     br.mark(BR_WPREP_DEC);
+    };
+    auto struct_enc = [&]() {
     if (run) {
     RUN(pm_conv3x3_fwd(s.bt.s_tensor, c.P + Y.enc_conv0.w, c.P + Y.enc_conv0.b, Gn, 1, 8, 4, 32, 0, s.c0, c.st));
     if (c.bn) bn_fwd(c, s.c0, Gn, 8, 128, Y.enc_bn1, true, nullptr, s.a0, s.m0, s.v0);
@@ -859,6 +865,11 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     lin(c, s.h1d, Y.enc_lin4, Gn, d, d, s.h2, false);
     lin(c, s.h2, Y.enc_s_bars, B, d, nb * d, s.zcat + d, false, nb * d, 2 * d);           // z_s = zcat[:, d:]
     }
+    br.mark(BR_ENC_S_FWD);
+    };
+    // the structure encoder FIRST (round 6): its output is wanted behind the encoder's eighth layer, the decoder's weight planes and row
+    // lists a stack later — in the other order the merge layer waited for this branch (PM_SENC_FIRST=0)
+    if (senc_first) { struct_enc(); dec_prep(); } else { dec_prep(); struct_enc(); }
     br.end();
   };
   // ---------------- content encoder (model.py:344-417)
@@ -928,7 +939,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
   float* const sbd_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
   float* const u1d_buf = dropping ? ar.f((size_t)Gn * d) : nullptr;
   if (run) {
-    branch_join(c, BR_ENC_FWD);
+    branch_join(c, BR_ENC_S_FWD);                     // the structure encoder's z_s
     s.zcat_d = drop(c, s.zcat, B, 2 * d, SITE_ENC_MERGE_IN, seed_enc, zcatd_buf);            // Encoder.dropout_layer, model.py:473
     lin(c, s.zcat_d, Y.enc_merge, B, d, 2 * d, s.m, false);
     bn_fwd(c, s.m, B, d, 1, Y.enc_bn_merge, true, nullptr, s.zg, s.mm, s.mv);
@@ -975,6 +986,7 @@ void forward(Ctx& c, float msg_p, uint32_t seed_enc, uint32_t seed_dec) {
     RUN(pm_conv3x3_fwd(s.a2, c.P + Y.dec_conv4.w, c.P + Y.dec_conv4.b, Gn, 8, 1, 4, 32, 0, s.s_logits, c.st));
   };
   if (run) branch_join(c, BR_WPREP_DEC);               // the decoder's weight planes and distance table are ready
+  if (run) branch_join(c, BR_ENC_FWD);                 // (the end of that branch: same stream, in order)
   s.dg.x0_src = s.cb; s.dg.x0_src_n = (int64_t)Gn * d;
   float* xdL = gcn_forward(c, xd0, Y.dec_gcn, s.dg, seed_dec, 1000, msg_p);
   if (run) structure_decoder();

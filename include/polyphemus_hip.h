@@ -866,7 +866,7 @@ typedef struct PmBatch {                                    /* device pointers o
                                                                gradients (pm_content_ce_scaled; data-parallel token mean) */
 } PmBatch;
 /* The step's A/B switches (environment variables PM_GCL_FUSED, PM_GCL_NO_DW, PM_NO_ROWS_W, PM_GCL_NO_CLASSES, PM_FUSED_CE,
- * PM_SIDE_STREAM, PM_SIDE_DELAY_US, PM_DAGG_BN, PM_DAGG_RES, PM_PLAN_SIDE, PM_CHORD_TABLES, PM_H2, PM_BAR_ROUTE, PM_GCL_OFFSET_LIMIT,
+ * PM_SIDE_STREAM, PM_SIDE_DELAY_US, PM_DAGG_BN, PM_DAGG_RES, PM_PLAN_SIDE, PM_CHORD_TABLES, PM_H2, PM_BAR_ROUTE, PM_PAD_SKIP, PM_UNEMBED_DW, PM_SENC_FIRST, PM_GCL_OFFSET_LIMIT,
  * PM_DEBUG: the complete list, csrc/vae_step.hip read_cfg) are read once, when the library is loaded; this re-reads them (host
  * only) so that one process can run one batch through two kernel sets.  Switches of earlier rounds that are no longer read:
  * PM_NO_ROWS_TN, PM_NO_UNEMBED_DH, PM_GCL_NO_BFRAG, PM_DENSE_DEG, PM_LATE_WGRADS, PM_DW_SIDE, PM_FUSED_HEADS. */
